@@ -1,0 +1,145 @@
+"""The CPU oracle (oracle/*.py) against fixtures generated from the real reference
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from oracle import unet2d_oracle as o2
+from oracle import unet3d_oracle as o3
+
+torch.set_num_threads(8)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def stat(t):
+    t = t.detach().double().flatten()
+    idx = torch.linspace(0, t.numel() - 1, steps=64).long()
+    return np.concatenate([[t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], t[idx].numpy()])
+
+
+def test_blocks2d():
+    g = load_golden("g1_blocks2d.npz")
+    p = {"b.first.weight": T(g["dc_p_first.weight"]), "b.first.bias": T(g["dc_p_first.bias"]),
+         "b.second.weight": T(g["dc_p_second.weight"]), "b.second.bias": T(g["dc_p_second.bias"])}
+    x = T(g["dc_x"]).requires_grad_(True)
+    ps = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    y = o2.double_conv(x, ps, "b")
+    assert torch.allclose(y, T(g["dc_y"]), atol=1e-6)
+    y.backward(T(g["dc_gy"]))
+    assert torch.allclose(x.grad, T(g["dc_gx"]), atol=1e-5)
+    assert torch.allclose(ps["b.first.weight"].grad, T(g["dc_g_first.weight"]), atol=1e-4)
+    # up-sample
+    xu = T(g["up_x"])
+    yu = F.conv_transpose2d(xu, T(g["up_w"]), T(g["up_b"]), stride=2)
+    assert torch.allclose(yu, T(g["up_y"]), atol=1e-6)
+    # down-sample incl. planted ties
+    xd = T(g["ds_x"]).requires_grad_(True)
+    yd = F.max_pool2d(xd, 2)
+    assert torch.equal(yd, T(g["ds_y"]))
+    yd.backward(T(g["ds_gy"]))
+    assert torch.equal(xd.grad, T(g["ds_gx"]))
+    # crop and concat: upsampled first
+    a, b = T(g["cc_a"]), T(g["cc_b"])
+    cc = torch.cat([a, o2.center_crop(b, 8, 8)], 1)
+    assert torch.equal(cc, T(g["cc_y"]))
+
+
+def _check_unet2d(tag, cin, cout):
+    g = load_golden(f"g2_unet_{tag}.npz")
+    p = o2.init_params(cin, cout, seed=0)
+    names = [str(n) for n in g["names"]]
+    assert names == list(p.keys())
+    ps = np.stack([stat(p[n]) for n in names])
+    assert np.array_equal(ps, g["param_stats"]), "seeded init differs from the reference"
+    images, labels = T(g["images"]), T(g["labels"])
+    loss, logits, grads = o2.loss_and_grads(p, images, labels)
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    assert torch.allclose(logits, T(g["logits"]), atol=1e-5)
+    am = o2.argmax_mask(logits) if cout > 1 else (logits > 0).long()
+    assert torch.equal(am, T(g["argmax"]))
+    gs = np.stack([stat(grads[n]) for n in names])
+    assert np.allclose(gs, g["grad_stats"], rtol=1e-3, atol=1e-6)
+    assert torch.allclose(grads["final_conv.weight"], T(g["g_final_w"]), atol=1e-5)
+    assert torch.allclose(grads["down_conv.0.first.weight"], T(g["g_down0_first_w"]), atol=1e-4, rtol=1e-3)
+    # 3 optimizer steps (clip 1.0, AdamW, HF decay split)
+    opt = o2.AdamW(p)
+    for step in range(3):
+        l, n, _ = o2.train_step(p, opt, images, labels)
+        assert abs(l.item() - g["step_losses"][step]) < 2e-5, (step, l.item(), g["step_losses"][step])
+        assert abs(n.item() - g["step_gradnorms"][step]) < 1e-3 * max(1.0, g["step_gradnorms"][step])
+        st = np.stack([stat(p[nm]) for nm in names])
+        assert np.allclose(st, g[f"param_stats_step{step + 1}"], rtol=2e-3, atol=2e-5), step
+
+
+def test_unet2d_1_2():
+    _check_unet2d("1_2", 1, 2)
+
+
+def test_unet2d_3_4():
+    _check_unet2d("3_4", 3, 4)
+
+
+def test_unet2d_1_1_bce():
+    _check_unet2d("1_1", 1, 1)
+
+
+def test_blocks3d():
+    g = load_golden("g3_blocks3d.npz")
+    p = {"s.groupnorm.weight": T(g["sc_p_groupnorm.weight"]), "s.groupnorm.bias": T(g["sc_p_groupnorm.bias"]),
+         "s.conv.weight": T(g["sc_p_conv.weight"])}
+    x = T(g["sc_x"]).requires_grad_(True)
+    y = o3.single_conv(x, p, "s", 8)
+    assert torch.allclose(y, T(g["sc_y"]), atol=1e-5)
+    y.backward(T(g["sc_gy"]))
+    assert torch.allclose(x.grad, T(g["sc_gx"]), atol=1e-4)
+    # decoder: nearest-upsample to the encoder size, cat (enc, x), DoubleConv
+    p = {}
+    for k in g.files:
+        if k.startswith("dec_p_"):
+            p["d." + k[len("dec_p_"):]] = T(g[k])
+    enc, low = T(g["dec_enc"]), T(g["dec_low"])
+    xx = F.interpolate(low, size=enc.shape[2:], mode="nearest")
+    xx = torch.cat((enc, xx), 1)
+    yy = o3.double_conv(xx, p, "d", 8)
+    assert torch.allclose(yy, T(g["dec_y"]), atol=1e-5)
+
+
+def test_unet3d_small():
+    g = load_golden("g3_unet3d_small.npz")
+    p = o3.init_params(1, 3, f_maps=[8, 16, 32], seed=0)
+    for k in p:
+        assert torch.equal(p[k], T(g["p_" + k])), k
+    x, t = T(g["x"]), T(g["t"])
+    loss, logits, grads = o3.loss_and_grads(p, x, t, num_levels=3, num_groups=4)
+    assert torch.allclose(logits, T(g["logits"]), atol=1e-5)
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    assert torch.equal(logits.argmax(1), T(g["argmax"]))
+    assert abs(o3.dice_loss(logits, t).item() - float(g["dice_loss"])) < 1e-6
+    assert abs(o3.hf_wrapper_loss(logits, t).item() - float(g["quirk_loss"])) < 1e-6
+    for k in p:
+        assert torch.allclose(grads[k], T(g["g_" + k]), atol=2e-5, rtol=1e-3), k
+
+
+def test_unet3d_default_width():
+    g = load_golden("g3_unet3d_default.npz")
+    p = o3.init_params(1, 3, seed=0)
+    names = [str(n) for n in g["names"]]
+    assert names == list(p.keys())
+    assert np.array_equal(np.stack([stat(p[n]) for n in names]), g["param_stats"])
+    loss, logits, grads = o3.loss_and_grads(p, T(g["x"]), T(g["t"]))
+    assert torch.allclose(logits, T(g["logits"]), atol=1e-5)
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    assert np.allclose(np.stack([stat(grads[n]) for n in names]), g["grad_stats"], rtol=1e-3, atol=1e-6)
+
+
+def test_bcedice_loss():
+    g = load_golden("g3_loss.npz")
+    lg = T(g["logits"]).requires_grad_(True)
+    l = o3.bce_dice_loss(lg, T(g["target"]))
+    assert abs(l.item() - float(g["loss"])) < 1e-7
+    l.backward()
+    assert torch.allclose(lg.grad, T(g["grad"]), atol=1e-8)
