@@ -1,0 +1,165 @@
+/* misamd.h - C ABI of the MI355X-native U-Net hot path (libmisamd.so).
+ *
+ * The reference (a-green-hand-jack/mdeical_image_segmentation) is pure Python: it has no FFI
+ * of its own.  Every entry point below replaces one or more ATen ops that the reference's
+ * nn.Modules invoke on the hot path; the reference call site is cited per function.  The
+ * Python host side (mdeical_image_segmentation_amd/) binds these with ctypes, passing raw
+ * device pointers (torch tensors are only the allocator) and the current HIP stream.
+ *
+ * Conventions
+ *   - activations are channels-last: NHWC (2-D) / NDHWC (3-D); a tensor view is
+ *     (pointer to channel 0 of pixel 0, ld = elements between consecutive pixels, C)
+ *     so that producers can write straight into a channel slice of a concat buffer;
+ *   - dtype: MIS_F32 (exact f32 MFMA, the parity mode) or MIS_BF16 (bf16 storage, f32 accumulate);
+ *   - every function enqueues on `stream` and never synchronises or allocates;
+ *   - return value 0 = ok, negative = error; mis_last_error() gives the thread-local message.
+ */
+#ifndef MISAMD_H
+#define MISAMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIS_F32 0
+#define MIS_BF16 1
+
+#define MIS_OK 0
+#define MIS_EINVAL (-1)
+#define MIS_EUNSUPPORTED (-2)
+#define MIS_EHIP (-3)
+
+/* epilogue store modes of mis_conv_igemm */
+#define MIS_OUT_PLAIN 0      /* y[pixel][c]                                                    */
+#define MIS_OUT_SHUFFLE2 1   /* GEMM column (ab*Cq + c) of pixel (h,w) -> pixel (2h+a, 2w+b), channel c */
+#define MIS_OUT_UNSHUFFLE2 2 /* channel c of pixel (h,w) -> pixel (h/2,w/2), channel ((h&1)*2+(w&1))*C + c */
+
+const char* mis_last_error(void);
+int mis_version(void);
+
+/* Implicit-GEMM convolution on MFMA: rows = output pixels, K = taps x Cin, columns = Cout.
+ * Replaces nn.Conv2d(k3,p1) fwd and its dgrad (model/unet2d/layers.py:122,125), nn.Conv3d(k3,p1)
+ * (model/unet3d/buildingblocks.py:64-66), ConvTranspose2d(k2,s2) fwd/dgrad as a 1x1 GEMM with a
+ * pixel-shuffle store (model/unet2d/layers.py:165) and the channel concat / nearest upsample
+ * (layers.py:186-190, buildingblocks.py:546-548,671-673) which become addressing. */
+typedef struct MisConvDesc {
+    int dtype;               /* MIS_F32 | MIS_BF16 */
+    int ksize;               /* 3 (3x3 or 3x3x3, pad 1, stride 1) or 1 */
+    int N, D, H, W;          /* pixel grid walked by the GEMM rows (D = 1 for 2-D) */
+    int Cin, Cout;           /* per-tap K and GEMM N; both multiples of the K chunk (64 bf16 / 32 f32) resp. 64 */
+    /* input: channels [0,Cin0) from x0, [Cin0,Cin) from x1 (x1 may be NULL when Cin0 == Cin).
+     * A source whose grid is exactly half of (D,H,W) along an axis is read with nearest addressing src = dst >> 1
+     * (F.interpolate(mode='nearest') of the reference for the 2x case; other ratios are MIS_EUNSUPPORTED). */
+    const void* x0; int x0_ld; int x0_D, x0_H, x0_W;
+    const void* x1; int x1_ld; int x1_D, x1_H, x1_W;
+    int Cin0;
+    /* optional per-(n, channel) affine applied to in-bounds input while staging (GroupNorm folded
+     * to a*x+b, buildingblocks.py:87-92): in_scale[n*Cin + c], in_shift[n*Cin + c]; NULL = none */
+    const float* in_scale; const float* in_shift;
+    const void* w;           /* packed [tap][Cout][Cin] in dtype (mis_pack_conv_weight) */
+    const float* bias;       /* [Cout] or NULL; with MIS_OUT_SHUFFLE2 indexed by c (= col % Cq) */
+    int relu;                /* epilogue max(x,0) */
+    const void* mask; int mask_ld; /* optional: out *= (mask[pixel][col] > 0), same grid as the rows (ReLU backward) */
+    /* outputs: columns [0,Cout0) -> y0, [Cout0,Cout) -> y1 (y1 may be NULL when Cout0 == Cout) */
+    void* y0; int y0_ld; int y0_mode;
+    void* y1; int y1_ld; int y1_mode;
+    int Cout0;
+} MisConvDesc;
+int mis_conv_igemm(const MisConvDesc* d, void* stream);
+
+/* Weight-gradient GEMM: dW[tap][ci][co] = sum_pixels x[pixel+tap][ci] * dy[pixel][co]   (split-K over pixel tiles,
+ * fp32 partial slabs + deterministic reduction).  Replaces the weight part of convolution_backward for
+ * Conv2d/Conv3d(k3,p1) and ConvTranspose2d(k2,s2) (as ksize 1 on the un-shuffled gradient). */
+typedef struct MisWgradDesc {
+    int dtype;
+    int ksize;               /* 3 or 1 */
+    int N, D, H, W;
+    int Cin, Cout;           /* x channels, dy channels */
+    const void* x0; int x0_ld; int x0_D, x0_H, x0_W;
+    const void* x1; int x1_ld; int x1_D, x1_H, x1_W;
+    int Cin0;
+    const float* in_scale; const float* in_shift;
+    const void* dy; int dy_ld;
+    float* workspace; size_t workspace_bytes;   /* >= mis_wgrad_workspace_bytes(d) */
+    float* dw;               /* output, fp32 */
+    int dw_layout;           /* 0: [Cout][Cin][taps] (nn.Conv weight), 1: [Cin][Cq][4] with dy column = ab*Cq + c (nn.ConvTranspose2d k2) */
+    float alpha;             /* dw = alpha * sum */
+} MisWgradDesc;
+size_t mis_wgrad_workspace_bytes(const MisWgradDesc* d);
+int mis_wgrad(const MisWgradDesc* d, void* stream);
+
+/* First layer (Cin = 1..4, fp32 NCHW image in, NHWC out): direct conv, forward and weight/bias gradient.
+ * model/unet2d/layers.py:122 for down_conv.0.first. */
+int mis_conv3x3_first_fwd(int dtype, const float* x_nchw, int N, int Cin, int H, int W, const float* w /*[64][Cin][3][3]*/,
+                          const float* bias, void* y, int y_ld, int Cout, void* stream);
+size_t mis_conv3x3_first_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout);
+int mis_conv3x3_first_wgrad(int dtype, const float* x_nchw, int N, int Cin, int H, int W, const void* dy, int dy_ld, int Cout,
+                            float* workspace, float* dw, float* db, void* stream);
+
+/* Column sums: out[c] = alpha * sum_pixels x[pixel][c] (+ fold: C = fold*Cq columns summed onto Cq outputs).
+ * Bias gradients of every conv (convolution_backward's bias part). */
+size_t mis_colsum_workspace_bytes(long long npix, int C);
+int mis_colsum(int dtype, const void* x, int ld, long long npix, int C, int fold, float alpha, float* workspace, float* out,
+               void* stream);
+
+/* MaxPool 2x2 (2-D) / 2x2x2 (3-D), stride 2, floor.  model/unet2d/layers.py:147; model/unet3d/buildingblocks.py:409-418. */
+int mis_maxpool2_fwd(int dtype, const void* x, int x_ld, void* y, int y_ld, int N, int D, int H, int W, int C, void* stream);
+/* dx = relu_mask(x) * (scatter(dy to the first max of each window) + (add ? add : 0)); dx may alias add. */
+int mis_maxpool2_bwd(int dtype, const void* x, int x_ld, const void* dy, int dy_ld, const void* add, int add_ld, void* dx, int dx_ld,
+                     int N, int D, int H, int W, int C, int relu_mask, void* stream);
+
+/* Weight repack: fp32 master in the reference layout -> packed operand layouts of mis_conv_igemm. */
+/* conv: w [Cout][Cin][taps] -> fwd pack [tap][Cout][Cin] and (optional) dgrad pack [tap'][Cin][Cout] with tap' mirrored */
+int mis_pack_conv_weight(int dtype, const float* w, int Cout, int Cin, int taps, void* w_fwd, void* w_dgrad, void* stream);
+/* convT k2s2: w [Cin][Cq][2][2] -> fwd pack [1][4*Cq][Cin] (row = ab*Cq + c) and dgrad pack [1][Cin][4*Cq] */
+int mis_pack_convt_weight(int dtype, const float* w, int Cin, int Cq, void* w_fwd, void* w_dgrad, void* stream);
+
+/* 1x1 segmentation head + loss + argmax (+ backward in the same pass).
+ * unet.py:89,127 (final_conv), unet.py:1184-1188 (CE | BCEWithLogits), argmax sites metrics.py:97 / predictor.py:167. */
+typedef struct MisHeadDesc {
+    int dtype;
+    int loss;                /* 0 = cross entropy (labels int64 [N,spatial]), 1 = BCE with logits (targets f32 [N,C,spatial]),
+                                2 = BCE + Dice (3-D, losses.py:167-178), -1 = no loss (inference) */
+    long long npix_per_image; int N; int Cfeat; int C;     /* Cfeat = 64 */
+    const void* y; int y_ld;       /* features (post-ReLU) */
+    const float* w; const float* b;/* [C][Cfeat], [C] */
+    const void* labels;
+    float* logits;           /* [N][C][spatial] fp32 (reference layout), may be NULL */
+    uint8_t* argmax;         /* [N][spatial] or NULL (C == 1: logits > 0) */
+    float* workspace; size_t workspace_bytes;
+    float* loss_out;         /* [1] (+ [1 + 3*C] dice sums for loss 2) */
+    /* backward (all NULL for forward only) */
+    void* dy; int dy_ld;     /* dL/dfeatures * (y > 0) */
+    float* dw; float* db;
+    float grad_scale;        /* dL/dloss */
+    float alpha, beta;       /* BCEDice weights */
+} MisHeadDesc;
+size_t mis_head_workspace_bytes(const MisHeadDesc* d);
+int mis_head_loss(const MisHeadDesc* d, void* stream);
+
+/* Global grad-norm clip + AdamW on flat fp32 buffers (HF Trainer: clip_grad_norm_(1.0) then torch.optim.AdamW). */
+size_t mis_adamw_workspace_bytes(long long n);
+int mis_sumsq(const float* g, long long n, float* workspace /* partials */, void* stream);
+int mis_adamw_step(float* p, const float* g, float* m, float* v, long long n, const float* sumsq_partials, int npartials,
+                   float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                   float* gradnorm_out, void* stream);
+int mis_sumsq_npartials(long long n);
+
+/* GroupNorm statistics (per sample, per channel sums) and finalisation to a*x+b. buildingblocks.py:87-92 */
+size_t mis_chanstats_workspace_bytes(int N, long long npix, int C);
+int mis_chanstats(int dtype, const void* x, int ld, int N, long long npix, int C, float* workspace, float* sum, float* sumsq,
+                  void* stream);
+
+/* layout helpers */
+int mis_nchw_to_nhwc(int dtype_out, const float* x, void* y, int y_ld, int N, int C, long long spatial, void* stream);
+int mis_nhwc_to_nchw(int dtype_in, const void* x, int x_ld, float* y, int N, int C, long long spatial, void* stream);
+
+/* test hooks: raw MFMA / LDS-transpose fragment probes (tests/test_gpu_fragments.py) */
+int mis_probe_mfma(int which, const float* a, const float* b, float* c, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

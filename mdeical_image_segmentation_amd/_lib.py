@@ -1,0 +1,154 @@
+"""ctypes binding of libmisamd.so (include/misamd.h).
+
+The shared library is the product; this module only marshals raw device pointers and sizes.
+There is NO fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmisamd.so")
+
+MIS_F32, MIS_BF16 = 0, 1
+OUT_PLAIN, OUT_SHUFFLE2, OUT_UNSHUFFLE2 = 0, 1, 2
+
+EXPORTS = [
+    "mis_last_error", "mis_version", "mis_conv_igemm", "mis_wgrad_workspace_bytes", "mis_wgrad",
+    "mis_conv3x3_first_fwd", "mis_conv3x3_first_wgrad_workspace_bytes", "mis_conv3x3_first_wgrad",
+    "mis_colsum_workspace_bytes", "mis_colsum", "mis_maxpool2_fwd", "mis_maxpool2_bwd",
+    "mis_pack_conv_weight", "mis_pack_convt_weight", "mis_head_workspace_bytes", "mis_head_loss",
+    "mis_adamw_workspace_bytes", "mis_sumsq", "mis_adamw_step", "mis_sumsq_npartials",
+    "mis_chanstats_workspace_bytes", "mis_chanstats", "mis_nchw_to_nhwc", "mis_nhwc_to_nchw", "mis_probe_mfma",
+]
+
+
+class MisError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("ksize", C.c_int),
+        ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("Cin", C.c_int), ("Cout", C.c_int),
+        ("x0", C.c_void_p), ("x0_ld", C.c_int), ("x0_D", C.c_int), ("x0_H", C.c_int), ("x0_W", C.c_int),
+        ("x1", C.c_void_p), ("x1_ld", C.c_int), ("x1_D", C.c_int), ("x1_H", C.c_int), ("x1_W", C.c_int),
+        ("Cin0", C.c_int),
+        ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
+        ("w", C.c_void_p), ("bias", C.c_void_p), ("relu", C.c_int),
+        ("mask", C.c_void_p), ("mask_ld", C.c_int),
+        ("y0", C.c_void_p), ("y0_ld", C.c_int), ("y0_mode", C.c_int),
+        ("y1", C.c_void_p), ("y1_ld", C.c_int), ("y1_mode", C.c_int),
+        ("Cout0", C.c_int),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("ksize", C.c_int),
+        ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("Cin", C.c_int), ("Cout", C.c_int),
+        ("x0", C.c_void_p), ("x0_ld", C.c_int), ("x0_D", C.c_int), ("x0_H", C.c_int), ("x0_W", C.c_int),
+        ("x1", C.c_void_p), ("x1_ld", C.c_int), ("x1_D", C.c_int), ("x1_H", C.c_int), ("x1_W", C.c_int),
+        ("Cin0", C.c_int),
+        ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
+        ("dy", C.c_void_p), ("dy_ld", C.c_int),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("dw", C.c_void_p), ("dw_layout", C.c_int), ("alpha", C.c_float),
+    ]
+
+
+class HeadDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("loss", C.c_int),
+        ("npix_per_image", C.c_longlong), ("N", C.c_int), ("Cfeat", C.c_int), ("C", C.c_int),
+        ("y", C.c_void_p), ("y_ld", C.c_int),
+        ("w", C.c_void_p), ("b", C.c_void_p),
+        ("labels", C.c_void_p),
+        ("logits", C.c_void_p), ("argmax", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("loss_out", C.c_void_p),
+        ("dy", C.c_void_p), ("dy_ld", C.c_int),
+        ("dw", C.c_void_p), ("db", C.c_void_p),
+        ("grad_scale", C.c_float), ("alpha", C.c_float), ("beta", C.c_float),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libmisamd.so (no GPU needed to load it). Raises MisError when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MisError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(make -C mdeical_image_segmentation_amd/csrc). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.mis_last_error.restype = C.c_char_p
+    lib.mis_version.restype = C.c_int
+    for name in ("mis_wgrad_workspace_bytes", "mis_head_workspace_bytes"):
+        getattr(lib, name).restype = C.c_size_t
+        getattr(lib, name).argtypes = [C.c_void_p]
+    lib.mis_conv3x3_first_wgrad_workspace_bytes.restype = C.c_size_t
+    lib.mis_conv3x3_first_wgrad_workspace_bytes.argtypes = [C.c_int] * 5
+    lib.mis_colsum_workspace_bytes.restype = C.c_size_t
+    lib.mis_colsum_workspace_bytes.argtypes = [C.c_longlong, C.c_int]
+    lib.mis_adamw_workspace_bytes.restype = C.c_size_t
+    lib.mis_adamw_workspace_bytes.argtypes = [C.c_longlong]
+    lib.mis_chanstats_workspace_bytes.restype = C.c_size_t
+    lib.mis_chanstats_workspace_bytes.argtypes = [C.c_int, C.c_longlong, C.c_int]
+    lib.mis_sumsq_npartials.restype = C.c_int
+    lib.mis_sumsq_npartials.argtypes = [C.c_longlong]
+
+    vp, i, ll, f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+    sigs = {
+        "mis_conv_igemm": [vp, vp],
+        "mis_wgrad": [vp, vp],
+        "mis_conv3x3_first_fwd": [i, vp, i, i, i, i, vp, vp, vp, i, i, vp],
+        "mis_conv3x3_first_wgrad": [i, vp, i, i, i, i, vp, i, i, vp, vp, vp, vp],
+        "mis_colsum": [i, vp, i, ll, i, i, f, vp, vp, vp],
+        "mis_maxpool2_fwd": [i, vp, i, vp, i, i, i, i, i, i, vp],
+        "mis_maxpool2_bwd": [i, vp, i, vp, i, vp, i, vp, i, i, i, i, i, i, i, vp],
+        "mis_pack_conv_weight": [i, vp, i, i, i, vp, vp, vp],
+        "mis_pack_convt_weight": [i, vp, i, i, vp, vp, vp],
+        "mis_head_loss": [vp, vp],
+        "mis_sumsq": [vp, ll, vp, vp],
+        "mis_adamw_step": [vp, vp, vp, vp, ll, vp, i, f, f, f, f, f, f, i, vp, vp],
+        "mis_chanstats": [i, vp, i, i, ll, i, vp, vp, vp, vp],
+        "mis_nchw_to_nhwc": [i, vp, vp, i, i, i, ll, vp],
+        "mis_nhwc_to_nchw": [i, vp, i, vp, i, i, ll, vp],
+        "mis_probe_mfma": [i, vp, vp, vp, vp],
+    }
+    for name, args in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().mis_last_error().decode("utf-8", "replace")
+        raise MisError(f"{what} failed (rc={rc}): {msg}")
+
+
+def dtype_code(torch_dtype):
+    import torch
+    if torch_dtype == torch.float32:
+        return MIS_F32
+    if torch_dtype == torch.bfloat16:
+        return MIS_BF16
+    raise MisError(f"unsupported dtype {torch_dtype}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

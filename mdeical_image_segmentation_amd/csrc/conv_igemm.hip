@@ -1,0 +1,414 @@
+// Implicit-GEMM convolution on MFMA for gfx950 (NHWC / NDHWC, im2col-free).
+//
+//   D[channel][pixel] = sum_{tap, ci} Wp[tap][channel][ci] * X[pixel + tap][ci]
+//
+// The MFMA "A" operand is the weight tile (rows = output channels), "B" is the pixel tile, so that a lane ends up
+// holding 4*NF consecutive output channels of ONE pixel and the epilogue stores 16..64 contiguous bytes per lane.
+// Per K chunk (128 bytes of input channels per pixel: 64 bf16 / 32 f32) the block stages the input HALO tile once
+// into LDS and then walks the taps, streaming only the [BN x 128 B] weight tile of each tap (double-buffered LDS,
+// next tile prefetched into registers while the MFMAs of the current tap issue).  Both LDS images are XOR-swizzled
+// in 16-byte chunks (chunk ^= row & 7) so every ds_read_b128 of a fragment is bank-conflict free.
+//
+// Replaces: nn.Conv2d(k3,p1)+bias+ReLU fwd / dgrad (reference model/unet2d/layers.py:122-126),
+//           nn.Conv3d(k3,p1) after GroupNorm (model/unet3d/buildingblocks.py:64-66,87-92),
+//           nn.ConvTranspose2d(k2,s2) fwd / dgrad as a 1x1 GEMM + pixel (un)shuffle (layers.py:165),
+//           torch.cat / F.interpolate(nearest) as input addressing (layers.py:186-190, buildingblocks.py:546-548,671-673).
+#include "common.hpp"
+
+struct SrcView {
+    const void* p;
+    int ld, D, H, W;
+};
+
+struct ConvArgs {
+    int N, D, H, W, Cin, Cout, Cin0, Cout0;
+    SrcView x0, x1;
+    const float* in_scale;
+    const float* in_shift;
+    const void* w;
+    const float* bias;
+    int relu;
+    const void* mask;
+    int mask_ld;
+    void* y0;
+    int y0_ld, y0_mode;
+    void* y1;
+    int y1_ld, y1_mode;
+    int tilesD, tilesH, tilesW, nSp, nCt;
+};
+
+template <int TD_, int TH_, int TW_, int KS_, bool IS3D_> struct Geom {
+    static constexpr int TD = TD_, TH = TH_, TW = TW_, KS = KS_;
+    static constexpr bool IS3D = IS3D_;
+    static constexpr int PAD = KS / 2;
+    static constexpr int PD = IS3D ? PAD : 0;
+    static constexpr int KD = IS3D ? KS : 1;
+    static constexpr int HD = TD + 2 * PD, HH = TH + 2 * PAD, HW = TW + 2 * PAD;
+    static constexpr int HP = HD * HH * HW;
+    static constexpr int M = TD * TH * TW;
+    static constexpr int TAPS = KD * KS * KS;
+};
+
+// Stage the halo tile of one K chunk: global (16 B per item) -> registers -> swizzled LDS.  Out-of-bounds pixels are
+// zero (the conv's zero padding applies AFTER the optional per-(n,c) affine, exactly like GroupNorm -> Conv).
+template <typename T, typename G>
+__device__ __forceinline__ void stage_halo(char* halo, const ConvArgs& a, int n, int d0, int h0, int w0, int c0, int tid) {
+    constexpr int EPC = Tr<T>::EPC;
+    const bool first = c0 < a.Cin0;
+    const SrcView s = first ? a.x0 : a.x1;
+    const int cl = first ? c0 : c0 - a.Cin0;
+    const int shd = (s.D != a.D), shh = (s.H != a.H), shw = (s.W != a.W);   // exact 2x nearest-upsample addressing
+    const T* base = reinterpret_cast<const T*>(s.p) + (size_t)n * s.D * s.H * s.W * s.ld + cl;
+    constexpr int ITEMS = G::HP * 8;
+    constexpr int BATCH = 3;
+#pragma unroll 1
+    for (int it0 = 0; it0 < ITEMS; it0 += 256 * BATCH) {
+        u32x4 v[BATCH];
+        int lofs[BATCH];
+        bool ok[BATCH];
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const int it = it0 + b * 256 + tid;
+            v[b] = u32x4{0u, 0u, 0u, 0u};
+            lofs[b] = -1;
+            ok[b] = false;
+            if (it < ITEMS) {
+                const int p = it >> 3, c16 = it & 7;
+                const int pz = p / (G::HH * G::HW);
+                const int pr = p - pz * (G::HH * G::HW);
+                const int py = pr / G::HW;
+                const int px = pr - py * G::HW;
+                const int z = d0 + pz - G::PD, y = h0 + py - G::PAD, x = w0 + px - G::PAD;
+                lofs[b] = p * 128 + ((c16 ^ (p & 7)) << 4);
+                if (z >= 0 && z < a.D && y >= 0 && y < a.H && x >= 0 && x < a.W) {
+                    const int off = (((z >> shd) * s.H + (y >> shh)) * s.W + (x >> shw)) * s.ld + c16 * EPC;
+                    v[b] = *reinterpret_cast<const u32x4*>(base + off);
+                    ok[b] = true;
+                }
+            }
+        }
+        if (a.in_scale != nullptr) {
+#pragma unroll
+            for (int b = 0; b < BATCH; ++b) {
+                if (ok[b]) {
+                    const int it = it0 + b * 256 + tid;
+                    const int c16 = it & 7;
+                    const float* sc = a.in_scale + (size_t)n * a.Cin + c0 + c16 * EPC;
+                    const float* sh = a.in_shift + (size_t)n * a.Cin + c0 + c16 * EPC;
+                    float f[EPC];
+                    unpack_chunk<T>(v[b], f);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
+                    v[b] = pack_chunk<T>(f);
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b)
+            if (lofs[b] >= 0) lds_write_b128(halo, lofs[b], v[b]);
+    }
+}
+
+template <typename T, int NV>
+__device__ __forceinline__ void store_run(T* dst, const float* v) {
+    // NV consecutive channels, dst is 16-byte aligned
+    constexpr int EPC = Tr<T>::EPC;
+#pragma unroll
+    for (int i = 0; i < NV; i += EPC) {
+        u32x4 c = pack_chunk<T>(v + i);
+        *reinterpret_cast<u32x4*>(dst + i) = c;
+    }
+}
+
+template <typename T, typename G, int WN, int NF>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int WM = 4 / WN;
+    static_assert(G::M == WM * 64, "tile pixels must be 64 per M-wave");
+    constexpr int WAVE_N = NF * 16;      // channels per wave
+    constexpr int BN = WN * WAVE_N;      // channels per block
+    constexpr int EPC = Tr<T>::EPC;
+    constexpr int CK = Tr<T>::CK;
+    constexpr int WI = BN * 8 / 256;     // 16-byte weight items per thread per tap
+    constexpr int NV = 4 * NF;           // consecutive output channels per lane
+    static_assert(WI >= 1, "");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* halo = smem;
+    char* wbuf = smem + G::HP * 128;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, lg = lane >> 4;
+
+    const int v = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = v / a.nSp;
+    const int sp = v - ct * a.nSp;
+    const int tpi = a.tilesD * a.tilesH * a.tilesW;
+    const int n = sp / tpi;
+    int r = sp - n * tpi;
+    const int td = r / (a.tilesH * a.tilesW);
+    r -= td * (a.tilesH * a.tilesW);
+    const int th = r / a.tilesW;
+    const int tw = r - th * a.tilesW;
+    const int d0 = td * G::TD, h0 = th * G::TH, w0 = tw * G::TW;
+    const int ncol0 = ct * BN;
+
+    int hb[4];
+#pragma unroll
+    for (int pf = 0; pf < 4; ++pf) {
+        const int m = wm * 64 + pf * 16 + li;
+        const int dz = m / (G::TH * G::TW);
+        const int hy = (m / G::TW) % G::TH;
+        const int wx = m % G::TW;
+        hb[pf] = (dz * G::HH + hy) * G::HW + wx;
+    }
+
+    f32x4 acc[NF][4];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int pf = 0; pf < 4; ++pf) acc[f][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int w_goff[WI], w_loff[WI];
+#pragma unroll
+    for (int k = 0; k < WI; ++k) {
+        const int it = tid + k * 256;
+        const int row = it >> 3, c16 = it & 7;
+        const int wv = row / WAVE_N, chw = row % WAVE_N;
+        const int aa = chw / NV, ff = (chw >> 2) % NF, bb = chw & 3;
+        const int lrow = wv * WAVE_N + ff * 16 + aa * 4 + bb;
+        w_goff[k] = (ncol0 + row) * a.Cin + c16 * EPC;
+        w_loff[k] = lrow * 128 + ((c16 ^ (lrow & 7)) << 4);
+    }
+    const T* wp = reinterpret_cast<const T*>(a.w);
+    const size_t tap_stride = (size_t)a.Cout * a.Cin;
+
+    u32x4 wreg[WI];
+#pragma unroll
+    for (int k = 0; k < WI; ++k) wreg[k] = *reinterpret_cast<const u32x4*>(wp + w_goff[k]);
+
+    const int nchunks = a.Cin / CK;
+    int cur = 0;
+#pragma unroll 1
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int c0 = chunk * CK;
+        __syncthreads();   // every wave is done with the previous chunk's halo
+        stage_halo<T, G>(halo, a, n, d0, h0, w0, c0, tid);
+#pragma unroll 1
+        for (int tap = 0; tap < G::TAPS; ++tap) {
+            char* wb = wbuf + cur * (BN * 128);
+#pragma unroll
+            for (int k = 0; k < WI; ++k) lds_write_b128(wb, w_loff[k], wreg[k]);
+            __syncthreads();
+            // prefetch the next weight tile while this tap computes
+            {
+                int ntap = tap + 1, nc0 = c0;
+                if (ntap == G::TAPS) {
+                    ntap = 0;
+                    nc0 = c0 + CK;
+                }
+                if (nc0 >= a.Cin) {   // last step: harmlessly re-load the current tile (keeps the loads unconditional)
+                    ntap = tap;
+                    nc0 = c0;
+                }
+                const T* wsrc = wp + (size_t)ntap * tap_stride + nc0;
+#pragma unroll
+                for (int k = 0; k < WI; ++k) wreg[k] = *reinterpret_cast<const u32x4*>(wsrc + w_goff[k]);
+            }
+            int tapoff;
+            if constexpr (G::KS == 1) {
+                tapoff = 0;
+            } else {
+                const int kd = tap / (G::KS * G::KS);
+                const int kr = tap - kd * (G::KS * G::KS);
+                const int kh = kr / G::KS, kw = kr - kh * G::KS;
+                tapoff = (kd * G::HH + kh) * G::HW + kw;
+            }
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg) {
+                u32x4 A[NF], B[4];
+                const int ch = kg * 4 + lg;
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+                    A[f] = lds_read_b128(wb, (wn * WAVE_N + f * 16 + li) * 128 + ((ch ^ (li & 7)) << 4));
+#pragma unroll
+                for (int pf = 0; pf < 4; ++pf) {
+                    const int p = hb[pf] + tapoff;
+                    B[pf] = lds_read_b128(halo, p * 128 + ((ch ^ (p & 7)) << 4));
+                }
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+#pragma unroll
+                    for (int pf = 0; pf < 4; ++pf) mma_b128<T>(acc[f][pf], A[f], B[pf]);
+            }
+            cur ^= 1;
+        }
+    }
+
+    // ---- epilogue: lane (li, lg) holds, per pixel fragment, NV consecutive columns -------------------------
+    const int colw = ncol0 + wn * WAVE_N;          // wave-uniform first column
+    const int col = colw + lg * NV;                // this lane's first column
+    const bool to0 = colw < a.Cout0;
+    T* ybase = reinterpret_cast<T*>(to0 ? a.y0 : a.y1);
+    const int yld = to0 ? a.y0_ld : a.y1_ld;
+    const int ymode = to0 ? a.y0_mode : a.y1_mode;
+    const int cview = to0 ? a.Cout0 : a.Cout - a.Cout0;    // columns routed to this output
+    const int lcol = to0 ? col : col - a.Cout0;
+    int bcol = col;                                         // bias index
+    int ab = 0, cq = 0;
+    if (ymode == MIS_OUT_SHUFFLE2) {
+        cq = cview >> 2;
+        ab = lcol / cq;
+        bcol = (to0 ? 0 : a.Cout0) + (lcol - ab * cq);      // bias is per real output channel c
+    }
+    float bv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) bv[i] = 0.f;
+    if (a.bias != nullptr) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) bv[i] = a.bias[bcol + i];
+    }
+#pragma unroll
+    for (int pf = 0; pf < 4; ++pf) {
+        const int m = wm * 64 + pf * 16 + li;
+        const int dz = m / (G::TH * G::TW);
+        const int hy = (m / G::TW) % G::TH;
+        const int wx = m % G::TW;
+        const int z = d0 + dz, y = h0 + hy, x = w0 + wx;
+        if (z < a.D && y < a.H && x < a.W) {
+            float o[NV];
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[f * 4 + q] = acc[f][pf][q] + bv[f * 4 + q];
+            if (a.relu) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) o[i] = fmaxf(o[i], 0.f);
+            }
+            const size_t pix = (((size_t)n * a.D + z) * a.H + y) * a.W + x;
+            if (a.mask != nullptr) {
+                const T* mp = reinterpret_cast<const T*>(a.mask) + pix * a.mask_ld + col;
+#pragma unroll
+                for (int i = 0; i < NV; i += EPC) {
+                    float mf[EPC];
+                    unpack_chunk<T>(*reinterpret_cast<const u32x4*>(mp + i), mf);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) o[i + e] = (mf[e] > 0.f) ? o[i + e] : 0.f;
+                }
+            }
+            T* dst;
+            if (ymode == MIS_OUT_PLAIN) {
+                dst = ybase + pix * yld + lcol;
+            } else if (ymode == MIS_OUT_SHUFFLE2) {
+                const int oy = 2 * y + (ab >> 1), ox = 2 * x + (ab & 1);
+                const size_t opix = ((size_t)n * (2 * a.H) + oy) * (size_t)(2 * a.W) + ox;
+                dst = ybase + opix * yld + (lcol - ab * cq);
+            } else {   // MIS_OUT_UNSHUFFLE2
+                const int oh = a.H >> 1, ow = a.W >> 1;
+                const size_t opix = ((size_t)n * oh + (y >> 1)) * ow + (x >> 1);
+                dst = ybase + opix * yld + ((y & 1) * 2 + (x & 1)) * cview + lcol;
+            }
+            store_run<T, NV>(dst, o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, typename G, int WN, int NF>
+static int launch_cfg(const MisConvDesc* d, hipStream_t stream) {
+    constexpr int BN = WN * NF * 16;
+    ConvArgs a;
+    a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
+    a.Cin0 = d->Cin0; a.Cout0 = d->Cout0;
+    a.x0 = SrcView{d->x0, d->x0_ld, d->x0_D, d->x0_H, d->x0_W};
+    a.x1 = SrcView{d->x1, d->x1_ld, d->x1_D, d->x1_H, d->x1_W};
+    a.in_scale = d->in_scale; a.in_shift = d->in_shift;
+    a.w = d->w; a.bias = d->bias; a.relu = d->relu; a.mask = d->mask; a.mask_ld = d->mask_ld;
+    a.y0 = d->y0; a.y0_ld = d->y0_ld; a.y0_mode = d->y0_mode;
+    a.y1 = d->y1; a.y1_ld = d->y1_ld; a.y1_mode = d->y1_mode;
+    a.tilesD = (d->D + G::TD - 1) / G::TD;
+    a.tilesH = (d->H + G::TH - 1) / G::TH;
+    a.tilesW = (d->W + G::TW - 1) / G::TW;
+    const long long nsp = (long long)d->N * a.tilesD * a.tilesH * a.tilesW;
+    a.nCt = d->Cout / BN;
+    MIS_REQUIRE(nsp * a.nCt < (1ll << 31), MIS_EUNSUPPORTED, "conv_igemm: grid too large");
+    a.nSp = (int)nsp;
+    const size_t lds = (size_t)G::HP * 128 + 2 * (size_t)BN * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, G, WN, NF>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<T, G, WN, NF>), dim3((unsigned)(nsp * a.nCt)), dim3(256), lds, stream, a);
+    MIS_LAUNCH_CHECK("conv_igemm");
+    return MIS_OK;
+}
+
+template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
+    const bool is3d = d->D > 1;
+    const bool wide = (d->Cout % 128) == 0;
+    if (d->ksize == 3) {
+        if (!is3d) {
+            if (wide) return launch_cfg<T, Geom<1, 8, 16, 3, false>, 2, 4>(d, s);
+            return launch_cfg<T, Geom<1, 16, 16, 3, false>, 1, 4>(d, s);
+        }
+        if (wide) return launch_cfg<T, Geom<4, 4, 8, 3, true>, 2, 4>(d, s);
+        return launch_cfg<T, Geom<4, 4, 8, 3, true>, 2, 2>(d, s);
+    }
+    if (!is3d) {
+        if (wide) return launch_cfg<T, Geom<1, 8, 16, 1, false>, 2, 4>(d, s);
+        return launch_cfg<T, Geom<1, 16, 16, 1, false>, 1, 4>(d, s);
+    }
+    if (wide) return launch_cfg<T, Geom<4, 4, 8, 1, true>, 2, 4>(d, s);
+    return launch_cfg<T, Geom<4, 4, 8, 1, true>, 2, 2>(d, s);
+}
+
+extern "C" int mis_conv_igemm(const MisConvDesc* d, void* stream) {
+    MIS_REQUIRE(d != nullptr, MIS_EINVAL, "conv_igemm: null descriptor");
+    MIS_REQUIRE(d->dtype == MIS_F32 || d->dtype == MIS_BF16, MIS_EINVAL, "conv_igemm: bad dtype %d", d->dtype);
+    const int CK = d->dtype == MIS_BF16 ? 64 : 32;
+    const int EPC = d->dtype == MIS_BF16 ? 8 : 4;
+    MIS_REQUIRE(d->ksize == 3 || d->ksize == 1, MIS_EUNSUPPORTED, "conv_igemm: ksize %d", d->ksize);
+    MIS_REQUIRE(d->N > 0 && d->D > 0 && d->H > 0 && d->W > 0, MIS_EINVAL, "conv_igemm: empty grid");
+    MIS_REQUIRE(d->Cin > 0 && d->Cin % CK == 0, MIS_EUNSUPPORTED, "conv_igemm: Cin %d must be a multiple of %d", d->Cin, CK);
+    MIS_REQUIRE(d->Cout > 0 && d->Cout % 64 == 0, MIS_EUNSUPPORTED, "conv_igemm: Cout %d must be a multiple of 64", d->Cout);
+    MIS_REQUIRE(d->x0 != nullptr && d->w != nullptr && d->y0 != nullptr, MIS_EINVAL, "conv_igemm: null pointer");
+    MIS_REQUIRE(d->Cin0 > 0 && d->Cin0 <= d->Cin && d->Cin0 % CK == 0, MIS_EINVAL, "conv_igemm: Cin0 %d", d->Cin0);
+    MIS_REQUIRE(d->Cin0 == d->Cin || d->x1 != nullptr, MIS_EINVAL, "conv_igemm: x1 missing");
+    MIS_REQUIRE(d->Cout0 > 0 && d->Cout0 <= d->Cout && d->Cout0 % 64 == 0, MIS_EINVAL, "conv_igemm: Cout0 %d", d->Cout0);
+    MIS_REQUIRE(d->Cout0 == d->Cout || d->y1 != nullptr, MIS_EINVAL, "conv_igemm: y1 missing");
+    MIS_REQUIRE(d->x0_ld % EPC == 0 && d->y0_ld % EPC == 0, MIS_EINVAL, "conv_igemm: ld must keep 16-byte alignment");
+    MIS_REQUIRE(d->x1 == nullptr || d->x1_ld % EPC == 0, MIS_EINVAL, "conv_igemm: x1_ld alignment");
+    MIS_REQUIRE(d->y1 == nullptr || d->y1_ld % EPC == 0, MIS_EINVAL, "conv_igemm: y1_ld alignment");
+    MIS_REQUIRE(d->mask == nullptr || d->mask_ld % EPC == 0, MIS_EINVAL, "conv_igemm: mask_ld alignment");
+    MIS_REQUIRE(d->x0_D > 0 && d->x0_H > 0 && d->x0_W > 0, MIS_EINVAL, "conv_igemm: x0 grid");
+    MIS_REQUIRE(d->x1 == nullptr || (d->x1_D > 0 && d->x1_H > 0 && d->x1_W > 0), MIS_EINVAL, "conv_igemm: x1 grid");
+    MIS_REQUIRE((d->in_scale == nullptr) == (d->in_shift == nullptr), MIS_EINVAL, "conv_igemm: in_scale/in_shift");
+    {
+        const SrcView srcs[2] = {{d->x0, d->x0_ld, d->x0_D, d->x0_H, d->x0_W}, {d->x1, d->x1_ld, d->x1_D, d->x1_H, d->x1_W}};
+        for (int i = 0; i < 2; ++i) {
+            if (srcs[i].p == nullptr) continue;
+            const bool okD = srcs[i].D == d->D || (srcs[i].D * 2 == d->D);
+            const bool okH = srcs[i].H == d->H || (srcs[i].H * 2 == d->H);
+            const bool okW = srcs[i].W == d->W || (srcs[i].W * 2 == d->W);
+            MIS_REQUIRE(okD && okH && okW, MIS_EUNSUPPORTED,
+                        "conv_igemm: source grid must equal the pixel grid or be exactly half of it");
+        }
+    }
+    const int modes[2] = {d->y0_mode, d->y1_mode};
+    const int views[2] = {d->Cout0, d->Cout - d->Cout0};
+    for (int i = 0; i < 2; ++i) {
+        if (i == 1 && d->y1 == nullptr) break;
+        MIS_REQUIRE(modes[i] >= 0 && modes[i] <= 2, MIS_EINVAL, "conv_igemm: output mode");
+        if (modes[i] != MIS_OUT_PLAIN) MIS_REQUIRE(d->D == 1, MIS_EUNSUPPORTED, "conv_igemm: (un)shuffle is 2-D only");
+        if (modes[i] == MIS_OUT_SHUFFLE2)
+            MIS_REQUIRE(views[i] % 256 == 0, MIS_EUNSUPPORTED, "conv_igemm: shuffle needs 4*Cq columns with Cq %% 64 == 0");
+        if (modes[i] == MIS_OUT_UNSHUFFLE2)
+            MIS_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0, MIS_EUNSUPPORTED, "conv_igemm: unshuffle needs even H, W");
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == MIS_BF16) return dispatch<__bf16>(d, s);
+    return dispatch<float>(d, s);
+}

@@ -1,0 +1,583 @@
+// HBM-bound kernels of the U-Net hot path (gfx950): first-layer direct conv (fwd + wgrad), per-channel sums
+// (bias gradients, GroupNorm statistics), 2x max-pool fwd / fused bwd, weight repack, layout converts.
+// All global accesses are 16 bytes per lane along the channel axis (NHWC), grids are capped and grid-strided.
+#include "common.hpp"
+
+// =========================================================================================================
+// First layer: x fp32 NCHW (Cin <= 4) -> y NHWC [pixel][64], 3x3 pad 1, bias, ReLU.   reference: layers.py:122-123
+// 8 lanes per pixel, 8 output channels per lane; weights as [tap*Cin+ci][64] floats in LDS.
+// =========================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void first_conv_fwd_kernel(const float* __restrict__ x, int N, int Cin, int H, int W,
+                                                             const float* __restrict__ w, const float* __restrict__ bias, T* y,
+                                                             int y_ld) {
+    __shared__ float wl[36 * 64];
+    __shared__ float bl[64];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 9 * Cin * 64; i += 256) {
+        const int co = i & 63, r = i >> 6;   // r = tap*Cin + ci
+        const int tap = r / Cin, ci = r - tap * Cin;
+        wl[i] = w[(co * Cin + ci) * 9 + tap];
+    }
+    if (tid < 64) bl[tid] = bias ? bias[tid] : 0.f;
+    __syncthreads();
+    const int cg = tid & 7;
+    const long long npix = (long long)N * H * W;
+    const long long HW = (long long)H * W;
+    for (long long p = (long long)blockIdx.x * 32 + (tid >> 3); p < npix; p += (long long)gridDim.x * 32) {
+        const int n = (int)(p / HW);
+        const int rem = (int)(p - (long long)n * HW);
+        const int yy = rem / W, xx = rem - yy * W;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = bl[cg * 8 + j];
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float* xp = x + ((long long)n * Cin + ci) * HW;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
+                float xv = 0.f;
+                if (sy >= 0 && sy < H && sx >= 0 && sx < W) xv = xp[(long long)sy * W + sx];
+                const float* wr = &wl[(tap * Cin + ci) * 64 + cg * 8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, wr[j], acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+        T* dst = y + p * y_ld + cg * 8;
+        if constexpr (sizeof(T) == 2) {
+            *reinterpret_cast<u32x4*>(dst) = pack_chunk<__bf16>(acc);
+        } else {
+            *reinterpret_cast<u32x4*>(dst) = pack_chunk<float>(acc);
+            *reinterpret_cast<u32x4*>(dst + 4) = pack_chunk<float>(acc + 4);
+        }
+    }
+}
+
+extern "C" int mis_conv3x3_first_fwd(int dtype, const float* x, int N, int Cin, int H, int W, const float* w, const float* bias, void* y,
+                                     int y_ld, int Cout, void* stream) {
+    MIS_REQUIRE(Cout == 64, MIS_EUNSUPPORTED, "first_fwd: Cout must be 64 (got %d)", Cout);
+    MIS_REQUIRE(Cin >= 1 && Cin <= 4, MIS_EUNSUPPORTED, "first_fwd: Cin must be 1..4 (got %d)", Cin);
+    MIS_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0, MIS_EINVAL, "first_fwd: bad argument");
+    MIS_REQUIRE(y_ld % 8 == 0, MIS_EINVAL, "first_fwd: y_ld alignment");
+    const long long npix = (long long)N * H * W;
+    long long blocks = (npix + 31) / 32;
+    if (blocks > 16384) blocks = 16384;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIS_BF16)
+        hipLaunchKernelGGL(first_conv_fwd_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, x, N, Cin, H, W, w, bias, (__bf16*)y, y_ld);
+    else
+        hipLaunchKernelGGL(first_conv_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, x, N, Cin, H, W, w, bias, (float*)y, y_ld);
+    MIS_LAUNCH_CHECK("first_conv_fwd");
+    return MIS_OK;
+}
+
+// dW[co][ci][tap] = sum_p x[p+tap][ci] * dy[p][co];  db[co] = sum_p dy[p][co].  blockIdx.y = ci.
+constexpr int FW_BLOCKS = 1024;
+template <typename T>
+__global__ __launch_bounds__(256) void first_conv_wgrad_kernel(const float* __restrict__ x, int N, int Cin, int H, int W, const T* dy,
+                                                               int dy_ld, float* __restrict__ partial /*[blocks][Cin][10][64]*/) {
+    __shared__ float red[4][10 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = tid & 7;
+    const int ci = blockIdx.y;
+    const long long npix = (long long)N * H * W;
+    const long long HW = (long long)H * W;
+    float acc[10][8];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+    for (long long p = (long long)blockIdx.x * 32 + (tid >> 3); p < npix; p += (long long)gridDim.x * 32) {
+        const int n = (int)(p / HW);
+        const int rem = (int)(p - (long long)n * HW);
+        const int yy = rem / W, xx = rem - yy * W;
+        float g[8];
+        const T* src = dy + p * dy_ld + cg * 8;
+        if constexpr (sizeof(T) == 2) {
+            unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(src), g);
+        } else {
+            unpack_chunk<float>(*reinterpret_cast<const u32x4*>(src), g);
+            unpack_chunk<float>(*reinterpret_cast<const u32x4*>(src + 4), g + 4);
+        }
+        const float* xp = x + ((long long)n * Cin + ci) * HW;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
+            float xv = 0.f;
+            if (sy >= 0 && sy < H && sx >= 0 && sx < W) xv = xp[(long long)sy * W + sx];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[tap][j] = fmaf(xv, g[j], acc[tap][j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[9][j] += g[j];
+    }
+    // lanes with equal (lane & 7) hold the same channels: reduce over lane bits 3..5
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[t][j];
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[t][j] = v;
+        }
+    if (lane < 8) {
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[wave][t * 64 + lane * 8 + j] = acc[t][j];
+    }
+    __syncthreads();
+    float* out = partial + ((size_t)blockIdx.x * Cin + ci) * 640;
+    for (int i = tid; i < 640; i += 256) out[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+
+__global__ void first_conv_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, int Cin, float* __restrict__ dw,
+                                               float* __restrict__ db) {
+    // one thread per (ci, t, co)
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Cin * 640) return;
+    const int ci = idx / 640, r = idx - ci * 640;
+    const int t = r >> 6, co = r & 63;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partial[((size_t)b * Cin + ci) * 640 + r];
+    if (t < 9) dw[(co * Cin + ci) * 9 + t] = s;
+    else if (ci == 0 && db != nullptr) db[co] = s;
+}
+
+extern "C" size_t mis_conv3x3_first_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout) {
+    (void)N; (void)H; (void)W; (void)Cout;
+    return (size_t)FW_BLOCKS * Cin * 640 * sizeof(float);
+}
+
+extern "C" int mis_conv3x3_first_wgrad(int dtype, const float* x, int N, int Cin, int H, int W, const void* dy, int dy_ld, int Cout,
+                                       float* workspace, float* dw, float* db, void* stream) {
+    MIS_REQUIRE(Cout == 64, MIS_EUNSUPPORTED, "first_wgrad: Cout must be 64");
+    MIS_REQUIRE(Cin >= 1 && Cin <= 4, MIS_EUNSUPPORTED, "first_wgrad: Cin must be 1..4");
+    MIS_REQUIRE(x && dy && workspace && dw, MIS_EINVAL, "first_wgrad: null pointer");
+    MIS_REQUIRE(dy_ld % 8 == 0, MIS_EINVAL, "first_wgrad: dy_ld alignment");
+    const long long npix = (long long)N * H * W;
+    long long blocks = (npix + 31) / 32;
+    if (blocks > FW_BLOCKS) blocks = FW_BLOCKS;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIS_BF16)
+        hipLaunchKernelGGL(first_conv_wgrad_kernel<__bf16>, dim3((unsigned)blocks, Cin), dim3(256), 0, s, x, N, Cin, H, W, (const __bf16*)dy,
+                           dy_ld, workspace);
+    else
+        hipLaunchKernelGGL(first_conv_wgrad_kernel<float>, dim3((unsigned)blocks, Cin), dim3(256), 0, s, x, N, Cin, H, W, (const float*)dy,
+                           dy_ld, workspace);
+    MIS_LAUNCH_CHECK("first_conv_wgrad");
+    hipLaunchKernelGGL(first_conv_wgrad_reduce_kernel, dim3((Cin * 640 + 255) / 256), dim3(256), 0, s, (const float*)workspace, (int)blocks,
+                       Cin, dw, db);
+    MIS_LAUNCH_CHECK("first_conv_wgrad_reduce");
+    return MIS_OK;
+}
+
+// =========================================================================================================
+// Per-channel sums over pixels (and sums of squares), per sample:  sum[n][c], sumsq[n][c].
+// Stage 1: blockIdx = (pixel slab, chunk group, n); stage 2 reduces the slabs in a fixed order.
+// =========================================================================================================
+constexpr int CS_SLABS = 256;
+template <typename T, bool SQ>
+__global__ __launch_bounds__(256) void chansum_kernel(const T* __restrict__ x, int ld, long long npix, int C, float* __restrict__ part_sum,
+                                                      float* __restrict__ part_sq) {
+    constexpr int EPC = Tr<T>::EPC;
+    __shared__ float red[256 * 8];
+    __shared__ float red2[SQ ? 256 * 8 : 1];
+    const int nchunks = C / EPC;
+    const int chb = nchunks < 256 ? nchunks : 256;     // chunks handled per block (power of two for our shapes, not required)
+    const int rows = 256 / chb;                        // pixel rows per block iteration
+    const int tid = threadIdx.x;
+    const int cl = tid % chb, r = tid / chb;
+    const int chunk = blockIdx.y * chb + cl;
+    const int n = blockIdx.z;
+    const int nslabs = gridDim.x;
+    float s[EPC], q[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s[e] = q[e] = 0.f;
+    if (chunk < nchunks && r < rows) {
+        const T* base = x + (size_t)n * npix * ld + (size_t)chunk * EPC;
+        for (long long p = (long long)blockIdx.x * rows + r; p < npix; p += (long long)nslabs * rows) {
+            float f[EPC];
+            unpack_chunk<T>(*reinterpret_cast<const u32x4*>(base + p * ld), f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                s[e] += f[e];
+                if (SQ) q[e] = fmaf(f[e], f[e], q[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        red[tid * EPC + e] = s[e];
+        if (SQ) red2[tid * EPC + e] = q[e];
+    }
+    __syncthreads();
+    if (r == 0 && chunk < nchunks) {
+        for (int k = 1; k < rows; ++k)
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                s[e] += red[(k * chb + cl) * EPC + e];
+                if (SQ) q[e] += red2[(k * chb + cl) * EPC + e];
+            }
+        float* o = part_sum + ((size_t)n * nslabs + blockIdx.x) * C + (size_t)chunk * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o[e] = s[e];
+        if (SQ) {
+            float* o2 = part_sq + ((size_t)n * nslabs + blockIdx.x) * C + (size_t)chunk * EPC;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o2[e] = q[e];
+        }
+    }
+}
+
+// out[n][c % Cq] = alpha * sum over slabs and folds
+__global__ void chansum_reduce_kernel(const float* __restrict__ part, int nslabs, int N, int C, int fold, float alpha, float* __restrict__ out) {
+    const int Cq = C / fold;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * Cq) return;
+    const int n = idx / Cq, c = idx - n * Cq;
+    double s = 0.0;
+    for (int f = 0; f < fold; ++f)
+        for (int k = 0; k < nslabs; ++k) s += (double)part[((size_t)n * nslabs + k) * C + f * Cq + c];
+    out[idx] = (float)(alpha * s);
+}
+
+static int chansum_slabs(long long npix, int C, int EPC) {
+    const int nchunks = C / EPC;
+    const int chb = nchunks < 256 ? nchunks : 256;
+    const int rows = 256 / chb;
+    long long want = (npix + rows * 8 - 1) / (rows * 8);
+    if (want < 1) want = 1;
+    if (want > CS_SLABS) want = CS_SLABS;
+    return (int)want;
+}
+
+template <typename T, bool SQ>
+static int chansum_launch(const void* x, int ld, int N, long long npix, int C, float* ws, float* sum, float* sumsq, int fold, float alpha,
+                          hipStream_t s) {
+    constexpr int EPC = Tr<T>::EPC;
+    const int nchunks = C / EPC;
+    const int chb = nchunks < 256 ? nchunks : 256;
+    const int ngroups = (nchunks + chb - 1) / chb;
+    const int nslabs = chansum_slabs(npix, C, EPC);
+    float* ps = ws;
+    float* pq = ws + (size_t)N * CS_SLABS * C;
+    hipLaunchKernelGGL((chansum_kernel<T, SQ>), dim3(nslabs, ngroups, N), dim3(256), 0, s, (const T*)x, ld, npix, C, ps, pq);
+    MIS_LAUNCH_CHECK("chansum");
+    const int Cq = C / fold;
+    hipLaunchKernelGGL(chansum_reduce_kernel, dim3((N * Cq + 255) / 256), dim3(256), 0, s, (const float*)ps, nslabs, N, C, fold, alpha, sum);
+    MIS_LAUNCH_CHECK("chansum_reduce");
+    if (SQ) {
+        hipLaunchKernelGGL(chansum_reduce_kernel, dim3((N * Cq + 255) / 256), dim3(256), 0, s, (const float*)pq, nslabs, N, C, fold, alpha, sumsq);
+        MIS_LAUNCH_CHECK("chansum_reduce_sq");
+    }
+    return MIS_OK;
+}
+
+extern "C" size_t mis_colsum_workspace_bytes(long long npix, int C) {
+    (void)npix;
+    return (size_t)CS_SLABS * C * sizeof(float);
+}
+extern "C" int mis_colsum(int dtype, const void* x, int ld, long long npix, int C, int fold, float alpha, float* workspace, float* out,
+                          void* stream) {
+    const int EPC = dtype == MIS_BF16 ? 8 : 4;
+    MIS_REQUIRE(x && workspace && out && npix > 0, MIS_EINVAL, "colsum: bad argument");
+    MIS_REQUIRE(C % EPC == 0 && ld % EPC == 0, MIS_EINVAL, "colsum: C / ld alignment");
+    MIS_REQUIRE(fold >= 1 && C % fold == 0, MIS_EINVAL, "colsum: fold");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIS_BF16) return chansum_launch<__bf16, false>(x, ld, 1, npix, C, workspace, out, nullptr, fold, alpha, s);
+    return chansum_launch<float, false>(x, ld, 1, npix, C, workspace, out, nullptr, fold, alpha, s);
+}
+extern "C" size_t mis_chanstats_workspace_bytes(int N, long long npix, int C) {
+    (void)npix;
+    return (size_t)2 * N * CS_SLABS * C * sizeof(float);
+}
+extern "C" int mis_chanstats(int dtype, const void* x, int ld, int N, long long npix, int C, float* workspace, float* sum, float* sumsq,
+                             void* stream) {
+    const int EPC = dtype == MIS_BF16 ? 8 : 4;
+    MIS_REQUIRE(x && workspace && sum && sumsq && npix > 0 && N > 0, MIS_EINVAL, "chanstats: bad argument");
+    MIS_REQUIRE(C % EPC == 0 && ld % EPC == 0, MIS_EINVAL, "chanstats: C / ld alignment");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIS_BF16) return chansum_launch<__bf16, true>(x, ld, N, npix, C, workspace, sum, sumsq, 1, 1.f, s);
+    return chansum_launch<float, true>(x, ld, N, npix, C, workspace, sum, sumsq, 1, 1.f, s);
+}
+
+// =========================================================================================================
+// MaxPool 2 (2-D: 2x2, 3-D: 2x2x2), stride 2, floor.  One thread per (output pixel, 16-byte channel chunk).
+// bwd recomputes the arg-max in PyTorch's scan order (kd, kh, kw; first maximum wins) instead of storing indices.
+// =========================================================================================================
+template <typename T, bool IS3D>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int x_ld, T* __restrict__ y, int y_ld, int N, int D, int H,
+                                                          int W, int C) {
+    constexpr int EPC = Tr<T>::EPC;
+    const int OD = IS3D ? D / 2 : 1, OH = H / 2, OW = W / 2;
+    const int nch = C / EPC;
+    const long long total = (long long)N * OD * OH * OW * nch;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        long long op = i / nch;
+        const int ox = (int)(op % OW); op /= OW;
+        const int oy = (int)(op % OH); op /= OH;
+        const int oz = (int)(op % OD);
+        const int n = (int)(op / OD);
+        float m[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) m[e] = -INFINITY;
+#pragma unroll
+        for (int kd = 0; kd < (IS3D ? 2 : 1); ++kd)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 2; ++kw) {
+                    const int z = IS3D ? 2 * oz + kd : 0;
+                    const size_t pix = (((size_t)n * D + z) * H + 2 * oy + kh) * W + 2 * ox + kw;
+                    float f[EPC];
+                    unpack_chunk<T>(*reinterpret_cast<const u32x4*>(x + pix * x_ld + (size_t)ch * EPC), f);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) m[e] = (f[e] > m[e]) ? f[e] : m[e];
+                }
+        const size_t opix = (((size_t)n * OD + oz) * OH + oy) * OW + ox;
+        *reinterpret_cast<u32x4*>(y + opix * y_ld + (size_t)ch * EPC) = pack_chunk<T>(m);
+    }
+}
+
+template <typename T, bool IS3D>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ dy, int dy_ld, const T* add,
+                                                          int add_ld, T* dx, int dx_ld, int N, int D, int H, int W, int C, int relu_mask) {
+    constexpr int EPC = Tr<T>::EPC;
+    constexpr int KD = IS3D ? 2 : 1;
+    const int OD = IS3D ? D / 2 : 1, OH = H / 2, OW = W / 2;
+    // windows cover ceil(size/2) so that trailing odd rows/cols (no pooling window) still receive mask(add)
+    const int WD = IS3D ? (D + 1) / 2 : 1, WH = (H + 1) / 2, WW = (W + 1) / 2;
+    const int nch = C / EPC;
+    const long long total = (long long)N * WD * WH * WW * nch;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        long long op = i / nch;
+        const int ox = (int)(op % WW); op /= WW;
+        const int oy = (int)(op % WH); op /= WH;
+        const int oz = (int)(op % WD);
+        const int n = (int)(op / WD);
+        const bool pooled = (oz < OD) && (oy < OH) && (ox < OW);
+        float g[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) g[e] = 0.f;
+        if (pooled) {
+            const size_t opix = (((size_t)n * OD + oz) * OH + oy) * OW + ox;
+            unpack_chunk<T>(*reinterpret_cast<const u32x4*>(dy + opix * dy_ld + (size_t)ch * EPC), g);
+        }
+        float xv[KD * 4][EPC];
+        bool inb[KD * 4];
+        size_t pixs[KD * 4];
+#pragma unroll
+        for (int k = 0; k < KD * 4; ++k) {
+            const int kd = k >> 2, kh = (k >> 1) & 1, kw = k & 1;
+            const int z = IS3D ? 2 * oz + kd : 0, yy = 2 * oy + kh, xx = 2 * ox + kw;
+            inb[k] = (z < D) && (yy < H) && (xx < W);
+            pixs[k] = (((size_t)n * D + z) * H + yy) * W + xx;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) xv[k][e] = -INFINITY;
+            if (inb[k]) unpack_chunk<T>(*reinterpret_cast<const u32x4*>(x + pixs[k] * x_ld + (size_t)ch * EPC), xv[k]);
+        }
+        int amax[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float m = xv[0][e];
+            int a = 0;
+#pragma unroll
+            for (int k = 1; k < KD * 4; ++k)
+                if (xv[k][e] > m) {
+                    m = xv[k][e];
+                    a = k;
+                }
+            amax[e] = a;
+        }
+#pragma unroll
+        for (int k = 0; k < KD * 4; ++k) {
+            if (!inb[k]) continue;
+            float o[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o[e] = 0.f;
+            if (add != nullptr) unpack_chunk<T>(*reinterpret_cast<const u32x4*>(add + pixs[k] * add_ld + (size_t)ch * EPC), o);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                if (pooled && amax[e] == k) o[e] += g[e];
+                if (relu_mask && !(xv[k][e] > 0.f)) o[e] = 0.f;
+            }
+            *reinterpret_cast<u32x4*>(dx + pixs[k] * dx_ld + (size_t)ch * EPC) = pack_chunk<T>(o);
+        }
+    }
+}
+
+static unsigned capped_grid(long long total, int per_block) {
+    long long b = (total + per_block - 1) / per_block;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+extern "C" int mis_maxpool2_fwd(int dtype, const void* x, int x_ld, void* y, int y_ld, int N, int D, int H, int W, int C, void* stream) {
+    const int EPC = dtype == MIS_BF16 ? 8 : 4;
+    MIS_REQUIRE(x && y && N > 0 && D > 0 && H > 1 && W > 1, MIS_EINVAL, "maxpool_fwd: bad argument");
+    MIS_REQUIRE(C % EPC == 0 && x_ld % EPC == 0 && y_ld % EPC == 0, MIS_EINVAL, "maxpool_fwd: alignment");
+    const bool is3d = D > 1;
+    const long long total = (long long)N * (is3d ? D / 2 : 1) * (H / 2) * (W / 2) * (C / EPC);
+    const unsigned g = capped_grid(total, 256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define MP_FWD(T, B3) hipLaunchKernelGGL((maxpool_fwd_kernel<T, B3>), dim3(g), dim3(256), 0, s, (const T*)x, x_ld, (T*)y, y_ld, N, D, H, W, C)
+    if (dtype == MIS_BF16) { if (is3d) MP_FWD(__bf16, true); else MP_FWD(__bf16, false); }
+    else { if (is3d) MP_FWD(float, true); else MP_FWD(float, false); }
+#undef MP_FWD
+    MIS_LAUNCH_CHECK("maxpool_fwd");
+    return MIS_OK;
+}
+
+extern "C" int mis_maxpool2_bwd(int dtype, const void* x, int x_ld, const void* dy, int dy_ld, const void* add, int add_ld, void* dx,
+                                int dx_ld, int N, int D, int H, int W, int C, int relu_mask, void* stream) {
+    const int EPC = dtype == MIS_BF16 ? 8 : 4;
+    MIS_REQUIRE(x && dy && dx && N > 0 && D > 0 && H > 1 && W > 1, MIS_EINVAL, "maxpool_bwd: bad argument");
+    MIS_REQUIRE(C % EPC == 0 && x_ld % EPC == 0 && dy_ld % EPC == 0 && dx_ld % EPC == 0, MIS_EINVAL, "maxpool_bwd: alignment");
+    MIS_REQUIRE(add == nullptr || add_ld % EPC == 0, MIS_EINVAL, "maxpool_bwd: add_ld alignment");
+    const bool is3d = D > 1;
+    const long long total = (long long)N * (is3d ? (D + 1) / 2 : 1) * ((H + 1) / 2) * ((W + 1) / 2) * (C / EPC);
+    const unsigned g = capped_grid(total, 256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define MP_BWD(T, B3)                                                                                                             \
+    hipLaunchKernelGGL((maxpool_bwd_kernel<T, B3>), dim3(g), dim3(256), 0, s, (const T*)x, x_ld, (const T*)dy, dy_ld, (const T*)add, \
+                       add_ld, (T*)dx, dx_ld, N, D, H, W, C, relu_mask)
+    if (dtype == MIS_BF16) { if (is3d) MP_BWD(__bf16, true); else MP_BWD(__bf16, false); }
+    else { if (is3d) MP_BWD(float, true); else MP_BWD(float, false); }
+#undef MP_BWD
+    MIS_LAUNCH_CHECK("maxpool_bwd");
+    return MIS_OK;
+}
+
+// =========================================================================================================
+// Weight repack (fp32 master, reference layout) -> MFMA operand layouts.  32x32 (co x ci) tiles through LDS so
+// both outputs are written with the contiguous index on consecutive lanes.
+// =========================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, T* __restrict__ wf,
+                                                        T* __restrict__ wd) {
+    __shared__ float tile[9][32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+    for (int t0 = 0; t0 < taps; t0 += 9) {
+        const int nt = (taps - t0) < 9 ? (taps - t0) : 9;
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int co = co0 + r, ci = ci0 + tx;
+            if (co < Cout && ci < Cin) {
+                const float* src = w + ((size_t)co * Cin + ci) * taps + t0;
+                for (int t = 0; t < nt; ++t) {
+                    const float v = src[t];
+                    tile[t][r][tx] = v;
+                    st_elem<T>(wf + ((size_t)(t0 + t) * Cout + co) * Cin + ci, v);
+                }
+            }
+        }
+        __syncthreads();
+        if (wd != nullptr) {
+            for (int r = ty; r < 32; r += 8) {
+                const int ci = ci0 + r, co = co0 + tx;
+                if (co < Cout && ci < Cin)
+                    for (int t = 0; t < nt; ++t) st_elem<T>(wd + ((size_t)(taps - 1 - (t0 + t)) * Cin + ci) * Cout + co, tile[t][tx][r]);
+            }
+        }
+    }
+}
+
+extern "C" int mis_pack_conv_weight(int dtype, const float* w, int Cout, int Cin, int taps, void* w_fwd, void* w_dgrad, void* stream) {
+    MIS_REQUIRE(w && w_fwd && Cout > 0 && Cin > 0 && taps > 0, MIS_EINVAL, "pack_conv: bad argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 g((Cin + 31) / 32, (Cout + 31) / 32);
+    if (dtype == MIS_BF16) hipLaunchKernelGGL(pack_conv_kernel<__bf16>, g, dim3(256), 0, s, w, Cout, Cin, taps, (__bf16*)w_fwd, (__bf16*)w_dgrad);
+    else hipLaunchKernelGGL(pack_conv_kernel<float>, g, dim3(256), 0, s, w, Cout, Cin, taps, (float*)w_fwd, (float*)w_dgrad);
+    MIS_LAUNCH_CHECK("pack_conv");
+    return MIS_OK;
+}
+
+// convT k2s2: w [Cin][Cq][4] -> fwd [ab*Cq + c][ci], dgrad [ci][ab*Cq + c]
+template <typename T>
+__global__ __launch_bounds__(256) void pack_convt_kernel(const float* __restrict__ w, int Cin, int Cq, T* __restrict__ wf, T* __restrict__ wd) {
+    __shared__ float tile[4][32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int ci0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, c = c0 + tx;
+        if (ci < Cin && c < Cq) {
+            const float* src = w + ((size_t)ci * Cq + c) * 4;
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab) {
+                const float v = src[ab];
+                tile[ab][r][tx] = v;
+                st_elem<T>(wd + (size_t)ci * (4 * Cq) + ab * Cq + c, v);
+            }
+        }
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, ci = ci0 + tx;
+        if (ci < Cin && c < Cq) {
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab) st_elem<T>(wf + ((size_t)ab * Cq + c) * Cin + ci, tile[ab][tx][r]);
+        }
+    }
+}
+
+extern "C" int mis_pack_convt_weight(int dtype, const float* w, int Cin, int Cq, void* w_fwd, void* w_dgrad, void* stream) {
+    MIS_REQUIRE(w && w_fwd && w_dgrad && Cin > 0 && Cq > 0, MIS_EINVAL, "pack_convt: bad argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 g((Cq + 31) / 32, (Cin + 31) / 32);
+    if (dtype == MIS_BF16) hipLaunchKernelGGL(pack_convt_kernel<__bf16>, g, dim3(256), 0, s, w, Cin, Cq, (__bf16*)w_fwd, (__bf16*)w_dgrad);
+    else hipLaunchKernelGGL(pack_convt_kernel<float>, g, dim3(256), 0, s, w, Cin, Cq, (float*)w_fwd, (float*)w_dgrad);
+    MIS_LAUNCH_CHECK("pack_convt");
+    return MIS_OK;
+}
+
+// =========================================================================================================
+// Layout converts (module boundaries / tests; not on the fused hot path)
+// =========================================================================================================
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int y_ld, int N, int C, long long S) {
+    const long long total = (long long)N * C * S;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long long ps = i / C;            // n*S + s
+        const long long n = ps / S, sp = ps - n * S;
+        st_elem<T>(y + ps * y_ld + c, x[(n * C + c) * S + sp]);
+    }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, int x_ld, float* __restrict__ y, int N, int C, long long S) {
+    const long long total = (long long)N * C * S;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long sp = i % S;
+        const long long nc = i / S;
+        const long long n = nc / C;
+        const int c = (int)(nc - n * C);
+        y[i] = ld_elem<T>(x + (n * S + sp) * x_ld + c);
+    }
+}
+extern "C" int mis_nchw_to_nhwc(int dtype_out, const float* x, void* y, int y_ld, int N, int C, long long spatial, void* stream) {
+    MIS_REQUIRE(x && y && N > 0 && C > 0 && spatial > 0, MIS_EINVAL, "nchw_to_nhwc: bad argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned g = capped_grid((long long)N * C * spatial, 256);
+    if (dtype_out == MIS_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(g), dim3(256), 0, s, x, (__bf16*)y, y_ld, N, C, spatial);
+    else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(g), dim3(256), 0, s, x, (float*)y, y_ld, N, C, spatial);
+    MIS_LAUNCH_CHECK("nchw_to_nhwc");
+    return MIS_OK;
+}
+extern "C" int mis_nhwc_to_nchw(int dtype_in, const void* x, int x_ld, float* y, int N, int C, long long spatial, void* stream) {
+    MIS_REQUIRE(x && y && N > 0 && C > 0 && spatial > 0, MIS_EINVAL, "nhwc_to_nchw: bad argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned g = capped_grid((long long)N * C * spatial, 256);
+    if (dtype_in == MIS_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, dim3(g), dim3(256), 0, s, (const __bf16*)x, x_ld, y, N, C, spatial);
+    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x, x_ld, y, N, C, spatial);
+    MIS_LAUNCH_CHECK("nhwc_to_nchw");
+    return MIS_OK;
+}

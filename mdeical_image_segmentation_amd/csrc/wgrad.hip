@@ -1,0 +1,430 @@
+// Weight-gradient GEMM on MFMA for gfx950:  dW[tap][ci][co] = sum_pixels X[pixel + tap][ci] * dY[pixel][co]
+//
+// The reduction (MFMA K) dimension is the PIXEL axis, which is the slow axis of both NHWC operands, so both MFMA
+// operands need a transposed LDS read.  bf16: ds_read_b64_tr_b16 (gfx950) from [pixel][channel] LDS images whose
+// pixel stride is 160 bytes (128 B of channels + 32 B pad): 8 consecutive pixels x 32 B then cover all 64 banks
+// once, so the transposed reads are conflict free with LINEAR addressing and every tap shift is an immediate
+// offset.  f32: plain ds_read_b32 + v_mfma_f32_16x16x4_f32 (exact f32, the parity mode).
+// A block owns one (64 ci x 64 co) [bf16] / (32 x 32) [f32] tile for ALL 3x3 in-plane taps and walks a slice of the
+// pixel tiles (split-K); fp32 partial slabs are reduced in a fixed order by a second kernel (bitwise reproducible,
+// no atomics) which also converts to the reference's [Cout][Cin][taps] layout.
+//
+// Replaces the weight part of aten::convolution_backward for nn.Conv2d/Conv3d(k3,p1) and nn.ConvTranspose2d(k2,s2)
+// (reference call sites: model/unet2d/layers.py:122,125,165; model/unet3d/buildingblocks.py:64-66).
+#include <stdlib.h>
+
+#include "common.hpp"
+
+struct WSrc {
+    const void* p;
+    int ld, D, H, W;
+};
+
+struct WgArgs {
+    int N, D, H, W, Cin, Cout, Cin0;
+    WSrc x0, x1;
+    const float* in_scale;
+    const float* in_shift;
+    const void* dy;
+    int dy_ld;
+    float* partial;
+    int tilesD, tilesH, tilesW, ntiles, nsplit, tps;
+    int nCi, nCo, KDn, TT;
+};
+
+template <int TD_, int TH_, int TW_, int KS_, bool IS3D_> struct WGeom {
+    static constexpr int TD = TD_, TH = TH_, TW = TW_, KS = KS_;
+    static constexpr bool IS3D = IS3D_;
+    static constexpr int PAD = KS / 2;
+    static constexpr int PD = IS3D ? PAD : 0;
+    static constexpr int PHH = TH + 2 * PAD, PHW = TW + 2 * PAD;
+    static constexpr int PHP = TD * PHH * PHW;      // one depth slab per kd
+    static constexpr int M = TD * TH * TW;
+    static constexpr int TAPS2 = KS * KS;           // in-plane taps handled by one block
+    static constexpr int QPR = TW / 4;
+};
+
+constexpr int PSTR = 160;   // LDS bytes per pixel row (128 data + 32 pad)
+
+template <typename T, typename G>
+__device__ __forceinline__ void wg_stage(char* lds_p, char* lds_q, const WgArgs& a, int n, int d0, int h0, int w0, int kd, int ci0,
+                                         int co0, int tid) {
+    constexpr int EPC = Tr<T>::EPC;
+    // ---- P: input halo slab ----
+    {
+        const bool first = ci0 < a.Cin0;
+        const WSrc s = first ? a.x0 : a.x1;
+        const int cl = first ? ci0 : ci0 - a.Cin0;
+        const int shd = (s.D != a.D), shh = (s.H != a.H), shw = (s.W != a.W);   // exact 2x nearest-upsample addressing
+        const T* base = reinterpret_cast<const T*>(s.p) + (size_t)n * s.D * s.H * s.W * s.ld + cl;
+        constexpr int ITEMS = G::PHP * 8;
+        constexpr int BATCH = 3;
+#pragma unroll 1
+        for (int it0 = 0; it0 < ITEMS; it0 += 256 * BATCH) {
+            u32x4 v[BATCH];
+            int lofs[BATCH];
+            bool ok[BATCH];
+#pragma unroll
+            for (int b = 0; b < BATCH; ++b) {
+                const int it = it0 + b * 256 + tid;
+                v[b] = u32x4{0u, 0u, 0u, 0u};
+                lofs[b] = -1;
+                ok[b] = false;
+                if (it < ITEMS) {
+                    const int p = it >> 3, c16 = it & 7;
+                    const int pz = p / (G::PHH * G::PHW);
+                    const int pr = p - pz * (G::PHH * G::PHW);
+                    const int py = pr / G::PHW;
+                    const int px = pr - py * G::PHW;
+                    const int z = d0 + pz + kd - G::PD, y = h0 + py - G::PAD, x = w0 + px - G::PAD;
+                    lofs[b] = p * PSTR + c16 * 16;
+                    if (z >= 0 && z < a.D && y >= 0 && y < a.H && x >= 0 && x < a.W) {
+                        const int off = (((z >> shd) * s.H + (y >> shh)) * s.W + (x >> shw)) * s.ld + c16 * EPC;
+                        v[b] = *reinterpret_cast<const u32x4*>(base + off);
+                        ok[b] = true;
+                    }
+                }
+            }
+            if (a.in_scale != nullptr) {
+#pragma unroll
+                for (int b = 0; b < BATCH; ++b) {
+                    if (ok[b]) {
+                        const int c16 = (it0 + b * 256 + tid) & 7;
+                        const float* sc = a.in_scale + (size_t)n * a.Cin + ci0 + c16 * EPC;
+                        const float* sh = a.in_shift + (size_t)n * a.Cin + ci0 + c16 * EPC;
+                        float f[EPC];
+                        unpack_chunk<T>(v[b], f);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
+                        v[b] = pack_chunk<T>(f);
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < BATCH; ++b)
+                if (lofs[b] >= 0) lds_write_b128(lds_p, lofs[b], v[b]);
+        }
+    }
+    // ---- Q: dY tile (no halo) ----
+    {
+        const T* base = reinterpret_cast<const T*>(a.dy) + co0;
+        constexpr int ITEMS = G::M * 8;   // 1024
+#pragma unroll
+        for (int b = 0; b < ITEMS / 256; ++b) {
+            const int it = b * 256 + tid;
+            const int m = it >> 3, c16 = it & 7;
+            const int dz = m / (G::TH * G::TW);
+            const int hy = (m / G::TW) % G::TH;
+            const int wx = m % G::TW;
+            const int z = d0 + dz, y = h0 + hy, x = w0 + wx;
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (z < a.D && y < a.H && x < a.W) {
+                const size_t pix = (((size_t)n * a.D + z) * a.H + y) * a.W + x;
+                v = *reinterpret_cast<const u32x4*>(base + pix * a.dy_ld + c16 * EPC);
+            }
+            lds_write_b128(lds_q, m * PSTR + c16 * 16, v);
+        }
+    }
+}
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ s16x4 tr_read(const char* lds_generic, int byte_off) {
+    // generic -> LDS address space: the low 32 bits of a generic LDS pointer are the LDS offset
+    const uint32_t addr = (uint32_t)(uintptr_t)(lds_generic) + (uint32_t)byte_off;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>(addr));
+}
+
+__device__ __forceinline__ uint32_t ld_u16(const char* base, int off) { return *reinterpret_cast<const uint16_t*>(base + off); }
+
+// bf16 operand fragment for lane (i = lane & 15, g = lane >> 4): 8 pixels (k = 8g + 4s + e) of channel cbase + i
+template <bool USE_TR>
+__device__ __forceinline__ bf16x8_t wg_frag_bf16(const char* img, int off_s0, int off_s1, int lane) {
+    // off_s*: for USE_TR the per-lane tr address (row q = (lane&15)>>2, 8-byte piece (lane&3));
+    //         for !USE_TR the byte offset of pixel (g, s, e = 0), channel cbase (then + e*PSTR + i*2)
+    if constexpr (USE_TR) {
+        const s16x4 lo = tr_read(img, off_s0);
+        const s16x4 hi = tr_read(img, off_s1);
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8_t, r);
+    } else {
+        const int i = lane & 15;
+        u32x4 r;
+        r[0] = ld_u16(img, off_s0 + 0 * PSTR + i * 2) | (ld_u16(img, off_s0 + 1 * PSTR + i * 2) << 16);
+        r[1] = ld_u16(img, off_s0 + 2 * PSTR + i * 2) | (ld_u16(img, off_s0 + 3 * PSTR + i * 2) << 16);
+        r[2] = ld_u16(img, off_s1 + 0 * PSTR + i * 2) | (ld_u16(img, off_s1 + 1 * PSTR + i * 2) << 16);
+        r[3] = ld_u16(img, off_s1 + 2 * PSTR + i * 2) | (ld_u16(img, off_s1 + 3 * PSTR + i * 2) << 16);
+        return __builtin_bit_cast(bf16x8_t, r);
+    }
+}
+
+template <typename T, typename G, bool USE_TR>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int FR = BF ? 2 : 1;          // 16x16 fragments per wave per dim
+    constexpr int CT = BF ? 64 : 32;        // channel tile (ci and co)
+    constexpr int TAPS2 = G::TAPS2;
+    static_assert(G::M == 128, "pixel tile must be 128");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_p = smem;
+    char* lds_q = smem + G::PHP * PSTR;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+
+    const int npairs = a.nCi * a.nCo;
+    int v = xcd_remap(blockIdx.x, gridDim.x);
+    const int pair = v % npairs;
+    v /= npairs;
+    const int kd = v % a.KDn;
+    const int split = v / a.KDn;
+    const int ci_t = pair / a.nCo, co_t = pair - ci_t * a.nCo;
+    const int ci0 = ci_t * CT, co0 = co_t * CT;
+
+    f32x4 acc[TAPS2][FR][FR];
+#pragma unroll
+    for (int t = 0; t < TAPS2; ++t)
+#pragma unroll
+        for (int fi = 0; fi < FR; ++fi)
+#pragma unroll
+            for (int fj = 0; fj < FR; ++fj) acc[t][fi][fj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int t_begin = split * a.tps;
+    int t_end = t_begin + a.tps;
+    if (t_end > a.ntiles) t_end = a.ntiles;
+    const int tpi = a.tilesD * a.tilesH * a.tilesW;
+
+#pragma unroll 1
+    for (int t = t_begin; t < t_end; ++t) {
+        const int n = t / tpi;
+        int r = t - n * tpi;
+        const int td = r / (a.tilesH * a.tilesW);
+        r -= td * (a.tilesH * a.tilesW);
+        const int th = r / a.tilesW;
+        const int tw = r - th * a.tilesW;
+        const int d0 = td * G::TD, h0 = th * G::TH, w0 = tw * G::TW;
+
+        __syncthreads();   // previous tile's reads are done
+        wg_stage<T, G>(lds_p, lds_q, a, n, d0, h0, w0, kd, ci0, co0, tid);
+        __syncthreads();
+
+        if constexpr (BF) {
+            const int q = li >> 2, pp = li & 3;
+#pragma unroll 1
+            for (int ks = 0; ks < 4; ++ks) {
+                int offP[2], offQ[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int u = (lg & 1) + 2 * s + 4 * (lg >> 1);
+                    const int mrow = u / G::QPR, mcol = (u % G::QPR) * 4;
+                    const int m0 = ks * 32 + mrow * G::TW + mcol;   // first pixel of the quad (same tile row for all 4)
+                    const int dz = m0 / (G::TH * G::TW);
+                    const int hy = (m0 / G::TW) % G::TH;
+                    const int wx = m0 % G::TW;
+                    const int p0 = (dz * G::PHH + hy) * G::PHW + wx;
+                    if constexpr (USE_TR) {
+                        offP[s] = (p0 + q) * PSTR + (pp >> 1) * 16 + (pp & 1) * 8;
+                        offQ[s] = (m0 + q) * PSTR + (pp >> 1) * 16 + (pp & 1) * 8;
+                    } else {
+                        offP[s] = p0 * PSTR;
+                        offQ[s] = m0 * PSTR;
+                    }
+                }
+                bf16x8_t B[FR];
+#pragma unroll
+                for (int fj = 0; fj < FR; ++fj) {
+                    const int cb = (wj * FR + fj) * 32;   // byte offset of the 16-channel fragment
+                    B[fj] = wg_frag_bf16<USE_TR>(lds_q, offQ[0] + cb, offQ[1] + cb, lane);
+                }
+#pragma unroll
+                for (int tap = 0; tap < TAPS2; ++tap) {
+                    const int kh = tap / G::KS, kw = tap % G::KS;
+                    const int toff = (kh * G::PHW + kw) * PSTR;
+                    bf16x8_t A[FR];
+#pragma unroll
+                    for (int fi = 0; fi < FR; ++fi) {
+                        const int cb = (wi * FR + fi) * 32;
+                        A[fi] = wg_frag_bf16<USE_TR>(lds_p, offP[0] + cb + toff, offP[1] + cb + toff, lane);
+                    }
+#pragma unroll
+                    for (int fi = 0; fi < FR; ++fi)
+#pragma unroll
+                        for (int fj = 0; fj < FR; ++fj)
+                            acc[tap][fi][fj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[fi], B[fj], acc[tap][fi][fj], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int kk = 0; kk < 32; ++kk) {
+                const int m = (kk >> 1) * 8 + (kk & 1) + 2 * lg;
+                const int dz = m / (G::TH * G::TW);
+                const int hy = (m / G::TW) % G::TH;
+                const int wx = m % G::TW;
+                const int p0 = (dz * G::PHH + hy) * G::PHW + wx;
+                const float b = *reinterpret_cast<const float*>(lds_q + m * PSTR + (wj * 16 + li) * 4);
+                const char* pa = lds_p + p0 * PSTR + (wi * 16 + li) * 4;
+#pragma unroll
+                for (int tap = 0; tap < TAPS2; ++tap) {
+                    const int kh = tap / G::KS, kw = tap % G::KS;
+                    const float av = *reinterpret_cast<const float*>(pa + (kh * G::PHW + kw) * PSTR);
+                    acc[tap][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc[tap][0][0], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- write this block's partial slab: partial[split][kd*TAPS2 + tap][ci][co] ----
+    float* out = a.partial + (size_t)split * a.TT * a.Cin * a.Cout;
+#pragma unroll
+    for (int tap = 0; tap < TAPS2; ++tap) {
+        const int gt = kd * TAPS2 + tap;
+#pragma unroll
+        for (int fi = 0; fi < FR; ++fi)
+#pragma unroll
+            for (int fj = 0; fj < FR; ++fj) {
+                const int co = co0 + (wj * FR + fj) * 16 + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = ci0 + (wi * FR + fi) * 16 + lg * 4 + r;
+                    out[((size_t)gt * a.Cin + ci) * a.Cout + co] = acc[tap][fi][fj][r];
+                }
+            }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int TT, int Cin, int Cout, float* __restrict__ dw,
+                                    int layout, float alpha) {
+    const size_t total = (size_t)TT * Cin * Cout;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(idx % Cout);
+        const size_t r = idx / Cout;
+        const int ci = (int)(r % Cin);
+        const int tap = (int)(r / Cin);
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * total + idx];
+        size_t o;
+        if (layout == 0) {
+            o = ((size_t)co * Cin + ci) * TT + tap;
+        } else {
+            const int cq = Cout >> 2;
+            const int ab = co / cq, c = co - ab * cq;
+            o = ((size_t)ci * cq + c) * 4 + ab;
+        }
+        dw[o] = alpha * s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct WgPlan {
+    int tilesD, tilesH, tilesW, ntiles, nsplit, tps, nCi, nCo, KDn, TT, CT;
+    bool is3d;
+};
+
+static int wg_plan(const MisWgradDesc* d, WgPlan* p) {
+    MIS_REQUIRE(d != nullptr, MIS_EINVAL, "wgrad: null descriptor");
+    MIS_REQUIRE(d->dtype == MIS_F32 || d->dtype == MIS_BF16, MIS_EINVAL, "wgrad: bad dtype");
+    MIS_REQUIRE(d->ksize == 3 || d->ksize == 1, MIS_EUNSUPPORTED, "wgrad: ksize %d", d->ksize);
+    MIS_REQUIRE(d->N > 0 && d->D > 0 && d->H > 0 && d->W > 0, MIS_EINVAL, "wgrad: empty grid");
+    p->CT = d->dtype == MIS_BF16 ? 64 : 32;
+    MIS_REQUIRE(d->Cin > 0 && d->Cin % p->CT == 0 && d->Cout > 0 && d->Cout % p->CT == 0, MIS_EUNSUPPORTED,
+                "wgrad: Cin %d / Cout %d must be multiples of %d", d->Cin, d->Cout, p->CT);
+    p->is3d = d->D > 1;
+    const int TD = p->is3d ? 2 : 1, TH = 8, TW = p->is3d ? 8 : 16;
+    p->tilesD = (d->D + TD - 1) / TD;
+    p->tilesH = (d->H + TH - 1) / TH;
+    p->tilesW = (d->W + TW - 1) / TW;
+    const long long nt = (long long)d->N * p->tilesD * p->tilesH * p->tilesW;
+    MIS_REQUIRE(nt < (1ll << 30), MIS_EUNSUPPORTED, "wgrad: too many pixel tiles");
+    p->ntiles = (int)nt;
+    p->nCi = d->Cin / p->CT;
+    p->nCo = d->Cout / p->CT;
+    p->KDn = (p->is3d && d->ksize == 3) ? 3 : 1;
+    p->TT = d->ksize == 3 ? (p->is3d ? 27 : 9) : 1;
+    const long long base = (long long)p->nCi * p->nCo * p->KDn;
+    long long want = (1024 + base - 1) / base;     // aim for >= ~1024 blocks (2 per CU x 2 rounds)
+    if (want < 1) want = 1;
+    if (want > nt) want = nt;
+    // keep the slab traffic bounded: at most 64 MiB of partials per layer unless a single split already exceeds it
+    const long long slab = (long long)p->TT * d->Cin * d->Cout * 4;
+    while (want > 1 && want * slab > (256ll << 20)) --want;
+    p->tps = (int)((nt + want - 1) / want);
+    p->nsplit = (int)((nt + p->tps - 1) / p->tps);
+    return MIS_OK;
+}
+
+extern "C" size_t mis_wgrad_workspace_bytes(const MisWgradDesc* d) {
+    WgPlan p;
+    if (wg_plan(d, &p) != MIS_OK) return 0;
+    return (size_t)p.nsplit * p.TT * d->Cin * d->Cout * sizeof(float);
+}
+
+template <typename T, typename G, bool USE_TR>
+static int wg_launch(const MisWgradDesc* d, const WgPlan& p, hipStream_t stream) {
+    WgArgs a;
+    a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cin0 = d->Cin0;
+    a.x0 = WSrc{d->x0, d->x0_ld, d->x0_D, d->x0_H, d->x0_W};
+    a.x1 = WSrc{d->x1, d->x1_ld, d->x1_D, d->x1_H, d->x1_W};
+    a.in_scale = d->in_scale; a.in_shift = d->in_shift;
+    a.dy = d->dy; a.dy_ld = d->dy_ld; a.partial = d->workspace;
+    a.tilesD = p.tilesD; a.tilesH = p.tilesH; a.tilesW = p.tilesW; a.ntiles = p.ntiles; a.nsplit = p.nsplit; a.tps = p.tps;
+    a.nCi = p.nCi; a.nCo = p.nCo; a.KDn = p.KDn; a.TT = p.TT;
+    const size_t lds = (size_t)(G::PHP + G::M) * PSTR;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, G, USE_TR>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const long long grid = (long long)p.nCi * p.nCo * p.KDn * p.nsplit;
+    MIS_REQUIRE(grid < (1ll << 31), MIS_EUNSUPPORTED, "wgrad: grid too large");
+    hipLaunchKernelGGL((wgrad_kernel<T, G, USE_TR>), dim3((unsigned)grid), dim3(256), lds, stream, a);
+    MIS_LAUNCH_CHECK("wgrad");
+    const size_t total = (size_t)p.TT * d->Cin * d->Cout;
+    unsigned rb = (unsigned)((total + 255) / 256);
+    if (rb > 8192) rb = 8192;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, (const float*)d->workspace, p.nsplit, p.TT, d->Cin,
+                       d->Cout, d->dw, d->dw_layout, d->alpha);
+    MIS_LAUNCH_CHECK("wgrad_reduce");
+    return MIS_OK;
+}
+
+template <typename T, bool USE_TR> static int wg_dispatch(const MisWgradDesc* d, const WgPlan& p, hipStream_t s) {
+    if (d->ksize == 3) {
+        if (!p.is3d) return wg_launch<T, WGeom<1, 8, 16, 3, false>, USE_TR>(d, p, s);
+        return wg_launch<T, WGeom<2, 8, 8, 3, true>, USE_TR>(d, p, s);
+    }
+    if (!p.is3d) return wg_launch<T, WGeom<1, 8, 16, 1, false>, USE_TR>(d, p, s);
+    return wg_launch<T, WGeom<2, 8, 8, 1, true>, USE_TR>(d, p, s);
+}
+
+extern "C" int mis_wgrad(const MisWgradDesc* d, void* stream) {
+    WgPlan p;
+    int rc = wg_plan(d, &p);
+    if (rc != MIS_OK) return rc;
+    const int EPC = d->dtype == MIS_BF16 ? 8 : 4;
+    MIS_REQUIRE(d->x0 != nullptr && d->dy != nullptr && d->dw != nullptr && d->workspace != nullptr, MIS_EINVAL, "wgrad: null pointer");
+    MIS_REQUIRE(d->Cin0 > 0 && d->Cin0 <= d->Cin && d->Cin0 % p.CT == 0, MIS_EINVAL, "wgrad: Cin0 %d", d->Cin0);
+    MIS_REQUIRE(d->Cin0 == d->Cin || d->x1 != nullptr, MIS_EINVAL, "wgrad: x1 missing");
+    MIS_REQUIRE(d->x0_ld % EPC == 0 && d->dy_ld % EPC == 0, MIS_EINVAL, "wgrad: ld alignment");
+    MIS_REQUIRE(d->x1 == nullptr || d->x1_ld % EPC == 0, MIS_EINVAL, "wgrad: x1_ld alignment");
+    MIS_REQUIRE((d->in_scale == nullptr) == (d->in_shift == nullptr), MIS_EINVAL, "wgrad: in_scale/in_shift");
+    MIS_REQUIRE(d->workspace_bytes >= mis_wgrad_workspace_bytes(d), MIS_EINVAL, "wgrad: workspace too small");
+    MIS_REQUIRE(d->dw_layout == 0 || (d->dw_layout == 1 && d->ksize == 1 && d->Cout % 4 == 0), MIS_EINVAL, "wgrad: dw_layout");
+    const WSrc srcs[2] = {{d->x0, d->x0_ld, d->x0_D, d->x0_H, d->x0_W}, {d->x1, d->x1_ld, d->x1_D, d->x1_H, d->x1_W}};
+    for (int i = 0; i < 2; ++i) {
+        if (srcs[i].p == nullptr) continue;
+        const bool okD = srcs[i].D == d->D || (srcs[i].D * 2 == d->D);
+        const bool okH = srcs[i].H == d->H || (srcs[i].H * 2 == d->H);
+        const bool okW = srcs[i].W == d->W || (srcs[i].W * 2 == d->W);
+        MIS_REQUIRE(okD && okH && okW, MIS_EUNSUPPORTED, "wgrad: source grid must equal the pixel grid or be exactly half of it");
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const char* e = getenv("MIS_WGRAD_NO_TR");
+    const bool use_tr = !(e != nullptr && e[0] == '1');
+    if (d->dtype == MIS_BF16) return use_tr ? wg_dispatch<__bf16, true>(d, p, s) : wg_dispatch<__bf16, false>(d, p, s);
+    return wg_dispatch<float, false>(d, p, s);
+}

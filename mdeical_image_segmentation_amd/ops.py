@@ -1,0 +1,254 @@
+"""Thin Python wrappers over the C ABI (include/misamd.h).  torch is used as the device allocator only:
+every wrapper passes raw pointers + sizes and enqueues on torch's current HIP stream."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (MIS_BF16, MIS_F32, OUT_PLAIN, OUT_SHUFFLE2, OUT_UNSHUFFLE2, ConvDesc, HeadDesc, WgradDesc, check,
+                   dtype_code, load, stream_ptr)
+
+
+class View:
+    """A channel slice [c0, c0+C) of a channels-last tensor (N, D, H, W, Ctot) or (N, H, W, Ctot)."""
+
+    def __init__(self, t, c0=0, C=None):
+        assert t.is_contiguous()
+        self.t = t
+        self.ld = t.shape[-1]
+        self.c0 = c0
+        self.C = (t.shape[-1] - c0) if C is None else C
+        assert 0 <= c0 and c0 + self.C <= self.ld
+        if t.dim() == 4:
+            self.N, self.H, self.W = t.shape[0], t.shape[1], t.shape[2]
+            self.D = 1
+        else:
+            self.N, self.D, self.H, self.W = t.shape[0], t.shape[1], t.shape[2], t.shape[3]
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr() + self.c0 * self.t.element_size()
+
+    @property
+    def dtype(self):
+        return self.t.dtype
+
+    @property
+    def npix(self):
+        return self.N * self.D * self.H * self.W
+
+
+def _v(x):
+    return x if isinstance(x, View) else View(x)
+
+
+def conv_igemm(x0, w_packed, y0, *, ksize, Cin, Cout, grid=None, x1=None, bias=None, relu=False, mask=None,
+               y0_mode=OUT_PLAIN, y1=None, y1_mode=OUT_PLAIN, Cout0=None, in_scale=None, in_shift=None):
+    """grid = (N, D, H, W) of the GEMM rows; defaults to x0's grid."""
+    lib = load()
+    x0 = _v(x0)
+    y0 = _v(y0)
+    d = ConvDesc()
+    d.dtype = dtype_code(x0.dtype)
+    d.ksize = ksize
+    if grid is None:
+        grid = (x0.N, x0.D, x0.H, x0.W)
+    d.N, d.D, d.H, d.W = grid
+    d.Cin, d.Cout = Cin, Cout
+    d.x0, d.x0_ld, d.x0_D, d.x0_H, d.x0_W = x0.ptr, x0.ld, x0.D, x0.H, x0.W
+    d.Cin0 = x0.C if x1 is not None else Cin
+    if x1 is not None:
+        x1 = _v(x1)
+        d.x1, d.x1_ld, d.x1_D, d.x1_H, d.x1_W = x1.ptr, x1.ld, x1.D, x1.H, x1.W
+        assert x0.C + x1.C == Cin
+    d.in_scale = None if in_scale is None else in_scale.data_ptr()
+    d.in_shift = None if in_shift is None else in_shift.data_ptr()
+    d.w = w_packed.data_ptr()
+    d.bias = None if bias is None else bias.data_ptr()
+    d.relu = 1 if relu else 0
+    if mask is not None:
+        mask = _v(mask)
+        d.mask, d.mask_ld = mask.ptr, mask.ld
+    d.y0, d.y0_ld, d.y0_mode = y0.ptr, y0.ld, y0_mode
+    d.Cout0 = Cout if Cout0 is None else Cout0
+    if y1 is not None:
+        y1 = _v(y1)
+        d.y1, d.y1_ld, d.y1_mode = y1.ptr, y1.ld, y1_mode
+    check(lib.mis_conv_igemm(C.byref(d), stream_ptr()), "mis_conv_igemm")
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    """Grow-only scratch buffers (caller-owned workspaces of the C ABI)."""
+    key = (tag, str(device))
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((max(nbytes, 1) + 3) // 4, dtype=torch.float32, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alpha=1.0, in_scale=None, in_shift=None):
+    lib = load()
+    x0 = _v(x0)
+    dy = _v(dy)
+    d = WgradDesc()
+    d.dtype = dtype_code(x0.dtype)
+    d.ksize = ksize
+    if grid is None:
+        grid = (dy.N, dy.D, dy.H, dy.W)
+    d.N, d.D, d.H, d.W = grid
+    d.Cin, d.Cout = Cin, Cout
+    d.x0, d.x0_ld, d.x0_D, d.x0_H, d.x0_W = x0.ptr, x0.ld, x0.D, x0.H, x0.W
+    d.Cin0 = x0.C if x1 is not None else Cin
+    if x1 is not None:
+        x1 = _v(x1)
+        d.x1, d.x1_ld, d.x1_D, d.x1_H, d.x1_W = x1.ptr, x1.ld, x1.D, x1.H, x1.W
+    d.in_scale = None if in_scale is None else in_scale.data_ptr()
+    d.in_shift = None if in_shift is None else in_shift.data_ptr()
+    d.dy, d.dy_ld = dy.ptr, dy.ld
+    d.dw, d.dw_layout, d.alpha = dw.data_ptr(), dw_layout, alpha
+    need = lib.mis_wgrad_workspace_bytes(C.byref(d))
+    if need == 0:
+        check(-1, "mis_wgrad_workspace_bytes")
+    ws = workspace(need, dy.t.device, "wgrad")
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    check(lib.mis_wgrad(C.byref(d), stream_ptr()), "mis_wgrad")
+
+
+def first_conv_fwd(x_nchw, w, bias, y):
+    lib = load()
+    y = _v(y)
+    N, Cin, H, W = x_nchw.shape
+    check(lib.mis_conv3x3_first_fwd(dtype_code(y.dtype), x_nchw.data_ptr(), N, Cin, H, W, w.data_ptr(),
+                                    None if bias is None else bias.data_ptr(), y.ptr, y.ld, y.C, stream_ptr()),
+          "mis_conv3x3_first_fwd")
+
+
+def first_conv_wgrad(x_nchw, dy, dw, db):
+    lib = load()
+    dy = _v(dy)
+    N, Cin, H, W = x_nchw.shape
+    ws = workspace(lib.mis_conv3x3_first_wgrad_workspace_bytes(N, Cin, H, W, dy.C), x_nchw.device, "first")
+    check(lib.mis_conv3x3_first_wgrad(dtype_code(dy.dtype), x_nchw.data_ptr(), N, Cin, H, W, dy.ptr, dy.ld, dy.C,
+                                      ws.data_ptr(), dw.data_ptr(), None if db is None else db.data_ptr(), stream_ptr()),
+          "mis_conv3x3_first_wgrad")
+
+
+def colsum(x, out, fold=1, alpha=1.0):
+    lib = load()
+    x = _v(x)
+    ws = workspace(lib.mis_colsum_workspace_bytes(x.npix, x.C), x.t.device, "colsum")
+    check(lib.mis_colsum(dtype_code(x.dtype), x.ptr, x.ld, x.npix, x.C, fold, alpha, ws.data_ptr(), out.data_ptr(),
+                         stream_ptr()), "mis_colsum")
+
+
+def chanstats(x, s, sq):
+    lib = load()
+    x = _v(x)
+    npix = x.D * x.H * x.W
+    ws = workspace(lib.mis_chanstats_workspace_bytes(x.N, npix, x.C), x.t.device, "chanstats")
+    check(lib.mis_chanstats(dtype_code(x.dtype), x.ptr, x.ld, x.N, npix, x.C, ws.data_ptr(), s.data_ptr(), sq.data_ptr(),
+                            stream_ptr()), "mis_chanstats")
+
+
+def maxpool2_fwd(x, y):
+    lib = load()
+    x, y = _v(x), _v(y)
+    check(lib.mis_maxpool2_fwd(dtype_code(x.dtype), x.ptr, x.ld, y.ptr, y.ld, x.N, x.D, x.H, x.W, x.C, stream_ptr()),
+          "mis_maxpool2_fwd")
+
+
+def maxpool2_bwd(x, dy, dx, add=None, relu_mask=True):
+    lib = load()
+    x, dy, dx = _v(x), _v(dy), _v(dx)
+    if add is not None:
+        add = _v(add)
+    check(lib.mis_maxpool2_bwd(dtype_code(x.dtype), x.ptr, x.ld, dy.ptr, dy.ld, None if add is None else add.ptr,
+                               0 if add is None else add.ld, dx.ptr, dx.ld, x.N, x.D, x.H, x.W, x.C, 1 if relu_mask else 0,
+                               stream_ptr()), "mis_maxpool2_bwd")
+
+
+def pack_conv_weight(w, w_fwd, w_dgrad=None):
+    """w: fp32 [Cout, Cin, *k] (reference layout) -> packed operands (dtype of w_fwd)."""
+    lib = load()
+    Cout, Cin = w.shape[0], w.shape[1]
+    taps = w[0, 0].numel()
+    check(lib.mis_pack_conv_weight(dtype_code(w_fwd.dtype), w.data_ptr(), Cout, Cin, taps, w_fwd.data_ptr(),
+                                   None if w_dgrad is None else w_dgrad.data_ptr(), stream_ptr()), "mis_pack_conv_weight")
+
+
+def pack_convt_weight(w, w_fwd, w_dgrad):
+    lib = load()
+    Cin, Cq = w.shape[0], w.shape[1]
+    check(lib.mis_pack_convt_weight(dtype_code(w_fwd.dtype), w.data_ptr(), Cin, Cq, w_fwd.data_ptr(), w_dgrad.data_ptr(),
+                                    stream_ptr()), "mis_pack_convt_weight")
+
+
+LOSS_NONE, LOSS_CE, LOSS_BCE, LOSS_BCEDICE = -1, 0, 1, 2
+
+
+def head_loss(y, w, b, *, loss, labels=None, logits=None, argmax=None, loss_out=None, dy=None, dw=None, db=None,
+              grad_scale=1.0, alpha=1.0, beta=1.0):
+    lib = load()
+    y = _v(y)
+    d = HeadDesc()
+    d.dtype = dtype_code(y.dtype)
+    d.loss = loss
+    d.npix_per_image = y.D * y.H * y.W
+    d.N, d.Cfeat, d.C = y.N, y.C, w.shape[0]
+    d.y, d.y_ld = y.ptr, y.ld
+    d.w, d.b = w.data_ptr(), b.data_ptr()
+    d.labels = None if labels is None else labels.data_ptr()
+    d.logits = None if logits is None else logits.data_ptr()
+    d.argmax = None if argmax is None else argmax.data_ptr()
+    d.loss_out = None if loss_out is None else loss_out.data_ptr()
+    if dy is not None:
+        dy = _v(dy)
+        d.dy, d.dy_ld = dy.ptr, dy.ld
+        d.dw, d.db = dw.data_ptr(), db.data_ptr()
+    d.grad_scale, d.alpha, d.beta = grad_scale, alpha, beta
+    ws = workspace(lib.mis_head_workspace_bytes(C.byref(d)), y.t.device, "head")
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    check(lib.mis_head_loss(C.byref(d), stream_ptr()), "mis_head_loss")
+
+
+def sumsq(g, partials):
+    lib = load()
+    check(lib.mis_sumsq(g.data_ptr(), g.numel(), partials.data_ptr(), stream_ptr()), "mis_sumsq")
+
+
+def sumsq_npartials(n):
+    return load().mis_sumsq_npartials(n)
+
+
+def adamw_step(p, g, m, v, *, partials, max_norm, lr, beta1, beta2, eps, weight_decay, step, gradnorm_out=None):
+    lib = load()
+    check(lib.mis_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                             None if partials is None else partials.data_ptr(), 0 if partials is None else partials.numel(),
+                             max_norm, lr, beta1, beta2, eps, weight_decay, step,
+                             None if gradnorm_out is None else gradnorm_out.data_ptr(), stream_ptr()), "mis_adamw_step")
+
+
+def nchw_to_nhwc(x, y):
+    """x: fp32 (N, C, *spatial) -> y channels-last view (dtype of y)."""
+    lib = load()
+    y = _v(y)
+    N, Cc = x.shape[0], x.shape[1]
+    S = x[0, 0].numel()
+    check(lib.mis_nchw_to_nhwc(dtype_code(y.dtype), x.data_ptr(), y.ptr, y.ld, N, Cc, S, stream_ptr()), "mis_nchw_to_nhwc")
+
+
+def nhwc_to_nchw(x, y):
+    lib = load()
+    x = _v(x)
+    S = x.D * x.H * x.W
+    check(lib.mis_nhwc_to_nchw(dtype_code(x.dtype), x.ptr, x.ld, y.data_ptr(), x.N, x.C, S, stream_ptr()), "mis_nhwc_to_nchw")
+
+
+def probe_mfma(which, a, b, c):
+    lib = load()
+    check(lib.mis_probe_mfma(which, a.data_ptr(), None if b is None else b.data_ptr(), c.data_ptr(), stream_ptr()),
+          "mis_probe_mfma")
