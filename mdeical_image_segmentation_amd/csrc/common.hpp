@@ -42,7 +42,7 @@ template <> struct Tr<__bf16> {
     static constexpr int CK = 64;
 };
 
-__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b16) { return __builtin_bit_cast(float, b16 << 16); }
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b16) { return __uint_as_float(b16 << 16); }
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
     __bf16 h = (__bf16)f;   // v_cvt_pk_bf16_f32, RNE, NaN preserved
     return (uint32_t)__builtin_bit_cast(uint16_t, h);
@@ -60,7 +60,10 @@ template <> __device__ __forceinline__ void st_elem<__bf16>(__bf16* p, float v) 
 template <typename T> __device__ __forceinline__ void unpack_chunk(const u32x4& c, float* f);
 template <> __device__ __forceinline__ void unpack_chunk<float>(const u32x4& c, float* f) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(float, c[i]);
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t u = c[i];   // (bit_cast straight from a vector element mis-compiles: copy to a scalar first)
+        f[i] = __uint_as_float(u);
+    }
 }
 template <> __device__ __forceinline__ void unpack_chunk<__bf16>(const u32x4& c, float* f) {
 #pragma unroll
@@ -73,7 +76,7 @@ template <typename T> __device__ __forceinline__ u32x4 pack_chunk(const float* f
 template <> __device__ __forceinline__ u32x4 pack_chunk<float>(const float* f) {
     u32x4 c;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) c[i] = __builtin_bit_cast(uint32_t, f[i]);
+    for (int i = 0; i < 4; ++i) c[i] = __float_as_uint(f[i]);
     return c;
 }
 template <> __device__ __forceinline__ u32x4 pack_chunk<__bf16>(const float* f) {
@@ -92,8 +95,10 @@ template <typename T> __device__ __forceinline__ void mma_b128(f32x4& acc, const
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a[i]), __builtin_bit_cast(float, b[i]), acc, 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t ua = a[i], ub = b[i];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ua), __uint_as_float(ub), acc, 0, 0, 0);
+        }
     }
 }
 

@@ -366,6 +366,7 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
 }
 
 extern "C" int mis_conv_igemm(const MisConvDesc* d, void* stream) {
+    (void)hipGetLastError();   // drop any stale (already handled) error of this thread
     MIS_REQUIRE(d != nullptr, MIS_EINVAL, "conv_igemm: null descriptor");
     MIS_REQUIRE(d->dtype == MIS_F32 || d->dtype == MIS_BF16, MIS_EINVAL, "conv_igemm: bad dtype %d", d->dtype);
     const int CK = d->dtype == MIS_BF16 ? 64 : 32;

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void first_conv_fwd_kernel(const float* __rest
 
 extern "C" int mis_conv3x3_first_fwd(int dtype, const float* x, int N, int Cin, int H, int W, const float* w, const float* bias, void* y,
                                      int y_ld, int Cout, void* stream) {
+    (void)hipGetLastError();   // drop any stale (already handled) error of this thread
     MIS_REQUIRE(Cout == 64, MIS_EUNSUPPORTED, "first_fwd: Cout must be 64 (got %d)", Cout);
     MIS_REQUIRE(Cin >= 1 && Cin <= 4, MIS_EUNSUPPORTED, "first_fwd: Cin must be 1..4 (got %d)", Cin);
     MIS_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0, MIS_EINVAL, "first_fwd: bad argument");
@@ -155,6 +156,7 @@ extern "C" size_t mis_conv3x3_first_wgrad_workspace_bytes(int N, int Cin, int H,
 
 extern "C" int mis_conv3x3_first_wgrad(int dtype, const float* x, int N, int Cin, int H, int W, const void* dy, int dy_ld, int Cout,
                                        float* workspace, float* dw, float* db, void* stream) {
+    (void)hipGetLastError();   // drop any stale (already handled) error of this thread
     MIS_REQUIRE(Cout == 64, MIS_EUNSUPPORTED, "first_wgrad: Cout must be 64");
     MIS_REQUIRE(Cin >= 1 && Cin <= 4, MIS_EUNSUPPORTED, "first_wgrad: Cin must be 1..4");
     MIS_REQUIRE(x && dy && workspace && dw, MIS_EINVAL, "first_wgrad: null pointer");
@@ -284,6 +286,7 @@ extern "C" size_t mis_colsum_workspace_bytes(long long npix, int C) {
 }
 extern "C" int mis_colsum(int dtype, const void* x, int ld, long long npix, int C, int fold, float alpha, float* workspace, float* out,
                           void* stream) {
+    (void)hipGetLastError();   // drop any stale (already handled) error of this thread
     const int EPC = dtype == MIS_BF16 ? 8 : 4;
     MIS_REQUIRE(x && workspace && out && npix > 0, MIS_EINVAL, "colsum: bad argument");
     MIS_REQUIRE(C % EPC == 0 && ld % EPC == 0, MIS_EINVAL, "colsum: C / ld alignment");
@@ -298,6 +301,7 @@ extern "C" size_t mis_chanstats_workspace_bytes(int N, long long npix, int C) {
 }
 extern "C" int mis_chanstats(int dtype, const void* x, int ld, int N, long long npix, int C, float* workspace, float* sum, float* sumsq,
                              void* stream) {
+    (void)hipGetLastError();   // drop any stale (already handled) error of this thread
     const int EPC = dtype == MIS_BF16 ? 8 : 4;
     MIS_REQUIRE(x && workspace && sum && sumsq && npix > 0 && N > 0, MIS_EINVAL, "chanstats: bad argument");
     MIS_REQUIRE(C % EPC == 0 && ld % EPC == 0, MIS_EINVAL, "chanstats: C / ld alignment");
@@ -421,6 +425,7 @@ static unsigned capped_grid(long long total, int per_block) {
 }
 
 extern "C" int mis_maxpool2_fwd(int dtype, const void* x, int x_ld, void* y, int y_ld, int N, int D, int H, int W, int C, void* stream) {
+    (void)hipGetLastError();   // drop any stale (already handled) error of this thread
     const int EPC = dtype == MIS_BF16 ? 8 : 4;
     MIS_REQUIRE(x && y && N > 0 && D > 0 && H > 1 && W > 1, MIS_EINVAL, "maxpool_fwd: bad argument");
     MIS_REQUIRE(C % EPC == 0 && x_ld % EPC == 0 && y_ld % EPC == 0, MIS_EINVAL, "maxpool_fwd: alignment");
@@ -438,6 +443,7 @@ extern "C" int mis_maxpool2_fwd(int dtype, const void* x, int x_ld, void* y, int
 
 extern "C" int mis_maxpool2_bwd(int dtype, const void* x, int x_ld, const void* dy, int dy_ld, const void* add, int add_ld, void* dx,
                                 int dx_ld, int N, int D, int H, int W, int C, int relu_mask, void* stream) {
+    (void)hipGetLastError();   // drop any stale (already handled) error of this thread
     const int EPC = dtype == MIS_BF16 ? 8 : 4;
     MIS_REQUIRE(x && dy && dx && N > 0 && D > 0 && H > 1 && W > 1, MIS_EINVAL, "maxpool_bwd: bad argument");
     MIS_REQUIRE(C % EPC == 0 && x_ld % EPC == 0 && dy_ld % EPC == 0 && dx_ld % EPC == 0, MIS_EINVAL, "maxpool_bwd: alignment");
@@ -492,6 +498,7 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict_
 }
 
 extern "C" int mis_pack_conv_weight(int dtype, const float* w, int Cout, int Cin, int taps, void* w_fwd, void* w_dgrad, void* stream) {
+    (void)hipGetLastError();   // drop any stale (already handled) error of this thread
     MIS_REQUIRE(w && w_fwd && Cout > 0 && Cin > 0 && taps > 0, MIS_EINVAL, "pack_conv: bad argument");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 g((Cin + 31) / 32, (Cout + 31) / 32);
@@ -530,6 +537,7 @@ __global__ __launch_bounds__(256) void pack_convt_kernel(const float* __restrict
 }
 
 extern "C" int mis_pack_convt_weight(int dtype, const float* w, int Cin, int Cq, void* w_fwd, void* w_dgrad, void* stream) {
+    (void)hipGetLastError();   // drop any stale (already handled) error of this thread
     MIS_REQUIRE(w && w_fwd && w_dgrad && Cin > 0 && Cq > 0, MIS_EINVAL, "pack_convt: bad argument");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 g((Cq + 31) / 32, (Cin + 31) / 32);
@@ -564,6 +572,7 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, int x_ld, float* __
     }
 }
 extern "C" int mis_nchw_to_nhwc(int dtype_out, const float* x, void* y, int y_ld, int N, int C, long long spatial, void* stream) {
+    (void)hipGetLastError();   // drop any stale (already handled) error of this thread
     MIS_REQUIRE(x && y && N > 0 && C > 0 && spatial > 0, MIS_EINVAL, "nchw_to_nhwc: bad argument");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const unsigned g = capped_grid((long long)N * C * spatial, 256);
@@ -573,6 +582,7 @@ extern "C" int mis_nchw_to_nhwc(int dtype_out, const float* x, void* y, int y_ld
     return MIS_OK;
 }
 extern "C" int mis_nhwc_to_nchw(int dtype_in, const void* x, int x_ld, float* y, int N, int C, long long spatial, void* stream) {
+    (void)hipGetLastError();   // drop any stale (already handled) error of this thread
     MIS_REQUIRE(x && y && N > 0 && C > 0 && spatial > 0, MIS_EINVAL, "nhwc_to_nchw: bad argument");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const unsigned g = capped_grid((long long)N * C * spatial, 256);

@@ -313,6 +313,7 @@ template <typename T> static int head_by_c(const MisHeadDesc* d, HeadArgs& a, un
 }
 
 extern "C" int mis_head_loss(const MisHeadDesc* d, void* stream) {
+    (void)hipGetLastError();   // drop any stale (already handled) error of this thread
     MIS_REQUIRE(d != nullptr, MIS_EINVAL, "head: null descriptor");
     MIS_REQUIRE(d->dtype == MIS_F32 || d->dtype == MIS_BF16, MIS_EINVAL, "head: dtype");
     MIS_REQUIRE(d->Cfeat == 64, MIS_EUNSUPPORTED, "head: Cfeat must be 64 (got %d)", d->Cfeat);

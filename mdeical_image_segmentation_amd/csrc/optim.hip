@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 }
 
 extern "C" int mis_sumsq_npartials(long long n) {
+    (void)hipGetLastError();   // drop any stale (already handled) error of this thread
     (void)n;
     return SS_BLOCKS;
 }
@@ -37,6 +38,7 @@ extern "C" size_t mis_adamw_workspace_bytes(long long n) {
     return SS_BLOCKS * sizeof(float);
 }
 extern "C" int mis_sumsq(const float* g, long long n, float* workspace, void* stream) {
+    (void)hipGetLastError();   // drop any stale (already handled) error of this thread
     MIS_REQUIRE(g && workspace && n > 0, MIS_EINVAL, "sumsq: bad argument");
     MIS_REQUIRE((reinterpret_cast<uintptr_t>(g) & 15) == 0, MIS_EINVAL, "sumsq: g must be 16-byte aligned");
     hipLaunchKernelGGL(sumsq_kernel, dim3(SS_BLOCKS), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, n, workspace);
@@ -89,6 +91,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 extern "C" int mis_adamw_step(float* p, const float* g, float* m, float* v, long long n, const float* sumsq_partials, int npartials,
                               float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float* gradnorm_out,
                               void* stream) {
+    (void)hipGetLastError();   // drop any stale (already handled) error of this thread
     MIS_REQUIRE(p && g && m && v && n > 0 && step >= 1, MIS_EINVAL, "adamw: bad argument");
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -150,6 +153,7 @@ __global__ void probe_kernel(int which, const float* __restrict__ a, const float
 }
 
 extern "C" int mis_probe_mfma(int which, const float* a, const float* b, float* c, void* stream) {
+    (void)hipGetLastError();   // drop any stale (already handled) error of this thread
     MIS_REQUIRE(which >= 0 && which <= 2 && a && c, MIS_EINVAL, "probe: bad argument");
     hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), which, a, b, c);
     MIS_LAUNCH_CHECK("probe");

@@ -402,6 +402,7 @@ template <typename T, bool USE_TR> static int wg_dispatch(const MisWgradDesc* d,
 }
 
 extern "C" int mis_wgrad(const MisWgradDesc* d, void* stream) {
+    (void)hipGetLastError();   // drop any stale (already handled) error of this thread
     WgPlan p;
     int rc = wg_plan(d, &p);
     if (rc != MIS_OK) return rc;

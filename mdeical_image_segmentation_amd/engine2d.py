@@ -263,8 +263,12 @@ class UNet2DEngine:
             ops.conv_igemm(dy, self.wd_[name], dx, ksize=3, Cin=cout, Cout=cin, mask=mask, y0_mode=dx_mode, y1=dx1,
                            Cout0=cout0)
 
-    def backward(self):
-        """Run after forward(train=True): fills self.G (reference-layout fp32 grads)."""
+    def backward(self, stage_cb=None):
+        """Run after forward(train=True): fills self.G (reference-layout fp32 grads).
+        stage_cb(module_prefixes) is called as soon as the gradients of those modules have been enqueued
+        (used by ddp.GradReducer to start their all-reduce while the rest of backward still runs)."""
+        cb = stage_cb if stage_cb is not None else (lambda names: None)
+        cb(["final_conv"])
         for j in range(3, -1, -1):
             l = 3 - j
             c = FEATS[l]
@@ -279,8 +283,10 @@ class UNet2DEngine:
             ops.wgrad(x_in, self.dys[j], self.G[up + ".weight"], ksize=1, Cin=2 * c, Cout=4 * c, dw_layout=1)
             ops.colsum(self.dys[j], self.G[up + ".bias"], fold=4)
             ops.conv_igemm(self.dys[j], self.wd_[up], g_in, ksize=1, Cin=4 * c, Cout=2 * c, mask=x_in)
+            cb([f"up_conv.{j}", f"up_sample.{j}"])
         self._bwd_conv(self.m1, self.g_m2, "middle_conv.second", 1024, 1024, dx=self.g_m1, mask=self.m1)
         self._bwd_conv(self.pooled[3], self.g_m1, "middle_conv.first", 512, 1024, dx=self.g_pooled[3])
+        cb(["middle_conv"])
         for l in range(3, -1, -1):
             c = FEATS[l]
             skip = View(self.cat[l], c, c)
@@ -290,6 +296,7 @@ class UNet2DEngine:
                 self._bwd_conv(self.pooled[l - 1], self.g_t1[l], f"down_conv.{l}.first", FEATS[l - 1], c, dx=self.g_pooled[l - 1])
             else:
                 ops.first_conv_wgrad(self._images, self.g_t1[0], self.G["down_conv.0.first.weight"], self.G["down_conv.0.first.bias"])
+            cb([f"down_conv.{l}"])
 
     # ---- optimizer -------------------------------------------------------------------------------------
     def optimizer_step(self, lr=None):

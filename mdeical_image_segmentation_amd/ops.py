@@ -42,6 +42,28 @@ def _v(x):
     return x if isinstance(x, View) else View(x)
 
 
+# Optional per-launch timing (bench.py): when PROFILE is a list, every MFMA kernel launch is bracketed by HIP
+# events on the launch stream and (kernel symbol key, algorithmic FLOPs, start, end) is appended.
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, key, flops):
+        self.key, self.flops = key, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if PROFILE is not None and exc[0] is None:
+            self.e1.record()
+            PROFILE.append((self.key, self.flops, self.e0, self.e1))
+        return False
+
+
 def conv_igemm(x0, w_packed, y0, *, ksize, Cin, Cout, grid=None, x1=None, bias=None, relu=False, mask=None,
                y0_mode=OUT_PLAIN, y1=None, y1_mode=OUT_PLAIN, Cout0=None, in_scale=None, in_shift=None):
     """grid = (N, D, H, W) of the GEMM rows; defaults to x0's grid."""
@@ -74,7 +96,11 @@ def conv_igemm(x0, w_packed, y0, *, ksize, Cin, Cout, grid=None, x1=None, bias=N
     if y1 is not None:
         y1 = _v(y1)
         d.y1, d.y1_ld, d.y1_mode = y1.ptr, y1.ld, y1_mode
-    check(lib.mis_conv_igemm(C.byref(d), stream_ptr()), "mis_conv_igemm")
+    taps = 1 if ksize == 1 else (27 if d.D > 1 else 9)
+    key = ("conv_igemm", "bf16" if d.dtype == MIS_BF16 else "f32", f"k{ksize}", "3d" if d.D > 1 else "2d",
+           "bn128" if Cout % 128 == 0 else "bn64")
+    with _Timed(key, 2.0 * d.N * d.D * d.H * d.W * taps * Cin * Cout):
+        check(lib.mis_conv_igemm(C.byref(d), stream_ptr()), "mis_conv_igemm")
 
 
 _ws_cache = {}
@@ -115,7 +141,10 @@ def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alph
         check(-1, "mis_wgrad_workspace_bytes")
     ws = workspace(need, dy.t.device, "wgrad")
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-    check(lib.mis_wgrad(C.byref(d), stream_ptr()), "mis_wgrad")
+    taps = 1 if ksize == 1 else (27 if d.D > 1 else 9)
+    key = ("wgrad", "bf16" if d.dtype == MIS_BF16 else "f32", f"k{ksize}", "3d" if d.D > 1 else "2d", "")
+    with _Timed(key, 2.0 * d.N * d.D * d.H * d.W * taps * Cin * Cout):
+        check(lib.mis_wgrad(C.byref(d), stream_ptr()), "mis_wgrad")
 
 
 def first_conv_fwd(x_nchw, w, bias, y):

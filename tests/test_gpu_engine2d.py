@@ -41,7 +41,9 @@ def test_fp32_engine_matches_reference_goldens(tag, cin, cout):
     names = [str(n) for n in g["names"]]
     # same seed => same parameters as the reference's `torch.manual_seed(0); UNet(cin, cout)`
     ps = np.stack([stat(eng.P[n]) for n in names])
-    assert np.array_equal(ps, g["param_stats"]), "seeded init differs from the reference"
+    # sampled values bit-identical; the double sums only up to summation order (thread count differs per box)
+    assert np.array_equal(ps[:, 3:], g["param_stats"][:, 3:]), "seeded init differs from the reference"
+    assert np.allclose(ps[:, :3], g["param_stats"][:, :3], rtol=1e-10, atol=1e-10), "seeded init differs from the reference"
     images = T(g["images"]).to(DEV)
     labels = T(g["labels"]).to(DEV)
     loss, logits, am = eng.forward(images, labels, train=True)
