@@ -85,6 +85,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise MisError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(make -C mdeical_image_segmentation_amd/csrc). There is no CPU fallback.")
+    # torch ships its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7); it must be in the process
+    # BEFORE libmisamd.so is loaded so that both share ONE runtime (device pointers, streams).  Loading ours first
+    # binds it to /opt/rocm's copy and its launches then fail with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tl):
+        C.CDLL(tl, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     lib.mis_last_error.restype = C.c_char_p
     lib.mis_version.restype = C.c_int
