@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="print a per-layer table of the MFMA kernels to stderr")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,8 +128,13 @@ def main():
         flop_img = FLOP_PER_IMAGE_512 * (args.size / 512.0) ** 2
         out["model_tflops"] = round(value * flop_img / 1e12, 1)
         if prof:
-            agg = {}
+            agg, layers = {}, {}
             for key, flops, e0, e1 in prof:
+                la = layers.setdefault(key, [0.0, 0.0, 0])
+                la[0] += flops
+                la[1] += e0.elapsed_time(e1) * 1e-3
+                la[2] += 1
+                key = key[:5]
                 a = agg.setdefault(key, [0.0, 0.0, 0])
                 a[0] += flops
                 a[1] += e0.elapsed_time(e1) * 1e-3
@@ -145,6 +151,10 @@ def main():
                                                              "launches_per_step": v[2] // args.steps}
                               for key, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
             out["mfma_kernel_ms_per_step"] = round(sum(v[1] for v in agg.values()) / args.steps * 1e3, 3)
+        if prof and args.layers:
+            for key, v in sorted(layers.items(), key=lambda kv: -kv[1][1]):
+                print(f"{v[1] / args.steps * 1e3:8.3f} ms/step {v[0] / v[1] / 1e12:7.1f} TF/s x{v[2] // args.steps}  {' '.join(k for k in key if k)}",
+                      file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             cb, cs = 2, 512
             v, sdt = cpu_baseline(cb, cs)

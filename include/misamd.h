@@ -86,6 +86,7 @@ typedef struct MisWgradDesc {
     float* dw;               /* output, fp32 */
     int dw_layout;           /* 0: [Cout][Cin][taps] (nn.Conv weight), 1: [Cin][Cq][4] with dy column = ab*Cq + c (nn.ConvTranspose2d k2) */
     float alpha;             /* dw = alpha * sum */
+    float* dbias;            /* optional: bias gradient = alpha * column sums of dy ([Cout], or [Cout/4] folded over (a,b) for layout 1) */
 } MisWgradDesc;
 size_t mis_wgrad_workspace_bytes(const MisWgradDesc* d);
 int mis_wgrad(const MisWgradDesc* d, void* stream);
@@ -129,7 +130,7 @@ typedef struct MisHeadDesc {
     float* logits;           /* [N][C][spatial] fp32 (reference layout), may be NULL */
     uint8_t* argmax;         /* [N][spatial] or NULL (C == 1: logits > 0) */
     float* workspace; size_t workspace_bytes;
-    float* loss_out;         /* [1] (+ [1 + 3*C] dice sums for loss 2) */
+    float* loss_out;         /* [1]; for loss 2: [2 + 3*C] = loss, bce mean, then the per-class sums I_c, P_c, T_c */
     /* backward (all NULL for forward only) */
     void* dy; int dy_ld;     /* dL/dfeatures * (y > 0) */
     float* dw; float* db;

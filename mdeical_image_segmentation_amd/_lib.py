@@ -55,6 +55,7 @@ class WgradDesc(C.Structure):
         ("dy", C.c_void_p), ("dy_ld", C.c_int),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("dw", C.c_void_p), ("dw_layout", C.c_int), ("alpha", C.c_float),
+        ("dbias", C.c_void_p),
     ]
 
 

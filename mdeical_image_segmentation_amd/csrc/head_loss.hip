@@ -226,17 +226,20 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
     for (int i = tid; i < NP; i += 256) out[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
 }
 
-// Final reduction over block partials (fixed order).  mode 0: PASS-0 results (loss / sums / grads), mode 1: pass-1 grads only.
-__global__ void head_reduce_kernel(const float* __restrict__ partial, int nblocks, int C, int loss, int mode, long long total, float alpha,
-                                   float beta, float* __restrict__ dw, float* __restrict__ db, float* __restrict__ loss_out) {
-    const int NP = C * 64 + C + 1 + 3 * C;
-    __shared__ double acc[HEAD_PSTRIDE];
-    for (int i = threadIdx.x; i < NP; i += blockDim.x) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += (double)partial[(size_t)b * HEAD_PSTRIDE + i];
-        acc[i] = s;
-    }
-    __syncthreads();
+// Final reduction over block partials (fixed order), two tiny kernels: (1) one wave per partial column -> double sums
+// in the workspace tail; (2) finalisation: grads, loss (mode 0: PASS-0 results, mode 1: BCE+Dice gradient pass).
+__global__ __launch_bounds__(256) void head_colreduce_kernel(const float* __restrict__ partial, int nblocks, int NP, double* __restrict__ sums) {
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (col >= NP) return;
+    double s = 0.0;
+    for (int b = lane; b < nblocks; b += 64) s += (double)partial[(size_t)b * HEAD_PSTRIDE + col];
+    s = wave_sum_d(s);
+    if (lane == 0) sums[col] = s;
+}
+
+__global__ void head_finalize_kernel(const double* __restrict__ acc, int C, int loss, int mode, long long total, float alpha, float beta,
+                                     float* __restrict__ dw, float* __restrict__ db, float* __restrict__ loss_out) {
     const bool write_grads = (mode == 1) || (loss == 0 || loss == 1);
     if (write_grads && dw != nullptr) {
         for (int i = threadIdx.x; i < C * 64; i += blockDim.x) dw[i] = (float)acc[i];
@@ -265,9 +268,20 @@ __global__ void head_reduce_kernel(const float* __restrict__ partial, int nblock
     }
 }
 
+static int head_reduce(const MisHeadDesc* d, int blocks, int C, int mode, long long total, hipStream_t s) {
+    const int NP = C * 64 + C + 1 + 3 * C;
+    double* sums = reinterpret_cast<double*>(d->workspace + (size_t)HEAD_BLOCKS * HEAD_PSTRIDE);
+    hipLaunchKernelGGL(head_colreduce_kernel, dim3((NP + 3) / 4), dim3(256), 0, s, (const float*)d->workspace, blocks, NP, sums);
+    MIS_LAUNCH_CHECK("head_colreduce");
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, s, (const double*)sums, C, d->loss, mode, total, d->alpha, d->beta, d->dw,
+                       d->db, d->loss_out);
+    MIS_LAUNCH_CHECK("head_finalize");
+    return MIS_OK;
+}
+
 extern "C" size_t mis_head_workspace_bytes(const MisHeadDesc* d) {
     (void)d;
-    return (size_t)HEAD_BLOCKS * HEAD_PSTRIDE * sizeof(float);
+    return (size_t)HEAD_BLOCKS * HEAD_PSTRIDE * sizeof(float) + HEAD_PSTRIDE * sizeof(double);
 }
 
 template <typename T, int C, int LOSS, int PASS> static void head_launch(const HeadArgs& a, unsigned blocks, hipStream_t s) {
@@ -288,16 +302,16 @@ template <typename T, int C> static int head_dispatch(const MisHeadDesc* d, Head
         default: MIS_REQUIRE(false, MIS_EINVAL, "head: loss %d", d->loss);
     }
     MIS_LAUNCH_CHECK("head");
-    hipLaunchKernelGGL(head_reduce_kernel, dim3(1), dim3(256), 0, s, (const float*)d->workspace, (int)blocks, C, d->loss, 0, total, d->alpha,
-                       d->beta, d->dw, d->db, d->loss_out);
-    MIS_LAUNCH_CHECK("head_reduce");
+    {
+        const int rc = head_reduce(d, (int)blocks, C, 0, total, s);
+        if (rc != MIS_OK) return rc;
+    }
     if (d->loss == 2 && train) {
         a.sums = d->loss_out + 1;   // [bce, I_c.., P_c.., T_c..]
         head_launch<T, C, 2, 1>(a, blocks, s);
         MIS_LAUNCH_CHECK("head_pass1");
-        hipLaunchKernelGGL(head_reduce_kernel, dim3(1), dim3(256), 0, s, (const float*)d->workspace, (int)blocks, C, d->loss, 1, total, d->alpha,
-                           d->beta, d->dw, d->db, d->loss_out);
-        MIS_LAUNCH_CHECK("head_reduce1");
+        const int rc = head_reduce(d, (int)blocks, C, 1, total, s);
+        if (rc != MIS_OK) return rc;
     }
     return MIS_OK;
 }

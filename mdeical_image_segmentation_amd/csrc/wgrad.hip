@@ -28,6 +28,7 @@ struct WgArgs {
     const void* dy;
     int dy_ld;
     float* partial;
+    float* bias_partial;   // [nsplit][Cout] column sums of dy (bias gradient), or nullptr
     int tilesD, tilesH, tilesW, ntiles, nsplit, tps;
     int nCi, nCo, KDn, TT;
 };
@@ -193,6 +194,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
 #pragma unroll
             for (int fj = 0; fj < FR; ++fj) acc[t][fi][fj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const bool do_bias = (a.bias_partial != nullptr) && (ci_t == 0) && (kd == 0);
+    float bsum = 0.f;
+    const int bco = tid % CT, bpart = tid / CT;           // CT columns x (256/CT) pixel groups
+    constexpr int BPIX = G::M / (256 / CT);               // pixels per group
+
     const int t_begin = split * a.tps;
     int t_end = t_begin + a.tps;
     if (t_end > a.ntiles) t_end = a.ntiles;
@@ -211,6 +217,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
         __syncthreads();   // previous tile's reads are done
         wg_stage<T, G>(lds_p, lds_q, a, n, d0, h0, w0, kd, ci0, co0, tid);
         __syncthreads();
+
+        if (do_bias) {
+#pragma unroll 8
+            for (int i = 0; i < BPIX; ++i) bsum += ld_elem<T>(reinterpret_cast<const T*>(lds_q + (bpart * BPIX + i) * PSTR) + bco);
+        }
 
         if constexpr (BF) {
             const int q = li >> 2, pp = li & 3;
@@ -277,6 +288,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
         }
     }
 
+    if (do_bias) {   // block-uniform
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < CT) {
+            float s = 0.f;
+            for (int k = 0; k < 256 / CT; ++k) s += red[k * CT + tid];
+            a.bias_partial[(size_t)split * a.Cout + co0 + tid] = s;
+        }
+    }
+
     // ---- write this block's partial slab: partial[split][kd*TAPS2 + tap][ci][co] ----
     float* out = a.partial + (size_t)split * a.TT * a.Cin * a.Cout;
 #pragma unroll
@@ -296,26 +319,82 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int TT, int Cin, int Cout, float* __restrict__ dw,
-                                    int layout, float alpha) {
-    const size_t total = (size_t)TT * Cin * Cout;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int co = (int)(idx % Cout);
-        const size_t r = idx / Cout;
-        const int ci = (int)(r % Cin);
-        const int tap = (int)(r / Cin);
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * total + idx];
-        size_t o;
+// Sum the split-K slabs in a fixed order and convert [tap][ci][co] -> the reference layout.  A block owns a
+// (32 co x 32 ci) tile for up to 9 taps at a time: slab reads are contiguous along co, dw writes are contiguous
+// along (ci, tap) for layout 0 / (c, ab) for layout 1, via an LDS transpose.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int TT, int Cin, int Cout,
+                                                           float* __restrict__ dw, int layout, float alpha) {
+    __shared__ float tile[9][32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
+    const size_t slab = (size_t)TT * Cin * Cout;
+    for (int t0 = 0; t0 < TT; t0 += 9) {
+        const int nt = (TT - t0) < 9 ? (TT - t0) : 9;
+        __syncthreads();
+        for (int t = 0; t < nt; ++t)
+            for (int r = ty; r < 32; r += 8) {
+                const int ci = ci0 + r, co = co0 + tx;
+                float s = 0.f;
+                if (ci < Cin && co < Cout) {
+                    const float* src = partial + ((size_t)(t0 + t) * Cin + ci) * Cout + co;
+                    for (int k = 0; k < nsplit; ++k) s += src[(size_t)k * slab];
+                }
+                tile[t][r][tx] = s * alpha;
+            }
+        __syncthreads();
         if (layout == 0) {
-            o = ((size_t)co * Cin + ci) * TT + tap;
+            // dw[co][ci][tap]: for one co, (ci, tap) is contiguous: 32*nt floats per co row of this tile
+            for (int r = ty; r < 32; r += 8) {
+                const int co = co0 + r;
+                if (co >= Cout) continue;
+                for (int e = tx; e < 32 * nt; e += 32) {
+                    const int cil = e / nt, t = e - cil * nt;
+                    if (ci0 + cil < Cin) dw[((size_t)co * Cin + ci0 + cil) * TT + t0 + t] = tile[t][cil][r];
+                }
+            }
         } else {
+            // dy column = ab*Cq + c -> dw[ci][c][ab]  (TT == 1)
             const int cq = Cout >> 2;
-            const int ab = co / cq, c = co - ab * cq;
-            o = ((size_t)ci * cq + c) * 4 + ab;
+            for (int r = ty; r < 32; r += 8) {
+                const int ci = ci0 + r, co = co0 + tx;
+                if (ci < Cin && co < Cout) {
+                    const int ab = co / cq, c = co - ab * cq;
+                    dw[((size_t)ci * cq + c) * 4 + ab] = tile[0][r][tx];
+                }
+            }
         }
-        dw[o] = alpha * s;
     }
+}
+
+// Stage 0 of the slab reduction when there are many splits: slab z <- sum of slabs {z, z+Z, z+2Z, ...} (in place,
+// element-wise, float4, fixed order), so that the transposing kernel below only has Z <= 16 slabs left to add.
+__global__ __launch_bounds__(256) void wgrad_prereduce_kernel(float* __restrict__ partial, int nsplit, int Z, size_t E4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int z = blockIdx.y;
+    if (i >= E4) return;
+    float4* p4 = reinterpret_cast<float4*>(partial);
+    float4 s = p4[(size_t)z * E4 + i];
+    for (int k = z + Z; k < nsplit; k += Z) {
+        const float4 v = p4[(size_t)k * E4 + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    p4[(size_t)z * E4 + i] = s;
+}
+
+// db[c] = alpha * sum over splits (and over the 4 (a,b) column groups for the transposed conv); one wave per output
+__global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ bp, int nsplit, int Cout, int fold, float alpha,
+                                                                float* __restrict__ db) {
+    const int cq = Cout / fold;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= cq) return;
+    float s = 0.f;
+    for (int i = lane; i < nsplit * fold; i += 64) {
+        const int k = i / fold, f = i - k * fold;
+        s += bp[(size_t)k * Cout + f * cq + c];
+    }
+    s = wave_sum(s);
+    if (lane == 0) db[c] = alpha * s;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -359,7 +438,7 @@ static int wg_plan(const MisWgradDesc* d, WgPlan* p) {
 extern "C" size_t mis_wgrad_workspace_bytes(const MisWgradDesc* d) {
     WgPlan p;
     if (wg_plan(d, &p) != MIS_OK) return 0;
-    return (size_t)p.nsplit * p.TT * d->Cin * d->Cout * sizeof(float);
+    return ((size_t)p.nsplit * p.TT * d->Cin * d->Cout + (size_t)p.nsplit * d->Cout) * sizeof(float);
 }
 
 template <typename T, typename G, bool USE_TR>
@@ -370,6 +449,7 @@ static int wg_launch(const MisWgradDesc* d, const WgPlan& p, hipStream_t stream)
     a.x1 = WSrc{d->x1, d->x1_ld, d->x1_D, d->x1_H, d->x1_W};
     a.in_scale = d->in_scale; a.in_shift = d->in_shift;
     a.dy = d->dy; a.dy_ld = d->dy_ld; a.partial = d->workspace;
+    a.bias_partial = d->dbias != nullptr ? d->workspace + (size_t)p.nsplit * p.TT * d->Cin * d->Cout : nullptr;
     a.tilesD = p.tilesD; a.tilesH = p.tilesH; a.tilesW = p.tilesW; a.ntiles = p.ntiles; a.nsplit = p.nsplit; a.tps = p.tps;
     a.nCi = p.nCi; a.nCo = p.nCo; a.KDn = p.KDn; a.TT = p.TT;
     const size_t lds = (size_t)(G::PHP + G::M) * PSTR;
@@ -383,12 +463,24 @@ static int wg_launch(const MisWgradDesc* d, const WgPlan& p, hipStream_t stream)
     MIS_REQUIRE(grid < (1ll << 31), MIS_EUNSUPPORTED, "wgrad: grid too large");
     hipLaunchKernelGGL((wgrad_kernel<T, G, USE_TR>), dim3((unsigned)grid), dim3(256), lds, stream, a);
     MIS_LAUNCH_CHECK("wgrad");
-    const size_t total = (size_t)p.TT * d->Cin * d->Cout;
-    unsigned rb = (unsigned)((total + 255) / 256);
-    if (rb > 8192) rb = 8192;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, (const float*)d->workspace, p.nsplit, p.TT, d->Cin,
-                       d->Cout, d->dw, d->dw_layout, d->alpha);
+    int nslab = p.nsplit;
+    const size_t E = (size_t)p.TT * d->Cin * d->Cout;     // multiple of 4 (channel tiles are multiples of 32)
+    if (nslab > 16) {
+        const int Z = 16;
+        hipLaunchKernelGGL(wgrad_prereduce_kernel, dim3((unsigned)((E / 4 + 255) / 256), Z), dim3(256), 0, stream, d->workspace, nslab, Z,
+                           E / 4);
+        MIS_LAUNCH_CHECK("wgrad_prereduce");
+        nslab = Z;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((d->Cout + 31) / 32, (d->Cin + 31) / 32), dim3(256), 0, stream,
+                       (const float*)d->workspace, nslab, p.TT, d->Cin, d->Cout, d->dw, d->dw_layout, d->alpha);
     MIS_LAUNCH_CHECK("wgrad_reduce");
+    if (d->dbias != nullptr) {
+        const int fold = d->dw_layout == 1 ? 4 : 1;
+        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((d->Cout / fold + 3) / 4), dim3(256), 0, stream,
+                           (const float*)a.bias_partial, p.nsplit, d->Cout, fold, d->alpha, d->dbias);
+        MIS_LAUNCH_CHECK("wgrad_bias_reduce");
+    }
     return MIS_OK;
 }
 

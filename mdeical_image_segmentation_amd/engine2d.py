@@ -257,8 +257,7 @@ class UNet2DEngine:
     # ---- backward --------------------------------------------------------------------------------------
     def _bwd_conv(self, x, dy, name, cin, cout, dx=None, mask=None, dx1=None, cout0=None, dx_mode=OUT_PLAIN):
         """grads of y = relu(conv3x3(x) + b) given dy = dL/d(pre-activation)."""
-        ops.wgrad(x, dy, self.G[name + ".weight"], ksize=3, Cin=cin, Cout=cout)
-        ops.colsum(dy, self.G[name + ".bias"])
+        ops.wgrad(x, dy, self.G[name + ".weight"], ksize=3, Cin=cin, Cout=cout, dbias=self.G[name + ".bias"])
         if dx is not None:
             ops.conv_igemm(dy, self.wd_[name], dx, ksize=3, Cin=cout, Cout=cin, mask=mask, y0_mode=dx_mode, y1=dx1,
                            Cout0=cout0)
@@ -280,8 +279,8 @@ class UNet2DEngine:
             self._bwd_conv(self.cat[l], self.g_u1[j], f"up_conv.{j}.first", 2 * c, c, dx=self.dys[j], dx1=self.g_skip[l],
                            cout0=c, dx_mode=OUT_UNSHUFFLE2)
             up = f"up_sample.{j}.up"
-            ops.wgrad(x_in, self.dys[j], self.G[up + ".weight"], ksize=1, Cin=2 * c, Cout=4 * c, dw_layout=1)
-            ops.colsum(self.dys[j], self.G[up + ".bias"], fold=4)
+            ops.wgrad(x_in, self.dys[j], self.G[up + ".weight"], ksize=1, Cin=2 * c, Cout=4 * c, dw_layout=1,
+                      dbias=self.G[up + ".bias"])
             ops.conv_igemm(self.dys[j], self.wd_[up], g_in, ksize=1, Cin=4 * c, Cout=2 * c, mask=x_in)
             cb([f"up_conv.{j}", f"up_sample.{j}"])
         self._bwd_conv(self.m1, self.g_m2, "middle_conv.second", 1024, 1024, dx=self.g_m1, mask=self.m1)

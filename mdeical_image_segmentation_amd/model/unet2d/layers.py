@@ -1,0 +1,203 @@
+"""Mirror of the reference's 2-D building blocks (model/unet2d/layers.py:103-192) on the HIP kernels.
+
+Each module keeps stock parameter containers (nn.Conv2d / nn.ConvTranspose2d: identical state-dict keys and
+shapes) but its forward/backward run through libmisamd: NCHW fp32 at the module boundary, NHWC inside.
+The fused whole-network path (engine2d.UNet2DEngine, used by UNet / UNetModel) does not go through these
+per-layer functions; they exist so that the blocks remain usable on their own.
+CUDA tensors only - there is no CPU fallback."""
+import torch
+from torch import nn
+
+from ... import ops
+from ..._lib import MisError
+
+__all__ = ["DoubleConvolution", "DownSample", "UpSample", "CropAndConcat", "unetConv2", "unetUp", "unetUp_origin"]
+
+
+def _compute_dtype():
+    import os
+    return torch.bfloat16 if os.environ.get("MISAMD_DTYPE", "f32").lower() in ("bf16", "bfloat16") else torch.float32
+
+
+def _need_cuda(x):
+    if x.device.type != "cuda":
+        raise MisError("mdeical_image_segmentation_amd runs on MI355X only: got a tensor on %s (no CPU fallback)" % x.device)
+
+
+def _to_nhwc(x, dtype):
+    N, C, H, W = x.shape
+    y = torch.empty(N, H, W, C, dtype=dtype, device=x.device)
+    ops.nchw_to_nhwc(x.contiguous().float(), y)
+    return y
+
+
+def _to_nchw(y):
+    N, H, W, C = y.shape
+    x = torch.empty(N, C, H, W, dtype=torch.float32, device=y.device)
+    ops.nhwc_to_nchw(y, x)
+    return x
+
+
+class _Conv3x3ReLU(torch.autograd.Function):
+    """y = relu(conv2d(x, w, b, padding=1)) - reference layers.py:122-126."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _need_cuda(x)
+        dt = _compute_dtype()
+        N, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        y = torch.empty(N, H, W, Cout, dtype=dt, device=x.device)
+        if Cin <= 4:
+            xin = x.contiguous().float()
+            ops.first_conv_fwd(xin, w.detach().contiguous(), b.detach(), y)
+            wd = None
+        else:
+            xin = _to_nhwc(x, dt)
+            wf = torch.empty(9, Cout, Cin, dtype=dt, device=x.device)
+            wd = torch.empty(9, Cin, Cout, dtype=dt, device=x.device)
+            ops.pack_conv_weight(w.detach().contiguous(), wf, wd)
+            ops.conv_igemm(xin, wf, y, ksize=3, Cin=Cin, Cout=Cout, bias=b.detach(), relu=True)
+        ctx.save_for_backward(xin, y)
+        ctx.wd = wd
+        ctx.shape = (N, Cin, H, W, Cout)
+        return _to_nchw(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xin, y = ctx.saved_tensors
+        N, Cin, H, W, Cout = ctx.shape
+        dt = y.dtype
+        g = _to_nhwc(gy, dt)
+        # dL/d(pre-activation) = gy * (y > 0)
+        g = torch.where(y > 0, g, torch.zeros_like(g))
+        dw = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=gy.device)
+        db = torch.empty(Cout, dtype=torch.float32, device=gy.device)
+        if Cin <= 4:
+            ops.first_conv_wgrad(xin, g, dw, db)
+            return None, dw, db
+        ops.wgrad(xin, g, dw, ksize=3, Cin=Cin, Cout=Cout)
+        ops.colsum(g, db)
+        dx = torch.empty(N, H, W, Cin, dtype=dt, device=gy.device)
+        ops.conv_igemm(g, ctx.wd, dx, ksize=3, Cin=Cout, Cout=Cin)
+        return _to_nchw(dx), dw, db
+
+
+class _MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        dt = _compute_dtype()
+        N, C, H, W = x.shape
+        xin = _to_nhwc(x, dt)
+        y = torch.empty(N, H // 2, W // 2, C, dtype=dt, device=x.device)
+        ops.maxpool2_fwd(xin, y)
+        ctx.save_for_backward(xin)
+        return _to_nchw(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (xin,) = ctx.saved_tensors
+        g = _to_nhwc(gy, xin.dtype)
+        dx = torch.empty_like(xin)
+        ops.maxpool2_bwd(xin, g, dx, add=None, relu_mask=False)
+        return _to_nchw(dx)
+
+
+class _ConvT2x2(torch.autograd.Function):
+    """y = conv_transpose2d(x, w, b, stride=2), w [Cin, Cout, 2, 2] - reference layers.py:165."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _need_cuda(x)
+        dt = _compute_dtype()
+        N, Cin, H, W = x.shape
+        Cq = w.shape[1]
+        xin = _to_nhwc(x, dt)
+        wf = torch.empty(4 * Cq, Cin, dtype=dt, device=x.device)
+        wd = torch.empty(Cin, 4 * Cq, dtype=dt, device=x.device)
+        ops.pack_convt_weight(w.detach().contiguous(), wf, wd)
+        y = torch.empty(N, 2 * H, 2 * W, Cq, dtype=dt, device=x.device)
+        ops.conv_igemm(xin, wf, y, ksize=1, Cin=Cin, Cout=4 * Cq, bias=b.detach(), y0_mode=ops.OUT_SHUFFLE2)
+        ctx.save_for_backward(xin)
+        ctx.wd = wd
+        ctx.shape = (N, Cin, H, W, Cq)
+        return _to_nchw(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (xin,) = ctx.saved_tensors
+        N, Cin, H, W, Cq = ctx.shape
+        dt = xin.dtype
+        # pixel-unshuffle the incoming gradient: (N, Cq, 2H, 2W) -> (N, H, W, 4*Cq) with column ab*Cq + c
+        g = gy.contiguous().float().view(N, Cq, H, 2, W, 2).permute(0, 2, 4, 3, 5, 1).reshape(N, H, W, 4 * Cq).to(dt).contiguous()
+        dw = torch.empty(Cin, Cq, 2, 2, dtype=torch.float32, device=gy.device)
+        db = torch.empty(Cq, dtype=torch.float32, device=gy.device)
+        ops.wgrad(xin, g, dw, ksize=1, Cin=Cin, Cout=4 * Cq, dw_layout=1)
+        ops.colsum(g, db, fold=4)
+        dx = torch.empty(N, H, W, Cin, dtype=dt, device=gy.device)
+        ops.conv_igemm(g, ctx.wd, dx, ksize=1, Cin=4 * Cq, Cout=Cin)
+        return _to_nchw(dx), dw, db
+
+
+class DoubleConvolution(nn.Module):
+    """Conv3x3(p1,bias) -> ReLU -> Conv3x3(p1,bias) -> ReLU, no norm (reference layers.py:103-133)."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.first = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1)
+        self.act1 = nn.ReLU()
+        self.second = nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1)
+        self.act2 = nn.ReLU()
+
+    def forward(self, x: torch.Tensor):
+        x = _Conv3x3ReLU.apply(x, self.first.weight, self.first.bias)
+        return _Conv3x3ReLU.apply(x, self.second.weight, self.second.bias)
+
+
+class DownSample(nn.Module):
+    """MaxPool2d(2) (reference layers.py:136-150)."""
+
+    def __init__(self):
+        super().__init__()
+        self.pool = nn.MaxPool2d(2)
+
+    def forward(self, x: torch.Tensor):
+        return _MaxPool2.apply(x)
+
+
+class UpSample(nn.Module):
+    """ConvTranspose2d(k2, s2) (reference layers.py:153-168)."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.up = nn.ConvTranspose2d(in_channels, out_channels, kernel_size=2, stride=2)
+
+    def forward(self, x: torch.Tensor):
+        return _ConvT2x2.apply(x, self.up.weight, self.up.bias)
+
+
+class CropAndConcat(nn.Module):
+    """center-crop the skip to x's size, cat([x, skip], 1): up-sampled channels first (reference layers.py:171-192).
+    Pure indexing (tensor plumbing); inside the fused engine it does not exist at all."""
+
+    def forward(self, x: torch.Tensor, contracting_x: torch.Tensor):
+        h, w = x.shape[2], x.shape[3]
+        H, W = contracting_x.shape[2], contracting_x.shape[3]
+        top = int(round((H - h) / 2.0))
+        left = int(round((W - w) / 2.0))
+        return torch.cat([x, contracting_x[:, :, top:top + h, left:left + w]], dim=1)
+
+
+def _out_of_scope(name, where):
+    class _Stub(nn.Module):
+        def __init__(self, *a, **k):
+            raise NotImplementedError(f"{name} ({where}) is outside the accelerated hot path (SURVEY.md §8f): "
+                                      "only the classic UNet is built")
+    _Stub.__name__ = name
+    return _Stub
+
+
+unetConv2 = _out_of_scope("unetConv2", "model/unet2d/layers.py:8-46")
+unetUp = _out_of_scope("unetUp", "model/unet2d/layers.py:49-74")
+unetUp_origin = _out_of_scope("unetUp_origin", "model/unet2d/layers.py:76-101")

@@ -1,0 +1,162 @@
+"""Mirror of the reference's model/unet2d/unet.py: `UNet` (:42-128) and the HuggingFace wrapper
+`UNetConfig` / `UNetModel` / `UNetModelOutput` (:1156-1213), executed by the fused MI355X engine.
+
+The nn.Module tree, parameter names and shapes are the reference's (stock nn.Conv2d / nn.ConvTranspose2d
+containers: checkpoints round-trip with the reference), but `UNet.forward` does not call the sub-modules: all 46
+parameters alias the engine's flat fp32 master buffer and one autograd.Function runs the whole network forward
+(and, in backward, the whole backward) through libmisamd.
+"""
+import os
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+from transformers import PretrainedConfig, PreTrainedModel
+from transformers.utils import ModelOutput
+
+from ... import ops
+from ..._lib import MisError
+from ...engine2d import UNet2DEngine
+from .layers import CropAndConcat, DoubleConvolution, DownSample, UpSample
+
+
+def _dtype_from(name):
+    name = (name or os.environ.get("MISAMD_DTYPE", "f32")).lower()
+    if name in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    if name in ("f32", "fp32", "float32"):
+        return torch.float32
+    raise MisError(f"compute dtype must be 'f32' or 'bf16', got {name!r}")
+
+
+class _FusedUNet(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, images, labels, owner, train, *params):
+        eng = owner._engine_for(images)
+        owner._sync_params_to_engine()
+        loss, logits, _ = eng.forward(images.contiguous().float(), labels, train=train)
+        ctx.owner = owner
+        ctx.train = train and labels is not None
+        out_loss = loss.clone().reshape(()) if loss is not None else images.new_zeros(())
+        return out_loss, logits.clone()
+
+    @staticmethod
+    def backward(ctx, g_loss, g_logits):
+        if not ctx.train:
+            raise MisError("backward through UNet needs labels (the loss is fused into the head kernel)")
+        owner = ctx.owner
+        eng = owner._engine
+        eng.backward()
+        grads = []
+        for name, p in owner.named_parameters():
+            grads.append(eng.G[name] * g_loss if p.requires_grad else None)
+        return (None, None, None, None, *grads)
+
+
+class UNet(nn.Module):
+    """Classic 4-level U-Net 64-128-256-512-1024 with a 1x1 head (reference unet.py:42-128)."""
+
+    def __init__(self, in_channels: int, out_channels: int, compute_dtype=None):
+        super().__init__()
+        self.down_conv = nn.ModuleList([DoubleConvolution(i, o) for i, o in [(in_channels, 64), (64, 128), (128, 256), (256, 512)]])
+        self.down_sample = nn.ModuleList([DownSample() for _ in range(4)])
+        self.middle_conv = DoubleConvolution(512, 1024)
+        self.up_sample = nn.ModuleList([UpSample(i, o) for i, o in [(1024, 512), (512, 256), (256, 128), (128, 64)]])
+        self.up_conv = nn.ModuleList([DoubleConvolution(i, o) for i, o in [(1024, 512), (512, 256), (256, 128), (128, 64)]])
+        self.concat = nn.ModuleList([CropAndConcat() for _ in range(4)])
+        self.final_conv = nn.Conv2d(64, out_channels, kernel_size=1)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self._compute_dtype = compute_dtype
+        self._engine = None
+
+    # ---- engine plumbing ----
+    def _engine_for(self, images):
+        if images.device.type != "cuda":
+            raise MisError(f"UNet runs on MI355X only: got input on {images.device} (no CPU fallback)")
+        if self._engine is None or self._engine.device != images.device:
+            eng = UNet2DEngine(self.in_channels, self.out_channels, dtype=_dtype_from(self._compute_dtype), device=images.device)
+            # alias every nn.Parameter onto the engine's flat fp32 master buffer
+            for name, p in self.named_parameters():
+                eng.P[name].copy_(p.detach().to(device=images.device, dtype=torch.float32))
+                p.data = eng.P[name]
+            self._engine = eng
+            self._versions = None
+        return self._engine
+
+    def _sync_params_to_engine(self):
+        eng = self._engine
+        vers = []
+        for name, p in self.named_parameters():
+            if p.data_ptr() != eng.P[name].data_ptr():          # e.g. after load_state_dict(assign=True) / .to()
+                eng.P[name].copy_(p.detach().to(torch.float32))
+                p.data = eng.P[name]
+            vers.append(p._version)
+        if vers != self._versions:                                # an optimizer (or a load) touched the weights
+            eng.repack()
+            self._versions = vers
+
+    def forward(self, images: torch.Tensor, labels: torch.Tensor = None, _train: bool = None):
+        train = self.training if _train is None else _train
+        loss, logits = _FusedUNet.apply(images, labels, self, train and labels is not None, *self.parameters())
+        if labels is None:
+            return logits
+        return logits, loss
+
+
+@dataclass
+class UNetModelOutput(ModelOutput):
+    loss: torch.FloatTensor = None
+    logits: torch.FloatTensor = None
+    labels: torch.LongTensor = None
+
+
+class UNetConfig(PretrainedConfig):
+    def __init__(self, in_channels=1, out_channels=1, unet_type="UNet", compute_dtype=None, **kwargs):
+        """unet_type: only "UNet" is accelerated (UNet_3Plus* are SURVEY.md §8f "next" rows).
+        compute_dtype: "f32" (default, the parity mode) or "bf16"; env MISAMD_DTYPE overrides the default."""
+        super().__init__(**kwargs)
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.unet_type = unet_type
+        self.compute_dtype = compute_dtype
+        self.label_names = "labels"
+        self.main_input_name = "images"
+        self.keys_to_ignore_at_inference = ["labels"]
+
+
+class UNetModel(PreTrainedModel):
+    config_class = UNetConfig
+    main_input_name = "images"
+    _no_split_modules = []
+
+    def __init__(self, config: UNetConfig):
+        super().__init__(config)
+        if config.unet_type == "UNet":
+            self.unet = UNet(config.in_channels, config.out_channels, compute_dtype=getattr(config, "compute_dtype", None))
+            # kept for interface parity (reference unet.py:1184-1188); the loss itself is computed in the head kernel
+            self.criterion = nn.CrossEntropyLoss() if config.out_channels > 1 else nn.BCEWithLogitsLoss()
+        else:
+            raise NotImplementedError(f"unet_type={config.unet_type!r}: only 'UNet' is built (UNet_3Plus* are out of the hot-path scope)")
+
+    def _init_weights(self, module):   # PyTorch default init already applied by the containers (as in the reference)
+        return
+
+    def forward(self, images: torch.Tensor, labels: torch.Tensor = None, **kwargs):
+        if labels is None:
+            logits = self.unet(images, None)
+            return UNetModelOutput(loss=None, logits=logits, labels=None)
+        logits, loss = self.unet(images, labels, _train=torch.is_grad_enabled())
+        return UNetModelOutput(loss=loss, logits=logits, labels=labels)
+
+
+def _stub(name):
+    class _S(nn.Module):
+        def __init__(self, *a, **k):
+            raise NotImplementedError(f"{name} is outside the accelerated hot path (SURVEY.md §8f3)")
+    _S.__name__ = name
+    return _S
+
+
+UNet_3Plus = _stub("UNet_3Plus")
+UNet_3Plus_DeepSup = _stub("UNet_3Plus_DeepSup")
+UNet_3Plus_DeepSup_CGM = _stub("UNet_3Plus_DeepSup_CGM")

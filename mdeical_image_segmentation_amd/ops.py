@@ -98,7 +98,7 @@ def conv_igemm(x0, w_packed, y0, *, ksize, Cin, Cout, grid=None, x1=None, bias=N
         d.y1, d.y1_ld, d.y1_mode = y1.ptr, y1.ld, y1_mode
     taps = 1 if ksize == 1 else (27 if d.D > 1 else 9)
     key = ("conv_igemm", "bf16" if d.dtype == MIS_BF16 else "f32", f"k{ksize}", "3d" if d.D > 1 else "2d",
-           "bn128" if Cout % 128 == 0 else "bn64")
+           "bn128" if Cout % 128 == 0 else "bn64", f"{d.N}x{d.D}x{d.H}x{d.W} {Cin}->{Cout}")
     with _Timed(key, 2.0 * d.N * d.D * d.H * d.W * taps * Cin * Cout):
         check(lib.mis_conv_igemm(C.byref(d), stream_ptr()), "mis_conv_igemm")
 
@@ -116,7 +116,7 @@ def workspace(nbytes, device, tag="default"):
     return buf
 
 
-def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alpha=1.0, in_scale=None, in_shift=None):
+def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alpha=1.0, in_scale=None, in_shift=None, dbias=None):
     lib = load()
     x0 = _v(x0)
     dy = _v(dy)
@@ -136,13 +136,15 @@ def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alph
     d.in_shift = None if in_shift is None else in_shift.data_ptr()
     d.dy, d.dy_ld = dy.ptr, dy.ld
     d.dw, d.dw_layout, d.alpha = dw.data_ptr(), dw_layout, alpha
+    d.dbias = None if dbias is None else dbias.data_ptr()
     need = lib.mis_wgrad_workspace_bytes(C.byref(d))
     if need == 0:
         check(-1, "mis_wgrad_workspace_bytes")
     ws = workspace(need, dy.t.device, "wgrad")
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     taps = 1 if ksize == 1 else (27 if d.D > 1 else 9)
-    key = ("wgrad", "bf16" if d.dtype == MIS_BF16 else "f32", f"k{ksize}", "3d" if d.D > 1 else "2d", "")
+    key = ("wgrad", "bf16" if d.dtype == MIS_BF16 else "f32", f"k{ksize}", "3d" if d.D > 1 else "2d", "",
+           f"{d.N}x{d.D}x{d.H}x{d.W} {Cin}->{Cout}")
     with _Timed(key, 2.0 * d.N * d.D * d.H * d.W * taps * Cin * Cout):
         check(lib.mis_wgrad(C.byref(d), stream_ptr()), "mis_wgrad")
 

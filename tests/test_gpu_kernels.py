@@ -174,7 +174,9 @@ def test_convtranspose_k2s2_fwd_dgrad_wgrad(dtype):
     ops.conv_igemm(dysd, wd, dx, ksize=1, Cin=4 * Cq, Cout=Cin, mask=xd)
     assert_close(from_nhwc(dx), xq.grad * (q(x, dtype) > 0), f"convT dgrad {dtype}", **tol(dtype, 4 * Cq))
     dw = torch.full((Cin, Cq, 2, 2), float("nan"), device=DEV)
-    ops.wgrad(xd, dysd, dw, ksize=1, Cin=Cin, Cout=4 * Cq, dw_layout=1)
+    dbf = torch.full((Cq,), float("nan"), device=DEV)
+    ops.wgrad(xd, dysd, dw, ksize=1, Cin=Cin, Cout=4 * Cq, dw_layout=1, dbias=dbf)
+    assert_close(dbf, bq.grad, f"convT bias grad fused {dtype}", rtol=1e-4, atol=1e-3)
     wt = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=5e-2)
     assert_close(dw, wq.grad, f"convT wgrad {dtype}", **wt)
     db = torch.full((Cq,), float("nan"), device=DEV)
@@ -198,7 +200,8 @@ def test_conv3x3_wgrad(case, dtype, no_tr):
     old = os.environ.get("MIS_WGRAD_NO_TR")
     os.environ["MIS_WGRAD_NO_TR"] = no_tr
     try:
-        ops.wgrad(to_nhwc(x, dtype), to_nhwc(dy, dtype), dw, ksize=3, Cin=Cin, Cout=Cout)
+        dbf = torch.full((Cout,), float("nan"), device=DEV)
+        ops.wgrad(to_nhwc(x, dtype), to_nhwc(dy, dtype), dw, ksize=3, Cin=Cin, Cout=Cout, dbias=dbf)
         torch.cuda.synchronize()
     finally:
         if old is None:
@@ -210,6 +213,7 @@ def test_conv3x3_wgrad(case, dtype, no_tr):
     db = torch.full((Cout,), float("nan"), device=DEV)
     ops.colsum(to_nhwc(dy, dtype), db)
     assert_close(db, q(dy, dtype).sum((0, 2, 3)), "bias grad", rtol=1e-4, atol=1e-3)
+    assert_close(dbf, q(dy, dtype).sum((0, 2, 3)), "bias grad fused in wgrad", rtol=1e-4, atol=1e-3)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
