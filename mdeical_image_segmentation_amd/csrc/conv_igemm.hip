@@ -13,6 +13,8 @@
 //           nn.Conv3d(k3,p1) after GroupNorm (model/unet3d/buildingblocks.py:64-66,87-92),
 //           nn.ConvTranspose2d(k2,s2) fwd / dgrad as a 1x1 GEMM + pixel (un)shuffle (layers.py:165),
 //           torch.cat / F.interpolate(nearest) as input addressing (layers.py:186-190, buildingblocks.py:546-548,671-673).
+#include <type_traits>
+
 #include "common.hpp"
 
 struct SrcView {
@@ -49,29 +51,27 @@ template <int TD_, int TH_, int TW_, int KS_, bool IS3D_> struct Geom {
     static constexpr int TAPS = KD * KS * KS;
 };
 
-// Stage the halo tile of one K chunk: global (16 B per item) -> registers -> swizzled LDS.  Out-of-bounds pixels are
-// zero (the conv's zero padding applies AFTER the optional per-(n,c) affine, exactly like GroupNorm -> Conv).
-template <typename T, typename G>
-__device__ __forceinline__ void stage_halo(char* halo, const ConvArgs& a, int n, int d0, int h0, int w0, int c0, int tid) {
-    constexpr int EPC = Tr<T>::EPC;
-    const bool first = c0 < a.Cin0;
-    const SrcView s = first ? a.x0 : a.x1;
-    const int cl = first ? c0 : c0 - a.Cin0;
-    const int shd = (s.D != a.D), shh = (s.H != a.H), shw = (s.W != a.W);   // exact 2x nearest-upsample addressing
-    const T* base = reinterpret_cast<const T*>(s.p) + (size_t)n * s.D * s.H * s.W * s.ld + cl;
-    constexpr int ITEMS = G::HP * 8;
-    constexpr int BATCH = 3;
-#pragma unroll 1
-    for (int it0 = 0; it0 < ITEMS; it0 += 256 * BATCH) {
-        u32x4 v[BATCH];
-        int lofs[BATCH];
-        bool ok[BATCH];
+// Halo tile of one K chunk: global (16 B per item) -> registers (load) ... -> swizzled LDS (store).  The two halves
+// are separate so that the global loads of chunk c+1 fly while the last tap of chunk c computes.  Out-of-bounds pixels
+// are zero (the conv's zero padding applies AFTER the optional per-(n,c) affine, exactly like GroupNorm -> Conv).
+template <typename T, typename G> struct HaloStager {
+    static constexpr int EPC = Tr<T>::EPC;
+    static constexpr int ITEMS = G::HP * 8;
+    static constexpr int HI = (ITEMS + 255) / 256;
+    u32x4 v[HI];
+    uint32_t okmask;
+
+    __device__ __forceinline__ void load(const ConvArgs& a, int n, int d0, int h0, int w0, int c0, int tid) {
+        const bool first = c0 < a.Cin0;
+        const SrcView s = first ? a.x0 : a.x1;
+        const int cl = first ? c0 : c0 - a.Cin0;
+        const int shd = (s.D != a.D), shh = (s.H != a.H), shw = (s.W != a.W);   // exact 2x nearest-upsample addressing
+        const T* base = reinterpret_cast<const T*>(s.p) + (size_t)n * s.D * s.H * s.W * s.ld + cl;
+        okmask = 0u;
 #pragma unroll
-        for (int b = 0; b < BATCH; ++b) {
-            const int it = it0 + b * 256 + tid;
+        for (int b = 0; b < HI; ++b) {
+            const int it = b * 256 + tid;
             v[b] = u32x4{0u, 0u, 0u, 0u};
-            lofs[b] = -1;
-            ok[b] = false;
             if (it < ITEMS) {
                 const int p = it >> 3, c16 = it & 7;
                 const int pz = p / (G::HH * G::HW);
@@ -79,35 +79,36 @@ __device__ __forceinline__ void stage_halo(char* halo, const ConvArgs& a, int n,
                 const int py = pr / G::HW;
                 const int px = pr - py * G::HW;
                 const int z = d0 + pz - G::PD, y = h0 + py - G::PAD, x = w0 + px - G::PAD;
-                lofs[b] = p * 128 + ((c16 ^ (p & 7)) << 4);
                 if (z >= 0 && z < a.D && y >= 0 && y < a.H && x >= 0 && x < a.W) {
                     const int off = (((z >> shd) * s.H + (y >> shh)) * s.W + (x >> shw)) * s.ld + c16 * EPC;
                     v[b] = *reinterpret_cast<const u32x4*>(base + off);
-                    ok[b] = true;
+                    okmask |= (1u << b);
                 }
             }
         }
-        if (a.in_scale != nullptr) {
+    }
+
+    __device__ __forceinline__ void store(char* halo, const ConvArgs& a, int n, int c0, int tid) {
 #pragma unroll
-            for (int b = 0; b < BATCH; ++b) {
-                if (ok[b]) {
-                    const int it = it0 + b * 256 + tid;
-                    const int c16 = it & 7;
+        for (int b = 0; b < HI; ++b) {
+            const int it = b * 256 + tid;
+            if (it < ITEMS) {
+                const int p = it >> 3, c16 = it & 7;
+                u32x4 val = v[b];
+                if (a.in_scale != nullptr && ((okmask >> b) & 1u)) {
                     const float* sc = a.in_scale + (size_t)n * a.Cin + c0 + c16 * EPC;
                     const float* sh = a.in_shift + (size_t)n * a.Cin + c0 + c16 * EPC;
                     float f[EPC];
-                    unpack_chunk<T>(v[b], f);
+                    unpack_chunk<T>(val, f);
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
-                    v[b] = pack_chunk<T>(f);
+                    val = pack_chunk<T>(f);
                 }
+                lds_write_b128(halo, p * 128 + ((c16 ^ (p & 7)) << 4), val);
             }
         }
-#pragma unroll
-        for (int b = 0; b < BATCH; ++b)
-            if (lofs[b] >= 0) lds_write_b128(halo, lofs[b], v[b]);
     }
-}
+};
 
 template <typename T, int NV>
 __device__ __forceinline__ void store_run(T* dst, const float* v) {
@@ -187,62 +188,74 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     u32x4 wreg[WI];
 #pragma unroll
     for (int k = 0; k < WI; ++k) wreg[k] = *reinterpret_cast<const u32x4*>(wp + w_goff[k]);
+    HaloStager<T, G> hs;
+    hs.load(a, n, d0, h0, w0, 0, tid);
+    hs.store(halo, a, n, 0, tid);
 
     const int nchunks = a.Cin / CK;
     int cur = 0;
+
+    // one tap: W regs -> LDS, barrier, issue the next global loads (kept ABOVE the MFMA cluster), MFMAs
+    auto tap_step = [&](int tap, int c0, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        char* wb = wbuf + cur * (BN * 128);
+#pragma unroll
+        for (int k = 0; k < WI; ++k) lds_write_b128(wb, w_loff[k], wreg[k]);
+        __syncthreads();
+        {
+            int ntap = tap + 1, nc0 = c0;
+            if (LAST) {
+                ntap = 0;
+                nc0 = c0 + CK;
+            }
+            if (nc0 >= a.Cin) {   // very last step: harmlessly re-load the current tiles (keeps the loads unconditional)
+                ntap = tap;
+                nc0 = c0;
+            }
+            const T* wsrc = wp + (size_t)ntap * tap_stride + nc0;
+#pragma unroll
+            for (int k = 0; k < WI; ++k) wreg[k] = *reinterpret_cast<const u32x4*>(wsrc + w_goff[k]);
+            if (LAST) hs.load(a, n, d0, h0, w0, nc0, tid);   // next chunk's halo flies under this tap's MFMAs
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int tapoff;
+        if constexpr (G::KS == 1) {
+            tapoff = 0;
+        } else {
+            const int kd = tap / (G::KS * G::KS);
+            const int kr = tap - kd * (G::KS * G::KS);
+            const int kh = kr / G::KS, kw = kr - kh * G::KS;
+            tapoff = (kd * G::HH + kh) * G::HW + kw;
+        }
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            u32x4 A[NF], B[4];
+            const int ch = kg * 4 + lg;
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+                A[f] = lds_read_b128(wb, (wn * WAVE_N + f * 16 + li) * 128 + ((ch ^ (li & 7)) << 4));
+#pragma unroll
+            for (int pf = 0; pf < 4; ++pf) {
+                const int p = hb[pf] + tapoff;
+                B[pf] = lds_read_b128(halo, p * 128 + ((ch ^ (p & 7)) << 4));
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int pf = 0; pf < 4; ++pf) mma_b128<T>(acc[f][pf], A[f], B[pf]);
+        }
+        cur ^= 1;
+    };
+
 #pragma unroll 1
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int c0 = chunk * CK;
-        __syncthreads();   // every wave is done with the previous chunk's halo
-        stage_halo<T, G>(halo, a, n, d0, h0, w0, c0, tid);
 #pragma unroll 1
-        for (int tap = 0; tap < G::TAPS; ++tap) {
-            char* wb = wbuf + cur * (BN * 128);
-#pragma unroll
-            for (int k = 0; k < WI; ++k) lds_write_b128(wb, w_loff[k], wreg[k]);
-            __syncthreads();
-            // prefetch the next weight tile while this tap computes
-            {
-                int ntap = tap + 1, nc0 = c0;
-                if (ntap == G::TAPS) {
-                    ntap = 0;
-                    nc0 = c0 + CK;
-                }
-                if (nc0 >= a.Cin) {   // last step: harmlessly re-load the current tile (keeps the loads unconditional)
-                    ntap = tap;
-                    nc0 = c0;
-                }
-                const T* wsrc = wp + (size_t)ntap * tap_stride + nc0;
-#pragma unroll
-                for (int k = 0; k < WI; ++k) wreg[k] = *reinterpret_cast<const u32x4*>(wsrc + w_goff[k]);
-            }
-            int tapoff;
-            if constexpr (G::KS == 1) {
-                tapoff = 0;
-            } else {
-                const int kd = tap / (G::KS * G::KS);
-                const int kr = tap - kd * (G::KS * G::KS);
-                const int kh = kr / G::KS, kw = kr - kh * G::KS;
-                tapoff = (kd * G::HH + kh) * G::HW + kw;
-            }
-#pragma unroll
-            for (int kg = 0; kg < 2; ++kg) {
-                u32x4 A[NF], B[4];
-                const int ch = kg * 4 + lg;
-#pragma unroll
-                for (int f = 0; f < NF; ++f)
-                    A[f] = lds_read_b128(wb, (wn * WAVE_N + f * 16 + li) * 128 + ((ch ^ (li & 7)) << 4));
-#pragma unroll
-                for (int pf = 0; pf < 4; ++pf) {
-                    const int p = hb[pf] + tapoff;
-                    B[pf] = lds_read_b128(halo, p * 128 + ((ch ^ (p & 7)) << 4));
-                }
-#pragma unroll
-                for (int f = 0; f < NF; ++f)
-#pragma unroll
-                    for (int pf = 0; pf < 4; ++pf) mma_b128<T>(acc[f][pf], A[f], B[pf]);
-            }
-            cur ^= 1;
+        for (int tap = 0; tap < G::TAPS - 1; ++tap) tap_step(tap, c0, std::false_type{});
+        tap_step(G::TAPS - 1, c0, std::true_type{});
+        if (chunk + 1 < nchunks) {
+            __syncthreads();   // every wave is done reading this chunk's halo
+            hs.store(halo, a, n, c0 + CK, tid);
         }
     }
 
