@@ -48,6 +48,7 @@ typedef struct MisConvDesc {
     int dtype;               /* MIS_F32 | MIS_BF16 */
     int ksize;               /* 3 (3x3 or 3x3x3, pad 1, stride 1) or 1 */
     int N, D, H, W;          /* pixel grid walked by the GEMM rows (D = 1 for 2-D) */
+    int is3d;                /* 1: volumetric op (3x3x3 taps for ksize 3) even when D == 1; 0: 2-D (D must be 1) */
     int Cin, Cout;           /* per-tap K and GEMM N; both multiples of the K chunk (64 bf16 / 32 f32) resp. 64 */
     /* input: channels [0,Cin0) from x0, [Cin0,Cin) from x1 (x1 may be NULL when Cin0 == Cin).
      * A source whose grid is exactly half of (D,H,W) along an axis is read with nearest addressing src = dst >> 1
@@ -76,6 +77,7 @@ typedef struct MisWgradDesc {
     int dtype;
     int ksize;               /* 3 or 1 */
     int N, D, H, W;
+    int is3d;                /* as in MisConvDesc */
     int Cin, Cout;           /* x channels, dy channels */
     const void* x0; int x0_ld; int x0_D, x0_H, x0_W;
     const void* x1; int x1_ld; int x1_D, x1_H, x1_W;
@@ -152,6 +154,30 @@ int mis_sumsq_npartials(long long n);
 size_t mis_chanstats_workspace_bytes(int N, long long npix, int C);
 int mis_chanstats(int dtype, const void* x, int ld, int N, long long npix, int C, float* workspace, float* sum, float* sumsq,
                   void* stream);
+
+/* GroupNorm folded around the 3-D convolutions (model/unet3d/buildingblocks.py:81-92, eps 1e-5).
+ * fwd: per-channel sums (mis_chanstats) of up to two sources (encoder features | nearest-upsampled features, mult 8)
+ *      -> per (n,c) scale/shift consumed by mis_conv_igemm / mis_wgrad (in_scale / in_shift), + mean/rstd per (n,g). */
+int mis_gn_fwd_finalize(const float* sum0, const float* sq0, int C0, float mult0, const float* sum1, const float* sq1, int C1, float mult1,
+                        int N, int G, double count, const float* gamma, const float* beta, float eps, int Cpad, float* scale, float* shift,
+                        float* mean, float* rstd, void* stream);
+/* bwd: S1 = sum dy, S2 = sum dy*x for one source (up != 0: source on the half grid, dy summed over the 8 children) */
+size_t mis_gn_bwd_stats_workspace_bytes(int N, int Cs);
+int mis_gn_bwd_stats(int dtype, const void* dy, int dy_ld, const void* x, int x_ld, int Cs, int up, int N, int D, int H, int W,
+                     float* workspace, float* S1, float* S2, int Ctot, int c_off, void* stream);
+int mis_gn_bwd_finalize(const float* S1, const float* S2, const float* mean, const float* rstd, const float* gamma, int N, int C, int G,
+                        double count, float* p, float* q, float* r, float* dgamma, float* dbeta, void* stream);
+/* dx = (p*sum_children(dy) + mult*(q*x + r)) [* (x > 0)] [+ add] for one source */
+int mis_gn_bwd_apply(int dtype, const void* dy, int dy_ld, const void* x, int x_ld, int Cs, int up, int N, int D, int H, int W, const float* p,
+                     const float* q, const float* r, int Ctot, int c_off, int relu_mask, const void* add, int add_ld, void* dx, int dx_ld,
+                     void* stream);
+/* first 3-D layer: fp32 single-channel volume, GroupNorm(1) affine per sample, Conv3d 1 -> Cout (<= 64) k3 p1, ReLU */
+int mis_first3d_fwd(int dtype, const float* x, const float* scale, const float* shift, int sstride, int N, int D, int H, int W, const float* w,
+                    int Cout, void* y, int y_ld, int Cpad, void* stream);
+size_t mis_first3d_bwd_workspace_bytes(void);
+int mis_first3d_bwd(int dtype, const float* x, const float* scale, const float* shift, int sstride, int N, int D, int H, int W, const void* dy,
+                    int dy_ld, int Cpad, const float* w, int Cout, float* workspace, float* dw, float* dxn, void* stream);
+int mis_relu_mask(int dtype, const void* dy, int dy_ld, const void* y, int y_ld, void* dx, int dx_ld, long long npix, int C, void* stream);
 
 /* layout helpers */
 int mis_nchw_to_nhwc(int dtype_out, const float* x, void* y, int y_ld, int N, int C, long long spatial, void* stream);

@@ -19,6 +19,8 @@ EXPORTS = [
     "mis_pack_conv_weight", "mis_pack_convt_weight", "mis_head_workspace_bytes", "mis_head_loss",
     "mis_adamw_workspace_bytes", "mis_sumsq", "mis_adamw_step", "mis_sumsq_npartials",
     "mis_chanstats_workspace_bytes", "mis_chanstats", "mis_nchw_to_nhwc", "mis_nhwc_to_nchw", "mis_probe_mfma",
+    "mis_gn_fwd_finalize", "mis_gn_bwd_stats_workspace_bytes", "mis_gn_bwd_stats", "mis_gn_bwd_finalize", "mis_gn_bwd_apply",
+    "mis_first3d_fwd", "mis_first3d_bwd_workspace_bytes", "mis_first3d_bwd", "mis_relu_mask",
 ]
 
 
@@ -29,7 +31,7 @@ class MisError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [
         ("dtype", C.c_int), ("ksize", C.c_int),
-        ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int), ("is3d", C.c_int),
         ("Cin", C.c_int), ("Cout", C.c_int),
         ("x0", C.c_void_p), ("x0_ld", C.c_int), ("x0_D", C.c_int), ("x0_H", C.c_int), ("x0_W", C.c_int),
         ("x1", C.c_void_p), ("x1_ld", C.c_int), ("x1_D", C.c_int), ("x1_H", C.c_int), ("x1_W", C.c_int),
@@ -46,7 +48,7 @@ class ConvDesc(C.Structure):
 class WgradDesc(C.Structure):
     _fields_ = [
         ("dtype", C.c_int), ("ksize", C.c_int),
-        ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int), ("is3d", C.c_int),
         ("Cin", C.c_int), ("Cout", C.c_int),
         ("x0", C.c_void_p), ("x0_ld", C.c_int), ("x0_D", C.c_int), ("x0_H", C.c_int), ("x0_W", C.c_int),
         ("x1", C.c_void_p), ("x1_ld", C.c_int), ("x1_D", C.c_int), ("x1_H", C.c_int), ("x1_W", C.c_int),
@@ -110,7 +112,11 @@ def load():
     lib.mis_sumsq_npartials.restype = C.c_int
     lib.mis_sumsq_npartials.argtypes = [C.c_longlong]
 
-    vp, i, ll, f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+    lib.mis_gn_bwd_stats_workspace_bytes.restype = C.c_size_t
+    lib.mis_gn_bwd_stats_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    lib.mis_first3d_bwd_workspace_bytes.restype = C.c_size_t
+    lib.mis_first3d_bwd_workspace_bytes.argtypes = []
+    vp, i, ll, f, dbl = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double
     sigs = {
         "mis_conv_igemm": [vp, vp],
         "mis_wgrad": [vp, vp],
@@ -128,6 +134,13 @@ def load():
         "mis_nchw_to_nhwc": [i, vp, vp, i, i, i, ll, vp],
         "mis_nhwc_to_nchw": [i, vp, i, vp, i, i, ll, vp],
         "mis_probe_mfma": [i, vp, vp, vp, vp],
+        "mis_gn_fwd_finalize": [vp, vp, i, f, vp, vp, i, f, i, i, dbl, vp, vp, f, i, vp, vp, vp, vp, vp],
+        "mis_gn_bwd_stats": [i, vp, i, vp, i, i, i, i, i, i, i, vp, vp, vp, i, i, vp],
+        "mis_gn_bwd_finalize": [vp, vp, vp, vp, vp, i, i, i, dbl, vp, vp, vp, vp, vp, vp],
+        "mis_gn_bwd_apply": [i, vp, i, vp, i, i, i, i, i, i, i, vp, vp, vp, i, i, i, vp, i, vp, i, vp],
+        "mis_first3d_fwd": [i, vp, vp, vp, i, i, i, i, i, vp, i, vp, i, i, vp],
+        "mis_first3d_bwd": [i, vp, vp, vp, i, i, i, i, i, vp, i, i, vp, i, vp, vp, vp, vp],
+        "mis_relu_mask": [i, vp, i, vp, i, vp, i, ll, i, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

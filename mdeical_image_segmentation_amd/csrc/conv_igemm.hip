@@ -360,7 +360,7 @@ static int launch_cfg(const MisConvDesc* d, hipStream_t stream) {
 }
 
 template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
-    const bool is3d = d->D > 1;
+    const bool is3d = d->is3d != 0;
     const bool wide = (d->Cout % 128) == 0;
     if (d->ksize == 3) {
         if (!is3d) {
@@ -386,6 +386,7 @@ extern "C" int mis_conv_igemm(const MisConvDesc* d, void* stream) {
     const int EPC = d->dtype == MIS_BF16 ? 8 : 4;
     MIS_REQUIRE(d->ksize == 3 || d->ksize == 1, MIS_EUNSUPPORTED, "conv_igemm: ksize %d", d->ksize);
     MIS_REQUIRE(d->N > 0 && d->D > 0 && d->H > 0 && d->W > 0, MIS_EINVAL, "conv_igemm: empty grid");
+    MIS_REQUIRE(d->is3d || d->D == 1, MIS_EINVAL, "conv_igemm: D must be 1 for a 2-D op");
     MIS_REQUIRE(d->Cin > 0 && d->Cin % CK == 0, MIS_EUNSUPPORTED, "conv_igemm: Cin %d must be a multiple of %d", d->Cin, CK);
     MIS_REQUIRE(d->Cout > 0 && d->Cout % 64 == 0, MIS_EUNSUPPORTED, "conv_igemm: Cout %d must be a multiple of 64", d->Cout);
     MIS_REQUIRE(d->x0 != nullptr && d->w != nullptr && d->y0 != nullptr, MIS_EINVAL, "conv_igemm: null pointer");
@@ -416,7 +417,7 @@ extern "C" int mis_conv_igemm(const MisConvDesc* d, void* stream) {
     for (int i = 0; i < 2; ++i) {
         if (i == 1 && d->y1 == nullptr) break;
         MIS_REQUIRE(modes[i] >= 0 && modes[i] <= 2, MIS_EINVAL, "conv_igemm: output mode");
-        if (modes[i] != MIS_OUT_PLAIN) MIS_REQUIRE(d->D == 1, MIS_EUNSUPPORTED, "conv_igemm: (un)shuffle is 2-D only");
+        if (modes[i] != MIS_OUT_PLAIN) MIS_REQUIRE(!d->is3d, MIS_EUNSUPPORTED, "conv_igemm: (un)shuffle is 2-D only");
         if (modes[i] == MIS_OUT_SHUFFLE2)
             MIS_REQUIRE(views[i] % 256 == 0, MIS_EUNSUPPORTED, "conv_igemm: shuffle needs 4*Cq columns with Cq %% 64 == 0");
         if (modes[i] == MIS_OUT_UNSHUFFLE2)

@@ -1,0 +1,575 @@
+// GroupNorm around the 3-D convolutions (reference model/unet3d/buildingblocks.py:81-92: 'gcr' = GroupNorm -> Conv3d -> ReLU,
+// eps 1e-5, num_groups 8 or 1 when C < 8) for gfx950.
+//
+// Forward: GroupNorm is folded to a per-(sample, channel) affine a*x+b that conv_igemm / wgrad apply while staging
+// their input tile, so the normalised tensor is never written.  This file computes a and b from per-channel sums
+// (mis_chanstats), including the virtual concat (encoder features | nearest-upsampled decoder features) where a
+// group may straddle both sources.
+// Backward: with dy = dL/d(GN output) from the conv's dgrad,
+//   S1[n,c] = sum_v dy, S2[n,c] = sum_v dy*x                                (gn_bwd_stats, 2-stage, fixed order)
+//   dbeta = sum_n S1, dgamma = sum_n rstd*(S2 - mean*S1)                     (gn_bwd_finalize)
+//   dx = p[n,c]*dy + q[n,c]*x + r[n,c]  with  p = rstd*gamma, q = -rstd^2*B/m, r = -q*mean - rstd*A/m,
+//        A = sum_{c in g} gamma*S1, B = sum_{c in g} gamma*rstd*(S2 - mean*S1)     (gn_bwd_apply; optional ReLU mask of x,
+//   optional accumulate, and for the upsampled source the 8 children of a coarse voxel are summed here)
+#include "common.hpp"
+
+// ---------------------------------------------------------------------------------------------------------
+// forward finalize: per (n, g) mean / rstd from per-channel sums of up to two sources; per (n, c) scale / shift
+// ---------------------------------------------------------------------------------------------------------
+__global__ void gn_fwd_finalize_kernel(const float* __restrict__ sum0, const float* __restrict__ sq0, int C0, float mult0,
+                                       const float* __restrict__ sum1, const float* __restrict__ sq1, int C1, float mult1, int N, int G,
+                                       double count, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                       int Cpad, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
+                                       float* __restrict__ rstd_out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * G) return;
+    const int n = idx / G, g = idx - n * G;
+    const int C = C0 + C1, cpg = C / G;
+    double s = 0.0, q = 0.0;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        if (c < C0) {
+            s += (double)sum0[n * C0 + c] * mult0;
+            q += (double)sq0[n * C0 + c] * mult0;
+        } else {
+            s += (double)sum1[n * C1 + (c - C0)] * mult1;
+            q += (double)sq1[n * C1 + (c - C0)] * mult1;
+        }
+    }
+    const double m = count * cpg;
+    const double mean = s / m;
+    double var = q / m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    mean_out[idx] = (float)mean;
+    rstd_out[idx] = (float)rstd;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        const double a = rstd * (double)gamma[c];
+        scale[n * Cpad + c] = (float)a;
+        shift[n * Cpad + c] = (float)((double)beta[c] - mean * a);
+    }
+    if (g == G - 1)   // zero the channel padding (a padded channel must stay exactly 0 after the affine)
+        for (int c = C; c < Cpad; ++c) {
+            scale[n * Cpad + c] = 0.f;
+            shift[n * Cpad + c] = 0.f;
+        }
+}
+
+extern "C" int mis_gn_fwd_finalize(const float* sum0, const float* sq0, int C0, float mult0, const float* sum1, const float* sq1, int C1,
+                                   float mult1, int N, int G, double count, const float* gamma, const float* beta, float eps, int Cpad,
+                                   float* scale, float* shift, float* mean, float* rstd, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(sum0 && sq0 && gamma && beta && scale && shift && mean && rstd, MIS_EINVAL, "gn_fwd_finalize: null pointer");
+    MIS_REQUIRE(N > 0 && G > 0 && C0 > 0 && C1 >= 0 && (C0 + C1) % G == 0 && Cpad >= C0 + C1, MIS_EINVAL, "gn_fwd_finalize: bad sizes");
+    MIS_REQUIRE(C1 == 0 || (sum1 && sq1), MIS_EINVAL, "gn_fwd_finalize: source 1 missing");
+    hipLaunchKernelGGL(gn_fwd_finalize_kernel, dim3((N * G + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), sum0, sq0, C0, mult0,
+                       sum1, sq1, C1, mult1, N, G, count, gamma, beta, eps, Cpad, scale, shift, mean, rstd);
+    MIS_LAUNCH_CHECK("gn_fwd_finalize");
+    return MIS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward statistics for ONE source of the (virtual concat) input:  S1 = sum dy, S2 = sum dy * x
+// grid (D,H,W) is the conv's pixel grid; with up != 0 the source lives on the half grid and each coarse voxel first sums
+// dy over its 2x2x2 children.  Stage 1 writes slab partials, stage 2 (gn_bwd_finalize) adds them in a fixed order.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int GB_SLABS = 128;
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__ dy, int dy_ld, const T* __restrict__ x, int x_ld, int Cs, int up,
+                                                           int D, int H, int W, float* __restrict__ part /*[N][slabs][2][Cs]*/) {
+    constexpr int EPC = Tr<T>::EPC;
+    __shared__ float red[2][256 * 8];
+    const int nchunks = Cs / EPC;
+    const int chb = nchunks < 256 ? nchunks : 256;
+    const int rows = 256 / chb;
+    const int tid = threadIdx.x, cl = tid % chb, r = tid / chb;
+    const int chunk = blockIdx.y * chb + cl;
+    const int n = blockIdx.z, nslabs = gridDim.x;
+    const int sD = up ? D / 2 : D, sH = up ? H / 2 : H, sW = up ? W / 2 : W;
+    const long long snp = (long long)sD * sH * sW;
+    float s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+    if (chunk < nchunks && r < rows) {
+        const T* xb = x + (size_t)n * snp * x_ld + (size_t)chunk * EPC;
+        const T* db = dy + (size_t)n * D * H * W * dy_ld + (size_t)chunk * EPC;
+        for (long long p = (long long)blockIdx.x * rows + r; p < snp; p += (long long)nslabs * rows) {
+            float xf[EPC], g[EPC];
+            unpack_chunk<T>(*reinterpret_cast<const u32x4*>(xb + p * x_ld), xf);
+            if (!up) {
+                unpack_chunk<T>(*reinterpret_cast<const u32x4*>(db + p * dy_ld), g);
+            } else {
+                const int xx = (int)(p % sW);
+                const long long t = p / sW;
+                const int yy = (int)(t % sH), zz = (int)(t / sH);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) g[e] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const size_t pix = ((size_t)(2 * zz + (k >> 2)) * H + 2 * yy + ((k >> 1) & 1)) * W + 2 * xx + (k & 1);
+                    float c[EPC];
+                    unpack_chunk<T>(*reinterpret_cast<const u32x4*>(db + pix * dy_ld), c);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) g[e] += c[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                s1[e] += g[e];
+                s2[e] = fmaf(g[e], xf[e], s2[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        red[0][tid * EPC + e] = s1[e];
+        red[1][tid * EPC + e] = s2[e];
+    }
+    __syncthreads();
+    if (r == 0 && chunk < nchunks) {
+        for (int k = 1; k < rows; ++k)
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                s1[e] += red[0][(k * chb + cl) * EPC + e];
+                s2[e] += red[1][(k * chb + cl) * EPC + e];
+            }
+        float* o = part + (((size_t)n * nslabs + blockIdx.x) * 2) * Cs + (size_t)chunk * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            o[e] = s1[e];
+            o[Cs + e] = s2[e];
+        }
+    }
+}
+
+__global__ void gn_bwd_statsum_kernel(const float* __restrict__ part, int nslabs, int N, int Cs, float* __restrict__ S1, float* __restrict__ S2,
+                                      int Ctot, int c_off) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * Cs) return;
+    const int n = idx / Cs, c = idx - n * Cs;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nslabs; ++k) {
+        a += (double)part[(((size_t)n * nslabs + k) * 2) * Cs + c];
+        b += (double)part[(((size_t)n * nslabs + k) * 2 + 1) * Cs + c];
+    }
+    S1[n * Ctot + c_off + c] = (float)a;
+    S2[n * Ctot + c_off + c] = (float)b;
+}
+
+extern "C" size_t mis_gn_bwd_stats_workspace_bytes(int N, int Cs) { return (size_t)N * GB_SLABS * 2 * Cs * sizeof(float); }
+
+extern "C" int mis_gn_bwd_stats(int dtype, const void* dy, int dy_ld, const void* x, int x_ld, int Cs, int up, int N, int D, int H, int W,
+                                float* workspace, float* S1, float* S2, int Ctot, int c_off, void* stream) {
+    (void)hipGetLastError();
+    const int EPC = dtype == MIS_BF16 ? 8 : 4;
+    MIS_REQUIRE(dy && x && workspace && S1 && S2, MIS_EINVAL, "gn_bwd_stats: null pointer");
+    MIS_REQUIRE(Cs > 0 && Cs % EPC == 0 && dy_ld % EPC == 0 && x_ld % EPC == 0 && c_off % EPC == 0, MIS_EINVAL, "gn_bwd_stats: alignment");
+    MIS_REQUIRE(!up || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0), MIS_EUNSUPPORTED, "gn_bwd_stats: upsampled source needs an even grid");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nchunks = Cs / EPC;
+    const int chb = nchunks < 256 ? nchunks : 256;
+    const int ngroups = (nchunks + chb - 1) / chb;
+    const int rows = 256 / chb;
+    const long long snp = (long long)(up ? D / 2 : D) * (up ? H / 2 : H) * (up ? W / 2 : W);
+    long long slabs = (snp + rows * 8 - 1) / (rows * 8);
+    if (slabs > GB_SLABS) slabs = GB_SLABS;
+    if (slabs < 1) slabs = 1;
+    const size_t coff = (size_t)c_off * (dtype == MIS_BF16 ? 2 : 4);
+    const char* dyp = reinterpret_cast<const char*>(dy) + coff;
+    if (dtype == MIS_BF16)
+        hipLaunchKernelGGL(gn_bwd_stats_kernel<__bf16>, dim3((unsigned)slabs, ngroups, N), dim3(256), 0, s, (const __bf16*)dyp, dy_ld, (const __bf16*)x,
+                           x_ld, Cs, up, D, H, W, workspace);
+    else
+        hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, dim3((unsigned)slabs, ngroups, N), dim3(256), 0, s, (const float*)dyp, dy_ld, (const float*)x,
+                           x_ld, Cs, up, D, H, W, workspace);
+    MIS_LAUNCH_CHECK("gn_bwd_stats");
+    hipLaunchKernelGGL(gn_bwd_statsum_kernel, dim3((N * Cs + 255) / 256), dim3(256), 0, s, (const float*)workspace, (int)slabs, N, Cs, S1, S2, Ctot,
+                       c_off);
+    MIS_LAUNCH_CHECK("gn_bwd_statsum");
+    return MIS_OK;
+}
+
+// per (n, g): A, B -> per (n, c): p, q, r ; dgamma, dbeta.   xmult[c] = 1 for same-grid channels, 8 for upsampled
+// (S1/S2 were summed over the SOURCE voxels with dy pre-summed over children, which is exactly the full-grid sum).
+__global__ void gn_bwd_finalize_kernel(const float* __restrict__ S1, const float* __restrict__ S2, const float* __restrict__ mean,
+                                       const float* __restrict__ rstd, const float* __restrict__ gamma, int N, int C, int G, double count,
+                                       float* __restrict__ p, float* __restrict__ q, float* __restrict__ r, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cpg = C / G;
+    if (idx < N * G) {
+        const int n = idx / G, g = idx - n * G;
+        const double mu = mean[idx], rs = rstd[idx];
+        double A = 0.0, B = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            const double s1 = S1[n * C + c], s2 = S2[n * C + c];
+            A += (double)gamma[c] * s1;
+            B += (double)gamma[c] * rs * (s2 - mu * s1);
+        }
+        const double m = count * cpg;
+        const double qq = -rs * rs * B / m;               // coefficient of x (B already carries one rstd)
+        const double rr = -qq * mu - rs * A / m;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            p[n * C + c] = (float)(rs * (double)gamma[c]);
+            q[n * C + c] = (float)qq;
+            r[n * C + c] = (float)rr;
+        }
+    }
+    if (idx < C) {
+        const int c = idx, g = c / cpg;
+        double dg = 0.0, db = 0.0;
+        for (int n = 0; n < N; ++n) {
+            const double mu = mean[n * G + g], rs = rstd[n * G + g];
+            const double s1 = S1[n * C + c], s2 = S2[n * C + c];
+            dg += rs * (s2 - mu * s1);
+            db += s1;
+        }
+        dgamma[c] = (float)dg;
+        dbeta[c] = (float)db;
+    }
+}
+
+extern "C" int mis_gn_bwd_finalize(const float* S1, const float* S2, const float* mean, const float* rstd, const float* gamma, int N, int C,
+                                   int G, double count, float* p, float* q, float* r, float* dgamma, float* dbeta, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(S1 && S2 && mean && rstd && gamma && p && q && r && dgamma && dbeta, MIS_EINVAL, "gn_bwd_finalize: null pointer");
+    MIS_REQUIRE(N > 0 && C > 0 && G > 0 && C % G == 0, MIS_EINVAL, "gn_bwd_finalize: sizes");
+    const int nthreads = (N * G > C) ? N * G : C;
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((nthreads + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), S1, S2, mean, rstd,
+                       gamma, N, C, G, count, p, q, r, dgamma, dbeta);
+    MIS_LAUNCH_CHECK("gn_bwd_finalize");
+    return MIS_OK;
+}
+
+// dx[source voxel][c] = (p*sum_children(dy) + mult*(q*x + r)) [* (x > 0)] [+ add]      (mult = 1 or 8)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ dy, int dy_ld, const T* __restrict__ x, int x_ld, int Cs, int up,
+                                                           int N, int D, int H, int W, const float* __restrict__ p, const float* __restrict__ q,
+                                                           const float* __restrict__ r, int Ctot, int c_off, int relu_mask, const T* add, int add_ld,
+                                                           T* dx, int dx_ld) {
+    constexpr int EPC = Tr<T>::EPC;
+    const int nch = Cs / EPC;
+    const int sD = up ? D / 2 : D, sH = up ? H / 2 : H, sW = up ? W / 2 : W;
+    const long long snp = (long long)sD * sH * sW;
+    const long long total = (long long)N * snp * nch;
+    const float mult = up ? 8.f : 1.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        const long long pp = i / nch;
+        const int n = (int)(pp / snp);
+        const long long sp = pp - (long long)n * snp;
+        float xf[EPC], g[EPC];
+        unpack_chunk<T>(*reinterpret_cast<const u32x4*>(x + ((size_t)n * snp + sp) * x_ld + (size_t)ch * EPC), xf);
+        const T* db = dy + (size_t)n * D * H * W * dy_ld + (size_t)ch * EPC;
+        if (!up) {
+            unpack_chunk<T>(*reinterpret_cast<const u32x4*>(db + (size_t)sp * dy_ld), g);
+        } else {
+            const int xx = (int)(sp % sW);
+            const long long t = sp / sW;
+            const int yy = (int)(t % sH), zz = (int)(t / sH);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) g[e] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const size_t pix = ((size_t)(2 * zz + (k >> 2)) * H + 2 * yy + ((k >> 1) & 1)) * W + 2 * xx + (k & 1);
+                float c[EPC];
+                unpack_chunk<T>(*reinterpret_cast<const u32x4*>(db + pix * dy_ld), c);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) g[e] += c[e];
+            }
+        }
+        const float* pc = p + (size_t)n * Ctot + c_off + ch * EPC;
+        const float* qc = q + (size_t)n * Ctot + c_off + ch * EPC;
+        const float* rc = r + (size_t)n * Ctot + c_off + ch * EPC;
+        float o[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float v = fmaf(pc[e], g[e], mult * fmaf(qc[e], xf[e], rc[e]));
+            if (relu_mask && !(xf[e] > 0.f)) v = 0.f;
+            o[e] = v;
+        }
+        if (add != nullptr) {
+            float af[EPC];
+            unpack_chunk<T>(*reinterpret_cast<const u32x4*>(add + ((size_t)n * snp + sp) * add_ld + (size_t)ch * EPC), af);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o[e] += af[e];
+        }
+        *reinterpret_cast<u32x4*>(dx + ((size_t)n * snp + sp) * dx_ld + (size_t)ch * EPC) = pack_chunk<T>(o);
+    }
+}
+
+extern "C" int mis_gn_bwd_apply(int dtype, const void* dy, int dy_ld, const void* x, int x_ld, int Cs, int up, int N, int D, int H, int W,
+                                const float* p, const float* q, const float* r, int Ctot, int c_off, int relu_mask, const void* add, int add_ld,
+                                void* dx, int dx_ld, void* stream) {
+    (void)hipGetLastError();
+    const int EPC = dtype == MIS_BF16 ? 8 : 4;
+    MIS_REQUIRE(dy && x && p && q && r && dx, MIS_EINVAL, "gn_bwd_apply: null pointer");
+    MIS_REQUIRE(Cs > 0 && Cs % EPC == 0 && dy_ld % EPC == 0 && x_ld % EPC == 0 && dx_ld % EPC == 0 && c_off % EPC == 0, MIS_EINVAL,
+                "gn_bwd_apply: alignment");
+    MIS_REQUIRE(add == nullptr || add_ld % EPC == 0, MIS_EINVAL, "gn_bwd_apply: add_ld");
+    MIS_REQUIRE(!up || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0), MIS_EUNSUPPORTED, "gn_bwd_apply: upsampled source needs an even grid");
+    const long long snp = (long long)(up ? D / 2 : D) * (up ? H / 2 : H) * (up ? W / 2 : W);
+    long long blocks = ((long long)N * snp * (Cs / EPC) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t coff = (size_t)c_off * (dtype == MIS_BF16 ? 2 : 4);
+    const char* dyp = reinterpret_cast<const char*>(dy) + coff;
+    if (dtype == MIS_BF16)
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, (const __bf16*)dyp, dy_ld, (const __bf16*)x, x_ld, Cs, up,
+                           N, D, H, W, p, q, r, Ctot, c_off, relu_mask, (const __bf16*)add, add_ld, (__bf16*)dx, dx_ld);
+    else
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dyp, dy_ld, (const float*)x, x_ld, Cs, up, N,
+                           D, H, W, p, q, r, Ctot, c_off, relu_mask, (const float*)add, add_ld, (float*)dx, dx_ld);
+    MIS_LAUNCH_CHECK("gn_bwd_apply");
+    return MIS_OK;
+}
+
+// =========================================================================================================
+// First 3-D layer: x fp32 [N][D][H][W] (one channel), GroupNorm(1 group) folded to a per-sample affine, Conv3d 1 -> Cout
+// (Cout <= 64, multiple of 8) 3x3x3 p1 no bias, ReLU.  reference: encoders.0 SingleConv1 (buildingblocks.py:202-211 with in=1).
+// 8 output channels per lane, Cout/8 lanes per voxel.  Output buffer may be wider than Cout: padding channels get 0.
+// =========================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void first3d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          int sstride, int N, int D, int H, int W, const float* __restrict__ w /*[Cout][27]*/, int Cout,
+                                                          T* y, int y_ld, int Cpad) {
+    __shared__ float wl[27 * 64];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 27 * 64; i += 256) {
+        const int co = i & 63, tap = i >> 6;
+        wl[i] = co < Cout ? w[co * 27 + tap] : 0.f;
+    }
+    __syncthreads();
+    const int lpv = Cpad / 8;                 // lanes per voxel (4 or 8)
+    const int vpb = 256 / lpv;
+    const int cg = tid % lpv;
+    const long long DHW = (long long)D * H * W, total = (long long)N * DHW;
+    for (long long v = (long long)blockIdx.x * vpb + tid / lpv; v < total; v += (long long)gridDim.x * vpb) {
+        const int n = (int)(v / DHW);
+        const long long rem = v - (long long)n * DHW;
+        const int xx = (int)(rem % W);
+        const long long t = rem / W;
+        const int yy = (int)(t % H), zz = (int)(t / H);
+        const float a = scale[n * sstride], b = shift[n * sstride];
+        const float* xp = x + (long long)n * DHW;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int sz = zz + tap / 9 - 1, sy = yy + (tap / 3) % 3 - 1, sx = xx + tap % 3 - 1;
+            float xv = 0.f;
+            if (sz >= 0 && sz < D && sy >= 0 && sy < H && sx >= 0 && sx < W) xv = fmaf(xp[((long long)sz * H + sy) * W + sx], a, b);
+            const float* wr = &wl[tap * 64 + cg * 8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, wr[j], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+        T* dst = y + (size_t)v * y_ld + cg * 8;
+        if constexpr (sizeof(T) == 2) {
+            *reinterpret_cast<u32x4*>(dst) = pack_chunk<__bf16>(acc);
+        } else {
+            *reinterpret_cast<u32x4*>(dst) = pack_chunk<float>(acc);
+            *reinterpret_cast<u32x4*>(dst + 4) = pack_chunk<float>(acc + 4);
+        }
+    }
+}
+
+extern "C" int mis_first3d_fwd(int dtype, const float* x, const float* scale, const float* shift, int sstride, int N, int D, int H, int W,
+                               const float* w, int Cout, void* y, int y_ld, int Cpad, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(x && scale && shift && w && y, MIS_EINVAL, "first3d_fwd: null pointer");
+    MIS_REQUIRE(Cout > 0 && Cout <= Cpad && (Cpad == 32 || Cpad == 64) && y_ld >= Cpad && y_ld % 8 == 0, MIS_EUNSUPPORTED,
+                "first3d_fwd: Cout %d / Cpad %d", Cout, Cpad);
+    const long long total = (long long)N * D * H * W;
+    const int vpb = 256 / (Cpad / 8);
+    long long blocks = (total + vpb - 1) / vpb;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIS_BF16)
+        hipLaunchKernelGGL(first3d_fwd_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, x, scale, shift, sstride, N, D, H, W, w, Cout, (__bf16*)y,
+                           y_ld, Cpad);
+    else
+        hipLaunchKernelGGL(first3d_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, x, scale, shift, sstride, N, D, H, W, w, Cout, (float*)y, y_ld,
+                           Cpad);
+    MIS_LAUNCH_CHECK("first3d_fwd");
+    return MIS_OK;
+}
+
+// backward of the first 3-D layer given dy = dL/d(pre-activation) [voxel][Cpad]:
+//   dW[co][tap] = sum_v xn[v+tap] * dy[v][co]   (xn = a*x+b in bounds, 0 outside)         blockIdx.y = kd slab (9 taps)
+//   dxn[v]      = sum_{tap,co} dy[v-tap][co] * W[co][tap]                                   (needed only for the GroupNorm grads)
+constexpr int F3_BLOCKS = 512;
+template <typename T>
+__global__ __launch_bounds__(256) void first3d_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            int sstride, int N, int D, int H, int W, const T* __restrict__ dy, int dy_ld, int Cpad,
+                                                            float* __restrict__ partial /*[blocks][3][9][64]*/) {
+    __shared__ float red[4][9 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lpv = Cpad / 8, vpb = 256 / lpv, cg = tid % lpv;
+    const int kd = blockIdx.y;
+    const long long DHW = (long long)D * H * W, total = (long long)N * DHW;
+    float acc[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+    for (long long v = (long long)blockIdx.x * vpb + tid / lpv; v < total; v += (long long)gridDim.x * vpb) {
+        const int n = (int)(v / DHW);
+        const long long rem = v - (long long)n * DHW;
+        const int xx = (int)(rem % W);
+        const long long t = rem / W;
+        const int yy = (int)(t % H), zz = (int)(t / H);
+        const float a = scale[n * sstride], b = shift[n * sstride];
+        const float* xp = x + (long long)n * DHW;
+        float g[8];
+        const T* src = dy + (size_t)v * dy_ld + cg * 8;
+        if constexpr (sizeof(T) == 2) {
+            unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(src), g);
+        } else {
+            unpack_chunk<float>(*reinterpret_cast<const u32x4*>(src), g);
+            unpack_chunk<float>(*reinterpret_cast<const u32x4*>(src + 4), g + 4);
+        }
+        const int sz = zz + kd - 1;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const int sy = yy + tp / 3 - 1, sx = xx + tp % 3 - 1;
+            float xv = 0.f;
+            if (sz >= 0 && sz < D && sy >= 0 && sy < H && sx >= 0 && sx < W) xv = fmaf(xp[((long long)sz * H + sy) * W + sx], a, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[tp][j] = fmaf(xv, g[j], acc[tp][j]);
+        }
+    }
+    // lanes with equal (lane % lpv) hold the same channels
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float vsum = acc[t][j];
+            for (int o = lpv; o < 64; o <<= 1) vsum += __shfl_xor(vsum, o, 64);
+            acc[t][j] = vsum;
+        }
+    for (int i = tid; i < 4 * 9 * 64; i += 256) (&red[0][0])[i] = 0.f;
+    __syncthreads();
+    if (lane < lpv) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[wave][t * 64 + lane * 8 + j] = acc[t][j];
+    }
+    __syncthreads();
+    float* out = partial + ((size_t)blockIdx.x * 3 + kd) * 576;
+    for (int i = tid; i < 576; i += 256) out[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+
+__global__ void first3d_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, int Cout, float* __restrict__ dw) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (kd, tp, co)
+    if (idx >= 3 * 576) return;
+    const int kd = idx / 576, r = idx - kd * 576;
+    const int tp = r >> 6, co = r & 63;
+    if (co >= Cout) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partial[((size_t)b * 3 + kd) * 576 + r];
+    dw[co * 27 + kd * 9 + tp] = s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void first3d_dgrad_kernel(const T* __restrict__ dy, int dy_ld, int Cpad, int N, int D, int H, int W,
+                                                            const float* __restrict__ w /*[Cout][27]*/, int Cout, float* __restrict__ dxn) {
+    constexpr int EPC = Tr<T>::EPC;
+    __shared__ float wl[27 * 64];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 27 * 64; i += 256) {
+        const int co = i & 63, tap = i >> 6;
+        wl[i] = co < Cout ? w[co * 27 + tap] : 0.f;
+    }
+    __syncthreads();
+    const long long DHW = (long long)D * H * W, total = (long long)N * DHW;
+    for (long long v = (long long)blockIdx.x * 256 + tid; v < total; v += (long long)gridDim.x * 256) {
+        const int n = (int)(v / DHW);
+        const long long rem = v - (long long)n * DHW;
+        const int xx = (int)(rem % W);
+        const long long t = rem / W;
+        const int yy = (int)(t % H), zz = (int)(t / H);
+        float s = 0.f;
+        for (int tap = 0; tap < 27; ++tap) {
+            // y[v'] used x[v' + tap - 1]  =>  x[v] contributes to y[v - (tap - 1)]
+            const int sz = zz - (tap / 9 - 1), sy = yy - ((tap / 3) % 3 - 1), sx = xx - (tap % 3 - 1);
+            if (sz < 0 || sz >= D || sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
+            const T* src = dy + ((size_t)n * DHW + ((size_t)sz * H + sy) * W + sx) * dy_ld;
+            for (int c = 0; c < Cout; c += EPC) {
+                float g[EPC];
+                unpack_chunk<T>(*reinterpret_cast<const u32x4*>(src + c), g);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) s = fmaf(g[e], wl[tap * 64 + c + e], s);
+            }
+        }
+        dxn[v] = s;
+    }
+}
+
+extern "C" size_t mis_first3d_bwd_workspace_bytes(void) { return (size_t)F3_BLOCKS * 3 * 576 * sizeof(float); }
+
+extern "C" int mis_first3d_bwd(int dtype, const float* x, const float* scale, const float* shift, int sstride, int N, int D, int H, int W,
+                               const void* dy, int dy_ld, int Cpad, const float* w, int Cout, float* workspace, float* dw, float* dxn,
+                               void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(x && scale && shift && dy && w && workspace && dw && dxn, MIS_EINVAL, "first3d_bwd: null pointer");
+    MIS_REQUIRE(Cout > 0 && Cout <= Cpad && Cout % 8 == 0 && (Cpad == 32 || Cpad == 64) && dy_ld % 8 == 0, MIS_EUNSUPPORTED, "first3d_bwd: sizes");
+    const long long total = (long long)N * D * H * W;
+    const int vpb = 256 / (Cpad / 8);
+    long long blocks = (total + vpb - 1) / vpb;
+    if (blocks > F3_BLOCKS) blocks = F3_BLOCKS;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    long long dblocks = (total + 255) / 256;
+    if (dblocks > 8192) dblocks = 8192;
+    if (dtype == MIS_BF16) {
+        hipLaunchKernelGGL(first3d_wgrad_kernel<__bf16>, dim3((unsigned)blocks, 3), dim3(256), 0, s, x, scale, shift, sstride, N, D, H, W, (const __bf16*)dy,
+                           dy_ld, Cpad, workspace);
+        MIS_LAUNCH_CHECK("first3d_wgrad");
+        hipLaunchKernelGGL(first3d_dgrad_kernel<__bf16>, dim3((unsigned)dblocks), dim3(256), 0, s, (const __bf16*)dy, dy_ld, Cpad, N, D, H, W, w, Cout, dxn);
+    } else {
+        hipLaunchKernelGGL(first3d_wgrad_kernel<float>, dim3((unsigned)blocks, 3), dim3(256), 0, s, x, scale, shift, sstride, N, D, H, W, (const float*)dy,
+                           dy_ld, Cpad, workspace);
+        MIS_LAUNCH_CHECK("first3d_wgrad");
+        hipLaunchKernelGGL(first3d_dgrad_kernel<float>, dim3((unsigned)dblocks), dim3(256), 0, s, (const float*)dy, dy_ld, Cpad, N, D, H, W, w, Cout, dxn);
+    }
+    MIS_LAUNCH_CHECK("first3d_dgrad");
+    hipLaunchKernelGGL(first3d_wgrad_reduce_kernel, dim3((3 * 576 + 255) / 256), dim3(256), 0, s, (const float*)workspace, (int)blocks, Cout, dw);
+    MIS_LAUNCH_CHECK("first3d_wgrad_reduce");
+    return MIS_OK;
+}
+
+// elementwise ReLU-mask: dx = dy * (y > 0)  (used where the mask cannot ride in a conv epilogue)
+template <typename T>
+__global__ void relu_mask_kernel(const T* __restrict__ dy, int dy_ld, const T* __restrict__ y, int y_ld, T* __restrict__ dx, int dx_ld, long long npix,
+                                 int C) {
+    constexpr int EPC = Tr<T>::EPC;
+    const int nch = C / EPC;
+    const long long total = npix * nch;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % nch);
+        const long long p = i / nch;
+        float g[EPC], f[EPC];
+        unpack_chunk<T>(*reinterpret_cast<const u32x4*>(dy + p * dy_ld + (size_t)ch * EPC), g);
+        unpack_chunk<T>(*reinterpret_cast<const u32x4*>(y + p * y_ld + (size_t)ch * EPC), f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) g[e] = f[e] > 0.f ? g[e] : 0.f;
+        *reinterpret_cast<u32x4*>(dx + p * dx_ld + (size_t)ch * EPC) = pack_chunk<T>(g);
+    }
+}
+extern "C" int mis_relu_mask(int dtype, const void* dy, int dy_ld, const void* y, int y_ld, void* dx, int dx_ld, long long npix, int C, void* stream) {
+    (void)hipGetLastError();
+    const int EPC = dtype == MIS_BF16 ? 8 : 4;
+    MIS_REQUIRE(dy && y && dx && npix > 0 && C % EPC == 0 && dy_ld % EPC == 0 && y_ld % EPC == 0 && dx_ld % EPC == 0, MIS_EINVAL, "relu_mask: bad argument");
+    long long blocks = (npix * (C / EPC) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIS_BF16)
+        hipLaunchKernelGGL(relu_mask_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, (const __bf16*)dy, dy_ld, (const __bf16*)y, y_ld, (__bf16*)dx, dx_ld, npix, C);
+    else
+        hipLaunchKernelGGL(relu_mask_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, dy_ld, (const float*)y, y_ld, (float*)dx, dx_ld, npix, C);
+    MIS_LAUNCH_CHECK("relu_mask");
+    return MIS_OK;
+}

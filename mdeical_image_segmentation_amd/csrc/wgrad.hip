@@ -411,7 +411,8 @@ static int wg_plan(const MisWgradDesc* d, WgPlan* p) {
     p->CT = d->dtype == MIS_BF16 ? 64 : 32;
     MIS_REQUIRE(d->Cin > 0 && d->Cin % p->CT == 0 && d->Cout > 0 && d->Cout % p->CT == 0, MIS_EUNSUPPORTED,
                 "wgrad: Cin %d / Cout %d must be multiples of %d", d->Cin, d->Cout, p->CT);
-    p->is3d = d->D > 1;
+    p->is3d = d->is3d != 0;
+    MIS_REQUIRE(d->is3d || d->D == 1, MIS_EINVAL, "wgrad: D must be 1 for a 2-D op");
     const int TD = p->is3d ? 2 : 1, TH = 8, TW = p->is3d ? 8 : 16;
     p->tilesD = (d->D + TD - 1) / TD;
     p->tilesH = (d->H + TH - 1) / TH;

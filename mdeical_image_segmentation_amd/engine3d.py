@@ -1,0 +1,358 @@
+"""Fused 3-D U-Net (pytorch-3dunet flavour) train-step engine on libmisamd (MI355X).
+
+Mirrors the reference's `UNet3D` (model/unet3d/model.py:13-194) with its defaults: layer order 'gcr'
+(GroupNorm -> Conv3d(k3, p1, no bias) -> ReLU, buildingblocks.py:14-159), DoubleConv channel plan
+(buildingblocks.py:202-215), MaxPool3d(2) between encoders (:409-418), nearest upsampling to the encoder's size and
+`cat((encoder_features, x), 1)` in the decoders (:546-548, :671-673), 1x1x1 head with bias (model.py:111), logits out,
+and `BCEDiceLoss(1, 1)` (losses.py:167-178).
+
+MI355X mapping: NDHWC activations; GroupNorm never materialises its output - per-(sample, channel) scale/shift are
+computed from per-channel sums and applied by the conv / wgrad kernels while they stage their input tile; the decoder's
+concat + nearest upsample are two-source addressing inside the same kernels (channels >= C_enc read the half-resolution
+tensor at (d>>1, h>>1, w>>1)); the GroupNorm backward is 2 reductions + one fused elementwise pass that also applies
+the ReLU mask, accumulates skip gradients and sums the 8 children of each coarse voxel for the upsampled source.
+"""
+import math
+
+import torch
+
+from . import ops
+from ._lib import MisError
+from .engine2d import FlatParams
+from .ops import View
+
+
+def layer_plan(in_channels, f_maps):
+    enc = []
+    for i, out in enumerate(f_maps):
+        cin = in_channels if i == 0 else f_maps[i - 1]
+        c1 = max(out // 2, cin)
+        enc.append([(cin, c1), (c1, out)])
+    dec = []
+    rf = list(reversed(f_maps))
+    for i in range(len(rf) - 1):
+        dec.append([(rf[i] + rf[i + 1], rf[i + 1]), (rf[i + 1], rf[i + 1])])
+    return enc, dec
+
+
+def unet3d_param_specs(in_channels, out_channels, f_maps):
+    enc, dec = layer_plan(in_channels, f_maps)
+    specs = []
+    for grp, plan in (("encoders", enc), ("decoders", dec)):
+        for i, convs in enumerate(plan):
+            for j, (ci, co) in enumerate(convs):
+                pre = f"{grp}.{i}.basic_module.SingleConv{j + 1}"
+                specs += [(f"{pre}.groupnorm.weight", (ci,)), (f"{pre}.groupnorm.bias", (ci,)), (f"{pre}.conv.weight", (co, ci, 3, 3, 3))]
+    specs += [("final_conv.weight", (out_channels, f_maps[0], 1, 1, 1)), ("final_conv.bias", (out_channels,))]
+    return specs
+
+
+def default_init3d_(params, seed=None):
+    """Same RNG stream as `torch.manual_seed(seed); UNet3D(...)` (GroupNorm init draws nothing)."""
+    if seed is not None:
+        torch.manual_seed(seed)
+    for name, p in params.items():
+        if name.endswith("groupnorm.weight"):
+            p.fill_(1.0)
+        elif name.endswith("groupnorm.bias"):
+            p.zero_()
+        elif name.endswith("conv.weight") or name == "final_conv.weight":
+            w = torch.empty(p.shape)
+            torch.nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+            p.copy_(w)
+        elif name == "final_conv.bias":
+            fan_in = params["final_conv.weight"].shape[1]
+            b = torch.empty(p.shape)
+            bound = 1.0 / math.sqrt(fan_in)
+            torch.nn.init.uniform_(b, -bound, bound)
+            p.copy_(b)
+
+
+class _SC:
+    """book-keeping of one SingleConv ('gcr')"""
+    pass
+
+
+class UNet3DEngine:
+    def __init__(self, in_channels=1, out_channels=3, f_maps=(64, 128, 256, 512), num_groups=8, dtype=torch.float32, device="cuda",
+                 seed=None, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3, max_grad_norm=1.0, alpha=1.0, beta=1.0):
+        if in_channels != 1:
+            raise MisError("UNet3DEngine: in_channels must be 1 (the direct first-layer kernel)")
+        if not (1 <= out_channels <= 4):
+            raise MisError("UNet3DEngine: out_channels must be 1..4")
+        f_maps = list(f_maps)
+        if f_maps[0] != 64 or any(f % 64 for f in f_maps):
+            raise MisError("UNet3DEngine: f_maps must start at 64 and be multiples of 64")
+        ops.load()
+        self.cin, self.cout, self.f_maps, self.G = in_channels, out_channels, f_maps, num_groups
+        self.dtype, self.device = dtype, torch.device(device)
+        self.levels = len(f_maps)
+        self.specs = unet3d_param_specs(in_channels, out_channels, f_maps)
+        self.flat = FlatParams(self.specs, self.device, lambda n: not n.endswith("bias"))
+        self.P, self.Gr = self.flat.param, self.flat.grad
+        self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.alpha, self.beta = alpha, beta
+        self.step_count = 0
+        host = {n: torch.empty(s) for n, s in self.specs}
+        default_init3d_(host, seed)
+        for n in host:
+            self.P[n].copy_(host[n])
+        self.ck = 64 if dtype == torch.bfloat16 else 32
+        self.c1 = max(f_maps[0] // 2, in_channels)                 # 32
+        self.c1p = (self.c1 + 63) // 64 * 64                       # 64: dgrad needs its GEMM-N (= Cin) in multiples of 64
+        # SingleConv descriptors
+        enc, dec = layer_plan(in_channels, f_maps)
+        self.sc = {}
+        for grp, plan in (("encoders", enc), ("decoders", dec)):
+            for i, convs in enumerate(plan):
+                for j, (ci, co) in enumerate(convs):
+                    s = _SC()
+                    s.name = f"{grp}.{i}.basic_module.SingleConv{j + 1}"
+                    s.cin, s.cout = ci, co
+                    s.cin_pad = (ci + 63) // 64 * 64 if ci > 1 else 1
+                    s.groups = 1 if ci < num_groups else num_groups
+                    s.first = (grp == "encoders" and i == 0 and j == 0)
+                    if not s.first:
+                        s.wf = torch.empty(27, co, s.cin_pad, dtype=dtype, device=self.device)
+                        s.wd = torch.empty(27, s.cin_pad, co, dtype=dtype, device=self.device)
+                        s.wpad = torch.zeros(co, s.cin_pad, 3, 3, 3, device=self.device) if s.cin_pad != ci else None
+                        s.dwpad = torch.zeros(co, s.cin_pad, 3, 3, 3, device=self.device) if s.cin_pad != ci else None
+                    self.sc[s.name] = s
+        self.partials = torch.zeros(ops.sumsq_npartials(self.flat.total), dtype=torch.float32, device=self.device)
+        self.gradnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.loss_buf = torch.zeros(32, dtype=torch.float32, device=self.device)
+        self._shape = None
+        self.repack()
+
+    # ---- parameters ------------------------------------------------------------------------------------
+    def state_dict(self):
+        return {n: self.P[n].detach().clone() for n, _ in self.specs}
+
+    def load_state_dict(self, sd, prefix=""):
+        for n, s in self.specs:
+            t = sd[prefix + n]
+            if tuple(t.shape) != tuple(s):
+                raise MisError(f"{n}: shape {tuple(t.shape)} != {s}")
+            self.P[n].copy_(t.to(torch.float32))
+        self.repack()
+
+    def repack(self):
+        for s in self.sc.values():
+            if s.first:
+                continue
+            w = self.P[s.name + ".conv.weight"]
+            if s.wpad is not None:
+                s.wpad[:, :s.cin] = w
+                w = s.wpad
+            ops.pack_conv_weight(w, s.wf, s.wd)
+
+    # ---- buffers ---------------------------------------------------------------------------------------
+    def _alloc(self, N, D, H, W):
+        if self._shape == (N, D, H, W):
+            return
+        div = 1 << (self.levels - 1)
+        if D % div or H % div or W % div:
+            raise MisError(f"the fused 3-D engine needs D, H, W divisible by {div}; got {D}x{H}x{W}")
+        dt, dev = self.dtype, self.device
+
+        def buf(l, c):
+            return torch.empty(N, D >> l, H >> l, W >> l, c, dtype=dt, device=dev)
+
+        L = self.levels
+        fm = self.f_maps
+        self.t_enc, self.e, self.pooled = [], [], []
+        self.g_t_enc, self.g_e, self.g_pooled = [], [], []
+        for l in range(L):
+            c_mid = self.sc[f"encoders.{l}.basic_module.SingleConv1"].cout
+            c_mid_p = self.c1p if l == 0 else c_mid
+            self.t_enc.append(buf(l, c_mid_p))
+            self.e.append(buf(l, fm[l]))
+            self.g_t_enc.append(buf(l, c_mid_p))
+            self.g_e.append(buf(l, fm[l]))
+            if l < L - 1:
+                self.pooled.append(buf(l + 1, fm[l]))
+                self.g_pooled.append(buf(l + 1, fm[l]))
+        self.t_dec, self.d, self.g_t_dec, self.g_d = [], [], [], []
+        for j in range(L - 1):
+            l = L - 2 - j
+            self.t_dec.append(buf(l, fm[l]))
+            self.d.append(buf(l, fm[l]))
+            self.g_t_dec.append(buf(l, fm[l]))
+            self.g_d.append(buf(l, fm[l]))
+        # per-SingleConv GroupNorm state and the dgrad buffer
+        for s in self.sc.values():
+            l = self._level(s.name)
+            cp = 4 if s.first else s.cin_pad
+            s.scale = torch.zeros(N, cp, device=dev)
+            s.shift = torch.zeros(N, cp, device=dev)
+            s.mean = torch.zeros(N, s.groups, device=dev)
+            s.rstd = torch.zeros(N, s.groups, device=dev)
+            cs = 4 if s.first else s.cin
+            s.S1, s.S2 = torch.zeros(N, cs, device=dev), torch.zeros(N, cs, device=dev)
+            s.p, s.q, s.r = torch.zeros(N, cs, device=dev), torch.zeros(N, cs, device=dev), torch.zeros(N, cs, device=dev)
+            s.sum0, s.sq0 = torch.zeros(N, cs, device=dev), torch.zeros(N, cs, device=dev)
+            s.sum1, s.sq1 = torch.zeros(N, cs, device=dev), torch.zeros(N, cs, device=dev)
+            s.dgam, s.dbet = torch.zeros(cs, device=dev), torch.zeros(cs, device=dev)
+        self.dyn = {}      # dgrad outputs, keyed by (level, channels): shared between SingleConvs of equal shape
+        for s in self.sc.values():
+            if s.first:
+                continue
+            key = (self._level(s.name), s.cin_pad)
+            if key not in self.dyn:
+                self.dyn[key] = buf(key[0], key[1])
+        self.dxn0 = torch.empty(N, D, H, W, dtype=torch.float32, device=dev)
+        self.logits = torch.empty(N, self.cout, D, H, W, dtype=torch.float32, device=dev)
+        self.argmax = torch.empty(N, D, H, W, dtype=torch.uint8, device=dev)
+        self._shape = (N, D, H, W)
+
+    def _level(self, name):
+        grp, i = name.split(".")[0], int(name.split(".")[1])
+        return i if grp == "encoders" else self.levels - 2 - i
+
+    # ---- forward ---------------------------------------------------------------------------------------
+    def _gn_fwd(self, s, src0, c0, src1=None, c1=0):
+        N = src0.shape[0]
+        count = src0.shape[1] * src0.shape[2] * src0.shape[3]
+        ops.chanstats(View(src0, 0, c0), s.sum0, s.sq0)
+        if src1 is not None:
+            ops.chanstats(View(src1, 0, c1), s.sum1, s.sq1)
+        ops.gn_fwd_finalize(s.sum0, s.sq0, c0, 1.0, s.sum1 if src1 is not None else None, s.sq1 if src1 is not None else None, c1, 8.0,
+                            N, s.groups, count, self.P[s.name + ".groupnorm.weight"], self.P[s.name + ".groupnorm.bias"], s.cin_pad,
+                            s.scale, s.shift, s.mean, s.rstd)
+
+    def _sc_fwd(self, s, src0, c0, y, src1=None, c1=0):
+        self._gn_fwd(s, src0, c0, src1, c1)
+        s.src0, s.c0, s.src1, s.c1 = src0, c0, src1, c1
+        grid = (src0.shape[0], src0.shape[1], src0.shape[2], src0.shape[3])
+        ops.conv_igemm(View(src0, 0, src0.shape[-1] if src1 is None else c0), s.wf, y, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid,
+                       x1=None if src1 is None else View(src1, 0, c1), relu=True, in_scale=s.scale, in_shift=s.shift)
+
+    def forward(self, x, target=None, train=True, grad_scale=1.0):
+        """x: fp32 (N,1,D,H,W) on the device; target: fp32 (N,C,D,H,W) in {0,1}. Returns (loss[1] or None, logits, argmax)."""
+        if x.dtype != torch.float32 or not x.is_contiguous() or x.device.type != "cuda" or x.dim() != 5 or x.shape[1] != 1:
+            raise MisError("x must be a contiguous fp32 CUDA tensor (N, 1, D, H, W)")
+        N, _, D, H, W = x.shape
+        self._alloc(N, D, H, W)
+        self._x = x
+        P, L = self.P, self.levels
+        npix = D * H * W
+        # first SingleConv: GroupNorm(1 group over the single channel) + direct conv
+        s = self.sc["encoders.0.basic_module.SingleConv1"]
+        xv = x.view(N, 1, 1, npix // 4, 4)
+        ops.chanstats(xv, s.sum0, s.sq0)
+        g4 = P[s.name + ".groupnorm.weight"].repeat(4)
+        b4 = P[s.name + ".groupnorm.bias"].repeat(4)
+        s.g4 = g4
+        ops.gn_fwd_finalize(s.sum0, s.sq0, 4, 1.0, None, None, 0, 1.0, N, 1, npix // 4, g4, b4, 4, s.scale, s.shift, s.mean, s.rstd)
+        ops.first3d_fwd(x, s.scale, s.shift, 4, P[s.name + ".conv.weight"], self.c1, self.t_enc[0], self.c1p)
+        self._sc_fwd(self.sc["encoders.0.basic_module.SingleConv2"], self.t_enc[0], self.c1, self.e[0])
+        for l in range(1, L):
+            ops.maxpool2_fwd(self.e[l - 1], self.pooled[l - 1])
+            s1 = self.sc[f"encoders.{l}.basic_module.SingleConv1"]
+            self._sc_fwd(s1, self.pooled[l - 1], s1.cin, self.t_enc[l])
+            s2 = self.sc[f"encoders.{l}.basic_module.SingleConv2"]
+            self._sc_fwd(s2, self.t_enc[l], s2.cin, self.e[l])
+        low = self.e[L - 1]
+        for j in range(L - 1):
+            l = L - 2 - j
+            s1 = self.sc[f"decoders.{j}.basic_module.SingleConv1"]
+            self._sc_fwd(s1, self.e[l], self.f_maps[l], self.t_dec[j], src1=low, c1=low.shape[-1])
+            s2 = self.sc[f"decoders.{j}.basic_module.SingleConv2"]
+            self._sc_fwd(s2, self.t_dec[j], s2.cin, self.d[j])
+            low = self.d[j]
+        wh = P["final_conv.weight"].view(self.cout, self.f_maps[0])
+        bh = P["final_conv.bias"]
+        feat = self.d[L - 2]
+        if target is None:
+            ops.head_loss(feat, wh, bh, loss=ops.LOSS_NONE, logits=self.logits, argmax=self.argmax)
+            return None, self.logits, self.argmax
+        if target.dtype != torch.float32 or tuple(target.shape) != (N, self.cout, D, H, W) or not target.is_contiguous():
+            raise MisError("target must be contiguous fp32 (N, C, D, H, W)")
+        kw = dict(loss=ops.LOSS_BCEDICE, labels=target, logits=self.logits, argmax=self.argmax, loss_out=self.loss_buf,
+                  alpha=self.alpha, beta=self.beta)
+        if train:
+            kw.update(dy=self.g_d[L - 2], dw=self.Gr["final_conv.weight"], db=self.Gr["final_conv.bias"], grad_scale=grad_scale)
+        ops.head_loss(feat, wh, bh, **kw)
+        return self.loss_buf[:1], self.logits, self.argmax
+
+    # ---- backward --------------------------------------------------------------------------------------
+    def _sc_bwd(self, s, g_y, dx0, mask0, add0=None, dx1=None):
+        """g_y = dL/d(pre-activation) of s's output.  Produces weight/GroupNorm grads and the input gradients."""
+        src0, c0, src1, c1 = s.src0, s.c0, s.src1, s.c1
+        N, D, H, W = src0.shape[0], src0.shape[1], src0.shape[2], src0.shape[3]
+        grid = (N, D, H, W)
+        x0v = View(src0, 0, src0.shape[-1] if src1 is None else c0)
+        x1v = None if src1 is None else View(src1, 0, c1)
+        dw = self.Gr[s.name + ".conv.weight"] if s.dwpad is None else s.dwpad
+        ops.wgrad(x0v, g_y, dw, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid, x1=x1v, in_scale=s.scale, in_shift=s.shift)
+        if s.dwpad is not None:
+            self.Gr[s.name + ".conv.weight"].copy_(s.dwpad[:, :s.cin])
+        dyn = self.dyn[(self._level(s.name), s.cin_pad)]
+        ops.conv_igemm(g_y, s.wd, dyn, ksize=3, Cin=s.cout, Cout=s.cin_pad, grid=grid)
+        ctot = c0 + c1
+        ops.gn_bwd_stats(dyn, View(src0, 0, c0), c0, False, grid, s.S1, s.S2, ctot, 0)
+        if src1 is not None:
+            ops.gn_bwd_stats(dyn, View(src1, 0, c1), c1, True, grid, s.S1, s.S2, ctot, c0)
+        ops.gn_bwd_finalize(s.S1, s.S2, s.mean, s.rstd, self.P[s.name + ".groupnorm.weight"], N, ctot, s.groups, D * H * W,
+                            s.p, s.q, s.r, self.Gr[s.name + ".groupnorm.weight"], self.Gr[s.name + ".groupnorm.bias"])
+        ops.gn_bwd_apply(dyn, View(src0, 0, c0), c0, False, grid, s.p, s.q, s.r, ctot, 0, View(dx0, 0, c0), relu_mask=mask0, add=add0)
+        if src1 is not None:
+            ops.gn_bwd_apply(dyn, View(src1, 0, c1), c1, True, grid, s.p, s.q, s.r, ctot, c0, dx1, relu_mask=True)
+
+    def backward(self, stage_cb=None):
+        cb = stage_cb if stage_cb is not None else (lambda names: None)
+        L = self.levels
+        cb(["final_conv"])
+        for j in range(L - 2, -1, -1):
+            l = L - 2 - j
+            s2 = self.sc[f"decoders.{j}.basic_module.SingleConv2"]
+            self._sc_bwd(s2, self.g_d[j], self.g_t_dec[j], mask0=True)
+            s1 = self.sc[f"decoders.{j}.basic_module.SingleConv1"]
+            low_grad = self.g_e[L - 1] if j == 0 else self.g_d[j - 1]
+            # encoder features also feed the pooling path: leave their gradient raw (masked + accumulated in pool-bwd),
+            # except the deepest-but-one level... every e[l], l < L-1, is pooled, so never mask here
+            self._sc_bwd(s1, self.g_t_dec[j], self.g_e[l], mask0=False, dx1=low_grad)
+            cb([f"decoders.{j}"])
+        for l in range(L - 1, 0, -1):
+            s2 = self.sc[f"encoders.{l}.basic_module.SingleConv2"]
+            self._sc_bwd(s2, self.g_e[l], self.g_t_enc[l], mask0=True)
+            s1 = self.sc[f"encoders.{l}.basic_module.SingleConv1"]
+            self._sc_bwd(s1, self.g_t_enc[l], self.g_pooled[l - 1], mask0=False)
+            # g_e[l-1] <- relu_mask(e[l-1]) * (scatter(g_pooled) + g_e[l-1] (from the decoder))
+            ops.maxpool2_bwd(self.e[l - 1], self.g_pooled[l - 1], self.g_e[l - 1], add=self.g_e[l - 1], relu_mask=True)
+            cb([f"encoders.{l}"])
+        s2 = self.sc["encoders.0.basic_module.SingleConv2"]
+        self._sc_bwd(s2, self.g_e[0], self.g_t_enc[0], mask0=True)
+        # first layer: weight grad + gradient w.r.t. the normalised input (for the 1-channel GroupNorm parameters)
+        s = self.sc["encoders.0.basic_module.SingleConv1"]
+        x = self._x
+        N, _, D, H, W = x.shape
+        npix = D * H * W
+        ops.first3d_bwd(x, s.scale, s.shift, 4, self.g_t_enc[0], self.c1p, self.P[s.name + ".conv.weight"], self.c1,
+                        self.Gr[s.name + ".conv.weight"], self.dxn0)
+        dv = self.dxn0.view(N, 1, 1, npix // 4, 4)
+        xv = x.view(N, 1, 1, npix // 4, 4)
+        ops.gn_bwd_stats(dv, xv, 4, False, (N, 1, 1, npix // 4), s.S1, s.S2, 4, 0)
+        ops.gn_bwd_finalize(s.S1, s.S2, s.mean, s.rstd, s.g4, N, 4, 1, npix // 4, s.p, s.q, s.r, s.dgam, s.dbet)
+        self.Gr[s.name + ".groupnorm.weight"].copy_(s.dgam.sum().reshape(1))
+        self.Gr[s.name + ".groupnorm.bias"].copy_(s.dbet.sum().reshape(1))
+        cb(["encoders.0"])
+
+    # ---- optimizer -------------------------------------------------------------------------------------
+    def optimizer_step(self, lr=None):
+        lr = self.lr if lr is None else lr
+        self.step_count += 1
+        f = self.flat
+        ops.sumsq(f.g, self.partials)
+        nd = f.n_decay
+        common = dict(partials=self.partials, max_norm=self.max_norm, lr=lr, beta1=self.betas[0], beta2=self.betas[1],
+                      eps=self.eps, step=self.step_count)
+        ops.adamw_step(f.p[:nd], f.g[:nd], f.m[:nd], f.v[:nd], weight_decay=self.wd, gradnorm_out=self.gradnorm, **common)
+        ops.adamw_step(f.p[nd:], f.g[nd:], f.m[nd:], f.v[nd:], weight_decay=0.0, **common)
+        self.repack()
+
+    def train_step(self, x, target, lr=None):
+        loss, _, _ = self.forward(x, target, train=True)
+        self.backward()
+        self.optimizer_step(lr)
+        return loss

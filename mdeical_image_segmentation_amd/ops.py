@@ -76,6 +76,7 @@ def conv_igemm(x0, w_packed, y0, *, ksize, Cin, Cout, grid=None, x1=None, bias=N
     if grid is None:
         grid = (x0.N, x0.D, x0.H, x0.W)
     d.N, d.D, d.H, d.W = grid
+    d.is3d = 1 if x0.t.dim() == 5 else 0
     d.Cin, d.Cout = Cin, Cout
     d.x0, d.x0_ld, d.x0_D, d.x0_H, d.x0_W = x0.ptr, x0.ld, x0.D, x0.H, x0.W
     d.Cin0 = x0.C if x1 is not None else Cin
@@ -96,8 +97,8 @@ def conv_igemm(x0, w_packed, y0, *, ksize, Cin, Cout, grid=None, x1=None, bias=N
     if y1 is not None:
         y1 = _v(y1)
         d.y1, d.y1_ld, d.y1_mode = y1.ptr, y1.ld, y1_mode
-    taps = 1 if ksize == 1 else (27 if d.D > 1 else 9)
-    key = ("conv_igemm", "bf16" if d.dtype == MIS_BF16 else "f32", f"k{ksize}", "3d" if d.D > 1 else "2d",
+    taps = 1 if ksize == 1 else (27 if d.is3d else 9)
+    key = ("conv_igemm", "bf16" if d.dtype == MIS_BF16 else "f32", f"k{ksize}", "3d" if d.is3d else "2d",
            "bn128" if Cout % 128 == 0 else "bn64", f"{d.N}x{d.D}x{d.H}x{d.W} {Cin}->{Cout}")
     with _Timed(key, 2.0 * d.N * d.D * d.H * d.W * taps * Cin * Cout):
         check(lib.mis_conv_igemm(C.byref(d), stream_ptr()), "mis_conv_igemm")
@@ -126,6 +127,7 @@ def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alph
     if grid is None:
         grid = (dy.N, dy.D, dy.H, dy.W)
     d.N, d.D, d.H, d.W = grid
+    d.is3d = 1 if dy.t.dim() == 5 else 0
     d.Cin, d.Cout = Cin, Cout
     d.x0, d.x0_ld, d.x0_D, d.x0_H, d.x0_W = x0.ptr, x0.ld, x0.D, x0.H, x0.W
     d.Cin0 = x0.C if x1 is not None else Cin
@@ -142,8 +144,8 @@ def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alph
         check(-1, "mis_wgrad_workspace_bytes")
     ws = workspace(need, dy.t.device, "wgrad")
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-    taps = 1 if ksize == 1 else (27 if d.D > 1 else 9)
-    key = ("wgrad", "bf16" if d.dtype == MIS_BF16 else "f32", f"k{ksize}", "3d" if d.D > 1 else "2d", "",
+    taps = 1 if ksize == 1 else (27 if d.is3d else 9)
+    key = ("wgrad", "bf16" if d.dtype == MIS_BF16 else "f32", f"k{ksize}", "3d" if d.is3d else "2d", "",
            f"{d.N}x{d.D}x{d.H}x{d.W} {Cin}->{Cout}")
     with _Timed(key, 2.0 * d.N * d.D * d.H * d.W * taps * Cin * Cout):
         check(lib.mis_wgrad(C.byref(d), stream_ptr()), "mis_wgrad")
@@ -283,3 +285,63 @@ def probe_mfma(which, a, b, c):
     lib = load()
     check(lib.mis_probe_mfma(which, a.data_ptr(), None if b is None else b.data_ptr(), c.data_ptr(), stream_ptr()),
           "mis_probe_mfma")
+
+
+# ---- GroupNorm / 3-D helpers ---------------------------------------------------------------------------
+def gn_fwd_finalize(sum0, sq0, C0, mult0, sum1, sq1, C1, mult1, N, G, count, gamma, beta, Cpad, scale, shift, mean, rstd, eps=1e-5):
+    lib = load()
+    check(lib.mis_gn_fwd_finalize(sum0.data_ptr(), sq0.data_ptr(), C0, mult0, None if sum1 is None else sum1.data_ptr(),
+                                  None if sq1 is None else sq1.data_ptr(), C1, mult1, N, G, float(count), gamma.data_ptr(), beta.data_ptr(),
+                                  eps, Cpad, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), stream_ptr()),
+          "mis_gn_fwd_finalize")
+
+
+def gn_bwd_stats(dy, x, Cs, up, grid, S1, S2, Ctot, c_off):
+    """dy: full-grid View over ALL Ctot channels; x: the source tensor View (Cs channels)."""
+    lib = load()
+    dy, x = _v(dy), _v(x)
+    N, D, H, W = grid
+    ws = workspace(lib.mis_gn_bwd_stats_workspace_bytes(N, Cs), x.t.device, "gnbwd")
+    check(lib.mis_gn_bwd_stats(dtype_code(x.dtype), dy.ptr, dy.ld, x.ptr, x.ld, Cs, 1 if up else 0, N, D, H, W, ws.data_ptr(),
+                               S1.data_ptr(), S2.data_ptr(), Ctot, c_off, stream_ptr()), "mis_gn_bwd_stats")
+
+
+def gn_bwd_finalize(S1, S2, mean, rstd, gamma, N, Cc, G, count, p, q, r, dgamma, dbeta):
+    lib = load()
+    check(lib.mis_gn_bwd_finalize(S1.data_ptr(), S2.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), N, Cc, G, float(count),
+                                  p.data_ptr(), q.data_ptr(), r.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), stream_ptr()),
+          "mis_gn_bwd_finalize")
+
+
+def gn_bwd_apply(dy, x, Cs, up, grid, p, q, r, Ctot, c_off, dx, relu_mask=False, add=None):
+    lib = load()
+    dy, x, dx = _v(dy), _v(x), _v(dx)
+    if add is not None:
+        add = _v(add)
+    N, D, H, W = grid
+    check(lib.mis_gn_bwd_apply(dtype_code(x.dtype), dy.ptr, dy.ld, x.ptr, x.ld, Cs, 1 if up else 0, N, D, H, W, p.data_ptr(), q.data_ptr(),
+                               r.data_ptr(), Ctot, c_off, 1 if relu_mask else 0, None if add is None else add.ptr,
+                               0 if add is None else add.ld, dx.ptr, dx.ld, stream_ptr()), "mis_gn_bwd_apply")
+
+
+def first3d_fwd(x, scale, shift, sstride, w, Cout, y, Cpad):
+    lib = load()
+    y = _v(y)
+    N, D, H, W = x.shape[0], x.shape[-3], x.shape[-2], x.shape[-1]
+    check(lib.mis_first3d_fwd(dtype_code(y.dtype), x.data_ptr(), scale.data_ptr(), shift.data_ptr(), sstride, N, D, H, W, w.data_ptr(), Cout,
+                              y.ptr, y.ld, Cpad, stream_ptr()), "mis_first3d_fwd")
+
+
+def first3d_bwd(x, scale, shift, sstride, dy, Cpad, w, Cout, dw, dxn):
+    lib = load()
+    dy = _v(dy)
+    N, D, H, W = x.shape[0], x.shape[-3], x.shape[-2], x.shape[-1]
+    ws = workspace(lib.mis_first3d_bwd_workspace_bytes(), x.device, "first3d")
+    check(lib.mis_first3d_bwd(dtype_code(dy.dtype), x.data_ptr(), scale.data_ptr(), shift.data_ptr(), sstride, N, D, H, W, dy.ptr, dy.ld, Cpad,
+                              w.data_ptr(), Cout, ws.data_ptr(), dw.data_ptr(), dxn.data_ptr(), stream_ptr()), "mis_first3d_bwd")
+
+
+def relu_mask(dy, y, dx):
+    lib = load()
+    dy, y, dx = _v(dy), _v(y), _v(dx)
+    check(lib.mis_relu_mask(dtype_code(y.dtype), dy.ptr, dy.ld, y.ptr, y.ld, dx.ptr, dx.ld, y.npix, y.C, stream_ptr()), "mis_relu_mask")

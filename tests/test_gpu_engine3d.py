@@ -1,0 +1,155 @@
+"""3-D U-Net engine (HIP) against the golden vectors from the reference (default-width UNet3D(1,3), 1x1x16^3) and against
+the CPU oracle on a second, non-cubic shape; GroupNorm helper kernels against torch.nn.functional.group_norm."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def stat(t):
+    t = t.detach().double().cpu().flatten()
+    idx = torch.linspace(0, t.numel() - 1, steps=64).long()
+    return np.concatenate([[t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], t[idx].numpy()])
+
+
+def _engine(dtype):
+    from mdeical_image_segmentation_amd.engine3d import UNet3DEngine
+    return UNet3DEngine(1, 3, dtype=dtype, device=DEV, seed=0)
+
+
+def test_fp32_engine3d_matches_reference_golden():
+    g = load_golden("g3_unet3d_default.npz")
+    eng = _engine(torch.float32)
+    names = [str(n) for n in g["names"]]
+    ps = np.stack([stat(eng.P[n]) for n in names])
+    assert np.array_equal(ps[:, 3:], g["param_stats"][:, 3:]), "seeded init differs from the reference"
+    x, t = T(g["x"]).to(DEV), T(g["t"]).to(DEV)
+    loss, logits, am = eng.forward(x, t, train=True)
+    ref = T(g["logits"])
+    d = (logits.cpu() - ref).abs().max().item()
+    assert d < 1e-4, f"logits max|diff| {d}"
+    assert abs(loss.item() - float(g["loss"])) < 1e-4, (loss.item(), float(g["loss"]))
+    top2 = ref.topk(2, dim=1).values
+    nt = (top2[:, 0] - top2[:, 1]) < 1e-4
+    assert int((am.cpu().long() != T(g["argmax"]))[~nt].sum()) == 0
+    eng.backward()
+    torch.cuda.synchronize()
+    gs = np.stack([stat(eng.Gr[n]) for n in names])
+    refg = g["grad_stats"]
+    for i, n in enumerate(names):
+        assert abs(gs[i, 1] - refg[i, 1]) <= 3e-3 * abs(refg[i, 1]) + 1e-6, (n, "abssum", gs[i, 1], refg[i, 1])
+        assert abs(gs[i, 0] - refg[i, 0]) <= 3e-3 * abs(refg[i, 1]) + 1e-6, (n, "sum", gs[i, 0], refg[i, 0])
+    assert torch.allclose(eng.Gr["final_conv.weight"].cpu(), T(g["g_final_w"]), rtol=2e-3, atol=1e-6)
+    eng.optimizer_step()
+    assert np.isfinite(eng.gradnorm.item())
+
+
+def test_fp32_engine3d_vs_oracle_noncubic():
+    from oracle import unet3d_oracle as o3
+    eng = _engine(torch.float32)
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 1, 8, 16, 24, generator=gen)
+    t = (torch.rand(2, 3, 8, 16, 24, generator=gen) > 0.5).float()
+    p = o3.init_params(1, 3, seed=0)
+    rl, rlogits, rgrads = o3.loss_and_grads(p, x, t)
+    loss, logits, am = eng.forward(x.to(DEV), t.to(DEV), train=True)
+    eng.backward()
+    assert (logits.cpu() - rlogits).abs().max().item() < 1e-4
+    assert abs(loss.item() - rl.item()) < 1e-4
+    for n, gref in rgrads.items():
+        a = eng.Gr[n].cpu()
+        err = (a - gref).abs().max().item()
+        # the two single-element GroupNorm grads of the first layer are sums of ~1e4 cancelling terms: absolute floor
+        floor = 2e-4 if gref.numel() == 1 else 1e-7
+        assert err <= 3e-3 * gref.abs().max().item() + floor, (n, err, gref.abs().max().item())
+
+
+def test_bf16_engine3d_close():
+    g = load_golden("g3_unet3d_default.npz")
+    eng = _engine(torch.bfloat16)
+    loss, logits, am = eng.forward(T(g["x"]).to(DEV), T(g["t"]).to(DEV), train=True)
+    eng.backward()
+    ref = T(g["logits"])
+    rel = (logits.cpu() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"bf16 3-D: logits rel err {rel:.3g}, loss {loss.item():.5f} vs {float(g['loss']):.5f}")
+    assert rel < 0.08
+    assert abs(loss.item() - float(g["loss"])) < 3e-2
+    a, b = eng.Gr["final_conv.weight"].cpu().flatten(), T(g["g_final_w"]).flatten()
+    assert torch.dot(a, b) / (a.norm() * b.norm()) > 0.98
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_groupnorm_conv3d_block(dtype):
+    """One 'gcr' SingleConv with a two-source (encoder | nearest-upsampled) input: forward and every gradient."""
+    from mdeical_image_segmentation_amd import ops
+    N, D, H, W, C0, C1, Co, G = 2, 4, 8, 8, 64, 128, 64, 8
+    gen = torch.Generator().manual_seed(4)
+    enc = F.relu(torch.randn(N, C0, D, H, W, generator=gen))
+    low = F.relu(torch.randn(N, C1, D // 2, H // 2, W // 2, generator=gen))
+    gamma = 1 + 0.2 * torch.randn(C0 + C1, generator=gen)
+    beta = 0.2 * torch.randn(C0 + C1, generator=gen)
+    w = torch.randn(Co, C0 + C1, 3, 3, 3, generator=gen) * 0.03
+    gy = torch.randn(N, Co, D, H, W, generator=gen)
+
+    def q(t):
+        return t.to(dtype).float()
+
+    e, l2, wq = q(enc).requires_grad_(True), q(low).requires_grad_(True), q(w).requires_grad_(True)
+    gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    xc = torch.cat((e, F.interpolate(l2, size=(D, H, W), mode="nearest")), 1)
+    y = F.relu(F.conv3d(F.group_norm(xc, G, gm, bt, eps=1e-5), wq, None, padding=1))
+    y.backward(q(gy))
+
+    def cl(t):
+        return t.permute(0, 2, 3, 4, 1).contiguous().to(dtype).to(DEV)
+
+    ed, ld = cl(enc), cl(low)
+    Ct = C0 + C1
+    s0, q0 = torch.zeros(N, C0, device=DEV), torch.zeros(N, C0, device=DEV)
+    s1, q1 = torch.zeros(N, C1, device=DEV), torch.zeros(N, C1, device=DEV)
+    ops.chanstats(ed, s0, q0)
+    ops.chanstats(ld, s1, q1)
+    scale, shift = torch.zeros(N, Ct, device=DEV), torch.zeros(N, Ct, device=DEV)
+    mean, rstd = torch.zeros(N, G, device=DEV), torch.zeros(N, G, device=DEV)
+    ops.gn_fwd_finalize(s0, q0, C0, 1.0, s1, q1, C1, 8.0, N, G, D * H * W, gamma.to(DEV), beta.to(DEV), Ct, scale, shift, mean, rstd)
+    wf = torch.empty(27, Co, Ct, dtype=dtype, device=DEV)
+    wd = torch.empty(27, Ct, Co, dtype=dtype, device=DEV)
+    ops.pack_conv_weight(w.to(DEV), wf, wd)
+    yd = torch.empty(N, D, H, W, Co, dtype=dtype, device=DEV)
+    ops.conv_igemm(ed, wf, yd, ksize=3, Cin=Ct, Cout=Co, grid=(N, D, H, W), x1=ld, relu=True, in_scale=scale, in_shift=shift)
+    tol = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    got = yd.float().cpu().permute(0, 4, 1, 2, 3)
+    assert torch.allclose(got, y.detach(), **tol), (got - y.detach()).abs().max()
+    # backward
+    gpre = cl(gy * (y.detach() > 0))
+    dw = torch.zeros(Co, Ct, 3, 3, 3, device=DEV)
+    ops.wgrad(ed, gpre, dw, ksize=3, Cin=Ct, Cout=Co, grid=(N, D, H, W), x1=ld, in_scale=scale, in_shift=shift)
+    wtol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float32 else dict(rtol=5e-2, atol=0.4)   # bf16: the normalised input is re-rounded
+    assert torch.allclose(dw.cpu(), wq.grad, **wtol), (dw.cpu() - wq.grad).abs().max()
+    dyn = torch.empty(N, D, H, W, Ct, dtype=dtype, device=DEV)
+    ops.conv_igemm(gpre, wd, dyn, ksize=3, Cin=Co, Cout=Ct, grid=(N, D, H, W))
+    S1, S2 = torch.zeros(N, Ct, device=DEV), torch.zeros(N, Ct, device=DEV)
+    ops.gn_bwd_stats(dyn, ed, C0, False, (N, D, H, W), S1, S2, Ct, 0)
+    ops.gn_bwd_stats(dyn, ld, C1, True, (N, D, H, W), S1, S2, Ct, C0)
+    p_, q_, r_ = (torch.zeros(N, Ct, device=DEV) for _ in range(3))
+    dg, db = torch.zeros(Ct, device=DEV), torch.zeros(Ct, device=DEV)
+    ops.gn_bwd_finalize(S1, S2, mean, rstd, gamma.to(DEV), N, Ct, G, D * H * W, p_, q_, r_, dg, db)
+    gt = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float32 else dict(rtol=6e-2, atol=0.15)
+    assert torch.allclose(dg.cpu(), gm.grad, **gt), (dg.cpu() - gm.grad).abs().max()
+    assert torch.allclose(db.cpu(), bt.grad, **gt), (db.cpu() - bt.grad).abs().max()
+    dx0 = torch.empty(N, D, H, W, C0, dtype=dtype, device=DEV)
+    dx1 = torch.empty(N, D // 2, H // 2, W // 2, C1, dtype=dtype, device=DEV)
+    ops.gn_bwd_apply(dyn, ed, C0, False, (N, D, H, W), p_, q_, r_, Ct, 0, dx0, relu_mask=False)
+    ops.gn_bwd_apply(dyn, ld, C1, True, (N, D, H, W), p_, q_, r_, Ct, C0, dx1, relu_mask=False)
+    xt = dict(rtol=2e-3, atol=2e-4) if dtype == torch.float32 else dict(rtol=6e-2, atol=3e-2)
+    assert torch.allclose(dx0.float().cpu().permute(0, 4, 1, 2, 3), e.grad, **xt), (dx0.float().cpu().permute(0, 4, 1, 2, 3) - e.grad).abs().max()
+    assert torch.allclose(dx1.float().cpu().permute(0, 4, 1, 2, 3), l2.grad, **xt), (dx1.float().cpu().permute(0, 4, 1, 2, 3) - l2.grad).abs().max()
