@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print a per-layer table of the MFMA kernels to stderr")
+    ap.add_argument("--workload", default="2d", choices=["2d", "3d"],
+                    help="2d = BASELINE configs[1] (headline); 3d = configs[3]: UNet3D(1,3) bs=2 128^3 (use --dtype f32)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -74,6 +76,9 @@ def main():
     from mdeical_image_segmentation_amd import ops
     from mdeical_image_segmentation_amd.ddp import GradReducer
     from mdeical_image_segmentation_amd.engine2d import UNet2DEngine
+
+    if args.workload == "3d":
+        return bench3d(args, rank, world, dev, dist)
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     eng = UNet2DEngine(1, 2, dtype=dtype, device=dev, seed=0)       # identical init on every rank
@@ -161,6 +166,81 @@ def main():
             out["cpu_baseline"] = {"value": round(v, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
                                    "sample": f"oracle (stock PyTorch CPU restatement of the reference) fp32 train step, bs={cb} {cs}x{cs}, "
                                              f"1 warm-up + 2 timed steps, {sdt:.2f} s/step"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+FLOP_PER_VOLUME_128 = 11359.7e9
+
+
+def bench3d(args, rank, world, dev, dist):
+    from mdeical_image_segmentation_amd import ops
+    from mdeical_image_segmentation_amd.ddp import GradReducer
+    from mdeical_image_segmentation_amd.engine3d import UNet3DEngine
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    batch = args.batch if args.batch != 32 else 2
+    size = args.size if args.size != 512 else 128
+    eng = UNet3DEngine(1, 3, dtype=dtype, device=dev, seed=0)
+    reducer = GradReducer(eng.flat) if world > 1 else None
+    g = torch.Generator().manual_seed(1000 + rank)
+    x = torch.randn(batch, 1, size, size, size, generator=g).to(dev)
+    t = (torch.rand(batch, 3, size, size, size, generator=g) > 0.5).float().to(dev)
+
+    def step():
+        eng.forward(x, t, train=True, grad_scale=1.0 / world)
+        if reducer is None:
+            eng.backward()
+        else:
+            eng.backward(stage_cb=reducer.stage_done)
+            reducer.finish()
+        eng.optimizer_step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_kernel_timing:
+        ops.PROFILE = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    if rank == 0:
+        value = world * batch * args.steps / dt
+        out = {"metric": f"volumes/sec (3D {size}^3 U-Net train step)", "value": round(value, 3), "unit": "volumes/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": f"unet3d 1-ch->3-class bs={batch}/GPU {size}^3, fwd+BCEDice+bwd+clip+AdamW, random-init weights",
+                          "global_batch": world * batch, "parallelism": f"dp{world}", "final_loss": round(eng.loss_buf[0].item(), 5)}}
+        out["model_tflops"] = round(value * FLOP_PER_VOLUME_128 * (size / 128.0) ** 3 / 1e12, 1)
+        if prof:
+            agg, layers = {}, {}
+            for key, flops, e0, e1 in prof:
+                la = layers.setdefault(key, [0.0, 0.0, 0])
+                la[0] += flops; la[1] += e0.elapsed_time(e1) * 1e-3; la[2] += 1
+                a = agg.setdefault(key[:5], [0.0, 0.0, 0])
+                a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+            key, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
+            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+            out["roofline"] = {"bound": "mfma", "achieved": round(fl / sec / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(fl / sec / 1e12 / peak, 4), "traffic": None, "kernel": "/".join(k for k in key if k),
+                               "launches": cnt, "avg_launch_ms": round(sec / cnt * 1e3, 3)}
+            out["mfma_kernel_ms_per_step"] = round(sum(v[1] for v in agg.values()) / args.steps * 1e3, 2)
+            if args.layers:
+                for k, v in sorted(layers.items(), key=lambda kv: -kv[1][1]):
+                    print(f"{v[1] / args.steps * 1e3:9.3f} ms/step {v[0] / v[1] / 1e12:7.1f} TF/s x{v[2] // args.steps}  {' '.join(x for x in k if x)}", file=sys.stderr)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

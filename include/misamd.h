@@ -179,6 +179,16 @@ int mis_first3d_bwd(int dtype, const float* x, const float* scale, const float* 
                     int dy_ld, int Cpad, const float* w, int Cout, float* workspace, float* dw, float* dxn, void* stream);
 int mis_relu_mask(int dtype, const void* dy, int dy_ld, const void* y, int y_ld, void* dx, int dx_ld, long long npix, int C, void* stream);
 
+/* On-device 3-D augmentation (augment/unet3d_augment/transforms.py:25-133,495-523,608-619). Volumes are (nvol, D, H, W),
+ * 4- or 8-byte elements for the geometric ops (raw fp32 / int64 labels), fp32 for the intensity ops; src != dst. */
+int mis_aug_flip_rot90(const void* src, void* dst, long long nvol, int D, int H, int W, int flipmask /*bit0 D, bit1 H, bit2 W*/, int k,
+                       int elem_size, void* stream);
+int mis_aug_rotate0(const void* src, void* dst, long long nvol, int D, int H, int W, int a0, int a1, const double* m4 /*host*/,
+                    const double* off2 /*host*/, int elem_size, void* stream);
+int mis_aug_pointwise(const float* src, float* dst, long long n, float a, float b, int do_clip, float lo, float hi, float noise_std,
+                      unsigned long long seed, void* stream);
+int mis_aug_contrast(const float* src, float* dst, long long n, float mean, float alpha, void* stream);
+
 /* layout helpers */
 int mis_nchw_to_nhwc(int dtype_out, const float* x, void* y, int y_ld, int N, int C, long long spatial, void* stream);
 int mis_nhwc_to_nchw(int dtype_in, const void* x, int x_ld, float* y, int N, int C, long long spatial, void* stream);

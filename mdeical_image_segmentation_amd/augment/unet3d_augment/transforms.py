@@ -1,0 +1,300 @@
+"""On-device mirror of the reference's 3-D augmentation (augment/unet3d_augment/transforms.py).
+
+Same class names, constructor arguments, seeding (`GLOBAL_RANDOM_STATE = RandomState(47)`, one seed per `Transformer`,
+every transform gets its own `RandomState(seed)` - transforms.py:12,721-753) and the same draw order per call, so raw
+and label pipelines stay in lock-step exactly like the reference.  The random PARAMETERS are drawn on the host from
+numpy's MT19937 streams (the reference's own generator); the volumes never leave HBM: every transform is one HIP
+gather / elementwise kernel (csrc/augment.hip).  Inputs may be numpy arrays (uploaded once) or CUDA tensors;
+outputs are CUDA tensors.  Differences, all loud or documented:
+  * RandomRotate supports order=0 (the class default, bit-exact vs scipy incl. 'reflect'); other orders raise;
+  * AdditiveGaussianNoise draws the decision and the std from the reference stream but the noise FIELD comes from an
+    on-device counter-based generator (same distribution, different values); `exact=True` generates the field with
+    numpy on the host instead;
+  * ElasticDeformation, Poisson noise, GaussianBlur3D, label->boundary transforms: out of scope.
+"""
+import ctypes as C
+import importlib
+
+import numpy as np
+import torch
+from scipy import special
+
+from ... import ops
+from ..._lib import MisError, check, load, stream_ptr
+
+GLOBAL_RANDOM_STATE = np.random.RandomState(47)
+
+
+def _dev(m):
+    if isinstance(m, np.ndarray):
+        m = torch.from_numpy(np.ascontiguousarray(m)).cuda()
+    if not isinstance(m, torch.Tensor) or m.device.type != "cuda":
+        raise MisError("augment: expected a numpy array or a CUDA tensor (the transforms run on MI355X only)")
+    if m.dim() not in (3, 4):
+        raise AssertionError("Supports only 3D (DxHxW) or 4D (CxDxHxW) images")
+    return m.contiguous()
+
+
+def _flip_rot90(m, flipmask, k):
+    m = _dev(m)
+    if flipmask == 0 and (k & 3) == 0:
+        return m
+    D, H, W = m.shape[-3:]
+    nvol = m.numel() // (D * H * W)
+    es = m.element_size()
+    if es not in (4, 8):
+        raise MisError(f"augment: unsupported element size {es} ({m.dtype})")
+    oshape = list(m.shape)
+    if k & 1:
+        oshape[-2], oshape[-1] = W, H
+    out = torch.empty(oshape, dtype=m.dtype, device=m.device)
+    check(load().mis_aug_flip_rot90(m.data_ptr(), out.data_ptr(), nvol, D, H, W, flipmask, k & 3, es, stream_ptr()), "mis_aug_flip_rot90")
+    return out
+
+
+class Compose(object):
+    def __init__(self, transforms):
+        self.transforms = transforms
+
+    def __call__(self, m):
+        for t in self.transforms:
+            m = t(m)
+        return m
+
+
+class RandomFlip:
+    """transforms.py:25-50: for axis in (0,1,2): flip if uniform() > axis_prob."""
+
+    def __init__(self, random_state, axis_prob=0.5, **kwargs):
+        assert random_state is not None, 'RandomState cannot be None'
+        self.random_state = random_state
+        self.axes = (0, 1, 2)
+        self.axis_prob = axis_prob
+
+    def __call__(self, m):
+        mask = 0
+        for axis in self.axes:
+            if self.random_state.uniform() > self.axis_prob:
+                mask |= 1 << axis
+        return _flip_rot90(m, mask, 0)
+
+
+class RandomRotate90:
+    """transforms.py:53-80: k = randint(0, 4); np.rot90(m, k, axes=(1, 2)) (the H-W plane)."""
+
+    def __init__(self, random_state, **kwargs):
+        self.random_state = random_state
+        self.axis = (1, 2)
+
+    def __call__(self, m):
+        k = self.random_state.randint(0, 4)
+        return _flip_rot90(m, 0, int(k))
+
+
+class RandomRotate:
+    """transforms.py:83-112: axis = axes[randint(len(axes))]; angle = randint(-spectrum, spectrum);
+    scipy.ndimage.rotate(reshape=False, order, mode='reflect', cval=-1)."""
+
+    def __init__(self, random_state, angle_spectrum=30, axes=None, mode='reflect', order=0, **kwargs):
+        if axes is None:
+            axes = [(1, 0), (2, 1), (2, 0)]
+        else:
+            assert isinstance(axes, list) and len(axes) > 0
+        self.random_state = random_state
+        self.angle_spectrum = angle_spectrum
+        self.axes = axes
+        self.mode = mode
+        self.order = order
+
+    def __call__(self, m):
+        axis = self.axes[self.random_state.randint(len(self.axes))]
+        angle = self.random_state.randint(-self.angle_spectrum, self.angle_spectrum)
+        if self.order != 0 or self.mode != 'reflect':
+            raise NotImplementedError("on-device RandomRotate: only order=0, mode='reflect' is built (spline orders are a next row)")
+        m = _dev(m)
+        D, H, W = m.shape[-3:]
+        a0, a1 = sorted(int(a) for a in axis)
+        # exactly scipy.ndimage.rotate's host arithmetic
+        c, s = special.cosdg(angle), special.sindg(angle)
+        rot = np.array([[c, s], [-s, c]])
+        shp = np.asarray((D, H, W))[[a0, a1]]
+        out_center = rot @ ((shp - 1) / 2)
+        in_center = (shp - 1) / 2
+        off = in_center - out_center
+        m4 = (C.c_double * 4)(rot[0, 0], rot[0, 1], rot[1, 0], rot[1, 1])
+        o2 = (C.c_double * 2)(off[0], off[1])
+        out = torch.empty_like(m)
+        nvol = m.numel() // (D * H * W)
+        check(load().mis_aug_rotate0(m.data_ptr(), out.data_ptr(), nvol, D, H, W, a0, a1, m4, o2, m.element_size(), stream_ptr()),
+              "mis_aug_rotate0")
+        return out
+
+
+class RandomContrast:
+    """transforms.py:115-133: if uniform() < p: alpha = uniform(a0, a1); clip(mean + alpha * (m - mean), -1, 1)."""
+
+    def __init__(self, random_state, alpha=(0.5, 1.5), mean=0.0, execution_probability=0.1, **kwargs):
+        self.random_state = random_state
+        assert len(alpha) == 2
+        self.alpha = alpha
+        self.mean = mean
+        self.execution_probability = execution_probability
+
+    def __call__(self, m):
+        if self.random_state.uniform() < self.execution_probability:
+            alpha = self.random_state.uniform(self.alpha[0], self.alpha[1])
+            m = _dev(m)
+            if m.dtype != torch.float32:
+                raise MisError("RandomContrast: fp32 volumes only")
+            out = torch.empty_like(m)
+            check(load().mis_aug_contrast(m.data_ptr(), out.data_ptr(), m.numel(), float(self.mean), float(alpha), stream_ptr()), "mis_aug_contrast")
+            return out
+        return m
+
+
+class Standardize:
+    """transforms.py:495-523: (m - mean) / clip(std, eps). Volume statistics are reduced on the device when not given."""
+
+    def __init__(self, eps=1e-10, mean=None, std=None, channelwise=False, **kwargs):
+        if mean is not None or std is not None:
+            assert mean is not None and std is not None
+        self.mean, self.std, self.eps, self.channelwise = mean, std, eps, channelwise
+
+    def __call__(self, m):
+        m = _dev(m)
+        if m.dtype != torch.float32:
+            raise MisError("Standardize: fp32 volumes only")
+        if self.channelwise:
+            raise NotImplementedError("Standardize(channelwise=True) is not built")
+        if self.mean is not None:
+            mean, std = float(self.mean), float(self.std)
+        else:
+            n = m.numel()
+            if n % 4:
+                raise MisError("Standardize: volume size must be a multiple of 4")
+            s = torch.zeros(1, 4, device=m.device)
+            q = torch.zeros(1, 4, device=m.device)
+            ops.chanstats(m.view(1, 1, 1, n // 4, 4), s, q)
+            tot, tot2 = s.double().sum().item(), q.double().sum().item()
+            mean = tot / n
+            std = max(tot2 / n - mean * mean, 0.0) ** 0.5
+        std = max(std, self.eps)
+        out = torch.empty_like(m)
+        a = 1.0 / std
+        check(load().mis_aug_pointwise(m.data_ptr(), out.data_ptr(), m.numel(), a, -mean * a, 0, 0.0, 0.0, 0.0, 0, stream_ptr()), "mis_aug_pointwise")
+        return out
+
+
+class Normalize:
+    """transforms.py:547-605 with fixed min_value / max_value (data-dependent min/max is not built)."""
+
+    def __init__(self, min_value=None, max_value=None, norm01=False, channelwise=False, eps=1e-10, **kwargs):
+        if min_value is None or max_value is None or channelwise:
+            raise NotImplementedError("on-device Normalize needs fixed scalar min_value and max_value")
+        assert max_value > min_value
+        self.min_value, self.max_value, self.norm01, self.eps = min_value, max_value, norm01, eps
+
+    def __call__(self, m):
+        m = _dev(m)
+        out = torch.empty_like(m)
+        a = 1.0 / (self.max_value - self.min_value + self.eps)
+        b = -self.min_value * a
+        if self.norm01:
+            args = (a, b, 1, 0.0, 1.0)
+        else:
+            args = (2 * a, 2 * b - 1, 1, -1.0, 1.0)
+        check(load().mis_aug_pointwise(m.data_ptr(), out.data_ptr(), m.numel(), *args, 0.0, 0, stream_ptr()), "mis_aug_pointwise")
+        return out
+
+
+class AdditiveGaussianNoise:
+    """transforms.py:608-619: if uniform() < p: std = uniform(scale); m + N(0, std)."""
+
+    def __init__(self, random_state, scale=(0.0, 1.0), execution_probability=0.1, exact=False, **kwargs):
+        self.execution_probability = execution_probability
+        self.random_state = random_state
+        self.scale = scale
+        self.exact = exact
+
+    def __call__(self, m):
+        if self.random_state.uniform() < self.execution_probability:
+            std = self.random_state.uniform(self.scale[0], self.scale[1])
+            m = _dev(m)
+            if self.exact:
+                noise = self.random_state.normal(0, std, size=tuple(m.shape))
+                return m + torch.from_numpy(noise).to(m.device, torch.float32)   # upload of a host-generated field (parity mode)
+            seed = int(self.random_state.randint(0, 2 ** 31 - 1))
+            out = torch.empty_like(m)
+            check(load().mis_aug_pointwise(m.data_ptr(), out.data_ptr(), m.numel(), 1.0, 0.0, 0, 0.0, 0.0, float(std), seed, stream_ptr()),
+                  "mis_aug_pointwise")
+            return out
+        return m
+
+
+class ToTensor:
+    """transforms.py:636-655: add the channel axis for 3-D inputs and cast; the data already lives on the device."""
+
+    def __init__(self, expand_dims, dtype=np.float32, **kwargs):
+        self.expand_dims = expand_dims
+        self.dtype = dtype
+
+    def __call__(self, m):
+        m = _dev(m)
+        if self.expand_dims and m.dim() == 3:
+            m = m.unsqueeze(0)
+        td = {np.float32: torch.float32, np.int64: torch.int64, "float32": torch.float32, "int64": torch.int64}.get(self.dtype, torch.float32)
+        return m.to(td)
+
+
+class LabelToTensor:
+    def __call__(self, m):
+        return _dev(m).to(torch.int64)
+
+
+def _unbuilt(name):
+    class _U:
+        def __init__(self, *a, **k):
+            raise NotImplementedError(f"{name}: not built on the device (SURVEY.md §8f2)")
+    _U.__name__ = name
+    return _U
+
+
+ElasticDeformation = _unbuilt("ElasticDeformation")
+AdditivePoissonNoise = _unbuilt("AdditivePoissonNoise")
+GaussianBlur3D = _unbuilt("GaussianBlur3D")
+PercentileNormalizer = _unbuilt("PercentileNormalizer")
+CropToFixed = _unbuilt("CropToFixed")
+
+
+class Transformer:
+    """transforms.py:721-753."""
+
+    def __init__(self, phase_config, base_config):
+        self.phase_config = phase_config
+        self.config_base = base_config
+        self.seed = GLOBAL_RANDOM_STATE.randint(10000000)
+
+    def raw_transform(self):
+        return self._create_transform('raw')
+
+    def label_transform(self):
+        return self._create_transform('label')
+
+    def weight_transform(self):
+        return self._create_transform('weight')
+
+    @staticmethod
+    def _transformer_class(class_name):
+        m = importlib.import_module(__name__)
+        return getattr(m, class_name)
+
+    def _create_transform(self, name):
+        assert name in self.phase_config, f'Could not find {name} transform'
+        return Compose([self._create_augmentation(c) for c in self.phase_config[name]])
+
+    def _create_augmentation(self, c):
+        config = dict(self.config_base)
+        config.update(c)
+        config['random_state'] = np.random.RandomState(self.seed)
+        aug_class = self._transformer_class(config['name'])
+        return aug_class(**config)

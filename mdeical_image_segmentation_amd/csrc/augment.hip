@@ -1,0 +1,185 @@
+// On-device 3-D augmentation (gfx950): the geometric transforms of the reference's numpy/scipy pipeline as exact index
+// gathers, and the intensity transforms as one elementwise pass.  HBM-bound, 4/8-byte elements, one thread per voxel.
+//
+// Reference (augment/unet3d_augment/transforms.py): RandomFlip :25-50 (np.flip per axis), RandomRotate90 :53-80
+// (np.rot90(m, k, axes=(1,2))), RandomRotate :83-112 (scipy.ndimage.rotate(reshape=False, order=0, mode='reflect'):
+// per-plane affine_transform; input coordinate = ((0 + i*m[d][0]) + j*m[d][1]) + offset[d] in double without fused
+// multiply-add, reflect about the half-sample edges, round half up, reflect the index), RandomContrast :115-133,
+// AdditiveGaussianNoise :608-619, Standardize :495-523.  The random PARAMETERS are drawn on the host from the same numpy
+// RandomState streams as the reference; only the Gaussian noise FIELD comes from an on-device counter-based generator.
+#include "common.hpp"
+
+// numpy / scipy evaluate these expressions without fused multiply-add: keep hipcc from contracting a*b+c in this file
+#pragma clang fp contract(off)
+
+template <typename E>
+__global__ __launch_bounds__(256) void aug_flip_rot90_kernel(const E* __restrict__ src, E* __restrict__ dst, long long nvol, int D, int H, int W,
+                                                             int flipmask, int k) {
+    // src (nvol, D, H, W) -> flip along the axes in flipmask (bit0 = D, bit1 = H, bit2 = W) -> rot90 k times in the (H, W) plane
+    const int OH = (k & 1) ? W : H, OW = (k & 1) ? H : W;
+    const long long per = (long long)D * OH * OW, total = nvol * per;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long v = i / per;
+        long long r = i - v * per;
+        const int x = (int)(r % OW);
+        r /= OW;
+        const int y = (int)(r % OH);
+        int z = (int)(r / OH);
+        // inverse rot90: out = np.rot90(in, k, axes=(1,2))
+        int iy, ix;
+        switch (k & 3) {
+            case 0: iy = y; ix = x; break;
+            case 1: iy = x; ix = W - 1 - y; break;            // out[y][x] = in[x][W-1-y]
+            case 2: iy = H - 1 - y; ix = W - 1 - x; break;
+            default: iy = H - 1 - x; ix = y; break;           // k = 3: out[y][x] = in[H-1-x][y]
+        }
+        if (flipmask & 1) z = D - 1 - z;
+        if (flipmask & 2) iy = H - 1 - iy;
+        if (flipmask & 4) ix = W - 1 - ix;
+        dst[i] = src[((v * D + z) * H + iy) * W + ix];
+    }
+}
+
+__device__ __forceinline__ double refl_coord(double x, int n) {
+    if (x < 0) {
+        const int sz2 = 2 * n;
+        if (x < -sz2) x = sz2 * (double)(long long)(-x / sz2) + x;
+        x = x < -n ? x + sz2 : ((x > -1e-15 ? 1e-15 : -x) - 1.0);
+    } else if (x > n - 1) {
+        const int sz2 = 2 * n;
+        x -= sz2 * (double)(long long)(x / sz2);
+        if (x >= n) x = sz2 - x - 1;
+    }
+    return x;
+}
+__device__ __forceinline__ int refl_idx(long long k, int n) {
+    const long long sz2 = 2LL * n;
+    if (k < 0) {
+        if (k < -sz2) k = sz2 * (-k / sz2) + k;
+        k = k < -n ? k + sz2 : -k - 1;
+    } else if (k > n - 1) {
+        k -= sz2 * (k / sz2);
+        if (k >= n) k = sz2 - k - 1;
+    }
+    return (int)k;
+}
+
+struct RotArgs {
+    double m00, m01, m10, m11, off0, off1;
+};
+
+template <typename E>
+__global__ __launch_bounds__(256) void aug_rotate0_kernel(const E* __restrict__ src, E* __restrict__ dst, long long nvol, int D, int H, int W, int a0,
+                                                          int a1, RotArgs ra) {
+    const long long per = (long long)D * H * W, total = nvol * per;
+    const int dims[3] = {D, H, W};
+    const int n0 = dims[a0], n1 = dims[a1];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long v = i / per;
+        long long r = i - v * per;
+        int c[3];
+        c[2] = (int)(r % W);
+        r /= W;
+        c[1] = (int)(r % H);
+        c[0] = (int)(r / H);
+        const double o0 = (double)c[a0], o1 = (double)c[a1];
+        // same operation order as scipy's C loop, no FMA contraction
+        double x0 = __dadd_rn(__dadd_rn(__dadd_rn(0.0, __dmul_rn(o0, ra.m00)), __dmul_rn(o1, ra.m01)), ra.off0);
+        double x1 = __dadd_rn(__dadd_rn(__dadd_rn(0.0, __dmul_rn(o0, ra.m10)), __dmul_rn(o1, ra.m11)), ra.off1);
+        x0 = refl_coord(x0, n0);
+        x1 = refl_coord(x1, n1);
+        c[a0] = refl_idx((long long)floor(x0 + 0.5), n0);
+        c[a1] = refl_idx((long long)floor(x1 + 0.5), n1);
+        dst[i] = src[((v * D + c[0]) * H + c[1]) * W + c[2]];
+    }
+}
+
+static unsigned aug_grid(long long total) {
+    long long b = (total + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+extern "C" int mis_aug_flip_rot90(const void* src, void* dst, long long nvol, int D, int H, int W, int flipmask, int k, int elem_size,
+                                  void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(src && dst && src != dst && nvol > 0 && D > 0 && H > 0 && W > 0, MIS_EINVAL, "aug_flip_rot90: bad argument");
+    MIS_REQUIRE(elem_size == 4 || elem_size == 8, MIS_EUNSUPPORTED, "aug_flip_rot90: element size %d", elem_size);
+    MIS_REQUIRE(k >= 0 && k <= 3 && flipmask >= 0 && flipmask <= 7, MIS_EINVAL, "aug_flip_rot90: k / flipmask");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned g = aug_grid(nvol * D * H * W);
+    if (elem_size == 4)
+        hipLaunchKernelGGL(aug_flip_rot90_kernel<uint32_t>, dim3(g), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, nvol, D, H, W, flipmask, k);
+    else
+        hipLaunchKernelGGL(aug_flip_rot90_kernel<uint64_t>, dim3(g), dim3(256), 0, s, (const uint64_t*)src, (uint64_t*)dst, nvol, D, H, W, flipmask, k);
+    MIS_LAUNCH_CHECK("aug_flip_rot90");
+    return MIS_OK;
+}
+
+extern "C" int mis_aug_rotate0(const void* src, void* dst, long long nvol, int D, int H, int W, int a0, int a1, const double* m4,
+                               const double* off2, int elem_size, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(src && dst && src != dst && m4 && off2 && nvol > 0 && D > 0 && H > 0 && W > 0, MIS_EINVAL, "aug_rotate0: bad argument");
+    MIS_REQUIRE(a0 >= 0 && a0 < a1 && a1 <= 2, MIS_EINVAL, "aug_rotate0: axes must be sorted and distinct");
+    MIS_REQUIRE(elem_size == 4 || elem_size == 8, MIS_EUNSUPPORTED, "aug_rotate0: element size %d", elem_size);
+    RotArgs ra{m4[0], m4[1], m4[2], m4[3], off2[0], off2[1]};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned g = aug_grid(nvol * D * H * W);
+    if (elem_size == 4)
+        hipLaunchKernelGGL(aug_rotate0_kernel<uint32_t>, dim3(g), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, nvol, D, H, W, a0, a1, ra);
+    else
+        hipLaunchKernelGGL(aug_rotate0_kernel<uint64_t>, dim3(g), dim3(256), 0, s, (const uint64_t*)src, (uint64_t*)dst, nvol, D, H, W, a0, a1, ra);
+    MIS_LAUNCH_CHECK("aug_rotate0");
+    return MIS_OK;
+}
+
+// y = a*x + b ; optional clip ; optional additive N(0, noise_std) from a counter-based generator (splitmix64 + Box-Muller)
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void aug_pointwise_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n, float a, float b,
+                                                            int do_clip, float lo, float hi, float noise_std, uint64_t seed) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float v = a * src[i] + b;           // numpy evaluates mean + alpha*(m - mean) unfused; callers fold only exact cases
+        if (do_clip) v = fminf(fmaxf(v, lo), hi);
+        if (noise_std > 0.f) {
+            const uint64_t h = splitmix64(seed ^ splitmix64((uint64_t)i));
+            const float u1 = ((float)(uint32_t)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);     // (0, 1)
+            const float u2 = ((float)(uint32_t)((h >> 8) & 0xFFFFFF) + 0.5f) * (1.0f / 16777216.0f);
+            v += noise_std * sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+        }
+        dst[i] = v;
+    }
+}
+
+// contrast exactly as numpy evaluates it in float32: clip(mean + alpha * (m - mean), -1, 1)
+__global__ __launch_bounds__(256) void aug_contrast_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n, float mean, float alpha) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float d = __fsub_rn(src[i], mean);
+        const float r = __fadd_rn(mean, __fmul_rn(alpha, d));
+        dst[i] = fminf(fmaxf(r, -1.f), 1.f);
+    }
+}
+
+extern "C" int mis_aug_pointwise(const float* src, float* dst, long long n, float a, float b, int do_clip, float lo, float hi, float noise_std,
+                                 unsigned long long seed, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(src && dst && n > 0, MIS_EINVAL, "aug_pointwise: bad argument");
+    hipLaunchKernelGGL(aug_pointwise_kernel, dim3(aug_grid(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, n, a, b, do_clip, lo, hi,
+                       noise_std, (uint64_t)seed);
+    MIS_LAUNCH_CHECK("aug_pointwise");
+    return MIS_OK;
+}
+
+extern "C" int mis_aug_contrast(const float* src, float* dst, long long n, float mean, float alpha, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(src && dst && n > 0, MIS_EINVAL, "aug_contrast: bad argument");
+    hipLaunchKernelGGL(aug_contrast_kernel, dim3(aug_grid(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, n, mean, alpha);
+    MIS_LAUNCH_CHECK("aug_contrast");
+    return MIS_OK;
+}

@@ -1,0 +1,98 @@
+"""3-D augmentation: the numpy oracle against golden vectors from the real reference classes (CPU), and the on-device
+transforms (HIP gather / elementwise kernels behind the reference's class names) against both (GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import augment_oracle as ao
+
+
+def _replay_single(g):
+    """replays the explicit-seed single-transform goldens with the oracle"""
+    v, sq = g["v"], g["sq"]
+    for s in range(8):
+        rs = np.random.RandomState(100 + s)
+        axes = [(1, 0), (2, 1), (2, 0)]
+        axis = axes[rs.randint(len(axes))]
+        angle = rs.randint(-30, 30)
+        yield f"rot_{s}", ao.rotate0(v, angle, axis)
+    for s in range(4):
+        rs = np.random.RandomState(200 + s)
+        mask = 0
+        for axis in (0, 1, 2):
+            if rs.uniform() > 0.5:
+                mask |= 1 << axis
+        yield f"flip_{s}", ao.flip(v, mask)
+    for s in range(6):
+        yield f"rot90_{s}", ao.rot90(sq, np.random.RandomState(300 + s).randint(0, 4))
+
+
+def test_oracle_matches_reference_goldens():
+    g = load_golden("g5_augment.npz")
+    for name, got in _replay_single(g):
+        assert np.array_equal(got, g[name]), name
+    assert int(g["transformer_seed"]) == 889991
+    p = ao.Pipeline(int(g["transformer_seed"]), [[2, 1]], 0.6, mean=0.05)
+    for i in range(6):
+        assert np.array_equal(p.raw(g["raw"]), g[f"pipe_raw_{i}"]), f"raw {i}"
+        assert np.array_equal(p.label(g["label"]), g[f"pipe_label_{i}"]), f"label {i}"
+    assert np.allclose(ao.standardize(g["v"]), g["std_auto"], atol=1e-6)
+    rs = np.random.RandomState(9)
+    rs.uniform()
+    assert np.array_equal(ao.contrast(g["v"], 0.05, rs.uniform(0.5, 1.5)), g["contrast"])
+
+
+@pytest.mark.gpu
+def test_device_transforms_match_reference_goldens():
+    from mdeical_image_segmentation_amd.augment.unet3d_augment import transforms as tr
+    g = load_golden("g5_augment.npz")
+    v, sq = g["v"], g["sq"]
+    for s in range(8):
+        out = tr.RandomRotate(np.random.RandomState(100 + s), angle_spectrum=30, mode="reflect", order=0)(v)
+        assert np.array_equal(out.cpu().numpy(), g[f"rot_{s}"]), f"rot_{s}"
+    for s in range(4):
+        assert np.array_equal(tr.RandomFlip(np.random.RandomState(200 + s))(v).cpu().numpy(), g[f"flip_{s}"]), f"flip_{s}"
+    for s in range(6):
+        assert np.array_equal(tr.RandomRotate90(np.random.RandomState(300 + s))(sq).cpu().numpy(), g[f"rot90_{s}"]), f"rot90_{s}"
+    assert np.array_equal(tr.RandomFlip(np.random.RandomState(7))(g["c4"]).cpu().numpy(), g["c4_flip"])
+    assert np.array_equal(tr.RandomRotate(np.random.RandomState(8), axes=[(2, 1)])(g["c4"]).cpu().numpy(), g["c4_rot"])
+    assert np.array_equal(tr.RandomContrast(np.random.RandomState(9), mean=0.05, execution_probability=1.0)(v).cpu().numpy(), g["contrast"])
+    assert np.allclose(tr.Standardize()(v).cpu().numpy(), g["std_auto"], atol=2e-6)
+    assert np.allclose(tr.Standardize(mean=0.1, std=0.5)(v).cpu().numpy(), g["std_fixed"], atol=1e-6)
+    assert np.allclose(tr.Normalize(min_value=-1.0, max_value=1.0)(v).cpu().numpy(), g["norm"], atol=1e-6)
+    # the Transformer, seeded like the reference's first Transformer of a process, raw and label in lock-step
+    tr.GLOBAL_RANDOM_STATE = np.random.RandomState(47)
+    axes = [[2, 1]]
+    cfg = {"raw": [{"name": "RandomFlip"}, {"name": "RandomRotate90"},
+                   {"name": "RandomRotate", "axes": axes, "angle_spectrum": 30, "mode": "reflect", "order": 0},
+                   {"name": "RandomContrast", "execution_probability": 0.6}],
+           "label": [{"name": "RandomFlip"}, {"name": "RandomRotate90"},
+                     {"name": "RandomRotate", "axes": axes, "angle_spectrum": 30, "mode": "reflect", "order": 0}]}
+    t = tr.Transformer(cfg, {"mean": 0.05, "std": 1.0})
+    assert t.seed == int(g["transformer_seed"])
+    rt, lt = t.raw_transform(), t.label_transform()
+    raw_d = torch.from_numpy(g["raw"]).cuda()
+    lab_d = torch.from_numpy(g["label"]).cuda()
+    for i in range(6):
+        assert np.array_equal(rt(raw_d).cpu().numpy(), g[f"pipe_raw_{i}"]), f"pipe raw {i}"
+        assert np.array_equal(lt(lab_d).cpu().numpy(), g[f"pipe_label_{i}"]), f"pipe label {i}"
+
+
+@pytest.mark.gpu
+def test_device_rotate_at_full_size_matches_oracle_and_noise_statistics():
+    from mdeical_image_segmentation_amd.augment.unet3d_augment import transforms as tr
+    rng = np.random.RandomState(1)
+    vol = rng.rand(32, 128, 128).astype(np.float32)
+    for seed in (1, 2, 3):
+        rs = np.random.RandomState(seed)
+        axes = [(1, 0), (2, 1), (2, 0)]
+        axis = axes[rs.randint(len(axes))]
+        angle = rs.randint(-30, 30)
+        out = tr.RandomRotate(np.random.RandomState(seed))(vol)
+        assert np.array_equal(out.cpu().numpy(), ao.rotate0(vol, angle, axis)), (seed, axis, angle)
+    z = torch.zeros(64, 64, 64, device="cuda")
+    n = tr.AdditiveGaussianNoise(np.random.RandomState(3), scale=(0.5, 0.5), execution_probability=1.0)(z)
+    assert abs(n.mean().item()) < 5e-3 and abs(n.std().item() - 0.5) < 5e-3
+    with pytest.raises(NotImplementedError):
+        tr.RandomRotate(np.random.RandomState(1), order=3)(vol)
