@@ -124,7 +124,8 @@ int mis_pack_convt_weight(int dtype, const float* w, int Cin, int Cq, void* w_fw
 typedef struct MisHeadDesc {
     int dtype;
     int loss;                /* 0 = cross entropy (labels int64 [N,spatial]), 1 = BCE with logits (targets f32 [N,C,spatial]),
-                                2 = BCE + Dice (3-D, losses.py:167-178), -1 = no loss (inference) */
+                                2 = BCE + Dice (3-D, losses.py:167-178), -1 = no loss (inference),
+                                3 = backward only from an external dL/dlogits given in `labels` (fp32 [N,C,spatial]) */
     long long npix_per_image; int N; int Cfeat; int C;     /* Cfeat = 64 */
     const void* y; int y_ld;       /* features (post-ReLU) */
     const float* w; const float* b;/* [C][Cfeat], [C] */

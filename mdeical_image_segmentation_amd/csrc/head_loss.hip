@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
     __shared__ float red[4][HEAD_PSTRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = tid % LPP;
-    const bool bwd = (PASS == 1) || (LOSS >= 0 && LOSS <= 1 && a.dy != nullptr);
+    const bool bwd = (PASS == 1) || (LOSS == 3) || (LOSS >= 0 && LOSS <= 1 && a.dy != nullptr);
 
     float wr[C][EPC];
 #pragma unroll
@@ -143,6 +143,10 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
             const float inv = 1.f / se;
 #pragma unroll
             for (int c = 0; c < C; ++c) dl[c] = a.grad_scale * inv_total * (ex[c] * inv - (lab == c ? 1.f : 0.f));
+        } else if constexpr (LOSS == 3) {
+            const float* ext = reinterpret_cast<const float*>(a.labels);
+#pragma unroll
+            for (int c = 0; c < C; ++c) dl[c] = a.grad_scale * ext[((size_t)n * C + c) * a.S + sp];
         } else if constexpr (LOSS == 1 || LOSS == 2) {
             const float* tg = reinterpret_cast<const float*>(a.labels);
 #pragma unroll
@@ -240,12 +244,12 @@ __global__ __launch_bounds__(256) void head_colreduce_kernel(const float* __rest
 
 __global__ void head_finalize_kernel(const double* __restrict__ acc, int C, int loss, int mode, long long total, float alpha, float beta,
                                      float* __restrict__ dw, float* __restrict__ db, float* __restrict__ loss_out) {
-    const bool write_grads = (mode == 1) || (loss == 0 || loss == 1);
+    const bool write_grads = (mode == 1) || (loss == 0 || loss == 1 || loss == 3);
     if (write_grads && dw != nullptr) {
         for (int i = threadIdx.x; i < C * 64; i += blockDim.x) dw[i] = (float)acc[i];
         for (int i = threadIdx.x; i < C; i += blockDim.x) db[i] = (float)acc[C * 64 + i];
     }
-    if (mode == 0 && threadIdx.x == 0 && loss_out != nullptr && loss >= 0) {
+    if (mode == 0 && threadIdx.x == 0 && loss_out != nullptr && loss >= 0 && loss != 3) {
         const double ls = acc[C * 64 + C];
         if (loss == 0) {
             loss_out[0] = (float)(ls / (double)total);
@@ -299,6 +303,7 @@ template <typename T, int C> static int head_dispatch(const MisHeadDesc* d, Head
             break;
         case 1: head_launch<T, C, 1, 0>(a, blocks, s); break;
         case 2: head_launch<T, C, 2, 0>(a, blocks, s); break;
+        case 3: head_launch<T, C, 3, 0>(a, blocks, s); break;
         default: MIS_REQUIRE(false, MIS_EINVAL, "head: loss %d", d->loss);
     }
     MIS_LAUNCH_CHECK("head");
@@ -333,7 +338,8 @@ extern "C" int mis_head_loss(const MisHeadDesc* d, void* stream) {
     MIS_REQUIRE(d->Cfeat == 64, MIS_EUNSUPPORTED, "head: Cfeat must be 64 (got %d)", d->Cfeat);
     MIS_REQUIRE(d->N > 0 && d->npix_per_image > 0, MIS_EINVAL, "head: empty input");
     MIS_REQUIRE(d->y && d->w && d->b && d->workspace, MIS_EINVAL, "head: null pointer");
-    MIS_REQUIRE(d->loss < 0 || (d->labels != nullptr && d->loss_out != nullptr), MIS_EINVAL, "head: labels / loss_out missing");
+    MIS_REQUIRE(d->loss < 0 || (d->labels != nullptr && (d->loss_out != nullptr || d->loss == 3)), MIS_EINVAL, "head: labels / loss_out missing");
+    MIS_REQUIRE(d->loss != 3 || d->dy != nullptr, MIS_EINVAL, "head: loss 3 (external dL/dlogits) is a backward-only mode");
     MIS_REQUIRE(d->dy == nullptr || (d->dw != nullptr && d->db != nullptr && d->loss >= 0), MIS_EINVAL, "head: backward needs dw, db and a loss");
     MIS_REQUIRE(d->workspace_bytes >= mis_head_workspace_bytes(d), MIS_EINVAL, "head: workspace too small");
     const int EPC = d->dtype == MIS_BF16 ? 8 : 4;

@@ -254,6 +254,12 @@ class UNet2DEngine:
             raise MisError("labels must be contiguous CUDA int64 (N,H,W) for C>1 or fp32 (N,C,H,W) for C==1; "
                            f"got {labels.dtype} {tuple(labels.shape)}")
 
+    def head_backward(self, dlogits):
+        """backward entry for an EXTERNAL loss: dlogits = dL/dlogits, fp32 (N, C, H, W); then call backward()."""
+        wh = self.P["final_conv.weight"].view(self.cout, 64)
+        ops.head_loss(self.u2[3], wh, self.P["final_conv.bias"], loss=ops.LOSS_EXTERNAL, labels=dlogits.contiguous(),
+                      dy=self.g_u2[3], dw=self.G["final_conv.weight"], db=self.G["final_conv.bias"])
+
     # ---- backward --------------------------------------------------------------------------------------
     def _bwd_conv(self, x, dy, name, cin, cout, dx=None, mask=None, dx1=None, cout0=None, dx_mode=OUT_PLAIN):
         """grads of y = relu(conv3x3(x) + b) given dy = dL/d(pre-activation)."""

@@ -275,6 +275,13 @@ class UNet3DEngine:
         ops.head_loss(feat, wh, bh, **kw)
         return self.loss_buf[:1], self.logits, self.argmax
 
+    def head_backward(self, dlogits):
+        """backward entry for an EXTERNAL loss: dlogits = dL/dlogits, fp32 (N, C, D, H, W); then call backward()."""
+        L = self.levels
+        wh = self.P["final_conv.weight"].view(self.cout, self.f_maps[0])
+        ops.head_loss(self.d[L - 2], wh, self.P["final_conv.bias"], loss=ops.LOSS_EXTERNAL, labels=dlogits.contiguous(),
+                      dy=self.g_d[L - 2], dw=self.Gr["final_conv.weight"], db=self.Gr["final_conv.bias"])
+
     # ---- backward --------------------------------------------------------------------------------------
     def _sc_bwd(self, s, g_y, dx0, mask0, add0=None, dx1=None):
         """g_y = dL/d(pre-activation) of s's output.  Produces weight/GroupNorm grads and the input gradients."""

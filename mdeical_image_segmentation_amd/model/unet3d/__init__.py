@@ -1,1 +1,1 @@
-"""Mirror of the reference's `model.unet3d` package (empty __init__ in the reference)."""
+"""Mirror of the reference's `model.unet3d` package (an empty __init__ in the reference; sub-modules are imported by path)."""

@@ -1,0 +1,101 @@
+"""Mirror of model/unet3d/buildingblocks.py (the 'gcr' / DoubleConv / Encoder / Decoder subset of the hot path).
+
+The classes are PARAMETER CONTAINERS with the reference's module tree (so state-dict keys are identical:
+`encoders.{i}.basic_module.SingleConv{j}.{groupnorm.weight,groupnorm.bias,conv.weight}`); the arithmetic of a whole
+network runs in engine3d.UNet3DEngine through one autograd.Function (see model.py). Calling a block on its own raises:
+stand-alone blocks are not part of the accelerated path."""
+import torch
+from torch import nn
+
+
+def create_conv(in_channels, out_channels, kernel_size, order, num_groups, padding, dropout_prob, is3d):
+    """buildingblocks.py:14-113 for order 'gcr' (GroupNorm -> Conv3d(no bias) -> ReLU)."""
+    if order != "gcr" or not is3d or kernel_size != 3 or padding != 1:
+        raise NotImplementedError("only layer_order='gcr', 3-D, kernel 3, padding 1 is built (SURVEY.md §8a-8)")
+    if in_channels < num_groups:
+        num_groups = 1
+    assert in_channels % num_groups == 0
+    return [("groupnorm", nn.GroupNorm(num_groups=num_groups, num_channels=in_channels)),
+            ("conv", nn.Conv3d(in_channels, out_channels, kernel_size, padding=padding, bias=False)),
+            ("ReLU", nn.ReLU(inplace=True))]
+
+
+class _ContainerOnly:
+    def forward(self, *a, **k):
+        raise NotImplementedError(f"{type(self).__name__} is a parameter container here: run the whole UNet3D (fused MI355X engine)")
+
+
+class SingleConv(_ContainerOnly, nn.Sequential):
+    def __init__(self, in_channels, out_channels, kernel_size=3, order="gcr", num_groups=8, padding=1, dropout_prob=0.1, is3d=True):
+        super().__init__()
+        for name, module in create_conv(in_channels, out_channels, kernel_size, order, num_groups, padding, dropout_prob, is3d):
+            self.add_module(name, module)
+
+
+class DoubleConv(_ContainerOnly, nn.Sequential):
+    """buildingblocks.py:162-252: encoder in -> max(in, out//2) -> out ; decoder in -> out -> out."""
+
+    def __init__(self, in_channels, out_channels, encoder, kernel_size=3, order="gcr", num_groups=8, padding=1, upscale=2,
+                 dropout_prob=0.1, is3d=True):
+        super().__init__()
+        if encoder:
+            c1_in = in_channels
+            c1_out = out_channels if upscale == 1 else out_channels // 2
+            if c1_out < in_channels:
+                c1_out = in_channels
+            c2_in, c2_out = c1_out, out_channels
+        else:
+            c1_in, c1_out = in_channels, out_channels
+            c2_in, c2_out = out_channels, out_channels
+        self.add_module("SingleConv1", SingleConv(c1_in, c1_out, kernel_size, order, num_groups, padding, dropout_prob, is3d))
+        self.add_module("SingleConv2", SingleConv(c2_in, c2_out, kernel_size, order, num_groups, padding, dropout_prob, is3d))
+
+
+class Encoder(_ContainerOnly, nn.Module):
+    def __init__(self, in_channels, out_channels, conv_kernel_size=3, apply_pooling=True, pool_kernel_size=2, pool_type="max",
+                 basic_module=DoubleConv, conv_layer_order="gcr", num_groups=8, padding=1, upscale=2, dropout_prob=0.1, is3d=True):
+        super().__init__()
+        if pool_type != "max" or pool_kernel_size != 2:
+            raise NotImplementedError("only MaxPool3d(2) is built")
+        self.pooling = nn.MaxPool3d(kernel_size=2) if apply_pooling else None
+        self.basic_module = basic_module(in_channels, out_channels, encoder=True, kernel_size=conv_kernel_size, order=conv_layer_order,
+                                         num_groups=num_groups, padding=padding, upscale=upscale, dropout_prob=dropout_prob, is3d=is3d)
+
+
+class InterpolateUpsampling(_ContainerOnly, nn.Module):
+    def __init__(self, mode="nearest"):
+        super().__init__()
+        if mode != "nearest":
+            raise NotImplementedError("only nearest upsampling is built")
+
+
+class Decoder(_ContainerOnly, nn.Module):
+    def __init__(self, in_channels, out_channels, conv_kernel_size=3, scale_factor=2, basic_module=DoubleConv, conv_layer_order="gcr",
+                 num_groups=8, padding=1, upsample="default", dropout_prob=0.1, is3d=True):
+        super().__init__()
+        if upsample not in ("default", "nearest") or basic_module is not DoubleConv:
+            raise NotImplementedError("only DoubleConv decoders with nearest upsampling + concat are built (SURVEY.md §8a-11)")
+        self.upsampling = InterpolateUpsampling("nearest")
+        self.basic_module = basic_module(in_channels, out_channels, encoder=False, kernel_size=conv_kernel_size, order=conv_layer_order,
+                                         num_groups=num_groups, padding=padding, dropout_prob=dropout_prob, is3d=is3d)
+
+
+def create_encoders(in_channels, f_maps, basic_module, conv_kernel_size, conv_padding, conv_upscale, dropout_prob, layer_order, num_groups,
+                    pool_kernel_size, is3d):
+    encoders = []
+    for i, out in enumerate(f_maps):
+        encoders.append(Encoder(in_channels if i == 0 else f_maps[i - 1], out, apply_pooling=(i != 0), basic_module=basic_module,
+                                conv_layer_order=layer_order, conv_kernel_size=conv_kernel_size, num_groups=num_groups,
+                                pool_kernel_size=pool_kernel_size, padding=conv_padding, upscale=conv_upscale, dropout_prob=dropout_prob,
+                                is3d=is3d))
+    return nn.ModuleList(encoders)
+
+
+def create_decoders(f_maps, basic_module, conv_kernel_size, conv_padding, layer_order, num_groups, upsample, dropout_prob, is3d):
+    decoders = []
+    rf = list(reversed(f_maps))
+    for i in range(len(rf) - 1):
+        decoders.append(Decoder(rf[i] + rf[i + 1], rf[i + 1], basic_module=basic_module, conv_layer_order=layer_order,
+                                conv_kernel_size=conv_kernel_size, num_groups=num_groups, padding=conv_padding, upsample=upsample,
+                                dropout_prob=dropout_prob, is3d=is3d))
+    return nn.ModuleList(decoders)

@@ -1,0 +1,125 @@
+"""Mirror of model/unet3d/model.py: `AbstractUNet` / `UNet3D` (:13-194) executed by engine3d.UNet3DEngine.
+
+`forward(x)` returns LOGITS (the reference disabled the final activation, model.py:145-149) and is differentiable: one
+autograd.Function runs the fused forward; its backward feeds the external dL/dlogits to the head kernel and then the
+fused backward.  Parameters are stock containers aliased onto the engine's flat fp32 master buffer."""
+import os
+
+import torch
+from torch import nn
+
+from ..._lib import MisError
+from ...engine3d import UNet3DEngine
+from .buildingblocks import DoubleConv, create_decoders, create_encoders
+from .utils import number_of_features_per_level
+
+
+def _dtype_from(name):
+    name = (name or os.environ.get("MISAMD_DTYPE", "f32")).lower()
+    if name in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    if name in ("f32", "fp32", "float32"):
+        return torch.float32
+    raise MisError(f"compute dtype must be 'f32' or 'bf16', got {name!r}")
+
+
+class _FusedUNet3D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, owner, *params):
+        eng = owner._engine_for(x)
+        owner._sync_params_to_engine()
+        _, logits, _ = eng.forward(x.contiguous().float(), None)
+        ctx.owner = owner
+        return logits.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        owner = ctx.owner
+        eng = owner._engine
+        eng.head_backward(g.contiguous().float())
+        eng.backward()
+        grads = [eng.Gr[name].clone() if p.requires_grad else None for name, p in owner.named_parameters()]
+        return (None, None, *grads)
+
+
+class AbstractUNet(nn.Module):
+    def __init__(self, in_channels, out_channels, final_sigmoid, basic_module, f_maps=64, layer_order="gcr", num_groups=8, num_levels=4,
+                 is_segmentation=True, conv_kernel_size=3, pool_kernel_size=2, conv_padding=1, conv_upscale=2, upsample="default",
+                 dropout_prob=0.1, is3d=True, compute_dtype=None):
+        super().__init__()
+        if isinstance(f_maps, int):
+            f_maps = number_of_features_per_level(f_maps, num_levels=num_levels)
+        assert isinstance(f_maps, (list, tuple)) and len(f_maps) > 1, "Required at least 2 levels in the U-Net"
+        if not is3d or basic_module is not DoubleConv:
+            raise NotImplementedError("only the 3-D DoubleConv U-Net (UNet3D) is built (SURVEY.md §8a-12)")
+        self.encoders = create_encoders(in_channels, f_maps, basic_module, conv_kernel_size, conv_padding, conv_upscale, dropout_prob,
+                                        layer_order, num_groups, pool_kernel_size, is3d)
+        self.decoders = create_decoders(f_maps, basic_module, conv_kernel_size, conv_padding, layer_order, num_groups, upsample,
+                                        dropout_prob, is3d)
+        self.final_conv = nn.Conv3d(f_maps[0], out_channels, 1)
+        if is_segmentation:
+            self.final_activation = nn.Sigmoid() if final_sigmoid else nn.Softmax(dim=1)
+        else:
+            self.final_activation = None
+        self._cfg = (in_channels, out_channels, list(f_maps), num_groups)
+        self._compute_dtype = compute_dtype
+        self._engine = None
+
+    def _engine_for(self, x):
+        if x.device.type != "cuda":
+            raise MisError(f"UNet3D runs on MI355X only: got input on {x.device} (no CPU fallback)")
+        if self._engine is None or self._engine.device != x.device:
+            cin, cout, f_maps, groups = self._cfg
+            eng = UNet3DEngine(cin, cout, f_maps=f_maps, num_groups=groups, dtype=_dtype_from(self._compute_dtype), device=x.device)
+            for name, p in self.named_parameters():
+                eng.P[name].copy_(p.detach().to(device=x.device, dtype=torch.float32))
+                p.data = eng.P[name]
+            self._engine = eng
+            self._versions = None
+        return self._engine
+
+    def _sync_params_to_engine(self):
+        eng = self._engine
+        vers = []
+        for name, p in self.named_parameters():
+            if p.data_ptr() != eng.P[name].data_ptr():
+                eng.P[name].copy_(p.detach().to(torch.float32))
+                p.data = eng.P[name]
+            vers.append(p._version)
+        if vers != self._versions:
+            eng.repack()
+            self._versions = vers
+
+    def forward(self, x):
+        return _FusedUNet3D.apply(x, self, *self.parameters())
+
+
+class UNet3D(AbstractUNet):
+    def __init__(self, in_channels, out_channels, final_sigmoid=True, f_maps=64, layer_order="gcr", num_groups=8, num_levels=4,
+                 is_segmentation=True, conv_padding=1, conv_upscale=2, upsample="default", dropout_prob=0.1, **kwargs):
+        super().__init__(in_channels=in_channels, out_channels=out_channels, final_sigmoid=final_sigmoid, basic_module=DoubleConv,
+                         f_maps=f_maps, layer_order=layer_order, num_groups=num_groups, num_levels=num_levels,
+                         is_segmentation=is_segmentation, conv_padding=conv_padding, conv_upscale=conv_upscale, upsample=upsample,
+                         dropout_prob=dropout_prob, is3d=True, compute_dtype=kwargs.get("compute_dtype"))
+
+
+def _stub(name):
+    class _S(nn.Module):
+        def __init__(self, *a, **k):
+            raise NotImplementedError(f"{name} is outside the accelerated hot path (SURVEY.md §8f4)")
+    _S.__name__ = name
+    return _S
+
+
+ResidualUNet3D = _stub("ResidualUNet3D")
+ResidualUNetSE3D = _stub("ResidualUNetSE3D")
+UNet2D = _stub("UNet2D")
+ResidualUNet2D = _stub("ResidualUNet2D")
+
+
+def get_model(model_config):
+    cfg = dict(model_config)
+    name = cfg.pop("name")
+    if name != "UNet3D":
+        raise NotImplementedError(f"get_model: only UNet3D is built, got {name}")
+    return UNet3D(**cfg)

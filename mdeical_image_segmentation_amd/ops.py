@@ -220,7 +220,7 @@ def pack_convt_weight(w, w_fwd, w_dgrad):
                                     stream_ptr()), "mis_pack_convt_weight")
 
 
-LOSS_NONE, LOSS_CE, LOSS_BCE, LOSS_BCEDICE = -1, 0, 1, 2
+LOSS_NONE, LOSS_CE, LOSS_BCE, LOSS_BCEDICE, LOSS_EXTERNAL = -1, 0, 1, 2, 3
 
 
 def head_loss(y, w, b, *, loss, labels=None, logits=None, argmax=None, loss_out=None, dy=None, dw=None, db=None,

@@ -110,3 +110,48 @@ def test_blocks_standalone_match_goldens(surface):
     assert torch.equal(y.cpu()[:, :4], torch.from_numpy(g["ds_y"]))
     y.backward(torch.cat([torch.from_numpy(g["ds_gy"])] * 2, 1).cuda())
     assert torch.equal(x8.grad.cpu()[:, :4], torch.from_numpy(g["ds_gx"]))
+
+
+def test_unet3d_mirror_names_and_seeded_init():
+    """model.unet3d.model.UNet3D: same 44 state-dict keys / shapes and the same seeded default init as the reference."""
+    from mdeical_image_segmentation_amd.model.unet3d.model import UNet3D
+    g = load_golden("g3_unet3d_default.npz")
+    torch.manual_seed(0)
+    m = UNet3D(1, 3)
+    names = [str(n) for n in g["names"]]
+    assert [k for k, _ in m.named_parameters()] == names
+    for attr in ("encoders", "decoders", "final_conv", "final_activation"):
+        assert hasattr(m, attr)
+    idx = torch.linspace(0, 1, steps=64)
+    for i, (k, p) in enumerate(m.named_parameters()):
+        t = p.detach().double().flatten()
+        ii = torch.linspace(0, t.numel() - 1, steps=64).long()
+        assert np.array_equal(t[ii].numpy(), g["param_stats"][i, 3:]), k
+    from mdeical_image_segmentation_amd import MisError
+    with pytest.raises(MisError):
+        m(torch.zeros(1, 1, 8, 8, 8))
+
+
+@pytest.mark.gpu
+def test_unet3d_mirror_autograd_with_external_loss():
+    """UNet3D mirror -> logits; the reference's BCEDiceLoss on top (external loss); grads through the fused backward."""
+    from mdeical_image_segmentation_amd.model.unet3d.losses import get_loss_criterion
+    from mdeical_image_segmentation_amd.model.unet3d.model import UNet3D
+    g = load_golden("g3_unet3d_default.npz")
+    torch.manual_seed(0)
+    m = UNet3D(1, 3).cuda()
+    x, t = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda()
+    logits = m(x)
+    assert (logits.detach().cpu() - torch.from_numpy(g["logits"])).abs().max().item() < 1e-4
+    cfg = {"loss": {"name": "BCEDiceLoss", "alpha": 1.0, "beta": 1.0}}
+    crit = get_loss_criterion(cfg)
+    assert "name" not in cfg["loss"]           # the factory pops, like the reference
+    loss = crit(logits, t)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    loss.backward()
+    names = [str(n) for n in g["names"]]
+    ref = g["grad_stats"]
+    for i, (k, p) in enumerate(m.named_parameters()):
+        a = p.grad.detach().double().cpu().flatten()
+        assert abs(a.abs().sum().item() - ref[i, 1]) <= 3e-3 * abs(ref[i, 1]) + 1e-6, k
+    assert torch.allclose(m.final_conv.weight.grad.cpu(), torch.from_numpy(g["g_final_w"]), rtol=2e-3, atol=1e-6)
