@@ -47,86 +47,88 @@ template <int TD_, int TH_, int TW_, int KS_, bool IS3D_> struct WGeom {
 
 constexpr int PSTR = 160;   // LDS bytes per pixel row (128 data + 32 pad)
 
-template <typename T, typename G>
-__device__ __forceinline__ void wg_stage(char* lds_p, char* lds_q, const WgArgs& a, int n, int d0, int h0, int w0, int kd, int ci0,
-                                         int co0, int tid) {
-    constexpr int EPC = Tr<T>::EPC;
-    // ---- P: input halo slab ----
-    {
-        const bool first = ci0 < a.Cin0;
-        const WSrc s = first ? a.x0 : a.x1;
-        const int cl = first ? ci0 : ci0 - a.Cin0;
-        const int shd = (s.D != a.D), shh = (s.H != a.H), shw = (s.W != a.W);   // exact 2x nearest-upsample addressing
-        const T* base = reinterpret_cast<const T*>(s.p) + (size_t)n * s.D * s.H * s.W * s.ld + cl;
-        constexpr int ITEMS = G::PHP * 8;
-        constexpr int BATCH = 3;
-#pragma unroll 1
-        for (int it0 = 0; it0 < ITEMS; it0 += 256 * BATCH) {
-            u32x4 v[BATCH];
-            int lofs[BATCH];
-            bool ok[BATCH];
+// Global -> registers (load) ... -> LDS (store) staging of one pixel tile: P = input halo slab, Q = dY tile.
+// Split so that tile t+1's loads are in flight while tile t's MFMAs run (the block is the only one on its CU in bf16).
+template <typename T, typename G> struct WgStager {
+    static constexpr int EPC = Tr<T>::EPC;
+    static constexpr int PITEMS = G::PHP * 8;
+    static constexpr int PI = (PITEMS + 255) / 256;
+    static constexpr int QI = G::M * 8 / 256;
+    u32x4 pv[PI], qv[QI];
+    uint32_t okmask;
+
+    __device__ __forceinline__ void load(const WgArgs& a, int n, int d0, int h0, int w0, int kd, int ci0, int co0, int tid) {
+        {
+            const bool first = ci0 < a.Cin0;
+            const WSrc s = first ? a.x0 : a.x1;
+            const int cl = first ? ci0 : ci0 - a.Cin0;
+            const int shd = (s.D != a.D), shh = (s.H != a.H), shw = (s.W != a.W);   // exact 2x nearest-upsample addressing
+            const T* base = reinterpret_cast<const T*>(s.p) + (size_t)n * s.D * s.H * s.W * s.ld + cl;
+            okmask = 0u;
 #pragma unroll
-            for (int b = 0; b < BATCH; ++b) {
-                const int it = it0 + b * 256 + tid;
-                v[b] = u32x4{0u, 0u, 0u, 0u};
-                lofs[b] = -1;
-                ok[b] = false;
-                if (it < ITEMS) {
+            for (int b = 0; b < PI; ++b) {
+                const int it = b * 256 + tid;
+                pv[b] = u32x4{0u, 0u, 0u, 0u};
+                if (it < PITEMS) {
                     const int p = it >> 3, c16 = it & 7;
                     const int pz = p / (G::PHH * G::PHW);
                     const int pr = p - pz * (G::PHH * G::PHW);
                     const int py = pr / G::PHW;
                     const int px = pr - py * G::PHW;
                     const int z = d0 + pz + kd - G::PD, y = h0 + py - G::PAD, x = w0 + px - G::PAD;
-                    lofs[b] = p * PSTR + c16 * 16;
                     if (z >= 0 && z < a.D && y >= 0 && y < a.H && x >= 0 && x < a.W) {
                         const int off = (((z >> shd) * s.H + (y >> shh)) * s.W + (x >> shw)) * s.ld + c16 * EPC;
-                        v[b] = *reinterpret_cast<const u32x4*>(base + off);
-                        ok[b] = true;
+                        pv[b] = *reinterpret_cast<const u32x4*>(base + off);
+                        okmask |= (1u << b);
                     }
                 }
             }
-            if (a.in_scale != nullptr) {
+        }
+        {
+            const T* base = reinterpret_cast<const T*>(a.dy) + co0;
 #pragma unroll
-                for (int b = 0; b < BATCH; ++b) {
-                    if (ok[b]) {
-                        const int c16 = (it0 + b * 256 + tid) & 7;
-                        const float* sc = a.in_scale + (size_t)n * a.Cin + ci0 + c16 * EPC;
-                        const float* sh = a.in_shift + (size_t)n * a.Cin + ci0 + c16 * EPC;
-                        float f[EPC];
-                        unpack_chunk<T>(v[b], f);
-#pragma unroll
-                        for (int e = 0; e < EPC; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
-                        v[b] = pack_chunk<T>(f);
-                    }
+            for (int b = 0; b < QI; ++b) {
+                const int it = b * 256 + tid;
+                const int m = it >> 3, c16 = it & 7;
+                const int dz = m / (G::TH * G::TW);
+                const int hy = (m / G::TW) % G::TH;
+                const int wx = m % G::TW;
+                const int z = d0 + dz, y = h0 + hy, x = w0 + wx;
+                qv[b] = u32x4{0u, 0u, 0u, 0u};
+                if (z < a.D && y < a.H && x < a.W) {
+                    const size_t pix = (((size_t)n * a.D + z) * a.H + y) * a.W + x;
+                    qv[b] = *reinterpret_cast<const u32x4*>(base + pix * a.dy_ld + c16 * EPC);
                 }
             }
-#pragma unroll
-            for (int b = 0; b < BATCH; ++b)
-                if (lofs[b] >= 0) lds_write_b128(lds_p, lofs[b], v[b]);
         }
     }
-    // ---- Q: dY tile (no halo) ----
-    {
-        const T* base = reinterpret_cast<const T*>(a.dy) + co0;
-        constexpr int ITEMS = G::M * 8;   // 1024
+
+    __device__ __forceinline__ void store(char* lds_p, char* lds_q, const WgArgs& a, int n, int ci0, int tid) {
 #pragma unroll
-        for (int b = 0; b < ITEMS / 256; ++b) {
+        for (int b = 0; b < PI; ++b) {
             const int it = b * 256 + tid;
-            const int m = it >> 3, c16 = it & 7;
-            const int dz = m / (G::TH * G::TW);
-            const int hy = (m / G::TW) % G::TH;
-            const int wx = m % G::TW;
-            const int z = d0 + dz, y = h0 + hy, x = w0 + wx;
-            u32x4 v = u32x4{0u, 0u, 0u, 0u};
-            if (z < a.D && y < a.H && x < a.W) {
-                const size_t pix = (((size_t)n * a.D + z) * a.H + y) * a.W + x;
-                v = *reinterpret_cast<const u32x4*>(base + pix * a.dy_ld + c16 * EPC);
+            if (it < PITEMS) {
+                const int p = it >> 3, c16 = it & 7;
+                u32x4 val = pv[b];
+                if (a.in_scale != nullptr && ((okmask >> b) & 1u)) {
+                    const float* sc = a.in_scale + (size_t)n * a.Cin + ci0 + c16 * EPC;
+                    const float* sh = a.in_shift + (size_t)n * a.Cin + ci0 + c16 * EPC;
+                    float f[EPC];
+                    unpack_chunk<T>(val, f);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
+                    val = pack_chunk<T>(f);
+                }
+                lds_write_b128(lds_p, p * PSTR + c16 * 16, val);
             }
-            lds_write_b128(lds_q, m * PSTR + c16 * 16, v);
+        }
+#pragma unroll
+        for (int b = 0; b < QI; ++b) {
+            const int it = b * 256 + tid;
+            lds_write_b128(lds_q, (it >> 3) * PSTR + (it & 7) * 16, qv[b]);
         }
     }
-}
+};
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
@@ -161,7 +163,7 @@ __device__ __forceinline__ bf16x8_t wg_frag_bf16(const char* img, int off_s0, in
 }
 
 template <typename T, typename G, bool USE_TR>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 1 : 2)) void wgrad_kernel(const WgArgs a) {
     constexpr bool BF = sizeof(T) == 2;
     constexpr int FR = BF ? 2 : 1;          // 16x16 fragments per wave per dim
     constexpr int CT = BF ? 64 : 32;        // channel tile (ci and co)
@@ -204,19 +206,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs a) {
     if (t_end > a.ntiles) t_end = a.ntiles;
     const int tpi = a.tilesD * a.tilesH * a.tilesW;
 
-#pragma unroll 1
-    for (int t = t_begin; t < t_end; ++t) {
-        const int n = t / tpi;
+    auto tile_coords = [&](int t, int& n, int& d0, int& h0, int& w0) {
+        n = t / tpi;
         int r = t - n * tpi;
         const int td = r / (a.tilesH * a.tilesW);
         r -= td * (a.tilesH * a.tilesW);
         const int th = r / a.tilesW;
         const int tw = r - th * a.tilesW;
-        const int d0 = td * G::TD, h0 = th * G::TH, w0 = tw * G::TW;
+        d0 = td * G::TD;
+        h0 = th * G::TH;
+        w0 = tw * G::TW;
+    };
+    WgStager<T, G> st;
+    int cn, cd0, ch0, cw0;
+    if (t_begin < t_end) {
+        tile_coords(t_begin, cn, cd0, ch0, cw0);
+        st.load(a, cn, cd0, ch0, cw0, kd, ci0, co0, tid);
+    }
 
+#pragma unroll 1
+    for (int t = t_begin; t < t_end; ++t) {
         __syncthreads();   // previous tile's reads are done
-        wg_stage<T, G>(lds_p, lds_q, a, n, d0, h0, w0, kd, ci0, co0, tid);
+        st.store(lds_p, lds_q, a, cn, ci0, tid);
         __syncthreads();
+        {   // next tile's loads fly under this tile's MFMAs (the last iteration harmlessly re-loads its own tile)
+            const int tn = (t + 1 < t_end) ? t + 1 : t;
+            tile_coords(tn, cn, cd0, ch0, cw0);
+            st.load(a, cn, cd0, ch0, cw0, kd, ci0, co0, tid);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 
         if (do_bias) {
 #pragma unroll 8

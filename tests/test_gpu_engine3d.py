@@ -54,26 +54,30 @@ def test_fp32_engine3d_matches_reference_golden():
 
 
 def test_fp32_engine3d_vs_oracle_noncubic():
+    """Non-cubic shape against the CPU oracle.  The reference's own fp32 backward is noisy on this net (its gradients differ
+    from an fp64 evaluation of the SAME graph by up to 9e-2 of max|g| on encoders.0), so gradients are judged against the
+    fp64 oracle: the engine must be at least as close to fp64 as twice the reference's fp32 path is (floor 3e-3)."""
     from oracle import unet3d_oracle as o3
     eng = _engine(torch.float32)
     gen = torch.Generator().manual_seed(9)
     x = torch.randn(2, 1, 8, 16, 24, generator=gen)
     t = (torch.rand(2, 3, 8, 16, 24, generator=gen) > 0.5).float()
     p = o3.init_params(1, 3, seed=0)
-    rl, rlogits, rgrads = o3.loss_and_grads(p, x, t)
+    rl, rlogits, g32 = o3.loss_and_grads(p, x, t)
+    _, _, g64 = o3.loss_and_grads({k: v.double() for k, v in p.items()}, x.double(), t.double())
     loss, logits, am = eng.forward(x.to(DEV), t.to(DEV), train=True)
     eng.backward()
     assert (logits.cpu() - rlogits).abs().max().item() < 1e-4
     assert abs(loss.item() - rl.item()) < 1e-4
-    for n, gref in rgrads.items():
-        a = eng.Gr[n].cpu()
-        err = (a - gref).abs().max().item()
-        # the two single-element GroupNorm grads of the first layer are sums of ~1e4 cancelling terms: absolute floor
-        floor = 2e-4 if gref.numel() == 1 else 1e-7
-        # encoders.0 sits below 18 GroupNorm backward passes (each subtracts group means: ill-conditioned in fp32 on BOTH
-        # sides); its kernels are exact in isolation (test_first3d_layer_kernels)
-        rel = 2e-2 if n.startswith("encoders.0.") else 3e-3
-        assert err <= rel * gref.abs().max().item() + floor, (n, err, gref.abs().max().item())
+    worst = 0.0
+    for n, gref in g64.items():
+        scale = gref.abs().max().item() + 1e-30
+        err = (eng.Gr[n].cpu().double() - gref).abs().max().item() / scale
+        ref_err = (g32[n].double() - gref).abs().max().item() / scale
+        worst = max(worst, err / max(ref_err, 1e-9))
+        floor = 2e-4 / scale if gref.numel() == 1 else 0.0
+        assert err <= max(2 * ref_err, 3e-3) + floor, (n, err, ref_err)
+    print(f"3-D grads vs fp64: worst (engine err / reference-fp32 err) = {worst:.2f}")
 
 
 def test_bf16_engine3d_close():
@@ -198,3 +202,43 @@ def test_first3d_layer_kernels(dtype):
     assert torch.allclose(dw.cpu(), w.grad, **wt), (dw.cpu() - w.grad).abs().max()
     xt = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
     assert torch.allclose(dxn.cpu(), xn.grad[:, 0], **xt), (dxn.cpu() - xn.grad[:, 0]).abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(1, 6, 12, 20), (2, 8, 16, 24), (1, 1, 2, 3)])
+def test_conv3d_fwd_dgrad_wgrad_ragged_multitile(shape, dtype):
+    from mdeical_image_segmentation_amd import ops
+    N, D, H, W = shape
+    Ci, Co = 64, 128
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(N, Ci, D, H, W, generator=gen)
+    w = torch.randn(Co, Ci, 3, 3, 3, generator=gen) * 0.03
+    gy = torch.randn(N, Co, D, H, W, generator=gen)
+
+    def q(t):
+        return t.to(dtype).float()
+
+    xq, wq = q(x).requires_grad_(True), q(w).requires_grad_(True)
+    y = F.conv3d(xq, wq, None, padding=1)
+    y.backward(q(gy))
+
+    def cl(t):
+        return t.permute(0, 2, 3, 4, 1).contiguous().to(dtype).to(DEV)
+
+    wf = torch.empty(27, Co, Ci, dtype=dtype, device=DEV)
+    wd = torch.empty(27, Ci, Co, dtype=dtype, device=DEV)
+    ops.pack_conv_weight(w.to(DEV), wf, wd)
+    xd, gd = cl(x), cl(gy)
+    yd = torch.full((N, D, H, W, Co), float("nan"), dtype=dtype, device=DEV)
+    ops.conv_igemm(xd, wf, yd, ksize=3, Cin=Ci, Cout=Co)
+    tol = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    assert torch.allclose(yd.float().cpu().permute(0, 4, 1, 2, 3), y.detach(), **tol)
+    dx = torch.full((N, D, H, W, Ci), float("nan"), dtype=dtype, device=DEV)
+    ops.conv_igemm(gd, wd, dx, ksize=3, Cin=Co, Cout=Ci)
+    assert torch.allclose(dx.float().cpu().permute(0, 4, 1, 2, 3), xq.grad, **tol)
+    dw = torch.full((Co, Ci, 3, 3, 3), float("nan"), device=DEV)
+    ops.wgrad(xd, gd, dw, ksize=3, Cin=Ci, Cout=Co)
+    k = N * D * H * W
+    wtol = dict(rtol=1e-3, atol=1e-4 * k ** 0.5) if dtype == torch.float32 else dict(rtol=3e-2, atol=2e-2 * k ** 0.5)
+    err = (dw.cpu() - wq.grad).abs().max().item()
+    assert torch.allclose(dw.cpu(), wq.grad, **wtol), (err, wq.grad.abs().max().item())
