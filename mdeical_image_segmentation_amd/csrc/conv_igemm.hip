@@ -13,6 +13,8 @@
 //           nn.Conv3d(k3,p1) after GroupNorm (model/unet3d/buildingblocks.py:64-66,87-92),
 //           nn.ConvTranspose2d(k2,s2) fwd / dgrad as a 1x1 GEMM + pixel (un)shuffle (layers.py:165),
 //           torch.cat / F.interpolate(nearest) as input addressing (layers.py:186-190, buildingblocks.py:546-548,671-673).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.hpp"
@@ -54,10 +56,10 @@ template <int TD_, int TH_, int TW_, int KS_, bool IS3D_> struct Geom {
 // Halo tile of one K chunk: global (16 B per item) -> registers (load) ... -> swizzled LDS (store).  The two halves
 // are separate so that the global loads of chunk c+1 fly while the last tap of chunk c computes.  Out-of-bounds pixels
 // are zero (the conv's zero padding applies AFTER the optional per-(n,c) affine, exactly like GroupNorm -> Conv).
-template <typename T, typename G> struct HaloStager {
+template <typename T, typename G, int NT> struct HaloStager {
     static constexpr int EPC = Tr<T>::EPC;
     static constexpr int ITEMS = G::HP * 8;
-    static constexpr int HI = (ITEMS + 255) / 256;
+    static constexpr int HI = (ITEMS + NT - 1) / NT;
     u32x4 v[HI];
     uint32_t okmask;
 
@@ -70,7 +72,7 @@ template <typename T, typename G> struct HaloStager {
         okmask = 0u;
 #pragma unroll
         for (int b = 0; b < HI; ++b) {
-            const int it = b * 256 + tid;
+            const int it = b * NT + tid;
             v[b] = u32x4{0u, 0u, 0u, 0u};
             if (it < ITEMS) {
                 const int p = it >> 3, c16 = it & 7;
@@ -91,7 +93,7 @@ template <typename T, typename G> struct HaloStager {
     __device__ __forceinline__ void store(char* halo, const ConvArgs& a, int n, int c0, int tid) {
 #pragma unroll
         for (int b = 0; b < HI; ++b) {
-            const int it = b * 256 + tid;
+            const int it = b * NT + tid;
             if (it < ITEMS) {
                 const int p = it >> 3, c16 = it & 7;
                 u32x4 val = v[b];
@@ -121,15 +123,20 @@ __device__ __forceinline__ void store_run(T* dst, const float* v) {
     }
 }
 
-template <typename T, typename G, int WN, int NF>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
-    constexpr int WM = 4 / WN;
+// NT threads (256: 4 waves, two blocks per CU; 512: 8 waves sharing one weight tile, one block per CU),
+// TPS taps per barrier interval (3 = one filter row: 96 MFMAs per wave between barriers instead of 32).
+template <typename T, typename G, int WN, int NF, int NT, int TPS>
+__global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int WM = (NT / 64) / WN;
+    static_assert(G::TAPS % TPS == 0, "taps per step must divide the tap count");
+    constexpr int NSTEPS = G::TAPS / TPS;
     static_assert(G::M == WM * 64, "tile pixels must be 64 per M-wave");
     constexpr int WAVE_N = NF * 16;      // channels per wave
     constexpr int BN = WN * WAVE_N;      // channels per block
     constexpr int EPC = Tr<T>::EPC;
     constexpr int CK = Tr<T>::CK;
-    constexpr int WI = BN * 8 / 256;     // 16-byte weight items per thread per tap
+    constexpr int WI = TPS * BN * 8 / NT;  // 16-byte weight items per thread per step
+    constexpr int WTILE = BN * 128;        // bytes of one tap's weight tile
     constexpr int NV = 4 * NF;           // consecutive output channels per lane
     static_assert(WI >= 1, "");
 
@@ -171,78 +178,88 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int pf = 0; pf < 4; ++pf) acc[f][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int w_goff[WI], w_loff[WI];
+    int w_goff[WI], w_loff[WI], w_tapl[WI];
 #pragma unroll
     for (int k = 0; k < WI; ++k) {
-        const int it = tid + k * 256;
+        const int itf = tid + k * NT;
+        const int tapl = itf / (BN * 8);
+        const int it = itf - tapl * (BN * 8);
+        w_tapl[k] = tapl;
         const int row = it >> 3, c16 = it & 7;
         const int wv = row / WAVE_N, chw = row % WAVE_N;
         const int aa = chw / NV, ff = (chw >> 2) % NF, bb = chw & 3;
         const int lrow = wv * WAVE_N + ff * 16 + aa * 4 + bb;
         w_goff[k] = (ncol0 + row) * a.Cin + c16 * EPC;
-        w_loff[k] = lrow * 128 + ((c16 ^ (lrow & 7)) << 4);
+        w_loff[k] = tapl * WTILE + lrow * 128 + ((c16 ^ (lrow & 7)) << 4);
     }
     const T* wp = reinterpret_cast<const T*>(a.w);
     const size_t tap_stride = (size_t)a.Cout * a.Cin;
 
     u32x4 wreg[WI];
 #pragma unroll
-    for (int k = 0; k < WI; ++k) wreg[k] = *reinterpret_cast<const u32x4*>(wp + w_goff[k]);
-    HaloStager<T, G> hs;
+    for (int k = 0; k < WI; ++k) wreg[k] = *reinterpret_cast<const u32x4*>(wp + (size_t)w_tapl[k] * tap_stride + w_goff[k]);
+    HaloStager<T, G, NT> hs;
     hs.load(a, n, d0, h0, w0, 0, tid);
     hs.store(halo, a, n, 0, tid);
 
     const int nchunks = a.Cin / CK;
     int cur = 0;
 
-    // one tap: W regs -> LDS, barrier, issue the next global loads (kept ABOVE the MFMA cluster), MFMAs
-    auto tap_step = [&](int tap, int c0, auto last_tag) {
+    // one step = TPS taps: W regs -> LDS, barrier, issue the next global loads (kept ABOVE the MFMA cluster), MFMAs
+    auto step_fn = [&](int step, int c0, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
-        char* wb = wbuf + cur * (BN * 128);
+        char* wb0 = wbuf + cur * (TPS * WTILE);
 #pragma unroll
-        for (int k = 0; k < WI; ++k) lds_write_b128(wb, w_loff[k], wreg[k]);
+        for (int k = 0; k < WI; ++k) lds_write_b128(wb0, w_loff[k], wreg[k]);
         __syncthreads();
         {
-            int ntap = tap + 1, nc0 = c0;
+            int nstep = step + 1, nc0 = c0;
             if (LAST) {
-                ntap = 0;
+                nstep = 0;
                 nc0 = c0 + CK;
             }
             if (nc0 >= a.Cin) {   // very last step: harmlessly re-load the current tiles (keeps the loads unconditional)
-                ntap = tap;
+                nstep = step;
                 nc0 = c0;
             }
-            const T* wsrc = wp + (size_t)ntap * tap_stride + nc0;
+            const T* wsrc = wp + (size_t)(nstep * TPS) * tap_stride + nc0;
 #pragma unroll
-            for (int k = 0; k < WI; ++k) wreg[k] = *reinterpret_cast<const u32x4*>(wsrc + w_goff[k]);
-            if (LAST) hs.load(a, n, d0, h0, w0, nc0, tid);   // next chunk's halo flies under this tap's MFMAs
+            for (int k = 0; k < WI; ++k) wreg[k] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)w_tapl[k] * tap_stride + w_goff[k]);
+            if (LAST) hs.load(a, n, d0, h0, w0, nc0, tid);   // next chunk's halo flies under this step's MFMAs
         }
         __builtin_amdgcn_sched_barrier(0);
-        int tapoff;
-        if constexpr (G::KS == 1) {
-            tapoff = 0;
-        } else {
-            const int kd = tap / (G::KS * G::KS);
-            const int kr = tap - kd * (G::KS * G::KS);
-            const int kh = kr / G::KS, kw = kr - kh * G::KS;
-            tapoff = (kd * G::HH + kh) * G::HW + kw;
-        }
 #pragma unroll
-        for (int kg = 0; kg < 2; ++kg) {
-            u32x4 A[NF], B[4];
-            const int ch = kg * 4 + lg;
-#pragma unroll
-            for (int f = 0; f < NF; ++f)
-                A[f] = lds_read_b128(wb, (wn * WAVE_N + f * 16 + li) * 128 + ((ch ^ (li & 7)) << 4));
-#pragma unroll
-            for (int pf = 0; pf < 4; ++pf) {
-                const int p = hb[pf] + tapoff;
-                B[pf] = lds_read_b128(halo, p * 128 + ((ch ^ (p & 7)) << 4));
+        for (int tl = 0; tl < TPS; ++tl) {
+            const int tap = step * TPS + tl;
+            const char* wb = wb0 + tl * WTILE;
+            int tapoff;
+            if constexpr (G::KS == 1) {
+                tapoff = 0;
+            } else {
+                const int kd = tap / (G::KS * G::KS);
+                const int kr = tap - kd * (G::KS * G::KS);
+                const int kh = kr / G::KS, kw = kr - kh * G::KS;
+                tapoff = (kd * G::HH + kh) * G::HW + kw;
             }
+            // (explicitly double-buffering these fragment reads behind sched_barriers measured 2-4 % SLOWER than
+            //  letting hipcc interleave ds_reads and MFMAs itself)
 #pragma unroll
-            for (int f = 0; f < NF; ++f)
+            for (int kg = 0; kg < 2; ++kg) {
+                u32x4 A[NF], B[4];
+                const int ch = kg * 4 + lg;
 #pragma unroll
-                for (int pf = 0; pf < 4; ++pf) mma_b128<T>(acc[f][pf], A[f], B[pf]);
+                for (int f = 0; f < NF; ++f)
+                    A[f] = lds_read_b128(wb, (wn * WAVE_N + f * 16 + li) * 128 + ((ch ^ (li & 7)) << 4));
+#pragma unroll
+                for (int pf = 0; pf < 4; ++pf) {
+                    const int p = hb[pf] + tapoff;
+                    B[pf] = lds_read_b128(halo, p * 128 + ((ch ^ (p & 7)) << 4));
+                }
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+#pragma unroll
+                    for (int pf = 0; pf < 4; ++pf) mma_b128<T>(acc[f][pf], A[f], B[pf]);
+            }
         }
         cur ^= 1;
     };
@@ -251,8 +268,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int c0 = chunk * CK;
 #pragma unroll 1
-        for (int tap = 0; tap < G::TAPS - 1; ++tap) tap_step(tap, c0, std::false_type{});
-        tap_step(G::TAPS - 1, c0, std::true_type{});
+        for (int st = 0; st < NSTEPS - 1; ++st) step_fn(st, c0, std::false_type{});
+        step_fn(NSTEPS - 1, c0, std::true_type{});
         if (chunk + 1 < nchunks) {
             __syncthreads();   // every wave is done reading this chunk's halo
             hs.store(halo, a, n, c0 + CK, tid);
@@ -328,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, typename G, int WN, int NF>
+template <typename T, typename G, int WN, int NF, int NT = 256, int TPS = 1>
 static int launch_cfg(const MisConvDesc* d, hipStream_t stream) {
     constexpr int BN = WN * NF * 16;
     ConvArgs a;
@@ -347,14 +364,14 @@ static int launch_cfg(const MisConvDesc* d, hipStream_t stream) {
     a.nCt = d->Cout / BN;
     MIS_REQUIRE(nsp * a.nCt < (1ll << 31), MIS_EUNSUPPORTED, "conv_igemm: grid too large");
     a.nSp = (int)nsp;
-    const size_t lds = (size_t)G::HP * 128 + 2 * (size_t)BN * 128;
+    const size_t lds = (size_t)G::HP * 128 + 2 * (size_t)TPS * BN * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, G, WN, NF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, G, WN, NF, NT, TPS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, G, WN, NF>), dim3((unsigned)(nsp * a.nCt)), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, G, WN, NF, NT, TPS>), dim3((unsigned)(nsp * a.nCt)), dim3(NT), lds, stream, a);
     MIS_LAUNCH_CHECK("conv_igemm");
     return MIS_OK;
 }
@@ -364,6 +381,8 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
     const bool wide = (d->Cout % 128) == 0;
     if (d->ksize == 3) {
         if (!is3d) {
+            static const int v2 = getenv("MIS_CONV_V1") == nullptr;
+            if (wide && v2) return launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3>(d, s);   // 8 waves, one filter row per barrier
             if (wide) return launch_cfg<T, Geom<1, 8, 16, 3, false>, 2, 4>(d, s);
             return launch_cfg<T, Geom<1, 16, 16, 3, false>, 1, 4>(d, s);
         }
