@@ -51,6 +51,11 @@ template <int TD_, int TH_, int TW_, int KS_, bool IS3D_> struct Geom {
     static constexpr int HP = HD * HH * HW;
     static constexpr int M = TD * TH * TW;
     static constexpr int TAPS = KD * KS * KS;
+    // 2-D tiles with 16-pixel rows: a fragment's 16 pixels are consecutive halo pixels, so a LINEAR image with a 160-byte
+    // pixel stride is bank-conflict free for ds_read_b128 and every tap shift becomes an immediate offset (no address VALU
+    // in the MFMA loop).  Other tiles keep the 128-byte XOR-swizzled image.
+    static constexpr bool LIN = (!IS3D) && (TW == 16);
+    static constexpr int HSTR = LIN ? 160 : 128;
 };
 
 // Halo tile of one K chunk: global (16 B per item) -> registers (load) ... -> swizzled LDS (store).  The two halves
@@ -106,7 +111,7 @@ template <typename T, typename G, int NT> struct HaloStager {
                     for (int e = 0; e < EPC; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
                     val = pack_chunk<T>(f);
                 }
-                lds_write_b128(halo, p * 128 + ((c16 ^ (p & 7)) << 4), val);
+                lds_write_b128(halo, G::LIN ? (p * G::HSTR + c16 * 16) : (p * 128 + ((c16 ^ (p & 7)) << 4)), val);
             }
         }
     }
@@ -125,12 +130,13 @@ __device__ __forceinline__ void store_run(T* dst, const float* v) {
 
 // NT threads (256: 4 waves, two blocks per CU; 512: 8 waves sharing one weight tile, one block per CU),
 // TPS taps per barrier interval (3 = one filter row: 96 MFMAs per wave between barriers instead of 32).
-template <typename T, typename G, int WN, int NF, int NT, int TPS>
+template <typename T, typename G, int WN, int NF, int NT, int TPS, int PF>
 __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int WM = (NT / 64) / WN;
+    constexpr int WAVE_M = PF * 16;      // pixels per wave
     static_assert(G::TAPS % TPS == 0, "taps per step must divide the tap count");
     constexpr int NSTEPS = G::TAPS / TPS;
-    static_assert(G::M == WM * 64, "tile pixels must be 64 per M-wave");
+    static_assert(G::M == WM * WAVE_M, "tile pixels must be PF*16 per M-wave");
     constexpr int WAVE_N = NF * 16;      // channels per wave
     constexpr int BN = WN * WAVE_N;      // channels per block
     constexpr int EPC = Tr<T>::EPC;
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const ConvArgs a) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* halo = smem;
-    char* wbuf = smem + G::HP * 128;
+    char* wbuf = smem + G::HP * G::HSTR;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -162,21 +168,21 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const ConvArgs a) {
     const int d0 = td * G::TD, h0 = th * G::TH, w0 = tw * G::TW;
     const int ncol0 = ct * BN;
 
-    int hb[4];
+    int hb[PF];
 #pragma unroll
-    for (int pf = 0; pf < 4; ++pf) {
-        const int m = wm * 64 + pf * 16 + li;
+    for (int pf = 0; pf < PF; ++pf) {
+        const int m = wm * WAVE_M + pf * 16 + li;
         const int dz = m / (G::TH * G::TW);
         const int hy = (m / G::TW) % G::TH;
         const int wx = m % G::TW;
         hb[pf] = (dz * G::HH + hy) * G::HW + wx;
     }
 
-    f32x4 acc[NF][4];
+    f32x4 acc[NF][PF];
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
-        for (int pf = 0; pf < 4; ++pf) acc[f][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int pf = 0; pf < PF; ++pf) acc[f][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int w_goff[WI], w_loff[WI], w_tapl[WI];
 #pragma unroll
@@ -245,20 +251,24 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const ConvArgs a) {
             //  letting hipcc interleave ds_reads and MFMAs itself)
 #pragma unroll
             for (int kg = 0; kg < 2; ++kg) {
-                u32x4 A[NF], B[4];
+                u32x4 A[NF], B[PF];
                 const int ch = kg * 4 + lg;
 #pragma unroll
                 for (int f = 0; f < NF; ++f)
                     A[f] = lds_read_b128(wb, (wn * WAVE_N + f * 16 + li) * 128 + ((ch ^ (li & 7)) << 4));
 #pragma unroll
-                for (int pf = 0; pf < 4; ++pf) {
-                    const int p = hb[pf] + tapoff;
-                    B[pf] = lds_read_b128(halo, p * 128 + ((ch ^ (p & 7)) << 4));
+                for (int pf = 0; pf < PF; ++pf) {
+                    if constexpr (G::LIN) {
+                        B[pf] = lds_read_b128(halo, (hb[pf] + tapoff) * G::HSTR + ch * 16);
+                    } else {
+                        const int p = hb[pf] + tapoff;
+                        B[pf] = lds_read_b128(halo, p * 128 + ((ch ^ (p & 7)) << 4));
+                    }
                 }
 #pragma unroll
                 for (int f = 0; f < NF; ++f)
 #pragma unroll
-                    for (int pf = 0; pf < 4; ++pf) mma_b128<T>(acc[f][pf], A[f], B[pf]);
+                    for (int pf = 0; pf < PF; ++pf) mma_b128<T>(acc[f][pf], A[f], B[pf]);
             }
         }
         cur ^= 1;
@@ -300,8 +310,8 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const ConvArgs a) {
         for (int i = 0; i < NV; ++i) bv[i] = a.bias[bcol + i];
     }
 #pragma unroll
-    for (int pf = 0; pf < 4; ++pf) {
-        const int m = wm * 64 + pf * 16 + li;
+    for (int pf = 0; pf < PF; ++pf) {
+        const int m = wm * WAVE_M + pf * 16 + li;
         const int dz = m / (G::TH * G::TW);
         const int hy = (m / G::TW) % G::TH;
         const int wx = m % G::TW;
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, typename G, int WN, int NF, int NT = 256, int TPS = 1>
+template <typename T, typename G, int WN, int NF, int NT = 256, int TPS = 1, int PF = 4>
 static int launch_cfg(const MisConvDesc* d, hipStream_t stream) {
     constexpr int BN = WN * NF * 16;
     ConvArgs a;
@@ -364,14 +374,14 @@ static int launch_cfg(const MisConvDesc* d, hipStream_t stream) {
     a.nCt = d->Cout / BN;
     MIS_REQUIRE(nsp * a.nCt < (1ll << 31), MIS_EUNSUPPORTED, "conv_igemm: grid too large");
     a.nSp = (int)nsp;
-    const size_t lds = (size_t)G::HP * 128 + 2 * (size_t)TPS * BN * 128;
+    const size_t lds = (size_t)G::HP * G::HSTR + 2 * (size_t)TPS * BN * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, G, WN, NF, NT, TPS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, G, WN, NF, NT, TPS, PF>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, G, WN, NF, NT, TPS>), dim3((unsigned)(nsp * a.nCt)), dim3(NT), lds, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, G, WN, NF, NT, TPS, PF>), dim3((unsigned)(nsp * a.nCt)), dim3(NT), lds, stream, a);
     MIS_LAUNCH_CHECK("conv_igemm");
     return MIS_OK;
 }
@@ -382,8 +392,11 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
     if (d->ksize == 3) {
         if (!is3d) {
             static const int v2 = getenv("MIS_CONV_V1") == nullptr;
+            static const int v3 = getenv("MIS_CONV_V3") != nullptr;
+            if (wide && v3 && sizeof(T) == 2) return launch_cfg<T, Geom<1, 32, 16, 3, false>, 2, 4, 512, 1, 8>(d, s);   // 8 waves, wave tile 128 px x 64 ch
             if (wide && v2) return launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3>(d, s);   // 8 waves, one filter row per barrier
             if (wide) return launch_cfg<T, Geom<1, 8, 16, 3, false>, 2, 4>(d, s);
+            if (v2 && (long long)d->H * d->W >= 64 * 64) return launch_cfg<T, Geom<1, 32, 16, 3, false>, 1, 4, 512, 3>(d, s);
             return launch_cfg<T, Geom<1, 16, 16, 3, false>, 1, 4>(d, s);
         }
         if (wide) return launch_cfg<T, Geom<4, 4, 8, 3, true>, 2, 4>(d, s);

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 1 : 2)) void wgrad_kernel(co
 // along (ci, tap) for layout 0 / (c, ab) for layout 1, via an LDS transpose.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int TT, int Cin, int Cout,
                                                            float* __restrict__ dw, int layout, float alpha) {
-    __shared__ float tile[9][32][33];
+    __shared__ float tile[32][9][33];     // [ci][tap][co]: both the fill (co fastest) and the drain ((ci,tap) fastest) are conflict free
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
     const size_t slab = (size_t)TT * Cin * Cout;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                     const float* src = partial + ((size_t)(t0 + t) * Cin + ci) * Cout + co;
                     for (int k = 0; k < nsplit; ++k) s += src[(size_t)k * slab];
                 }
-                tile[t][r][tx] = s * alpha;
+                tile[r][t][tx] = s * alpha;
             }
         __syncthreads();
         if (layout == 0) {
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                 if (co >= Cout) continue;
                 for (int e = tx; e < 32 * nt; e += 32) {
                     const int cil = e / nt, t = e - cil * nt;
-                    if (ci0 + cil < Cin) dw[((size_t)co * Cin + ci0 + cil) * TT + t0 + t] = tile[t][cil][r];
+                    if (ci0 + cil < Cin) dw[((size_t)co * Cin + ci0 + cil) * TT + t0 + t] = tile[cil][t][r];
                 }
             }
         } else {
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                 const int ci = ci0 + r, co = co0 + tx;
                 if (ci < Cin && co < Cout) {
                     const int ab = co / cq, c = co - ab * cq;
-                    dw[((size_t)ci * cq + c) * 4 + ab] = tile[0][r][tx];
+                    dw[((size_t)ci * cq + c) * 4 + ab] = tile[r][0][tx];
                 }
             }
         }
@@ -484,8 +484,8 @@ static int wg_launch(const MisWgradDesc* d, const WgPlan& p, hipStream_t stream)
     MIS_LAUNCH_CHECK("wgrad");
     int nslab = p.nsplit;
     const size_t E = (size_t)p.TT * d->Cin * d->Cout;     // multiple of 4 (channel tiles are multiples of 32)
-    if (nslab > 16) {
-        const int Z = 16;
+    if (nslab > 4) {
+        const int Z = 4;
         hipLaunchKernelGGL(wgrad_prereduce_kernel, dim3((unsigned)((E / 4 + 255) / 256), Z), dim3(256), 0, stream, d->workspace, nslab, Z,
                            E / 4);
         MIS_LAUNCH_CHECK("wgrad_prereduce");
