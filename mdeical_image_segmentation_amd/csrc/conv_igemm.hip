@@ -129,8 +129,10 @@ __device__ __forceinline__ void store_run(T* dst, const float* v) {
 }
 
 // NT threads (256: 4 waves, two blocks per CU; 512: 8 waves sharing one weight tile, one block per CU),
-// TPS taps per barrier interval (3 = one filter row: 96 MFMAs per wave between barriers instead of 32).
-template <typename T, typename G, int WN, int NF, int NT, int TPS, int PF>
+// TPS taps per barrier interval (3 = one filter row: 96 MFMAs per wave between barriers instead of 32),
+// PF pixel fragments per wave, PERSIST: the block walks tiles v, v+G, v+2G, ... and fetches the next tile's halo and first
+// weight tile under the last MFMA cluster of the current tile (only the first tile of a block pays the load latency).
+template <typename T, typename G, int WN, int NF, int NT, int TPS, int PF, bool PERSIST>
 __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int WM = (NT / 64) / WN;
     constexpr int WAVE_M = PF * 16;      // pixels per wave
@@ -155,18 +157,29 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const ConvArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 15, lg = lane >> 4;
 
-    const int v = xcd_remap(blockIdx.x, gridDim.x);
-    const int ct = v / a.nSp;
-    const int sp = v - ct * a.nSp;
-    const int tpi = a.tilesD * a.tilesH * a.tilesW;
-    const int n = sp / tpi;
-    int r = sp - n * tpi;
-    const int td = r / (a.tilesH * a.tilesW);
-    r -= td * (a.tilesH * a.tilesW);
-    const int th = r / a.tilesW;
-    const int tw = r - th * a.tilesW;
-    const int d0 = td * G::TD, h0 = th * G::TH, w0 = tw * G::TW;
-    const int ncol0 = ct * BN;
+    const int total_tiles = a.nSp * a.nCt;
+    const int tstride = PERSIST ? (int)gridDim.x : total_tiles;     // non-persistent: exactly one tile per block
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    if (tile >= total_tiles) return;   // block-uniform
+
+    // cout-tile major, spatial minor: concurrently running blocks share the weight tile, neighbours share halos
+    int n, d0, h0, w0, ncol0;
+    auto decode = [&](int t, int& tn, int& td0, int& th0, int& tw0, int& tcol) {
+        const int ct = t / a.nSp;
+        const int sp = t - ct * a.nSp;
+        const int tpi = a.tilesD * a.tilesH * a.tilesW;
+        tn = sp / tpi;
+        int r = sp - tn * tpi;
+        const int td = r / (a.tilesH * a.tilesW);
+        r -= td * (a.tilesH * a.tilesW);
+        const int th = r / a.tilesW;
+        const int tw = r - th * a.tilesW;
+        td0 = td * G::TD;
+        th0 = th * G::TH;
+        tw0 = tw * G::TW;
+        tcol = ct * BN;
+    };
+    decode(tile, n, d0, h0, w0, ncol0);
 
     int hb[PF];
 #pragma unroll
@@ -195,167 +208,188 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const ConvArgs a) {
         const int wv = row / WAVE_N, chw = row % WAVE_N;
         const int aa = chw / NV, ff = (chw >> 2) % NF, bb = chw & 3;
         const int lrow = wv * WAVE_N + ff * 16 + aa * 4 + bb;
-        w_goff[k] = (ncol0 + row) * a.Cin + c16 * EPC;
+        w_goff[k] = row * a.Cin + c16 * EPC;                 // + ncol0 * Cin per tile
         w_loff[k] = tapl * WTILE + lrow * 128 + ((c16 ^ (lrow & 7)) << 4);
     }
     const T* wp = reinterpret_cast<const T*>(a.w);
     const size_t tap_stride = (size_t)a.Cout * a.Cin;
+    const int nchunks = a.Cin / CK;
 
     u32x4 wreg[WI];
+    {
+        const T* wsrc = wp + (size_t)ncol0 * a.Cin;
 #pragma unroll
-    for (int k = 0; k < WI; ++k) wreg[k] = *reinterpret_cast<const u32x4*>(wp + (size_t)w_tapl[k] * tap_stride + w_goff[k]);
+        for (int k = 0; k < WI; ++k) wreg[k] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)w_tapl[k] * tap_stride + w_goff[k]);
+    }
     HaloStager<T, G, NT> hs;
     hs.load(a, n, d0, h0, w0, 0, tid);
     hs.store(halo, a, n, 0, tid);
-
-    const int nchunks = a.Cin / CK;
     int cur = 0;
 
-    // one step = TPS taps: W regs -> LDS, barrier, issue the next global loads (kept ABOVE the MFMA cluster), MFMAs
-    auto step_fn = [&](int step, int c0, auto last_tag) {
-        constexpr bool LAST = decltype(last_tag)::value;
-        char* wb0 = wbuf + cur * (TPS * WTILE);
+#pragma unroll 1
+    for (; tile < total_tiles; tile += tstride) {
+        const bool has_next = PERSIST && (tile + tstride < total_tiles);
+        int nn = n, nd0 = d0, nh0 = h0, nw0 = w0, ncolN = ncol0;
+        if (has_next) decode(tile + tstride, nn, nd0, nh0, nw0, ncolN);
+
+        // one step = TPS taps: W regs -> LDS, barrier, issue the next global loads (kept ABOVE the MFMA cluster), MFMAs
+        auto step_fn = [&](int step, int c0, auto last_tag) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            char* wb0 = wbuf + cur * (TPS * WTILE);
 #pragma unroll
-        for (int k = 0; k < WI; ++k) lds_write_b128(wb0, w_loff[k], wreg[k]);
-        __syncthreads();
-        {
-            int nstep = step + 1, nc0 = c0;
-            if (LAST) {
-                nstep = 0;
-                nc0 = c0 + CK;
-            }
-            if (nc0 >= a.Cin) {   // very last step: harmlessly re-load the current tiles (keeps the loads unconditional)
-                nstep = step;
-                nc0 = c0;
-            }
-            const T* wsrc = wp + (size_t)(nstep * TPS) * tap_stride + nc0;
-#pragma unroll
-            for (int k = 0; k < WI; ++k) wreg[k] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)w_tapl[k] * tap_stride + w_goff[k]);
-            if (LAST) hs.load(a, n, d0, h0, w0, nc0, tid);   // next chunk's halo flies under this step's MFMAs
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int tl = 0; tl < TPS; ++tl) {
-            const int tap = step * TPS + tl;
-            const char* wb = wb0 + tl * WTILE;
-            int tapoff;
-            if constexpr (G::KS == 1) {
-                tapoff = 0;
-            } else {
-                const int kd = tap / (G::KS * G::KS);
-                const int kr = tap - kd * (G::KS * G::KS);
-                const int kh = kr / G::KS, kw = kr - kh * G::KS;
-                tapoff = (kd * G::HH + kh) * G::HW + kw;
-            }
-            // (explicitly double-buffering these fragment reads behind sched_barriers measured 2-4 % SLOWER than
-            //  letting hipcc interleave ds_reads and MFMAs itself)
-#pragma unroll
-            for (int kg = 0; kg < 2; ++kg) {
-                u32x4 A[NF], B[PF];
-                const int ch = kg * 4 + lg;
-#pragma unroll
-                for (int f = 0; f < NF; ++f)
-                    A[f] = lds_read_b128(wb, (wn * WAVE_N + f * 16 + li) * 128 + ((ch ^ (li & 7)) << 4));
-#pragma unroll
-                for (int pf = 0; pf < PF; ++pf) {
-                    if constexpr (G::LIN) {
-                        B[pf] = lds_read_b128(halo, (hb[pf] + tapoff) * G::HSTR + ch * 16);
-                    } else {
-                        const int p = hb[pf] + tapoff;
-                        B[pf] = lds_read_b128(halo, p * 128 + ((ch ^ (p & 7)) << 4));
+            for (int k = 0; k < WI; ++k) lds_write_b128(wb0, w_loff[k], wreg[k]);
+            __syncthreads();
+            {
+                int nstep = step + 1, nc0 = c0, col = ncol0;
+                int hn = n, hd0 = d0, hh0 = h0, hw0 = w0;        // whose halo to fetch (LAST only)
+                if (LAST) {
+                    nstep = 0;
+                    nc0 = c0 + CK;
+                    if (nc0 >= a.Cin) {       // tile finished: next tile's chunk 0, or (very last step) a harmless re-load
+                        nc0 = 0;
+                        col = ncolN;
+                        hn = nn; hd0 = nd0; hh0 = nh0; hw0 = nw0;
                     }
                 }
+                const T* wsrc = wp + (size_t)(nstep * TPS) * tap_stride + (size_t)col * a.Cin + nc0;
+#pragma unroll
+                for (int k = 0; k < WI; ++k) wreg[k] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)w_tapl[k] * tap_stride + w_goff[k]);
+                if (LAST) hs.load(a, hn, hd0, hh0, hw0, nc0, tid);   // flies under this step's MFMAs
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tl = 0; tl < TPS; ++tl) {
+                const int tap = step * TPS + tl;
+                const char* wb = wb0 + tl * WTILE;
+                int tapoff;
+                if constexpr (G::KS == 1) {
+                    tapoff = 0;
+                } else {
+                    const int kd = tap / (G::KS * G::KS);
+                    const int kr = tap - kd * (G::KS * G::KS);
+                    const int kh = kr / G::KS, kw = kr - kh * G::KS;
+                    tapoff = (kd * G::HH + kh) * G::HW + kw;
+                }
+                // (explicitly double-buffering these fragment reads behind sched_barriers, or weaving them with
+                //  sched_group_barrier, measured 2-4 % SLOWER than letting hipcc interleave ds_reads and MFMAs itself)
+#pragma unroll
+                for (int kg = 0; kg < 2; ++kg) {
+                    u32x4 A[NF], B[PF];
+                    const int ch = kg * 4 + lg;
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+                        A[f] = lds_read_b128(wb, (wn * WAVE_N + f * 16 + li) * 128 + ((ch ^ (li & 7)) << 4));
+#pragma unroll
+                    for (int pf = 0; pf < PF; ++pf) {
+                        if constexpr (G::LIN) {
+                            B[pf] = lds_read_b128(halo, (hb[pf] + tapoff) * G::HSTR + ch * 16);
+                        } else {
+                            const int p = hb[pf] + tapoff;
+                            B[pf] = lds_read_b128(halo, p * 128 + ((ch ^ (p & 7)) << 4));
+                        }
+                    }
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+#pragma unroll
+                        for (int pf = 0; pf < PF; ++pf) mma_b128<T>(acc[f][pf], A[f], B[pf]);
+                }
+            }
+            cur ^= 1;
+        };
+
+#pragma unroll 1
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int c0 = chunk * CK;
+#pragma unroll 1
+            for (int st = 0; st < NSTEPS - 1; ++st) step_fn(st, c0, std::false_type{});
+            step_fn(NSTEPS - 1, c0, std::true_type{});
+            if (chunk + 1 < nchunks) {
+                __syncthreads();   // every wave is done reading this chunk's halo
+                hs.store(halo, a, n, c0 + CK, tid);
+            }
+        }
+
+        // ---- epilogue: lane (li, lg) holds, per pixel fragment, NV consecutive columns ---------------------
+        {
+            const int colw = ncol0 + wn * WAVE_N;          // wave-uniform first column
+            const int col = colw + lg * NV;                // this lane's first column
+            const bool to0 = colw < a.Cout0;
+            T* ybase = reinterpret_cast<T*>(to0 ? a.y0 : a.y1);
+            const int yld = to0 ? a.y0_ld : a.y1_ld;
+            const int ymode = to0 ? a.y0_mode : a.y1_mode;
+            const int cview = to0 ? a.Cout0 : a.Cout - a.Cout0;    // columns routed to this output
+            const int lcol = to0 ? col : col - a.Cout0;
+            int bcol = col;                                         // bias index
+            int ab = 0, cq = 0;
+            if (ymode == MIS_OUT_SHUFFLE2) {
+                cq = cview >> 2;
+                ab = lcol / cq;
+                bcol = (to0 ? 0 : a.Cout0) + (lcol - ab * cq);      // bias is per real output channel c
+            }
+            float bv[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) bv[i] = 0.f;
+            if (a.bias != nullptr) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) bv[i] = a.bias[bcol + i];
+            }
+#pragma unroll
+            for (int pf = 0; pf < PF; ++pf) {
+                const int m = wm * WAVE_M + pf * 16 + li;
+                const int dz = m / (G::TH * G::TW);
+                const int hy = (m / G::TW) % G::TH;
+                const int wx = m % G::TW;
+                const int z = d0 + dz, y = h0 + hy, x = w0 + wx;
+                float o[NV];
 #pragma unroll
                 for (int f = 0; f < NF; ++f)
 #pragma unroll
-                    for (int pf = 0; pf < PF; ++pf) mma_b128<T>(acc[f][pf], A[f], B[pf]);
-            }
-        }
-        cur ^= 1;
-    };
-
-#pragma unroll 1
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int c0 = chunk * CK;
-#pragma unroll 1
-        for (int st = 0; st < NSTEPS - 1; ++st) step_fn(st, c0, std::false_type{});
-        step_fn(NSTEPS - 1, c0, std::true_type{});
-        if (chunk + 1 < nchunks) {
-            __syncthreads();   // every wave is done reading this chunk's halo
-            hs.store(halo, a, n, c0 + CK, tid);
-        }
-    }
-
-    // ---- epilogue: lane (li, lg) holds, per pixel fragment, NV consecutive columns -------------------------
-    const int colw = ncol0 + wn * WAVE_N;          // wave-uniform first column
-    const int col = colw + lg * NV;                // this lane's first column
-    const bool to0 = colw < a.Cout0;
-    T* ybase = reinterpret_cast<T*>(to0 ? a.y0 : a.y1);
-    const int yld = to0 ? a.y0_ld : a.y1_ld;
-    const int ymode = to0 ? a.y0_mode : a.y1_mode;
-    const int cview = to0 ? a.Cout0 : a.Cout - a.Cout0;    // columns routed to this output
-    const int lcol = to0 ? col : col - a.Cout0;
-    int bcol = col;                                         // bias index
-    int ab = 0, cq = 0;
-    if (ymode == MIS_OUT_SHUFFLE2) {
-        cq = cview >> 2;
-        ab = lcol / cq;
-        bcol = (to0 ? 0 : a.Cout0) + (lcol - ab * cq);      // bias is per real output channel c
-    }
-    float bv[NV];
+                    for (int q = 0; q < 4; ++q) {
+                        o[f * 4 + q] = acc[f][pf][q] + bv[f * 4 + q];
+                        acc[f][pf][q] = 0.f;
+                    }
+                if (z < a.D && y < a.H && x < a.W) {
+                    if (a.relu) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) bv[i] = 0.f;
-    if (a.bias != nullptr) {
+                        for (int i = 0; i < NV; ++i) o[i] = fmaxf(o[i], 0.f);
+                    }
+                    const size_t pix = (((size_t)n * a.D + z) * a.H + y) * a.W + x;
+                    if (a.mask != nullptr) {
+                        const T* mp = reinterpret_cast<const T*>(a.mask) + pix * a.mask_ld + col;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) bv[i] = a.bias[bcol + i];
-    }
+                        for (int i = 0; i < NV; i += EPC) {
+                            float mf[EPC];
+                            unpack_chunk<T>(*reinterpret_cast<const u32x4*>(mp + i), mf);
 #pragma unroll
-    for (int pf = 0; pf < PF; ++pf) {
-        const int m = wm * WAVE_M + pf * 16 + li;
-        const int dz = m / (G::TH * G::TW);
-        const int hy = (m / G::TW) % G::TH;
-        const int wx = m % G::TW;
-        const int z = d0 + dz, y = h0 + hy, x = w0 + wx;
-        if (z < a.D && y < a.H && x < a.W) {
-            float o[NV];
-#pragma unroll
-            for (int f = 0; f < NF; ++f)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) o[f * 4 + q] = acc[f][pf][q] + bv[f * 4 + q];
-            if (a.relu) {
-#pragma unroll
-                for (int i = 0; i < NV; ++i) o[i] = fmaxf(o[i], 0.f);
-            }
-            const size_t pix = (((size_t)n * a.D + z) * a.H + y) * a.W + x;
-            if (a.mask != nullptr) {
-                const T* mp = reinterpret_cast<const T*>(a.mask) + pix * a.mask_ld + col;
-#pragma unroll
-                for (int i = 0; i < NV; i += EPC) {
-                    float mf[EPC];
-                    unpack_chunk<T>(*reinterpret_cast<const u32x4*>(mp + i), mf);
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) o[i + e] = (mf[e] > 0.f) ? o[i + e] : 0.f;
+                            for (int e = 0; e < EPC; ++e) o[i + e] = (mf[e] > 0.f) ? o[i + e] : 0.f;
+                        }
+                    }
+                    T* dst;
+                    if (ymode == MIS_OUT_PLAIN) {
+                        dst = ybase + pix * yld + lcol;
+                    } else if (ymode == MIS_OUT_SHUFFLE2) {
+                        const int oy = 2 * y + (ab >> 1), ox = 2 * x + (ab & 1);
+                        const size_t opix = ((size_t)n * (2 * a.H) + oy) * (size_t)(2 * a.W) + ox;
+                        dst = ybase + opix * yld + (lcol - ab * cq);
+                    } else {   // MIS_OUT_UNSHUFFLE2
+                        const int oh = a.H >> 1, ow = a.W >> 1;
+                        const size_t opix = ((size_t)n * oh + (y >> 1)) * ow + (x >> 1);
+                        dst = ybase + opix * yld + ((y & 1) * 2 + (x & 1)) * cview + lcol;
+                    }
+                    store_run<T, NV>(dst, o);
                 }
             }
-            T* dst;
-            if (ymode == MIS_OUT_PLAIN) {
-                dst = ybase + pix * yld + lcol;
-            } else if (ymode == MIS_OUT_SHUFFLE2) {
-                const int oy = 2 * y + (ab >> 1), ox = 2 * x + (ab & 1);
-                const size_t opix = ((size_t)n * (2 * a.H) + oy) * (size_t)(2 * a.W) + ox;
-                dst = ybase + opix * yld + (lcol - ab * cq);
-            } else {   // MIS_OUT_UNSHUFFLE2
-                const int oh = a.H >> 1, ow = a.W >> 1;
-                const size_t opix = ((size_t)n * oh + (y >> 1)) * ow + (x >> 1);
-                dst = ybase + opix * yld + ((y & 1) * 2 + (x & 1)) * cview + lcol;
-            }
-            store_run<T, NV>(dst, o);
+        }
+        if (has_next) {
+            __syncthreads();   // every wave is done reading this tile's last halo
+            hs.store(halo, a, nn, 0, tid);
+            n = nn; d0 = nd0; h0 = nh0; w0 = nw0; ncol0 = ncolN;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, typename G, int WN, int NF, int NT = 256, int TPS = 1, int PF = 4>
+template <typename T, typename G, int WN, int NF, int NT = 256, int TPS = 1, int PF = 4, bool PERSIST = false>
 static int launch_cfg(const MisConvDesc* d, hipStream_t stream) {
     constexpr int BN = WN * NF * 16;
     ConvArgs a;
@@ -377,11 +411,11 @@ static int launch_cfg(const MisConvDesc* d, hipStream_t stream) {
     const size_t lds = (size_t)G::HP * G::HSTR + 2 * (size_t)TPS * BN * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, G, WN, NF, NT, TPS, PF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, G, WN, NF, NT, TPS, PF, PERSIST>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, G, WN, NF, NT, TPS, PF>), dim3((unsigned)(nsp * a.nCt)), dim3(NT), lds, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, G, WN, NF, NT, TPS, PF, PERSIST>), dim3((unsigned)((PERSIST && nsp * a.nCt > 256) ? 256 : nsp * a.nCt)), dim3(NT), lds, stream, a);
     MIS_LAUNCH_CHECK("conv_igemm");
     return MIS_OK;
 }
@@ -394,9 +428,12 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
             static const int v2 = getenv("MIS_CONV_V1") == nullptr;
             static const int v3 = getenv("MIS_CONV_V3") != nullptr;
             if (wide && v3 && sizeof(T) == 2) return launch_cfg<T, Geom<1, 32, 16, 3, false>, 2, 4, 512, 1, 8>(d, s);   // 8 waves, wave tile 128 px x 64 ch
-            if (wide && v2) return launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3>(d, s);   // 8 waves, one filter row per barrier
+            // persistent tiles pay off when a tile has few K steps (prologue latency dominates); deep layers run ~5 % faster without
+            const bool shallow = d->Cin <= 2 * (int)Tr<T>::CK;
+            if (wide && v2 && shallow) return launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3, 4, true>(d, s);
+            if (wide && v2) return launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3, 4, false>(d, s);   // 8 waves, one filter row per barrier
             if (wide) return launch_cfg<T, Geom<1, 8, 16, 3, false>, 2, 4>(d, s);
-            if (v2 && (long long)d->H * d->W >= 64 * 64) return launch_cfg<T, Geom<1, 32, 16, 3, false>, 1, 4, 512, 3>(d, s);
+            if (v2 && (long long)d->H * d->W >= 64 * 64) return launch_cfg<T, Geom<1, 32, 16, 3, false>, 1, 4, 512, 3, 4, true>(d, s);
             return launch_cfg<T, Geom<1, 16, 16, 3, false>, 1, 4>(d, s);
         }
         if (wide) return launch_cfg<T, Geom<4, 4, 8, 3, true>, 2, 4>(d, s);
