@@ -431,7 +431,7 @@ static int wg_plan(const MisWgradDesc* d, WgPlan* p) {
                 "wgrad: Cin %d / Cout %d must be multiples of %d", d->Cin, d->Cout, p->CT);
     p->is3d = d->is3d != 0;
     MIS_REQUIRE(d->is3d || d->D == 1, MIS_EINVAL, "wgrad: D must be 1 for a 2-D op");
-    const int TD = p->is3d ? 2 : 1, TH = 8, TW = p->is3d ? 8 : 16;
+    const int TD = 1, TH = 8, TW = 16;
     p->tilesD = (d->D + TD - 1) / TD;
     p->tilesH = (d->H + TH - 1) / TH;
     p->tilesW = (d->W + TW - 1) / TW;
@@ -506,10 +506,10 @@ static int wg_launch(const MisWgradDesc* d, const WgPlan& p, hipStream_t stream)
 template <typename T, bool USE_TR> static int wg_dispatch(const MisWgradDesc* d, const WgPlan& p, hipStream_t s) {
     if (d->ksize == 3) {
         if (!p.is3d) return wg_launch<T, WGeom<1, 8, 16, 3, false>, USE_TR>(d, p, s);
-        return wg_launch<T, WGeom<2, 8, 8, 3, true>, USE_TR>(d, p, s);
+        return wg_launch<T, WGeom<1, 8, 16, 3, true>, USE_TR>(d, p, s);   // one depth slice per tile: same register budget as 2-D
     }
     if (!p.is3d) return wg_launch<T, WGeom<1, 8, 16, 1, false>, USE_TR>(d, p, s);
-    return wg_launch<T, WGeom<2, 8, 8, 1, true>, USE_TR>(d, p, s);
+    return wg_launch<T, WGeom<1, 8, 16, 1, true>, USE_TR>(d, p, s);
 }
 
 extern "C" int mis_wgrad(const MisWgradDesc* d, void* stream) {
