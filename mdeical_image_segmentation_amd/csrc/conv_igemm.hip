@@ -132,7 +132,12 @@ __device__ __forceinline__ void store_run(T* dst, const float* v) {
 // TPS taps per barrier interval (3 = one filter row: 96 MFMAs per wave between barriers instead of 32),
 // PF pixel fragments per wave, PERSIST: the block walks tiles v, v+G, v+2G, ... and fetches the next tile's halo and first
 // weight tile under the last MFMA cluster of the current tile (only the first tile of a block pays the load latency).
-template <typename T, typename G, int WN, int NF, int NT, int TPS, int PF, bool PERSIST>
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glob_void_t;
+
+// WDMA: the weight tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPRs, no
+// ds_write pass); the image stays XOR-swizzled by permuting the per-lane SOURCE address (the DMA destination is lane-linear).
+template <typename T, typename G, int WN, int NF, int NT, int TPS, int PF, bool PERSIST, bool WDMA>
 __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int WM = (NT / 64) / WN;
     constexpr int WAVE_M = PF * 16;      // pixels per wave
@@ -210,17 +215,40 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const ConvArgs a) {
         const int lrow = wv * WAVE_N + ff * 16 + aa * 4 + bb;
         w_goff[k] = row * a.Cin + c16 * EPC;                 // + ncol0 * Cin per tile
         w_loff[k] = tapl * WTILE + lrow * 128 + ((c16 ^ (lrow & 7)) << 4);
+        if constexpr (WDMA) {
+            // DMA instruction q of this step fills LDS bytes [q*1024, q*1024+1024): lane l -> 16-byte slot q*64 + l.
+            // Which (weight row, K chunk) must land there follows from inverting the read-side swizzle / row permutation.
+            const int q = wave * WI + k;
+            const int slot = q * 64 + lane;
+            const int dtap = slot / (BN * 8);
+            const int rem = slot - dtap * (BN * 8);
+            const int lr = rem >> 3, pos = rem & 7;
+            const int dc16 = pos ^ (lr & 7);
+            const int dwv = lr / WAVE_N, j = lr % WAVE_N;
+            const int dff = j / 16, daa = (j % 16) / 4, dbb = j & 3;
+            const int drow = dwv * WAVE_N + daa * NV + dff * 4 + dbb;
+            w_tapl[k] = dtap;
+            w_goff[k] = drow * a.Cin + dc16 * EPC;
+            w_loff[k] = q * 1024;                                // wave-uniform LDS byte offset of the instruction
+        }
     }
     const T* wp = reinterpret_cast<const T*>(a.w);
     const size_t tap_stride = (size_t)a.Cout * a.Cin;
     const int nchunks = a.Cin / CK;
 
-    u32x4 wreg[WI];
-    {
-        const T* wsrc = wp + (size_t)ncol0 * a.Cin;
+    u32x4 wreg[WDMA ? 1 : WI];
+    auto w_fetch = [&](const T* wsrc, char* wdst) {   // next step's weight tile: registers, or straight into LDS buffer wdst
 #pragma unroll
-        for (int k = 0; k < WI; ++k) wreg[k] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)w_tapl[k] * tap_stride + w_goff[k]);
-    }
+        for (int k = 0; k < WI; ++k) {
+            const T* g = wsrc + (size_t)w_tapl[k] * tap_stride + w_goff[k];
+            if constexpr (WDMA) {
+                __builtin_amdgcn_global_load_lds((glob_void_t*)g, (lds_void_t*)(wdst + __builtin_amdgcn_readfirstlane(w_loff[k])), 16, 0, 0);
+            } else {
+                wreg[k] = *reinterpret_cast<const u32x4*>(g);
+            }
+        }
+    };
+    w_fetch(wp + (size_t)ncol0 * a.Cin, wbuf);
     HaloStager<T, G, NT> hs;
     hs.load(a, n, d0, h0, w0, 0, tid);
     hs.store(halo, a, n, 0, tid);
@@ -236,9 +264,11 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const ConvArgs a) {
         auto step_fn = [&](int step, int c0, auto last_tag) {
             constexpr bool LAST = decltype(last_tag)::value;
             char* wb0 = wbuf + cur * (TPS * WTILE);
+            if constexpr (!WDMA) {
 #pragma unroll
-            for (int k = 0; k < WI; ++k) lds_write_b128(wb0, w_loff[k], wreg[k]);
-            __syncthreads();
+                for (int k = 0; k < WI; ++k) lds_write_b128(wb0, w_loff[k], wreg[k]);
+            }
+            __syncthreads();   // WDMA: hipcc drains the in-flight LDS-DMA (vmcnt(0)) before this barrier
             {
                 int nstep = step + 1, nc0 = c0, col = ncol0;
                 int hn = n, hd0 = d0, hh0 = h0, hw0 = w0;        // whose halo to fetch (LAST only)
@@ -251,9 +281,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const ConvArgs a) {
                         hn = nn; hd0 = nd0; hh0 = nh0; hw0 = nw0;
                     }
                 }
-                const T* wsrc = wp + (size_t)(nstep * TPS) * tap_stride + (size_t)col * a.Cin + nc0;
-#pragma unroll
-                for (int k = 0; k < WI; ++k) wreg[k] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)w_tapl[k] * tap_stride + w_goff[k]);
+                w_fetch(wp + (size_t)(nstep * TPS) * tap_stride + (size_t)col * a.Cin + nc0, wbuf + (cur ^ 1) * (TPS * WTILE));
                 if (LAST) hs.load(a, hn, hd0, hh0, hw0, nc0, tid);   // flies under this step's MFMAs
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -389,7 +417,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, typename G, int WN, int NF, int NT = 256, int TPS = 1, int PF = 4, bool PERSIST = false>
+template <typename T, typename G, int WN, int NF, int NT = 256, int TPS = 1, int PF = 4, bool PERSIST = false, bool WDMA = false>
 static int launch_cfg(const MisConvDesc* d, hipStream_t stream) {
     constexpr int BN = WN * NF * 16;
     ConvArgs a;
@@ -411,11 +439,11 @@ static int launch_cfg(const MisConvDesc* d, hipStream_t stream) {
     const size_t lds = (size_t)G::HP * G::HSTR + 2 * (size_t)TPS * BN * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, G, WN, NF, NT, TPS, PF, PERSIST>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, G, WN, NF, NT, TPS, PF, PERSIST, WDMA>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, G, WN, NF, NT, TPS, PF, PERSIST>), dim3((unsigned)((PERSIST && nsp * a.nCt > 256) ? 256 : nsp * a.nCt)), dim3(NT), lds, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, G, WN, NF, NT, TPS, PF, PERSIST, WDMA>), dim3((unsigned)((PERSIST && nsp * a.nCt > 256) ? 256 : nsp * a.nCt)), dim3(NT), lds, stream, a);
     MIS_LAUNCH_CHECK("conv_igemm");
     return MIS_OK;
 }
@@ -430,10 +458,12 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
             if (wide && v3 && sizeof(T) == 2) return launch_cfg<T, Geom<1, 32, 16, 3, false>, 2, 4, 512, 1, 8>(d, s);   // 8 waves, wave tile 128 px x 64 ch
             // persistent tiles pay off when a tile has few K steps (prologue latency dominates); deep layers run ~5 % faster without
             const bool shallow = d->Cin <= 2 * (int)Tr<T>::CK;
-            if (wide && v2 && shallow) return launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3, 4, true>(d, s);
+            if (wide && v2 && shallow) return launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3, 4, true, true>(d, s);
+            static const int dma = getenv("MIS_CONV_NODMA") == nullptr;
+            if (wide && v2 && dma) return launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3, 4, false, true>(d, s);
             if (wide && v2) return launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3, 4, false>(d, s);   // 8 waves, one filter row per barrier
             if (wide) return launch_cfg<T, Geom<1, 8, 16, 3, false>, 2, 4>(d, s);
-            if (v2 && (long long)d->H * d->W >= 64 * 64) return launch_cfg<T, Geom<1, 32, 16, 3, false>, 1, 4, 512, 3, 4, true>(d, s);
+            if (v2 && (long long)d->H * d->W >= 64 * 64) return launch_cfg<T, Geom<1, 32, 16, 3, false>, 1, 4, 512, 3, 4, true, true>(d, s);
             return launch_cfg<T, Geom<1, 16, 16, 3, false>, 1, 4>(d, s);
         }
         if (wide) return launch_cfg<T, Geom<4, 4, 8, 3, true>, 2, 4>(d, s);
