@@ -75,20 +75,15 @@ class AbstractUNet(nn.Module):
                 eng.P[name].copy_(p.detach().to(device=x.device, dtype=torch.float32))
                 p.data = eng.P[name]
             self._engine = eng
-            self._versions = None
         return self._engine
 
     def _sync_params_to_engine(self):
         eng = self._engine
-        vers = []
         for name, p in self.named_parameters():
             if p.data_ptr() != eng.P[name].data_ptr():
                 eng.P[name].copy_(p.detach().to(torch.float32))
                 p.data = eng.P[name]
-            vers.append(p._version)
-        if vers != self._versions:
-            eng.repack()
-            self._versions = vers
+        eng.repack()                                        # every call: see model/unet2d/unet.py
 
     def forward(self, x):
         return _FusedUNet3D.apply(x, self, *self.parameters())
