@@ -180,6 +180,19 @@ int mis_first3d_bwd(int dtype, const float* x, const float* scale, const float* 
                     int dy_ld, int Cpad, const float* w, int Cout, float* workspace, float* dw, float* dxn, void* stream);
 int mis_relu_mask(int dtype, const void* dy, int dy_ld, const void* y, int y_ld, void* dx, int dx_ld, long long npix, int C, void* stream);
 
+/* BatchNorm2d of the `unetConv2` block (model/unet2d/layers.py:17-25: Conv2d(bias) -> BatchNorm2d -> ReLU; eps 1e-5, momentum 0.1).
+ * fwd: mis_chanstats(z) -> mis_bn_fwd_finalize (batch statistics; running_mean/var updated in place with the unbiased variance;
+ *      training == 0 uses the running statistics) -> per (n,c) scale/shift [N][C] -> mis_affine_act (y = relu(z*scale+shift)).
+ * bwd: g = dy*(y>0) (mis_relu_mask), S1 = sum g, S2 = sum g*z (mis_gn_bwd_stats) -> mis_bn_bwd_finalize -> p,q,r [N][C] for
+ *      mis_gn_bwd_apply (dz = p*g + q*z + r) and dgamma, dbeta. count_total = N*H*W. */
+int mis_bn_fwd_finalize(const float* sum, const float* sumsq, int N, int C, double count_total, const float* gamma, const float* beta,
+                        float eps, float momentum, float* running_mean, float* running_var, int training, float* scale, float* shift,
+                        float* mean, float* rstd, void* stream);
+int mis_bn_bwd_finalize(const float* S1, const float* S2, const float* mean, const float* rstd, const float* gamma, int N, int C,
+                        double count_total, int training, float* p, float* q, float* r, float* dgamma, float* dbeta, void* stream);
+int mis_affine_act(int dtype, const void* x, int x_ld, void* y, int y_ld, int N, long long npix, int C, const float* scale,
+                   const float* shift, int relu, void* stream);
+
 /* On-device 3-D augmentation (augment/unet3d_augment/transforms.py:25-133,495-523,608-619). Volumes are (nvol, D, H, W),
  * 4- or 8-byte elements for the geometric ops (raw fp32 / int64 labels), fp32 for the intensity ops; src != dst. */
 int mis_aug_flip_rot90(const void* src, void* dst, long long nvol, int D, int H, int W, int flipmask /*bit0 D, bit1 H, bit2 W*/, int k,

@@ -21,6 +21,7 @@ EXPORTS = [
     "mis_chanstats_workspace_bytes", "mis_chanstats", "mis_nchw_to_nhwc", "mis_nhwc_to_nchw", "mis_probe_mfma",
     "mis_gn_fwd_finalize", "mis_gn_bwd_stats_workspace_bytes", "mis_gn_bwd_stats", "mis_gn_bwd_finalize", "mis_gn_bwd_apply",
     "mis_first3d_fwd", "mis_first3d_bwd_workspace_bytes", "mis_first3d_bwd", "mis_relu_mask",
+    "mis_bn_fwd_finalize", "mis_bn_bwd_finalize", "mis_affine_act",
     "mis_aug_flip_rot90", "mis_aug_rotate0", "mis_aug_pointwise", "mis_aug_contrast",
 ]
 
@@ -142,6 +143,9 @@ def load():
         "mis_first3d_fwd": [i, vp, vp, vp, i, i, i, i, i, vp, i, vp, i, i, vp],
         "mis_first3d_bwd": [i, vp, vp, vp, i, i, i, i, i, vp, i, i, vp, i, vp, vp, vp, vp],
         "mis_relu_mask": [i, vp, i, vp, i, vp, i, ll, i, vp],
+        "mis_bn_fwd_finalize": [vp, vp, i, i, dbl, vp, vp, f, f, vp, vp, i, vp, vp, vp, vp, vp],
+        "mis_bn_bwd_finalize": [vp, vp, vp, vp, vp, i, i, dbl, i, vp, vp, vp, vp, vp, vp],
+        "mis_affine_act": [i, vp, i, vp, i, i, ll, i, vp, vp, i, vp],
         "mis_aug_flip_rot90": [vp, vp, ll, i, i, i, i, i, i, vp],
         "mis_aug_rotate0": [vp, vp, ll, i, i, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double), i, vp],
         "mis_aug_pointwise": [vp, vp, ll, f, f, i, f, f, f, C.c_ulonglong, vp],

@@ -198,6 +198,116 @@ def _out_of_scope(name, where):
     return _Stub
 
 
-unetConv2 = _out_of_scope("unetConv2", "model/unet2d/layers.py:8-46")
+def _pad64(c):
+    return (c + 63) // 64 * 64
+
+
+class _Conv3x3BNReLU(torch.autograd.Function):
+    """y = relu(batch_norm(conv2d(x, w, b, padding=1))) - reference layers.py:17-25 (one `conv%d` Sequential of unetConv2).
+    Input channels are zero-padded to a multiple of 64 (the K tile of the MFMA kernels); running statistics are updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, eps, momentum):
+        _need_cuda(x)
+        dt = _compute_dtype()
+        dev = x.device
+        N, Cin, H, W = x.shape
+        Cout, Cp = w.shape[0], _pad64(Cin)
+        if Cout % 64:
+            raise MisError(f"unetConv2: out_size {Cout} must be a multiple of 64")
+        xin = torch.zeros(N, H, W, Cp, dtype=dt, device=dev) if Cp != Cin else torch.empty(N, H, W, Cp, dtype=dt, device=dev)
+        ops.nchw_to_nhwc(x.contiguous().float(), ops.View(xin, 0, Cin))
+        wpad = w.detach().float()
+        if Cp != Cin:
+            wpad = torch.zeros(Cout, Cp, 3, 3, dtype=torch.float32, device=dev)
+            wpad[:, :Cin] = w.detach()
+        wf = torch.empty(9, Cout, Cp, dtype=dt, device=dev)
+        wd = torch.empty(9, Cp, Cout, dtype=dt, device=dev)
+        ops.pack_conv_weight(wpad.contiguous(), wf, wd)
+        z = torch.empty(N, H, W, Cout, dtype=dt, device=dev)
+        ops.conv_igemm(xin, wf, z, ksize=3, Cin=Cp, Cout=Cout, bias=b.detach().float())
+        f32 = dict(dtype=torch.float32, device=dev)
+        scale, shift = torch.empty(N, Cout, **f32), torch.empty(N, Cout, **f32)
+        mean, rstd = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
+        s = sq = None
+        if training:
+            s, sq = torch.empty(N, Cout, **f32), torch.empty(N, Cout, **f32)
+            ops.chanstats(z, s, sq)
+        ops.bn_fwd_finalize(s, sq, N, Cout, N * H * W, gamma.detach().float(), beta.detach().float(), running_mean, running_var, training,
+                            scale, shift, mean, rstd, eps=eps, momentum=momentum)
+        y = torch.empty_like(z)
+        ops.affine_act(z, y, scale, shift, relu=True)
+        ctx.save_for_backward(xin, z, y, mean, rstd, gamma.detach().float())
+        ctx.wd, ctx.training = wd, training
+        ctx.shape = (N, Cin, H, W, Cout, Cp)
+        return _to_nchw(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xin, z, y, mean, rstd, gamma = ctx.saved_tensors
+        N, Cin, H, W, Cout, Cp = ctx.shape
+        dt, dev = y.dtype, gy.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        g = _to_nhwc(gy, dt)
+        ops.relu_mask(g, y, g)                                   # g = gy * (y > 0)
+        S1, S2 = torch.empty(N, Cout, **f32), torch.empty(N, Cout, **f32)
+        ops.gn_bwd_stats(g, z, Cout, False, (N, 1, H, W), S1, S2, Cout, 0)
+        p, q, r = (torch.empty(N, Cout, **f32) for _ in range(3))
+        dgamma, dbeta = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
+        ops.bn_bwd_finalize(S1, S2, mean, rstd, gamma, N, Cout, N * H * W, ctx.training, p, q, r, dgamma, dbeta)
+        dz = torch.empty_like(z)
+        ops.gn_bwd_apply(g, z, Cout, False, (N, 1, H, W), p, q, r, Cout, 0, dz)
+        dwp = torch.empty(Cout, Cp, 3, 3, **f32)
+        db = torch.empty(Cout, **f32)
+        ops.wgrad(xin, dz, dwp, ksize=3, Cin=Cp, Cout=Cout, dbias=db)
+        dw = dwp[:, :Cin].contiguous() if Cp != Cin else dwp
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxp = torch.empty(N, H, W, Cp, dtype=dt, device=dev)
+            ops.conv_igemm(dz, ctx.wd, dxp, ksize=3, Cin=Cout, Cout=Cp)
+            dx = torch.empty(N, Cin, H, W, **f32)
+            ops.nhwc_to_nchw(ops.View(dxp, 0, Cin), dx)
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None
+
+
+class unetConv2(nn.Module):
+    """n x [Conv2d(ks 3, s 1, p 1, bias) -> BatchNorm2d -> ReLU] (or without the norm), kaiming-normal init - the reference's
+    "BN" double-conv block (model/unet2d/layers.py:8-46).  Containers are stock nn.Sequential(Conv2d, BatchNorm2d, ReLU) named
+    conv1..convN, so state-dict keys (incl. running_mean / running_var / num_batches_tracked) equal the reference's."""
+
+    def __init__(self, in_size, out_size, is_batchnorm, n=2, ks=3, stride=1, padding=1):
+        super().__init__()
+        if ks != 3 or stride != 1 or padding != 1:
+            raise NotImplementedError("unetConv2 on MI355X: only ks=3, stride=1, padding=1 (every use in the reference) is built")
+        from .init_weights import init_weights
+        self.n, self.ks, self.stride, self.padding = n, ks, stride, padding
+        self.is_batchnorm = bool(is_batchnorm)
+        for i in range(1, n + 1):
+            mods = [nn.Conv2d(in_size, out_size, ks, stride, padding)]
+            if is_batchnorm:
+                mods.append(nn.BatchNorm2d(out_size))
+            mods.append(nn.ReLU(inplace=True))
+            setattr(self, "conv%d" % i, nn.Sequential(*mods))
+            in_size = out_size
+        for m in self.children():
+            init_weights(m, init_type="kaiming")
+
+    def forward(self, inputs):
+        x = inputs
+        for i in range(1, self.n + 1):
+            seq = getattr(self, "conv%d" % i)
+            conv = seq[0]
+            if not self.is_batchnorm:
+                x = _Conv3x3ReLU.apply(x, conv.weight, conv.bias)
+                continue
+            bn = seq[1]
+            training = self.training or not bn.track_running_stats
+            if self.training and bn.track_running_stats:
+                bn.num_batches_tracked += 1
+            x = _Conv3x3BNReLU.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
+                                     bn.eps, bn.momentum)
+        return x
+
+
 unetUp = _out_of_scope("unetUp", "model/unet2d/layers.py:49-74")
 unetUp_origin = _out_of_scope("unetUp_origin", "model/unet2d/layers.py:76-101")

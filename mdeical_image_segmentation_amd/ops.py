@@ -345,3 +345,25 @@ def relu_mask(dy, y, dx):
     lib = load()
     dy, y, dx = _v(dy), _v(y), _v(dx)
     check(lib.mis_relu_mask(dtype_code(y.dtype), dy.ptr, dy.ld, y.ptr, y.ld, dx.ptr, dx.ld, y.npix, y.C, stream_ptr()), "mis_relu_mask")
+
+
+def bn_fwd_finalize(s, sq, N, Cc, count_total, gamma, beta, running_mean, running_var, training, scale, shift, mean, rstd, eps=1e-5, momentum=0.1):
+    lib = load()
+    check(lib.mis_bn_fwd_finalize(None if s is None else s.data_ptr(), None if sq is None else sq.data_ptr(), N, Cc, float(count_total),
+                                  gamma.data_ptr(), beta.data_ptr(), eps, momentum, None if running_mean is None else running_mean.data_ptr(),
+                                  None if running_var is None else running_var.data_ptr(), 1 if training else 0, scale.data_ptr(),
+                                  shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), stream_ptr()), "mis_bn_fwd_finalize")
+
+
+def bn_bwd_finalize(S1, S2, mean, rstd, gamma, N, Cc, count_total, training, p, q, r, dgamma, dbeta):
+    lib = load()
+    check(lib.mis_bn_bwd_finalize(S1.data_ptr(), S2.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), N, Cc, float(count_total),
+                                  1 if training else 0, p.data_ptr(), q.data_ptr(), r.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                  stream_ptr()), "mis_bn_bwd_finalize")
+
+
+def affine_act(x, y, scale, shift, relu=True):
+    lib = load()
+    x, y = _v(x), _v(y)
+    check(lib.mis_affine_act(dtype_code(x.dtype), x.ptr, x.ld, y.ptr, y.ld, x.N, x.D * x.H * x.W, x.C, scale.data_ptr(), shift.data_ptr(),
+                             1 if relu else 0, stream_ptr()), "mis_affine_act")

@@ -173,3 +173,18 @@ def train_step(p, opt, images, labels, max_grad_norm=1.0, lr=None):
 def argmax_mask(logits):
     """trainer/metrcis.py:159 (commented) / model/unet3d/predictor.py:167: channel argmax, lowest index on ties."""
     return logits.argmax(dim=1)
+
+
+def unet_conv2(x, p, n=2, is_batchnorm=True, training=True, eps=1e-5, momentum=0.1):
+    """`unetConv2` (reference model/unet2d/layers.py:8-46): n x [Conv2d(3, s1, p1, bias) -> BatchNorm2d -> ReLU].
+    p: state-dict style {"conv1.0.weight", "conv1.0.bias", "conv1.1.weight", "conv1.1.bias", "conv1.1.running_mean", ...};
+    in training mode the running statistics in p are REPLACED by their updated values (momentum 0.1, unbiased variance)."""
+    for i in range(1, n + 1):
+        x = F.conv2d(x, p[f"conv{i}.0.weight"], p[f"conv{i}.0.bias"], padding=1)
+        if is_batchnorm:
+            rm, rv = p[f"conv{i}.1.running_mean"].clone(), p[f"conv{i}.1.running_var"].clone()
+            x = F.batch_norm(x, rm, rv, p[f"conv{i}.1.weight"], p[f"conv{i}.1.bias"], training, momentum, eps)
+            if training:
+                p[f"conv{i}.1.running_mean"], p[f"conv{i}.1.running_var"] = rm, rv
+        x = F.relu(x)
+    return x

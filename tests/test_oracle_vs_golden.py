@@ -146,3 +146,30 @@ def test_bcedice_loss():
     assert abs(l.item() - float(g["loss"])) < 1e-7
     l.backward()
     assert torch.allclose(lg.grad, T(g["grad"]), atol=1e-8)
+
+
+def _g4_state(g, tag):
+    return {k[len(tag) + 4:]: T(g[k]).clone() for k in g.files if k.startswith(f"{tag}_p0_")}
+
+
+def test_unetconv2_batchnorm_variant():
+    """oracle.unet_conv2 against the real reference's unetConv2 (train-mode output, grads, running stats; eval-mode output)."""
+    g = load_golden("g4_unetconv2.npz")
+    for tag, n in (("a", 2), ("b", 1)):
+        p = _g4_state(g, tag)
+        ps = {k: (v.requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in p.items()}
+        x = T(g[f"{tag}_x"]).requires_grad_(True)
+        y = o2.unet_conv2(x, ps, n=n, training=True)
+        assert torch.allclose(y, T(g[f"{tag}_y"]), atol=1e-5)
+        y.backward(T(g[f"{tag}_gy"]))
+        assert torch.allclose(x.grad, T(g[f"{tag}_gx"]), atol=1e-4)
+        for k in g.files:
+            if k.startswith(f"{tag}_g_"):
+                assert torch.allclose(ps[k[len(tag) + 3:]].grad, T(g[k]), rtol=1e-4, atol=2e-4), k
+            if k.startswith(f"{tag}_p1_") and "running" in k:
+                assert torch.allclose(ps[k[len(tag) + 4:]], T(g[k]), atol=1e-6), k
+        with torch.no_grad():
+            ye = o2.unet_conv2(T(g[f"{tag}_x"]), ps, n=n, training=False)
+        assert torch.allclose(ye, T(g[f"{tag}_y_eval"]), atol=1e-5)
+    p = _g4_state(g, "c")
+    assert torch.allclose(o2.unet_conv2(T(g["c_x"]), p, n=2, is_batchnorm=False), T(g["c_y"]), atol=1e-5)
