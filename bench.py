@@ -187,14 +187,16 @@ def bench3d(args, rank, world, dev, dist):
     x = torch.randn(batch, 1, size, size, size, generator=g).to(dev)
     t = (torch.rand(batch, 3, size, size, size, generator=g) > 0.5).float().to(dev)
 
-    # on-device augmentation inside the timed step: flip + rot90 + rotate (order 0, +-30 deg, reflect)
-    # on raw and targets in lock-step, contrast (p=1) + Gaussian noise (p=1) on raw; parameters from the reference's streams
+    # on-device augmentation inside the timed step: flip + rot90 + rotate (+-30 deg, reflect; cubic spline
+    # order 3 on raw, order 0 on targets) on raw and targets in lock-step, contrast (p=1) + Gaussian noise (p=1) on raw; parameters from the reference's streams
     import numpy as np
     from mdeical_image_segmentation_amd.augment.unet3d_augment import transforms as tr
     tr.GLOBAL_RANDOM_STATE = np.random.RandomState(47 + rank)
-    geo = [{"name": "RandomFlip"}, {"name": "RandomRotate90"},
-           {"name": "RandomRotate", "axes": [[2, 1]], "angle_spectrum": 30, "mode": "reflect", "order": 0}]
-    tf = tr.Transformer({"raw": geo + [{"name": "RandomContrast", "execution_probability": 1.0},
+    def geo_(order):
+        return [{"name": "RandomFlip"}, {"name": "RandomRotate90"},
+                {"name": "RandomRotate", "axes": [[2, 1]], "angle_spectrum": 30, "mode": "reflect", "order": order}]
+    geo = geo_(0)
+    tf = tr.Transformer({"raw": geo_(3) + [{"name": "RandomContrast", "execution_probability": 1.0},
                                        {"name": "AdditiveGaussianNoise", "execution_probability": 1.0, "scale": [0.0, 0.1]}],
                          "label": geo}, {"mean": 0.0, "std": 1.0})
     rt, lt = tf.raw_transform(), tf.label_transform()
@@ -238,7 +240,7 @@ def bench3d(args, rank, world, dev, dist):
         out = {"metric": f"volumes/sec (3D {size}^3 U-Net train step)", "value": round(value, 3), "unit": "volumes/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": f"unet3d 1-ch->3-class bs={batch}/GPU {size}^3, on-device augment (flip+rot90+rotate order0+contrast+noise) + fwd+BCEDice+bwd+clip+AdamW, random-init weights",
+               "config": {"workload": f"unet3d 1-ch->3-class bs={batch}/GPU {size}^3, on-device augment (flip+rot90+rotate[order 3 raw / 0 targets]+contrast+noise) + fwd+BCEDice+bwd+clip+AdamW, random-init weights",
                           "global_batch": world * batch, "parallelism": f"dp{world}", "final_loss": round(eng.loss_buf[0].item(), 5)}}
         out["model_tflops"] = round(value * FLOP_PER_VOLUME_128 * (size / 128.0) ** 3 / 1e12, 1)
         if prof:

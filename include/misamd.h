@@ -199,6 +199,10 @@ int mis_aug_flip_rot90(const void* src, void* dst, long long nvol, int D, int H,
                        int elem_size, void* stream);
 int mis_aug_rotate0(const void* src, void* dst, long long nvol, int D, int H, int W, int a0, int a1, const double* m4 /*host*/,
                     const double* off2 /*host*/, int elem_size, void* stream);
+/* order-3 (cubic spline) variant, fp32 volumes: workspace = nvol*D*H*W doubles (the float64 spline coefficients scipy keeps) */
+size_t mis_aug_rotate3_workspace_bytes(long long nvol, int D, int H, int W);
+int mis_aug_rotate3(const float* src, float* dst, double* workspace, long long nvol, int D, int H, int W, int a0, int a1,
+                    const double* m4 /*host*/, const double* off2 /*host*/, void* stream);
 int mis_aug_pointwise(const float* src, float* dst, long long n, float a, float b, int do_clip, float lo, float hi, float noise_std,
                       unsigned long long seed, void* stream);
 int mis_aug_contrast(const float* src, float* dst, long long n, float mean, float alpha, void* stream);

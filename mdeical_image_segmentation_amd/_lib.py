@@ -22,7 +22,7 @@ EXPORTS = [
     "mis_gn_fwd_finalize", "mis_gn_bwd_stats_workspace_bytes", "mis_gn_bwd_stats", "mis_gn_bwd_finalize", "mis_gn_bwd_apply",
     "mis_first3d_fwd", "mis_first3d_bwd_workspace_bytes", "mis_first3d_bwd", "mis_relu_mask",
     "mis_bn_fwd_finalize", "mis_bn_bwd_finalize", "mis_affine_act",
-    "mis_aug_flip_rot90", "mis_aug_rotate0", "mis_aug_pointwise", "mis_aug_contrast",
+    "mis_aug_flip_rot90", "mis_aug_rotate0", "mis_aug_rotate3_workspace_bytes", "mis_aug_rotate3", "mis_aug_pointwise", "mis_aug_contrast",
 ]
 
 
@@ -118,6 +118,8 @@ def load():
     lib.mis_gn_bwd_stats_workspace_bytes.argtypes = [C.c_int, C.c_int]
     lib.mis_first3d_bwd_workspace_bytes.restype = C.c_size_t
     lib.mis_first3d_bwd_workspace_bytes.argtypes = []
+    lib.mis_aug_rotate3_workspace_bytes.restype = C.c_size_t
+    lib.mis_aug_rotate3_workspace_bytes.argtypes = [C.c_longlong, C.c_int, C.c_int, C.c_int]
     vp, i, ll, f, dbl = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double
     sigs = {
         "mis_conv_igemm": [vp, vp],
@@ -148,6 +150,7 @@ def load():
         "mis_affine_act": [i, vp, i, vp, i, i, ll, i, vp, vp, i, vp],
         "mis_aug_flip_rot90": [vp, vp, ll, i, i, i, i, i, i, vp],
         "mis_aug_rotate0": [vp, vp, ll, i, i, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double), i, vp],
+        "mis_aug_rotate3": [vp, vp, vp, ll, i, i, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double), vp],
         "mis_aug_pointwise": [vp, vp, ll, f, f, i, f, f, f, C.c_ulonglong, vp],
         "mis_aug_contrast": [vp, vp, ll, f, f, vp],
     }

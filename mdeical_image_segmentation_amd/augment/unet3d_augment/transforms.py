@@ -6,7 +6,8 @@ and label pipelines stay in lock-step exactly like the reference.  The random PA
 numpy's MT19937 streams (the reference's own generator); the volumes never leave HBM: every transform is one HIP
 gather / elementwise kernel (csrc/augment.hip).  Inputs may be numpy arrays (uploaded once) or CUDA tensors;
 outputs are CUDA tensors.  Differences, all loud or documented:
-  * RandomRotate supports order=0 (the class default, bit-exact vs scipy incl. 'reflect'); other orders raise;
+  * RandomRotate supports order=0 (the class default, bit-exact vs scipy incl. 'reflect') and order=3 (cubic spline, fp64
+    coefficients like scipy; equal to scipy up to float32 rounding); other orders raise;
   * AdditiveGaussianNoise draws the decision and the std from the reference stream but the noise FIELD comes from an
     on-device counter-based generator (same distribution, different values); `exact=True` generates the field with
     numpy on the host instead;
@@ -109,9 +110,12 @@ class RandomRotate:
     def __call__(self, m):
         axis = self.axes[self.random_state.randint(len(self.axes))]
         angle = self.random_state.randint(-self.angle_spectrum, self.angle_spectrum)
-        if self.order != 0 or self.mode != 'reflect':
-            raise NotImplementedError("on-device RandomRotate: only order=0, mode='reflect' is built (spline orders are a next row)")
+        if self.order not in (0, 3) or self.mode != 'reflect':
+            raise NotImplementedError("on-device RandomRotate: order 0 (class default) and 3 (the configs' raw setting) with "
+                                      "mode='reflect' are built")
         m = _dev(m)
+        if self.order == 3 and m.dtype != torch.float32:
+            raise MisError("RandomRotate(order=3): fp32 volumes only (labels use order 0)")
         D, H, W = m.shape[-3:]
         a0, a1 = sorted(int(a) for a in axis)
         # exactly scipy.ndimage.rotate's host arithmetic
@@ -125,6 +129,11 @@ class RandomRotate:
         o2 = (C.c_double * 2)(off[0], off[1])
         out = torch.empty_like(m)
         nvol = m.numel() // (D * H * W)
+        if self.order == 3:
+            lib = load()
+            ws = ops.workspace(lib.mis_aug_rotate3_workspace_bytes(nvol, D, H, W), m.device, "rotate3")
+            check(lib.mis_aug_rotate3(m.data_ptr(), out.data_ptr(), ws.data_ptr(), nvol, D, H, W, a0, a1, m4, o2, stream_ptr()), "mis_aug_rotate3")
+            return out
         check(load().mis_aug_rotate0(m.data_ptr(), out.data_ptr(), nvol, D, H, W, a0, a1, m4, o2, m.element_size(), stream_ptr()),
               "mis_aug_rotate0")
         return out

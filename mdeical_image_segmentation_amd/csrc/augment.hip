@@ -7,6 +7,8 @@
 // multiply-add, reflect about the half-sample edges, round half up, reflect the index), RandomContrast :115-133,
 // AdditiveGaussianNoise :608-619, Standardize :495-523.  The random PARAMETERS are drawn on the host from the same numpy
 // RandomState streams as the reference; only the Gaussian noise FIELD comes from an on-device counter-based generator.
+#include <math.h>
+
 #include "common.hpp"
 
 // numpy / scipy evaluate these expressions without fused multiply-add: keep hipcc from contracting a*b+c in this file
@@ -131,6 +133,133 @@ extern "C" int mis_aug_rotate0(const void* src, void* dst, long long nvol, int D
     else
         hipLaunchKernelGGL(aug_rotate0_kernel<uint64_t>, dim3(g), dim3(256), 0, s, (const uint64_t*)src, (uint64_t*)dst, nvol, D, H, W, a0, a1, ra);
     MIS_LAUNCH_CHECK("aug_rotate0");
+    return MIS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// RandomRotate with order=3 (the reference's raw-volume setting in its 3-D configs; class default is 0):
+// scipy.ndimage.rotate(reshape=False, order=3, mode='reflect') = per rotation plane
+//   1. spline_filter to float64 coefficients: along plane axis 0, then plane axis 1 (scipy ni_splines.c, cubic pole sqrt(3)-2,
+//      gain (1-z)(1-1/z), exact 'reflect' initialisation of the causal recursion, anti-causal c[n-1] *= z/(z-1))
+//   2. at each output voxel the rotated coordinate (same unfused arithmetic as order 0), reflected, start = floor(x)-1, the
+//      4x4 cubic B-spline weights, support indices reflected, t += (coef * w_row) * w_col in row-major tap order, cast to float.
+// One thread per line for the recursive filter (fp64, sequential along the line by nature), one thread per voxel for step 2.
+// ---------------------------------------------------------------------------------------------------------
+template <typename Src>
+__global__ __launch_bounds__(256) void aug_spline3_filter_kernel(const Src* __restrict__ src, double* __restrict__ coef, long long nvol, int D, int H,
+                                                                 int W, int ax, double z, double z_n) {
+    const int dims[3] = {D, H, W};
+    const long long strides[3] = {(long long)H * W, (long long)W, 1};
+    const int n = dims[ax];
+    const long long st = strides[ax];
+    const int o1 = ax == 0 ? 1 : 0, o2 = ax == 2 ? 1 : 2;       // the two other axes
+    const long long nlines = nvol * dims[o1] * dims[o2];
+    const double gain = (1.0 - z) * (1.0 - 1.0 / z);
+    for (long long l = (long long)blockIdx.x * 256 + threadIdx.x; l < nlines; l += (long long)gridDim.x * 256) {
+        const int i2 = (int)(l % dims[o2]);
+        const long long t = l / dims[o2];
+        const int i1 = (int)(t % dims[o1]);
+        const long long v = t / dims[o1];
+        const long long base = v * D * H * W + i1 * strides[o1] + i2 * strides[o2];
+        const Src* s = src + base;
+        double* c = coef + base;
+        if (n == 1) {
+            c[0] = (double)s[0] * gain;
+            continue;
+        }
+        // causal initialisation over the half-sample-symmetric extension
+        const double c0 = (double)s[0] * gain;
+        double acc = c0 + z_n * ((double)s[(n - 1) * st] * gain);
+        double z_i = z;
+        for (int i = 1; i < n; ++i) {
+            acc = acc + z_i * ((double)s[i * st] * gain + z_n * ((double)s[(n - 1 - i) * st] * gain));
+            z_i *= z;
+        }
+        acc = acc * (z / (1.0 - z_n * z_n));
+        double prev = acc + c0;
+        c[0] = prev;
+        for (int i = 1; i < n; ++i) {
+            prev = (double)s[i * st] * gain + z * prev;
+            c[i * st] = prev;
+        }
+        prev = prev * (z / (z - 1.0));
+        c[(n - 1) * st] = prev;
+        for (int i = n - 2; i >= 0; --i) {
+            prev = z * (prev - c[i * st]);
+            c[i * st] = prev;
+        }
+    }
+}
+
+__device__ __forceinline__ void spline3_weights(double x, long long& start, double* w) {
+    const double f = floor(x);
+    const double y = x - f, zc = 1.0 - y;
+    w[1] = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0;
+    w[2] = (zc * zc * (zc - 2.0) * 3.0 + 4.0) / 6.0;
+    w[0] = zc * zc * zc / 6.0;
+    w[3] = 1.0 - w[0] - w[1] - w[2];
+    start = (long long)f - 1;
+}
+
+__global__ __launch_bounds__(256) void aug_rotate3_kernel(const double* __restrict__ coef, float* __restrict__ dst, long long nvol, int D, int H, int W,
+                                                          int a0, int a1, RotArgs ra) {
+    const long long per = (long long)D * H * W, total = nvol * per;
+    const int dims[3] = {D, H, W};
+    const long long strides[3] = {(long long)H * W, (long long)W, 1};
+    const int n0 = dims[a0], n1 = dims[a1];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long v = i / per;
+        long long r = i - v * per;
+        int c[3];
+        c[2] = (int)(r % W);
+        r /= W;
+        c[1] = (int)(r % H);
+        c[0] = (int)(r / H);
+        const double o0 = (double)c[a0], o1 = (double)c[a1];
+        double x0 = __dadd_rn(__dadd_rn(__dadd_rn(0.0, __dmul_rn(o0, ra.m00)), __dmul_rn(o1, ra.m01)), ra.off0);
+        double x1 = __dadd_rn(__dadd_rn(__dadd_rn(0.0, __dmul_rn(o0, ra.m10)), __dmul_rn(o1, ra.m11)), ra.off1);
+        x0 = refl_coord(x0, n0);
+        x1 = refl_coord(x1, n1);
+        long long s0, s1;
+        double w0[4], w1[4];
+        spline3_weights(x0, s0, w0);
+        spline3_weights(x1, s1, w1);
+        long long k1[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) k1[b] = (long long)refl_idx(s1 + b, n1) * strides[a1];
+        const long long rest = v * per + (long long)c[0] * strides[0] + (long long)c[1] * strides[1] + (long long)c[2] * strides[2] -
+                               (long long)c[a0] * strides[a0] - (long long)c[a1] * strides[a1];
+        double t = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const long long rowoff = rest + (long long)refl_idx(s0 + a, n0) * strides[a0];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) t += (coef[rowoff + k1[b]] * w0[a]) * w1[b];
+        }
+        dst[i] = (float)t;
+    }
+}
+
+extern "C" size_t mis_aug_rotate3_workspace_bytes(long long nvol, int D, int H, int W) {
+    return (size_t)nvol * D * H * W * sizeof(double);
+}
+
+extern "C" int mis_aug_rotate3(const float* src, float* dst, double* workspace, long long nvol, int D, int H, int W, int a0, int a1,
+                               const double* m4, const double* off2, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(src && dst && workspace && src != dst && m4 && off2 && nvol > 0 && D > 0 && H > 0 && W > 0, MIS_EINVAL, "aug_rotate3: bad argument");
+    MIS_REQUIRE(a0 >= 0 && a0 < a1 && a1 <= 2, MIS_EINVAL, "aug_rotate3: axes must be sorted and distinct");
+    RotArgs ra{m4[0], m4[1], m4[2], m4[3], off2[0], off2[1]};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int dims[3] = {D, H, W};
+    const double z = sqrt(3.0) - 2.0;
+    const long long vox = nvol * D * H * W;
+    hipLaunchKernelGGL(aug_spline3_filter_kernel<float>, dim3(aug_grid(vox / dims[a0])), dim3(256), 0, s, src, workspace, nvol, D, H, W, a0, z,
+                       pow(z, (double)dims[a0]));
+    hipLaunchKernelGGL(aug_spline3_filter_kernel<double>, dim3(aug_grid(vox / dims[a1])), dim3(256), 0, s, (const double*)workspace, workspace, nvol, D, H,
+                       W, a1, z, pow(z, (double)dims[a1]));
+    hipLaunchKernelGGL(aug_rotate3_kernel, dim3(aug_grid(vox)), dim3(256), 0, s, (const double*)workspace, dst, nvol, D, H, W, a0, a1, ra);
+    MIS_LAUNCH_CHECK("aug_rotate3");
     return MIS_OK;
 }
 

@@ -73,6 +73,76 @@ def rotate0(m, angle, axes):
     return np.moveaxis(out, (0, 1), (a0, a1))
 
 
+_POLE3 = np.sqrt(3.0) - 2.0
+
+
+def spline_filter3_line(c):
+    """scipy ni_splines.c (scipy 1.15, third-party): cubic B-spline prefilter of one line, mode 'reflect' (half-sample symmetric):
+    gain (1-z)(1-1/z), exact causal initialisation over the reflected signal, causal and anti-causal recursions.
+    c: float64 array, filtered along axis 0 (vectorised over the other axes)."""
+    z = _POLE3
+    n = c.shape[0]
+    c = c * ((1.0 - z) * (1.0 - 1.0 / z))
+    if n == 1:
+        return c
+    z_n = z ** n
+    c0 = c[0].copy()
+    acc = c[0] + z_n * c[n - 1]
+    z_i = z
+    for i in range(1, n):
+        acc = acc + z_i * (c[i] + z_n * c[n - 1 - i])
+        z_i *= z
+    acc = acc * (z / (1.0 - z_n * z_n))
+    c[0] = acc + c0
+    for i in range(1, n):
+        c[i] = c[i] + z * c[i - 1]
+    c[n - 1] = c[n - 1] * (z / (z - 1.0))
+    for i in range(n - 2, -1, -1):
+        c[i] = z * (c[i + 1] - c[i])
+    return c
+
+
+def rotate3(m, angle, axes):
+    """scipy.ndimage.rotate(m, angle, axes=axes, reshape=False, order=3, mode='reflect') for a 3-D float array: per plane,
+    spline_filter (float64, axis 0 then axis 1 of the plane) and cubic interpolation at the rotated coordinates; support points
+    beyond the edges follow the 'reflect' index rule; result cast to m.dtype."""
+    a0, a1 = sorted(axes)
+    c, s = special.cosdg(angle), special.sindg(angle)
+    rot = np.array([[c, s], [-s, c]])
+    shp = np.asarray(m.shape)[[a0, a1]]
+    off = (shp - 1) / 2 - rot @ ((shp - 1) / 2)
+    n0, n1 = int(shp[0]), int(shp[1])
+    mm = np.moveaxis(m, (a0, a1), (0, 1)).astype(np.float64)
+    co = spline_filter3_line(mm.copy())
+    co = np.moveaxis(spline_filter3_line(np.moveaxis(co, 1, 0).copy()), 0, 1)
+    i = np.arange(n0, dtype=np.float64)[:, None]
+    j = np.arange(n1, dtype=np.float64)[None, :]
+    x0 = _refl_coord(((0.0 + i * rot[0, 0]) + j * rot[0, 1]) + off[0], n0)
+    x1 = _refl_coord(((0.0 + i * rot[1, 0]) + j * rot[1, 1]) + off[1], n1)
+
+    def weights(x):
+        f = np.floor(x)
+        y = x - f
+        zc = 1.0 - y
+        w1 = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0
+        w2 = (zc * zc * (zc - 2.0) * 3.0 + 4.0) / 6.0
+        w0 = zc * zc * zc / 6.0
+        w3 = 1.0 - w0 - w1 - w2
+        return f.astype(np.int64) - 1, (w0, w1, w2, w3)
+
+    s0, w0 = weights(x0)
+    s1, w1 = weights(x1)
+    out = np.zeros((n0, n1) + mm.shape[2:], dtype=np.float64)
+    for a in range(4):
+        k0 = _refl_idx(s0 + a, n0)
+        for b in range(4):
+            k1 = _refl_idx(s1 + b, n1)
+            wgt = (w0[a] * w1[b]).reshape((n0, n1) + (1,) * (mm.ndim - 2))
+            cf = co[k0, k1]
+            out = out + (cf * w0[a].reshape(wgt.shape)) * w1[b].reshape(wgt.shape)
+    return np.moveaxis(out, (0, 1), (a0, a1)).astype(m.dtype)
+
+
 def contrast(m, mean, alpha):
     return np.clip(mean + alpha * (m - mean), -1, 1)
 

@@ -57,6 +57,11 @@ def main():
     out["std_fixed"] = tr.Standardize(mean=0.1, std=0.5)(v)
     out["contrast"] = tr.RandomContrast(np.random.RandomState(9), mean=0.05, execution_probability=1.0)(v)
     out["norm"] = tr.Normalize(min_value=-1.0, max_value=1.0)(v)
+    # (3) cubic-spline rotation (order=3: the raw-volume setting of the reference's 3-D configs), all planes + 4-D input
+    for s in range(6):
+        rr = tr.RandomRotate(np.random.RandomState(400 + s), angle_spectrum=30, mode="reflect", order=3)
+        out[f"rot3_{s}"] = np.ascontiguousarray(rr(v))
+    out["c4_rot3"] = np.ascontiguousarray(tr.RandomRotate(np.random.RandomState(8), axes=[(2, 1)], order=3)(c4))
     np.savez_compressed(os.path.join(HERE, "g5_augment.npz"), **out)
     print("wrote g5_augment.npz", sum(a.nbytes for a in out.values()) // 1024, "KiB; seed", t.seed)
 

@@ -38,6 +38,10 @@ def test_oracle_matches_reference_goldens():
         assert np.array_equal(p.raw(g["raw"]), g[f"pipe_raw_{i}"]), f"raw {i}"
         assert np.array_equal(p.label(g["label"]), g[f"pipe_label_{i}"]), f"label {i}"
     assert np.allclose(ao.standardize(g["v"]), g["std_auto"], atol=1e-6)
+    for s in range(6):      # cubic-spline rotation: float64 spline coefficients, result equal up to float32 rounding
+        rs = np.random.RandomState(400 + s)
+        axis = [(1, 0), (2, 1), (2, 0)][rs.randint(3)]
+        assert np.allclose(ao.rotate3(g["v"], rs.randint(-30, 30), axis), g[f"rot3_{s}"], rtol=0, atol=5e-7), f"rot3_{s}"
     rs = np.random.RandomState(9)
     rs.uniform()
     assert np.array_equal(ao.contrast(g["v"], 0.05, rs.uniform(0.5, 1.5)), g["contrast"])
@@ -57,6 +61,10 @@ def test_device_transforms_match_reference_goldens():
         assert np.array_equal(tr.RandomRotate90(np.random.RandomState(300 + s))(sq).cpu().numpy(), g[f"rot90_{s}"]), f"rot90_{s}"
     assert np.array_equal(tr.RandomFlip(np.random.RandomState(7))(g["c4"]).cpu().numpy(), g["c4_flip"])
     assert np.array_equal(tr.RandomRotate(np.random.RandomState(8), axes=[(2, 1)])(g["c4"]).cpu().numpy(), g["c4_rot"])
+    for s in range(6):
+        out = tr.RandomRotate(np.random.RandomState(400 + s), angle_spectrum=30, mode="reflect", order=3)(v)
+        assert np.allclose(out.cpu().numpy(), g[f"rot3_{s}"], rtol=0, atol=5e-7), f"rot3_{s}"
+    assert np.allclose(tr.RandomRotate(np.random.RandomState(8), axes=[(2, 1)], order=3)(g["c4"]).cpu().numpy(), g["c4_rot3"], rtol=0, atol=5e-7)
     assert np.array_equal(tr.RandomContrast(np.random.RandomState(9), mean=0.05, execution_probability=1.0)(v).cpu().numpy(), g["contrast"])
     assert np.allclose(tr.Standardize()(v).cpu().numpy(), g["std_auto"], atol=2e-6)
     assert np.allclose(tr.Standardize(mean=0.1, std=0.5)(v).cpu().numpy(), g["std_fixed"], atol=1e-6)
@@ -94,5 +102,12 @@ def test_device_rotate_at_full_size_matches_oracle_and_noise_statistics():
     z = torch.zeros(64, 64, 64, device="cuda")
     n = tr.AdditiveGaussianNoise(np.random.RandomState(3), scale=(0.5, 0.5), execution_probability=1.0)(z)
     assert abs(n.mean().item()) < 5e-3 and abs(n.std().item() - 0.5) < 5e-3
+    for seed in (4, 5):                                   # order 3 at full plane size against the oracle (= scipy up to fp32 rounding)
+        rs = np.random.RandomState(seed)
+        axis = [(1, 0), (2, 1), (2, 0)][rs.randint(3)]
+        angle = rs.randint(-30, 30)
+        out = tr.RandomRotate(np.random.RandomState(seed), order=3)(vol).cpu().numpy()
+        ref = ao.rotate3(vol, angle, axis)
+        assert np.abs(out - ref).max() < 5e-7, (seed, axis, angle, np.abs(out - ref).max())
     with pytest.raises(NotImplementedError):
-        tr.RandomRotate(np.random.RandomState(1), order=3)(vol)
+        tr.RandomRotate(np.random.RandomState(1), order=2)(vol)
