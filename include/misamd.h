@@ -180,6 +180,12 @@ int mis_first3d_bwd(int dtype, const float* x, const float* scale, const float* 
                     int dy_ld, int Cpad, const float* w, int Cout, float* workspace, float* dw, float* dxn, void* stream);
 int mis_relu_mask(int dtype, const void* dy, int dy_ld, const void* y, int y_ld, void* dx, int dx_ld, long long npix, int C, void* stream);
 
+/* 'deconv' upsampling of the 3-D decoders: ConvTranspose3d(k3, s2, p1, no bias) then nearest resize 2n-1 -> 2n
+ * (model/unet3d/buildingblocks.py:676-728).  The contraction is mis_conv_igemm (ksize 1, 27*C columns: cols[i][k*C+c], k = (kd*3+kh)*3+kw);
+ * col2im gathers cols (N,d,h,w,27*C) into u (N,2d,2h,2w,C; row stride u_ld); im2col is its adjoint: gu -> gcols (N,d,h,w,27*C). */
+int mis_convt3_col2im(int dtype, const void* cols, void* u, int u_ld, int N, int d, int h, int w, int C, void* stream);
+int mis_convt3_im2col(int dtype, const void* gu, int gu_ld, void* gcols, int N, int d, int h, int w, int C, void* stream);
+
 /* BatchNorm2d of the `unetConv2` block (model/unet2d/layers.py:17-25: Conv2d(bias) -> BatchNorm2d -> ReLU; eps 1e-5, momentum 0.1).
  * fwd: mis_chanstats(z) -> mis_bn_fwd_finalize (batch statistics; running_mean/var updated in place with the unbiased variance;
  *      training == 0 uses the running statistics) -> per (n,c) scale/shift [N][C] -> mis_affine_act (y = relu(z*scale+shift)).

@@ -22,7 +22,7 @@ from .engine2d import FlatParams
 from .ops import View
 
 
-def layer_plan(in_channels, f_maps):
+def layer_plan(in_channels, f_maps, upsample="default"):
     enc = []
     for i, out in enumerate(f_maps):
         cin = in_channels if i == 0 else f_maps[i - 1]
@@ -31,15 +31,23 @@ def layer_plan(in_channels, f_maps):
     dec = []
     rf = list(reversed(f_maps))
     for i in range(len(rf) - 1):
-        dec.append([(rf[i] + rf[i + 1], rf[i + 1]), (rf[i + 1], rf[i + 1])])
+        # 'deconv' (buildingblocks.py:604-626): the transposed conv halves the channels first, the DoubleConv sees rf[i]
+        dec.append([(rf[i] + rf[i + 1] if upsample != "deconv" else rf[i], rf[i + 1]), (rf[i + 1], rf[i + 1])])
     return enc, dec
 
 
-def unet3d_param_specs(in_channels, out_channels, f_maps):
-    enc, dec = layer_plan(in_channels, f_maps)
+def _ct_name(j):
+    return f"decoders.{j}.upsampling.upsample.conv_transposed.weight"
+
+
+def unet3d_param_specs(in_channels, out_channels, f_maps, upsample="default"):
+    enc, dec = layer_plan(in_channels, f_maps, upsample)
+    rf = list(reversed(f_maps))
     specs = []
     for grp, plan in (("encoders", enc), ("decoders", dec)):
         for i, convs in enumerate(plan):
+            if grp == "decoders" and upsample == "deconv":     # registered before basic_module (buildingblocks.py:504-534)
+                specs.append((_ct_name(i), (rf[i], rf[i + 1], 3, 3, 3)))
             for j, (ci, co) in enumerate(convs):
                 pre = f"{grp}.{i}.basic_module.SingleConv{j + 1}"
                 specs += [(f"{pre}.groupnorm.weight", (ci,)), (f"{pre}.groupnorm.bias", (ci,)), (f"{pre}.conv.weight", (co, ci, 3, 3, 3))]
@@ -56,7 +64,7 @@ def default_init3d_(params, seed=None):
             p.fill_(1.0)
         elif name.endswith("groupnorm.bias"):
             p.zero_()
-        elif name.endswith("conv.weight") or name == "final_conv.weight":
+        elif name.endswith("conv.weight") or name.endswith("conv_transposed.weight") or name == "final_conv.weight":
             w = torch.empty(p.shape)
             torch.nn.init.kaiming_uniform_(w, a=math.sqrt(5))
             p.copy_(w)
@@ -75,7 +83,11 @@ class _SC:
 
 class UNet3DEngine:
     def __init__(self, in_channels=1, out_channels=3, f_maps=(64, 128, 256, 512), num_groups=8, dtype=torch.float32, device="cuda",
-                 seed=None, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3, max_grad_norm=1.0, alpha=1.0, beta=1.0):
+                 seed=None, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3, max_grad_norm=1.0, alpha=1.0, beta=1.0,
+                 upsample="default"):
+        if upsample not in ("default", "nearest", "deconv"):
+            raise MisError(f"UNet3DEngine: upsample must be 'default'/'nearest' or 'deconv', got {upsample!r}")
+        self.deconv = upsample == "deconv"
         if in_channels != 1:
             raise MisError("UNet3DEngine: in_channels must be 1 (the direct first-layer kernel)")
         if not (1 <= out_channels <= 4):
@@ -87,7 +99,7 @@ class UNet3DEngine:
         self.cin, self.cout, self.f_maps, self.G = in_channels, out_channels, f_maps, num_groups
         self.dtype, self.device = dtype, torch.device(device)
         self.levels = len(f_maps)
-        self.specs = unet3d_param_specs(in_channels, out_channels, f_maps)
+        self.specs = unet3d_param_specs(in_channels, out_channels, f_maps, upsample)
         self.flat = FlatParams(self.specs, self.device, lambda n: not n.endswith("bias"))
         self.P, self.Gr = self.flat.param, self.flat.grad
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
@@ -101,7 +113,18 @@ class UNet3DEngine:
         self.c1 = max(f_maps[0] // 2, in_channels)                 # 32
         self.c1p = (self.c1 + 63) // 64 * 64                       # 64: dgrad needs its GEMM-N (= Cin) in multiples of 64
         # SingleConv descriptors
-        enc, dec = layer_plan(in_channels, f_maps)
+        enc, dec = layer_plan(in_channels, f_maps, upsample)
+        self.ct = []                                               # transposed-conv upsamplers ('deconv')
+        if self.deconv:
+            rf = list(reversed(f_maps))
+            for j in range(len(rf) - 1):
+                t = _SC()
+                t.name, t.cin, t.cout = _ct_name(j), rf[j], rf[j + 1]
+                t.w2d = torch.empty(27 * t.cout, t.cin, 1, device=self.device)             # row k*Cout + co, fp32
+                t.wf = torch.empty(1, 27 * t.cout, t.cin, dtype=dtype, device=self.device)  # GEMM operand of the forward
+                t.wd = torch.empty(1, t.cin, 27 * t.cout, dtype=dtype, device=self.device)  # ... of the input gradient
+                t.dw2d = torch.empty(27 * t.cout, t.cin, device=self.device)
+                self.ct.append(t)
         self.sc = {}
         for grp, plan in (("encoders", enc), ("decoders", dec)):
             for i, convs in enumerate(plan):
@@ -145,6 +168,9 @@ class UNet3DEngine:
                 s.wpad[:, :s.cin] = w
                 w = s.wpad
             ops.pack_conv_weight(w, s.wf, s.wd)
+        for t in self.ct:       # W [Cin][Cout][27] -> [27*Cout][Cin] (row k*Cout + co), then the two packed GEMM operands
+            t.w2d.view(27, t.cout, t.cin).copy_(self.P[t.name].view(t.cin, t.cout, 27).permute(2, 1, 0))
+            ops.pack_conv_weight(t.w2d, t.wf, t.wd)
 
     # ---- buffers ---------------------------------------------------------------------------------------
     def _alloc(self, N, D, H, W):
@@ -173,8 +199,12 @@ class UNet3DEngine:
                 self.pooled.append(buf(l + 1, fm[l]))
                 self.g_pooled.append(buf(l + 1, fm[l]))
         self.t_dec, self.d, self.g_t_dec, self.g_d = [], [], [], []
+        self.up, self.g_up = [], []
         for j in range(L - 1):
             l = L - 2 - j
+            if self.deconv:
+                self.up.append(buf(l, fm[l]))
+                self.g_up.append(buf(l, fm[l]))
             self.t_dec.append(buf(l, fm[l]))
             self.d.append(buf(l, fm[l]))
             self.g_t_dec.append(buf(l, fm[l]))
@@ -200,6 +230,9 @@ class UNet3DEngine:
             key = (self._level(s.name), s.cin_pad)
             if key not in self.dyn:
                 self.dyn[key] = buf(key[0], key[1])
+        if self.deconv:     # one column buffer (N, d, h, w, 27*Cout) shared by all levels and by forward / backward
+            self.cols_elems = max(N * (D >> (l + 1)) * (H >> (l + 1)) * (W >> (l + 1)) * 27 * fm[l] for l in range(L - 1))
+            self.cols = torch.empty(self.cols_elems, dtype=dt, device=dev)
         self.dxn0 = torch.empty(N, D, H, W, dtype=torch.float32, device=dev)
         self.logits = torch.empty(N, self.cout, D, H, W, dtype=torch.float32, device=dev)
         self.argmax = torch.empty(N, D, H, W, dtype=torch.uint8, device=dev)
@@ -216,7 +249,8 @@ class UNet3DEngine:
         ops.chanstats(View(src0, 0, c0), s.sum0, s.sq0)
         if src1 is not None:
             ops.chanstats(View(src1, 0, c1), s.sum1, s.sq1)
-        ops.gn_fwd_finalize(s.sum0, s.sq0, c0, 1.0, s.sum1 if src1 is not None else None, s.sq1 if src1 is not None else None, c1, 8.0,
+        mult1 = 8.0 if (src1 is not None and src1.shape[1] != src0.shape[1]) else 1.0     # nearest-upsampled source: 8 children per voxel
+        ops.gn_fwd_finalize(s.sum0, s.sq0, c0, 1.0, s.sum1 if src1 is not None else None, s.sq1 if src1 is not None else None, c1, mult1,
                             N, s.groups, count, self.P[s.name + ".groupnorm.weight"], self.P[s.name + ".groupnorm.bias"], s.cin_pad,
                             s.scale, s.shift, s.mean, s.rstd)
 
@@ -226,6 +260,28 @@ class UNet3DEngine:
         grid = (src0.shape[0], src0.shape[1], src0.shape[2], src0.shape[3])
         ops.conv_igemm(View(src0, 0, src0.shape[-1] if src1 is None else c0), s.wf, y, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid,
                        x1=None if src1 is None else View(src1, 0, c1), relu=True, in_scale=s.scale, in_shift=s.shift)
+
+    def _cols_view(self, low, cout):
+        n, d, h, w = low.shape[:4]
+        return self.cols[:n * d * h * w * 27 * cout].view(n, d, h, w, 27 * cout)
+
+    def _ct_fwd(self, j, low):
+        """ConvTranspose3d(k3, s2, p1) of `low` as a 27*Cout-column GEMM + gather, resized to the encoder grid -> self.up[j]"""
+        t = self.ct[j]
+        t.src = low
+        cols = self._cols_view(low, t.cout)
+        ops.conv_igemm(low, t.wf, cols, ksize=1, Cin=t.cin, Cout=27 * t.cout)
+        ops.convt3_col2im(cols, self.up[j])
+        return self.up[j]
+
+    def _ct_bwd(self, j, low_grad):
+        t = self.ct[j]
+        low = t.src
+        gcols = self._cols_view(low, t.cout)
+        ops.convt3_im2col(self.g_up[j], gcols)
+        ops.wgrad(low, gcols, t.dw2d, ksize=1, Cin=t.cin, Cout=27 * t.cout)
+        self.Gr[t.name].view(t.cin, t.cout, 27).copy_(t.dw2d.view(27, t.cout, t.cin).permute(2, 1, 0))
+        ops.conv_igemm(gcols, t.wd, low_grad, ksize=1, Cin=27 * t.cout, Cout=t.cin, mask=low)      # low is a ReLU output
 
     def forward(self, x, target=None, train=True, grad_scale=1.0):
         """x: fp32 (N,1,D,H,W) on the device; target: fp32 (N,C,D,H,W) in {0,1}. Returns (loss[1] or None, logits, argmax)."""
@@ -256,6 +312,8 @@ class UNet3DEngine:
         for j in range(L - 1):
             l = L - 2 - j
             s1 = self.sc[f"decoders.{j}.basic_module.SingleConv1"]
+            if self.deconv:
+                low = self._ct_fwd(j, low)
             self._sc_fwd(s1, self.e[l], self.f_maps[l], self.t_dec[j], src1=low, c1=low.shape[-1])
             s2 = self.sc[f"decoders.{j}.basic_module.SingleConv2"]
             self._sc_fwd(s2, self.t_dec[j], s2.cin, self.d[j])
@@ -283,7 +341,7 @@ class UNet3DEngine:
                       dy=self.g_d[L - 2], dw=self.Gr["final_conv.weight"], db=self.Gr["final_conv.bias"])
 
     # ---- backward --------------------------------------------------------------------------------------
-    def _sc_bwd(self, s, g_y, dx0, mask0, add0=None, dx1=None):
+    def _sc_bwd(self, s, g_y, dx0, mask0, add0=None, dx1=None, up1=True):
         """g_y = dL/d(pre-activation) of s's output.  Produces weight/GroupNorm grads and the input gradients."""
         src0, c0, src1, c1 = s.src0, s.c0, s.src1, s.c1
         N, D, H, W = src0.shape[0], src0.shape[1], src0.shape[2], src0.shape[3]
@@ -299,12 +357,13 @@ class UNet3DEngine:
         ctot = c0 + c1
         ops.gn_bwd_stats(dyn, View(src0, 0, c0), c0, False, grid, s.S1, s.S2, ctot, 0)
         if src1 is not None:
-            ops.gn_bwd_stats(dyn, View(src1, 0, c1), c1, True, grid, s.S1, s.S2, ctot, c0)
+            ops.gn_bwd_stats(dyn, View(src1, 0, c1), c1, up1, grid, s.S1, s.S2, ctot, c0)
         ops.gn_bwd_finalize(s.S1, s.S2, s.mean, s.rstd, self.P[s.name + ".groupnorm.weight"], N, ctot, s.groups, D * H * W,
                             s.p, s.q, s.r, self.Gr[s.name + ".groupnorm.weight"], self.Gr[s.name + ".groupnorm.bias"])
         ops.gn_bwd_apply(dyn, View(src0, 0, c0), c0, False, grid, s.p, s.q, s.r, ctot, 0, View(dx0, 0, c0), relu_mask=mask0, add=add0)
         if src1 is not None:
-            ops.gn_bwd_apply(dyn, View(src1, 0, c1), c1, True, grid, s.p, s.q, s.r, ctot, c0, dx1, relu_mask=True)
+            # nearest source = a ReLU output on the half grid (mask here); 'deconv' source = the linear transposed-conv output
+            ops.gn_bwd_apply(dyn, View(src1, 0, c1), c1, up1, grid, s.p, s.q, s.r, ctot, c0, dx1, relu_mask=up1)
 
     def backward(self, stage_cb=None):
         cb = stage_cb if stage_cb is not None else (lambda names: None)
@@ -318,7 +377,11 @@ class UNet3DEngine:
             low_grad = self.g_e[L - 1] if j == 0 else self.g_d[j - 1]
             # encoder features also feed the pooling path: leave their gradient raw (masked + accumulated in pool-bwd),
             # except the deepest-but-one level... every e[l], l < L-1, is pooled, so never mask here
-            self._sc_bwd(s1, self.g_t_dec[j], self.g_e[l], mask0=False, dx1=low_grad)
+            if self.deconv:
+                self._sc_bwd(s1, self.g_t_dec[j], self.g_e[l], mask0=False, dx1=self.g_up[j], up1=False)
+                self._ct_bwd(j, low_grad)
+            else:
+                self._sc_bwd(s1, self.g_t_dec[j], self.g_e[l], mask0=False, dx1=low_grad)
             cb([f"decoders.{j}"])
         for l in range(L - 1, 0, -1):
             s2 = self.sc[f"encoders.{l}.basic_module.SingleConv2"]

@@ -69,13 +69,33 @@ class InterpolateUpsampling(_ContainerOnly, nn.Module):
             raise NotImplementedError("only nearest upsampling is built")
 
 
+class TransposeConvUpsampling(_ContainerOnly, nn.Module):
+    """buildingblocks.py:676-728: ConvTranspose3d(k, stride=scale, padding=1, bias=False) + F.interpolate(size) - parameter container
+    (`upsample.conv_transposed.weight`); computed by engine3d._ct_fwd / _ct_bwd."""
+
+    class Upsample(_ContainerOnly, nn.Module):
+        def __init__(self, conv_transposed, is3d):
+            super().__init__()
+            self.conv_transposed = conv_transposed
+            self.is3d = is3d
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, scale_factor=2, is3d=True):
+        super().__init__()
+        if not is3d or kernel_size != 3 or scale_factor != 2:
+            raise NotImplementedError("only ConvTranspose3d(k3, s2, p1) upsampling is built")
+        self.upsample = self.Upsample(nn.ConvTranspose3d(in_channels, out_channels, kernel_size=3, stride=2, padding=1, bias=False), is3d)
+
+
 class Decoder(_ContainerOnly, nn.Module):
     def __init__(self, in_channels, out_channels, conv_kernel_size=3, scale_factor=2, basic_module=DoubleConv, conv_layer_order="gcr",
                  num_groups=8, padding=1, upsample="default", dropout_prob=0.1, is3d=True):
         super().__init__()
-        if upsample not in ("default", "nearest") or basic_module is not DoubleConv:
-            raise NotImplementedError("only DoubleConv decoders with nearest upsampling + concat are built (SURVEY.md §8a-11)")
-        self.upsampling = InterpolateUpsampling("nearest")
+        if upsample not in ("default", "nearest", "deconv") or basic_module is not DoubleConv:
+            raise NotImplementedError("only DoubleConv decoders with nearest or 'deconv' upsampling + concat are built (SURVEY.md §8a-11)")
+        if upsample == "deconv":
+            self.upsampling = TransposeConvUpsampling(in_channels, out_channels, kernel_size=conv_kernel_size, scale_factor=scale_factor, is3d=is3d)
+        else:
+            self.upsampling = InterpolateUpsampling("nearest")
         self.basic_module = basic_module(in_channels, out_channels, encoder=False, kernel_size=conv_kernel_size, order=conv_layer_order,
                                          num_groups=num_groups, padding=padding, dropout_prob=dropout_prob, is3d=is3d)
 
@@ -95,7 +115,8 @@ def create_decoders(f_maps, basic_module, conv_kernel_size, conv_padding, layer_
     decoders = []
     rf = list(reversed(f_maps))
     for i in range(len(rf) - 1):
-        decoders.append(Decoder(rf[i] + rf[i + 1], rf[i + 1], basic_module=basic_module, conv_layer_order=layer_order,
+        in_feature_num = rf[i] + rf[i + 1] if upsample != "deconv" else rf[i]
+        decoders.append(Decoder(in_feature_num, rf[i + 1], basic_module=basic_module, conv_layer_order=layer_order,
                                 conv_kernel_size=conv_kernel_size, num_groups=num_groups, padding=conv_padding, upsample=upsample,
                                 dropout_prob=dropout_prob, is3d=is3d))
     return nn.ModuleList(decoders)

@@ -61,7 +61,7 @@ class AbstractUNet(nn.Module):
             self.final_activation = nn.Sigmoid() if final_sigmoid else nn.Softmax(dim=1)
         else:
             self.final_activation = None
-        self._cfg = (in_channels, out_channels, list(f_maps), num_groups)
+        self._cfg = (in_channels, out_channels, list(f_maps), num_groups, "deconv" if upsample == "deconv" else "default")
         self._compute_dtype = compute_dtype
         self._engine = None
 
@@ -69,8 +69,9 @@ class AbstractUNet(nn.Module):
         if x.device.type != "cuda":
             raise MisError(f"UNet3D runs on MI355X only: got input on {x.device} (no CPU fallback)")
         if self._engine is None or self._engine.device != x.device:
-            cin, cout, f_maps, groups = self._cfg
-            eng = UNet3DEngine(cin, cout, f_maps=f_maps, num_groups=groups, dtype=_dtype_from(self._compute_dtype), device=x.device)
+            cin, cout, f_maps, groups, upsample = self._cfg
+            eng = UNet3DEngine(cin, cout, f_maps=f_maps, num_groups=groups, dtype=_dtype_from(self._compute_dtype), device=x.device,
+                               upsample=upsample)
             for name, p in self.named_parameters():
                 eng.P[name].copy_(p.detach().to(device=x.device, dtype=torch.float32))
                 p.data = eng.P[name]

@@ -367,3 +367,18 @@ def affine_act(x, y, scale, shift, relu=True):
     x, y = _v(x), _v(y)
     check(lib.mis_affine_act(dtype_code(x.dtype), x.ptr, x.ld, y.ptr, y.ld, x.N, x.D * x.H * x.W, x.C, scale.data_ptr(), shift.data_ptr(),
                              1 if relu else 0, stream_ptr()), "mis_affine_act")
+
+
+def convt3_col2im(cols, u):
+    """cols: (N, d, h, w, 27*C) contiguous; u: View/tensor (N, 2d, 2h, 2w, C)."""
+    lib = load()
+    u = _v(u)
+    N, d, h, w = cols.shape[:4]
+    check(lib.mis_convt3_col2im(dtype_code(cols.dtype), cols.data_ptr(), u.ptr, u.ld, N, d, h, w, u.C, stream_ptr()), "mis_convt3_col2im")
+
+
+def convt3_im2col(gu, gcols):
+    lib = load()
+    gu = _v(gu)
+    N, d, h, w = gcols.shape[:4]
+    check(lib.mis_convt3_im2col(dtype_code(gcols.dtype), gu.ptr, gu.ld, gcols.data_ptr(), N, d, h, w, gu.C, stream_ptr()), "mis_convt3_im2col")

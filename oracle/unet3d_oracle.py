@@ -25,8 +25,9 @@ def _groups(num_channels, num_groups):
     return 1 if num_channels < num_groups else num_groups
 
 
-def layer_plan(in_channels, f_maps=64, num_levels=4):
-    """Returns (encoders, decoders): lists of [(cin, cout), (cin, cout)] per DoubleConv."""
+def layer_plan(in_channels, f_maps=64, num_levels=4, upsample="default"):
+    """Returns (encoders, decoders): lists of [(cin, cout), (cin, cout)] per DoubleConv.
+    upsample='deconv' (buildingblocks.py:604-626): the decoder's DoubleConv sees f[i] channels (encoder f[i+1] + transposed-conv f[i+1])."""
     if isinstance(f_maps, int):
         f_maps = number_of_features_per_level(f_maps, num_levels)
     enc = []
@@ -39,17 +40,20 @@ def layer_plan(in_channels, f_maps=64, num_levels=4):
     dec = []
     rf = list(reversed(f_maps))
     for i in range(len(rf) - 1):
-        cin = rf[i] + rf[i + 1]
+        cin = rf[i] + rf[i + 1] if upsample != "deconv" else rf[i]
         out = rf[i + 1]
         dec.append([(cin, out), (out, out)])
     return enc, dec, f_maps
 
 
-def param_specs(in_channels, out_channels, f_maps=64, num_levels=4):
-    enc, dec, f_maps = layer_plan(in_channels, f_maps, num_levels)
+def param_specs(in_channels, out_channels, f_maps=64, num_levels=4, upsample="default"):
+    enc, dec, f_maps = layer_plan(in_channels, f_maps, num_levels, upsample)
+    rf = list(reversed(f_maps))
     specs = []
     for grp, plan in (("encoders", enc), ("decoders", dec)):
         for i, convs in enumerate(plan):
+            if grp == "decoders" and upsample == "deconv":   # registered before basic_module (buildingblocks.py:504-534)
+                specs.append((f"decoders.{i}.upsampling.upsample.conv_transposed.weight", (rf[i], rf[i + 1], 3, 3, 3)))
             for j, (ci, co) in enumerate(convs):
                 pre = f"{grp}.{i}.basic_module.SingleConv{j + 1}"
                 specs.append((f"{pre}.groupnorm.weight", (ci,)))
@@ -60,16 +64,16 @@ def param_specs(in_channels, out_channels, f_maps=64, num_levels=4):
     return specs
 
 
-def init_params(in_channels, out_channels, f_maps=64, num_levels=4, seed=0):
+def init_params(in_channels, out_channels, f_maps=64, num_levels=4, seed=0, upsample="default"):
     """Same RNG order as torch.manual_seed(seed); UNet3D(in, out, f_maps=...) (GroupNorm init draws nothing)."""
     torch.manual_seed(seed)
     p = {}
-    for name, shape in param_specs(in_channels, out_channels, f_maps, num_levels):
+    for name, shape in param_specs(in_channels, out_channels, f_maps, num_levels, upsample):
         if name.endswith("groupnorm.weight"):
             p[name] = torch.ones(shape)
         elif name.endswith("groupnorm.bias"):
             p[name] = torch.zeros(shape)
-        elif name.endswith("conv.weight") and not name.startswith("final"):
+        elif (name.endswith("conv.weight") or name.endswith("conv_transposed.weight")) and not name.startswith("final"):
             w = torch.empty(shape)
             torch.nn.init.kaiming_uniform_(w, a=math.sqrt(5))
             p[name] = w
@@ -98,7 +102,7 @@ def double_conv(x, p, pre, num_groups=8):
     return single_conv(x, p, f"{pre}.basic_module.SingleConv2", num_groups)
 
 
-def unet3d_forward(p, x, num_levels=4, num_groups=8):
+def unet3d_forward(p, x, num_levels=4, num_groups=8, upsample="default"):
     feats = []
     for i in range(num_levels):
         if i > 0:
@@ -107,6 +111,8 @@ def unet3d_forward(p, x, num_levels=4, num_groups=8):
         feats.insert(0, x)
     feats = feats[1:]
     for i, enc in enumerate(feats):
+        if upsample == "deconv":   # TransposeConvUpsampling (buildingblocks.py:676-728): ConvTranspose3d(k3, s2, p1, no bias), then resize
+            x = F.conv_transpose3d(x, p[f"decoders.{i}.upsampling.upsample.conv_transposed.weight"], None, stride=2, padding=1)
         x = F.interpolate(x, size=enc.shape[2:], mode="nearest")
         x = torch.cat((enc, x), dim=1)
         x = double_conv(x, p, f"decoders.{i}", num_groups)
@@ -140,9 +146,9 @@ def hf_wrapper_loss(logits, target, alpha=1.0, beta=1.0):
     return bce_dice_loss(torch.sigmoid(logits), target, alpha, beta)
 
 
-def loss_and_grads(p, x, target, num_levels=4, num_groups=8):
+def loss_and_grads(p, x, target, num_levels=4, num_groups=8, upsample="default"):
     ps = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
-    logits = unet3d_forward(ps, x, num_levels, num_groups)
+    logits = unet3d_forward(ps, x, num_levels, num_groups, upsample)
     loss = bce_dice_loss(logits, target)
     loss.backward()
     return loss.detach(), logits.detach(), {k: v.grad.detach() for k, v in ps.items()}

@@ -173,3 +173,19 @@ def test_unetconv2_batchnorm_variant():
         assert torch.allclose(ye, T(g[f"{tag}_y_eval"]), atol=1e-5)
     p = _g4_state(g, "c")
     assert torch.allclose(o2.unet_conv2(T(g["c_x"]), p, n=2, is_batchnorm=False), T(g["c_y"]), atol=1e-5)
+
+
+def test_unet3d_deconv_upsampling():
+    """upsample='deconv' (ConvTranspose3d k3 s2 p1 + nearest resize, buildingblocks.py:676-728): oracle vs the real reference."""
+    g = load_golden("g3_unet3d_deconv.npz")
+    p = {k[4:]: T(g[k]) for k in g.files if k.startswith("s_p_")}
+    assert [n for n, _ in o3.param_specs(1, 3, [8, 16, 32], upsample="deconv")] == list(p.keys())
+    loss, logits, grads = o3.loss_and_grads(p, T(g["s_x"]), T(g["s_t"]), num_levels=3, num_groups=4, upsample="deconv")
+    assert torch.allclose(logits, T(g["s_logits"]), atol=1e-5)
+    assert abs(loss.item() - float(g["s_loss"])) < 1e-6
+    for k, v in grads.items():
+        assert torch.allclose(v, T(g["s_g_" + k]), rtol=1e-3, atol=1e-5), k
+    po = o3.init_params(1, 3, f_maps=[64, 128, 256], num_levels=3, seed=0, upsample="deconv")
+    assert list(po.keys()) == [str(n) for n in g["names"]]
+    ps = np.stack([stat(v) for v in po.values()])
+    assert np.array_equal(ps[:, 3:], g["param_stats"][:, 3:])
