@@ -417,6 +417,278 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Weight-stationary 3x3 kernel for the 64 -> 64 channel bf16 layers at full resolution (down_conv.0.second, up_conv.3.second and
+// their dgrads: the layers with the lowest FLOP per byte of the net).  All 9 taps of the [64 x 64] filter (72 KiB) are loaded
+// into LDS ONCE per block; a persistent block then only streams 32x16-pixel halo tiles: two barriers per tile and no weight
+// traffic.  The next tile's halo is fetched into registers at the top of the current tile's MFMA loop, so its HBM latency hides
+// under a whole tile of compute.  With only 288 MFMAs per wave and tile, the VALU work around them decides the speed, so every
+// tile-invariant quantity lives in registers: per-item global byte offsets (added to a scalar tile base: saddr loads, no
+// per-item address arithmetic), LDS offsets, the output offsets; interior tiles skip all bounds checks; the bias is the
+// accumulator's initial value; ReLU and the ReLU mask are applied on packed bf16 pairs.
+// Halo image: 128-byte pixels, 16-byte chunk position XORed with (column & 7) - a fragment's 16 pixels are 16 consecutive
+// columns of one halo row, which makes every ds_read_b128 conflict-free while a tap's row shift stays an immediate offset.
+// ---------------------------------------------------------------------------------------------------------
+struct WS64 {
+    static constexpr int TH = 32, TW = 16, HH = 34, HW = 18, HP = HH * HW;
+    static constexpr int NT = 512;
+    static constexpr int WBYTES = 9 * 64 * 128;           // 73,728: weights first (tap offsets mostly fit ds immediates)
+    static constexpr int HBYTES = HP * 128;               // 78,336
+    static constexpr int ITEMS = HP * 8;
+    static constexpr int HI = (ITEMS + NT - 1) / NT;      // 10
+    static constexpr int LAST = ITEMS - (HI - 1) * NT;    // threads with a valid last item
+};
+
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {        // max as signed 16-bit: negative floats have the sign bit set
+    const s16x2_t z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, v), z));
+}
+__device__ __forceinline__ uint32_t mask_bf16x2(uint32_t v, uint32_t m) {   // v where the bf16 mask value is > 0, else 0
+    typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+    const s16x2_t z = {0, 0};
+    const u16x2_t one = {1, 1};
+    const u16x2_t pos = __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, m), z)), one);
+    return __builtin_bit_cast(uint32_t, (u16x2_t)(__builtin_bit_cast(u16x2_t, v) * pos));
+}
+
+__global__ __launch_bounds__(512, 2) void conv64_ws_kernel(const ConvArgs a) {
+    using T = __bf16;
+    constexpr int EPC = 8, NF = 4, PF = 4, NV = 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wlds = smem;
+    char* halo = smem + WS64::WBYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wm = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+
+    const int total_tiles = a.nSp;
+    const int tstride = (int)gridDim.x;
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    if (tile >= total_tiles) return;
+
+    // ---- the whole filter, once: [tap][row'][128 B], row' permuted so that a lane ends up with 16 consecutive channels ----
+    {
+        const T* wp = reinterpret_cast<const T*>(a.w);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int it = tid + k * WS64::NT;                 // 4608 items = 9 taps x 64 rows x 8 chunks
+            const int tap = it >> 9, r = (it >> 3) & 63, c16 = it & 7;
+            const int aa = r / NV, ff = (r >> 2) % NF, bb = r & 3;
+            const int lrow = ff * 16 + aa * 4 + bb;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(wp + ((size_t)tap * 64 + r) * 64 + c16 * EPC);
+            lds_write_b128(wlds, tap * 8192 + lrow * 128 + ((c16 ^ (lrow & 7)) << 4), v);
+        }
+    }
+
+    // ---- tile-invariant per-thread staging tables ----
+    int rel[WS64::HI], lo[WS64::HI];
+#pragma unroll
+    for (int b = 0; b < WS64::HI; ++b) {
+        int it = b * WS64::NT + tid;
+        if (it >= WS64::ITEMS) it = WS64::ITEMS - 1;
+        const int p = it >> 3, c16 = it & 7;
+        const int py = p / WS64::HW, px = p - py * WS64::HW;
+        rel[b] = ((py * a.W + px) * a.x0.ld + c16 * EPC) * 2;           // bytes from the tile's halo origin
+        lo[b] = p * 128 + ((c16 ^ (px & 7)) << 4);
+    }
+    const bool last_ok = tid < WS64::LAST;
+
+    const int tpi = a.tilesH * a.tilesW;
+    auto decode = [&](int t, int& tn, int& th0, int& tw0) {
+        tn = t / tpi;
+        const int r = t - tn * tpi;
+        const int th = r / a.tilesW;
+        th0 = th * WS64::TH;
+        tw0 = (r - th * a.tilesW) * WS64::TW;
+    };
+    u32x4 hv[WS64::HI];
+    auto h_load = [&](int n, int h0, int w0) {
+        // halo origin = pixel (h0 - 1, w0 - 1); may lie before the buffer for border tiles (those items are never dereferenced)
+        const char* gbase = reinterpret_cast<const char*>(a.x0.p) + (((long long)n * a.H + (h0 - 1)) * a.W + (w0 - 1)) * (long long)a.x0.ld * 2;
+        const bool interior = h0 >= 1 && h0 + WS64::TH + 1 <= a.H && w0 >= 1 && w0 + WS64::TW + 1 <= a.W;     // block-uniform
+        if (interior) {
+#pragma unroll
+            for (int b = 0; b < WS64::HI - 1; ++b) hv[b] = *reinterpret_cast<const u32x4*>(gbase + (uint32_t)rel[b]);
+            hv[WS64::HI - 1] = u32x4{0u, 0u, 0u, 0u};
+            if (last_ok) hv[WS64::HI - 1] = *reinterpret_cast<const u32x4*>(gbase + (uint32_t)rel[WS64::HI - 1]);
+        } else {
+#pragma unroll
+            for (int b = 0; b < WS64::HI; ++b) {
+                const int p = (b * WS64::NT + tid) >> 3;              // border tiles only: recompute the item's halo coordinates
+                const int py = p / WS64::HW, px = p - py * WS64::HW;
+                const bool ok = (uint32_t)(h0 - 1 + py) < (uint32_t)a.H && (uint32_t)(w0 - 1 + px) < (uint32_t)a.W && (b < WS64::HI - 1 || last_ok);
+                hv[b] = u32x4{0u, 0u, 0u, 0u};
+                if (ok) hv[b] = *reinterpret_cast<const u32x4*>(gbase + (uint32_t)rel[b]);
+            }
+        }
+    };
+    auto h_store = [&]() {
+#pragma unroll
+        for (int b = 0; b < WS64::HI - 1; ++b) lds_write_b128(halo, lo[b], hv[b]);
+        if (last_ok) lds_write_b128(halo, lo[WS64::HI - 1], hv[WS64::HI - 1]);
+    };
+
+    int n, h0, w0;
+    decode(tile, n, h0, w0);
+    h_load(n, h0, w0);
+    h_store();
+
+    // fragment addresses: B (pixels) = column part per (kw, kg) in a register + (pf + kh) * row stride as an immediate
+    int bcol[3][2], acol[2];
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+        const int ch = kg * 4 + lg;
+        acol[kg] = li * 128 + ((ch ^ (li & 7)) << 4);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int px = li + kw;
+            bcol[kw][kg] = (wm * 4 * WS64::HW + px) * 128 + ((ch ^ (px & 7)) << 4);
+        }
+    }
+    constexpr int ROWB = WS64::HW * 128;   // 2304
+
+    // lane (li, lg) owns, per pixel row pf, channels lg*16 .. lg*16+15 of pixel (h0 + wm*4 + pf, w0 + li)
+    const int col = lg * NV;
+    const uint32_t orel = (uint32_t)(((wm * 4) * a.W + li) * a.y0_ld + col) * 2u;       // bytes from the tile's first output pixel
+    const uint32_t mrel = (uint32_t)(((wm * 4) * a.W + li) * a.mask_ld + col) * 2u;
+    f32x4 bv[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        bv[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias != nullptr) bv[f] = *reinterpret_cast<const f32x4*>(a.bias + col + f * 4);
+    }
+    f32x4 acc[NF][PF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int pf = 0; pf < PF; ++pf) acc[f][pf] = bv[f];           // the bias is the accumulator's initial value
+
+#ifdef MIS_WS64_STAMPS
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define STAMP(i) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); st[i] += tn_ - tprev; tprev = tn_; }
+#else
+#define STAMP(i)
+#endif
+#pragma unroll 1
+    for (; tile < total_tiles; tile += tstride) {
+        const bool has_next = tile + tstride < total_tiles;
+        int nn = n, nh0 = h0, nw0 = w0;
+        if (has_next) decode(tile + tstride, nn, nh0, nw0);
+        __syncthreads();                       // this tile's halo (and, first time, the filter) is in LDS
+        STAMP(0)
+        if (has_next) h_load(nn, nh0, nw0);    // in flight during the 288 MFMAs below
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(1)
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh) {
+            const char* hrow = halo + kh * ROWB;
+            const char* wrow = wlds + kh * (3 * 8192);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+                for (int kg = 0; kg < 2; ++kg) {
+                    u32x4 A[NF], B[PF];
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) A[f] = lds_read_b128(wrow, acol[kg] + kw * 8192 + f * 2048);
+#pragma unroll
+                    for (int pf = 0; pf < PF; ++pf) B[pf] = lds_read_b128(hrow, bcol[kw][kg] + pf * ROWB);
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+#pragma unroll
+                        for (int pf = 0; pf < PF; ++pf) mma_b128<T>(acc[f][pf], A[f], B[pf]);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(2)
+        __syncthreads();                       // every wave is done reading this halo
+        STAMP(3)
+        if (has_next) h_store();
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(4)
+        // ---- epilogue ----
+        {
+            const long long opix = ((long long)n * a.H + h0) * a.W + w0;
+            char* obase = reinterpret_cast<char*>(a.y0) + opix * a.y0_ld * 2;
+            const char* mbase = reinterpret_cast<const char*>(a.mask) + opix * a.mask_ld * 2;
+            const bool full = h0 + WS64::TH <= a.H && w0 + WS64::TW <= a.W;      // block-uniform
+#pragma unroll
+            for (int pf = 0; pf < PF; ++pf) {
+                u32x4 o[2];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    o[f >> 1][(f & 1) * 2] = pack_bf16x2(acc[f][pf][0], acc[f][pf][1]);
+                    o[f >> 1][(f & 1) * 2 + 1] = pack_bf16x2(acc[f][pf][2], acc[f][pf][3]);
+                    acc[f][pf] = bv[f];
+                }
+                if (full || (h0 + wm * 4 + pf < a.H && w0 + li < a.W)) {
+                    if (a.relu) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) o[i >> 2][i & 3] = relu_bf16x2(o[i >> 2][i & 3]);
+                    }
+                    if (a.mask != nullptr) {
+                        const u32x4* mp = reinterpret_cast<const u32x4*>(mbase + (mrel + (uint32_t)(pf * a.W * a.mask_ld * 2)));
+                        const u32x4 m0 = mp[0], m1 = mp[1];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            o[0][i] = mask_bf16x2(o[0][i], m0[i]);
+                            o[1][i] = mask_bf16x2(o[1][i], m1[i]);
+                        }
+                    }
+                    u32x4* dst = reinterpret_cast<u32x4*>(obase + (orel + (uint32_t)(pf * a.W * a.y0_ld * 2)));
+                    dst[0] = o[0];
+                    dst[1] = o[1];
+                }
+            }
+        }
+        n = nn; h0 = nh0; w0 = nw0;
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(5)
+    }
+#ifdef MIS_WS64_STAMPS
+    if (a.y1 != nullptr && lane == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(a.y1) + ((size_t)blockIdx.x * 8 + wm) * 8;
+        for (int i = 0; i < 6; ++i) o[i] = st[i];
+        o[6] = __builtin_amdgcn_s_memrealtime();
+        o[7] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+}
+
+static int launch_ws64(const MisConvDesc* d, hipStream_t stream) {
+    ConvArgs a;
+    a.N = d->N; a.D = 1; a.H = d->H; a.W = d->W; a.Cin = 64; a.Cout = 64; a.Cin0 = 64; a.Cout0 = 64;
+    a.x0 = SrcView{d->x0, d->x0_ld, 1, d->x0_H, d->x0_W};
+    a.x1 = SrcView{nullptr, 0, 0, 0, 0};
+    a.in_scale = nullptr; a.in_shift = nullptr;
+    a.w = d->w; a.bias = d->bias; a.relu = d->relu; a.mask = d->mask; a.mask_ld = d->mask_ld;
+    a.y0 = d->y0; a.y0_ld = d->y0_ld; a.y0_mode = MIS_OUT_PLAIN;
+    a.y1 = nullptr; a.y1_ld = 0; a.y1_mode = 0;
+#ifdef MIS_WS64_STAMPS
+    a.y1 = d->y1;
+#endif
+    a.tilesD = 1;
+    a.tilesH = (d->H + WS64::TH - 1) / WS64::TH;
+    a.tilesW = (d->W + WS64::TW - 1) / WS64::TW;
+    const long long nsp = (long long)d->N * a.tilesH * a.tilesW;
+    MIS_REQUIRE(nsp < (1ll << 31), MIS_EUNSUPPORTED, "conv_igemm: grid too large");
+    // per-thread byte offsets inside one halo / output tile are kept in 32 bits
+    MIS_REQUIRE((long long)(WS64::HH + 1) * d->W * (d->x0_ld > d->y0_ld ? d->x0_ld : d->y0_ld) * 2 < (1ll << 31), MIS_EUNSUPPORTED,
+                "conv_igemm: row too long for the 64-channel weight-stationary kernel");
+    a.nSp = (int)nsp;
+    a.nCt = 1;
+    const size_t lds = (size_t)WS64::WBYTES + WS64::HBYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv64_ws_kernel, dim3((unsigned)(nsp > 256 ? 256 : nsp)), dim3(WS64::NT), lds, stream, a);
+    MIS_LAUNCH_CHECK("conv_igemm(ws64)");
+    return MIS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 template <typename T, typename G, int WN, int NF, int NT = 256, int TPS = 1, int PF = 4, bool PERSIST = false, bool WDMA = false>
 static int launch_cfg(const MisConvDesc* d, hipStream_t stream) {
     constexpr int BN = WN * NF * 16;
@@ -463,6 +735,11 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
             if (wide && v2 && dma) return launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3, 4, false, true>(d, s);
             if (wide && v2) return launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3, 4, false>(d, s);   // 8 waves, one filter row per barrier
             if (wide) return launch_cfg<T, Geom<1, 8, 16, 3, false>, 2, 4>(d, s);
+            if constexpr (sizeof(T) == 2) {
+                static const int ws = getenv("MIS_CONV_NOWS64") == nullptr;
+                const bool plain = d->x1 == nullptr && d->in_scale == nullptr && d->y0_mode == MIS_OUT_PLAIN && d->x0_H == d->H && d->x0_W == d->W;
+                if (ws && plain && d->Cin == 64 && d->Cout == 64 && (long long)d->N * d->H * d->W >= 256ll * 512 && (d->mask == nullptr || d->mask_ld % 8 == 0)) return launch_ws64(d, s);
+            }
             if (v2 && (long long)d->H * d->W >= 64 * 64) return launch_cfg<T, Geom<1, 32, 16, 3, false>, 1, 4, 512, 3, 4, true, true>(d, s);
             return launch_cfg<T, Geom<1, 16, 16, 3, false>, 1, 4>(d, s);
         }

@@ -117,6 +117,31 @@ def test_conv3x3_fwd(case, dtype):
     assert_close(from_nhwc(y), want, f"conv3x3 fwd {case} {dtype}", **tol(dtype, 9 * Cin))
 
 
+@pytest.mark.parametrize("shape", [(2, 256, 256), (3, 250, 203), (1, 512, 272)])
+def test_conv3x3_weight_stationary_64_to_64(shape):
+    """bf16 64 -> 64 layers of at least 128K pixels run the weight-stationary persistent kernel (conv64_ws_kernel): ragged
+    32x16 tiles, bias + ReLU, ReLU mask (dgrad form) and an output that is a channel slice of a wider buffer."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    N, H, W = shape
+    x = rnd(N, 64, H, W, seed=30)
+    w = rnd(64, 64, 3, 3, seed=31, scale=(9 * 64) ** -0.5)
+    b = rnd(64, seed=32)
+    xd = to_nhwc(x, dtype)
+    wf = torch.empty(9, 64, 64, dtype=dtype, device=DEV)
+    ops.pack_conv_weight(w.to(DEV), wf, None)
+    ybuf = torch.full((N, H, W, 128), float("nan"), dtype=dtype, device=DEV)
+    ops.conv_igemm(xd, wf, ops.View(ybuf, 64, 64), ksize=3, Cin=64, Cout=64, bias=b.to(DEV), relu=True)
+    want = F.relu(F.conv2d(q(x, dtype), q(w, dtype), b, padding=1))
+    assert_close(from_nhwc(ybuf[..., 64:].contiguous()), want, f"ws64 fwd {shape}", **tol(dtype, 9 * 64))
+    assert torch.isnan(ybuf[..., :64].float()).all(), "ws64 wrote outside its channel slice"
+    m = rnd(N, 64, H, W, seed=33)
+    y2 = torch.full((N, H, W, 64), float("nan"), dtype=dtype, device=DEV)
+    ops.conv_igemm(xd, wf, y2, ksize=3, Cin=64, Cout=64, mask=to_nhwc(m, dtype))
+    want2 = F.conv2d(q(x, dtype), q(w, dtype), None, padding=1) * (q(m, dtype) > 0)
+    assert_close(from_nhwc(y2), want2, f"ws64 mask {shape}", **tol(dtype, 9 * 64))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv3x3_dgrad_mask_and_split_outputs(dtype):
     """dgrad = conv with the mirrored pack; ReLU mask in the epilogue; and the dual-destination epilogue used by
