@@ -213,6 +213,13 @@ int mis_aug_pointwise(const float* src, float* dst, long long n, float a, float 
                       unsigned long long seed, void* stream);
 int mis_aug_contrast(const float* src, float* dst, long long n, float mean, float alpha, void* stream);
 
+/* Evaluation metrics of the 2-D trainer (trainer/metrcis.py:61-109,153-168 `compute_metrics`): sigmoid with +1e-6 in the denominator,
+ * threshold = global mean probability, per-sample IoU / Dice, mean over samples.  values, labels: fp32 (N, npix); out[3] = {iou, dice, threshold}.
+ * values_are_logits = 0 with a given threshold gives compute_iou / compute_dice on ready-made predictions. */
+size_t mis_seg_metrics_workspace_bytes(int N, long long npix);
+int mis_seg_metrics(const float* values, const float* labels, int N, long long npix, int values_are_logits, int auto_threshold, float threshold,
+                    void* workspace, float* out, void* stream);
+
 /* layout helpers */
 int mis_nchw_to_nhwc(int dtype_out, const float* x, void* y, int y_ld, int N, int C, long long spatial, void* stream);
 int mis_nhwc_to_nchw(int dtype_in, const void* x, int x_ld, float* y, int N, int C, long long spatial, void* stream);

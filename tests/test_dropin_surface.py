@@ -48,7 +48,9 @@ def test_cpu_input_fails_loudly(surface):
         unet2d.UNetModel(unet2d.UNetConfig(1, 1, "UNet_3Plus"))
 
 
+@pytest.mark.gpu
 def test_compute_metrics_formulas(surface):
+    """compute_metrics runs on the device (csrc/metrics.hip); golden parity is in tests/test_gpu_metrics.py"""
     _, _, trainer = surface
 
     class P:
@@ -64,7 +66,7 @@ def test_compute_metrics_formulas(surface):
     pr, lb = (probs > thr).astype(np.float32), p.label_ids[:, 0]
     inter = (pr * lb).sum((1, 2))
     iou = (inter / np.maximum(pr.sum((1, 2)) + lb.sum((1, 2)) - inter, 1e-6)).mean()
-    assert abs(out["iou"] - iou) < 1e-7
+    assert abs(out["iou"] - iou) < 1e-6
     assert 0.0 <= out["dice"] <= 1.0
 
 

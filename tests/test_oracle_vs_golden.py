@@ -189,3 +189,15 @@ def test_unet3d_deconv_upsampling():
     assert list(po.keys()) == [str(n) for n in g["names"]]
     ps = np.stack([stat(v) for v in po.values()])
     assert np.array_equal(ps[:, 3:], g["param_stats"][:, 3:])
+
+
+def test_eval_metrics_oracle():
+    """oracle.metrics_oracle against the real reference's compute_metrics / compute_iou / compute_dice (g6_metrics.npz)."""
+    from oracle import metrics_oracle as mo
+    g = load_golden("g6_metrics.npz")
+    for tag in "abc":
+        r = mo.compute_metrics(g[f"{tag}_logits"], g[f"{tag}_labels"])
+        assert abs(r["iou"] - float(g[f"{tag}_iou"])) < 1e-7 and abs(r["dice"] - float(g[f"{tag}_dice"])) < 1e-7, tag
+        lg, lb = g[f"{tag}_logits"][:, 0], g[f"{tag}_labels"][:, 0]
+        assert abs(mo.compute_iou(lg, lb, 0.5) - float(g[f"{tag}_iou05"])) < 1e-7
+        assert abs(mo.compute_dice(lg, lb, 0.5) - float(g[f"{tag}_dice05"])) < 1e-7
