@@ -220,6 +220,18 @@ size_t mis_seg_metrics_workspace_bytes(int N, long long npix);
 int mis_seg_metrics(const float* values, const float* labels, int N, long long npix, int values_are_logits, int auto_threshold, float threshold,
                     void* workspace, float* out, void* stream);
 
+/* Patch-tiled volume prediction (model/unet3d/predictor.py:85-168; dataset/unet3d_dataset/utils.py:85-125,314-361).
+ * gather: patches[p] (C, PD, PH, PW) = the volume window starting at origins[p] - halo, np.pad(mode='reflect') outside the volume
+ *         (origins: device int32 (NP, 3) positions of the patch INTERIORS in the unpadded volume; PD = interior + 2*hd, ...);
+ * accumulate: halo cut off, map[c][origin + v] += act(pred[c][halo + v]), norm[origin + v] += 1 (uint8, one launch per patch = the
+ *         reference's accumulation order); channel >= 0 keeps only that channel (prediction_channel);
+ * finalize: prob = map / norm and/or seg = argmax_c (first maximum), uint16. */
+int mis_patch_gather_reflect(const float* vol, int C, int D, int H, int W, const int* origins, int NP, int PD, int PH, int PW, int hd, int hh,
+                             int hw, float* patches, void* stream);
+int mis_patch_accumulate(const float* pred, int C, int PD, int PH, int PW, int hd, int hh, int hw, int activation, int channel, int oz, int oy,
+                         int ox, float* map, unsigned char* norm, int D, int H, int W, void* stream);
+int mis_pred_finalize(const float* map, const unsigned char* norm, int C, long long nvox, float* prob, unsigned short* seg, void* stream);
+
 /* layout helpers */
 int mis_nchw_to_nhwc(int dtype_out, const float* x, void* y, int y_ld, int N, int C, long long spatial, void* stream);
 int mis_nhwc_to_nchw(int dtype_in, const void* x, int x_ld, float* y, int N, int C, long long spatial, void* stream);

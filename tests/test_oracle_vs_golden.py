@@ -201,3 +201,26 @@ def test_eval_metrics_oracle():
         lg, lb = g[f"{tag}_logits"][:, 0], g[f"{tag}_labels"][:, 0]
         assert abs(mo.compute_iou(lg, lb, 0.5) - float(g[f"{tag}_iou05"])) < 1e-7
         assert abs(mo.compute_dice(lg, lb, 0.5) - float(g[f"{tag}_dice05"])) < 1e-7
+
+
+def test_patch_tiled_predictor_oracle():
+    """oracle.predictor_oracle + the 3-D oracle net against the replay of the reference's predictor loop on its own SliceBuilder /
+    mirror_pad / remove_padding / UNet3D (g8_predictor.npz)."""
+    from oracle import predictor_oracle as po
+    g = load_golden("g8_predictor.npz")
+    raw = g["raw"]
+    patch, stride, halo = tuple(int(v) for v in g["patch"]), tuple(int(v) for v in g["stride"]), tuple(int(v) for v in g["halo"])
+    assert [[s.start for s in idx] for idx in po.build_slices(raw.shape, patch, stride)] == g["origins"].tolist()
+    p = o3.init_params(1, 3, f_maps=[64, 128], num_levels=2, seed=0)
+
+    def model_fn(x):
+        with torch.no_grad():
+            return o3.unet3d_forward(p, torch.from_numpy(x), num_levels=2).numpy()
+
+    res = po.predict_volume(model_fn, raw, patch, stride, halo, 3)
+    flat = res.reshape(-1)
+    assert np.allclose(flat[g["sample_idx"]], g["sample"], atol=2e-5)
+    seg = np.argmax(res, axis=0).astype("uint16")
+    top2 = np.sort(res, axis=0)[-2:]
+    near = (top2[1] - top2[0]) < 1e-4
+    assert np.array_equal(seg[~near], g["seg"][~near])
