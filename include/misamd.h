@@ -89,6 +89,9 @@ typedef struct MisWgradDesc {
     int dw_layout;           /* 0: [Cout][Cin][taps] (nn.Conv weight), 1: [Cin][Cq][4] with dy column = ab*Cq + c (nn.ConvTranspose2d k2) */
     float alpha;             /* dw = alpha * sum */
     float* dbias;            /* optional: bias gradient = alpha * column sums of dy ([Cout], or [Cout/4] folded over (a,b) for layout 1) */
+    void* reduce_stream;     /* optional second HIP stream: the slab reduction (HBM-bound) is enqueued there, ordered after the MFMA kernel by
+                              * an event, so that it runs under the caller's next kernel on `stream`.  The caller joins reduce_stream before
+                              * reading dw / dbias and before reusing the workspace. NULL: everything on `stream`. */
 } MisWgradDesc;
 size_t mis_wgrad_workspace_bytes(const MisWgradDesc* d);
 int mis_wgrad(const MisWgradDesc* d, void* stream);

@@ -60,6 +60,7 @@ class WgradDesc(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("dw", C.c_void_p), ("dw_layout", C.c_int), ("alpha", C.c_float),
         ("dbias", C.c_void_p),
+        ("reduce_stream", C.c_void_p),
     ]
 
 

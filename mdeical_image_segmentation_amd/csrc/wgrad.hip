@@ -482,6 +482,15 @@ static int wg_launch(const MisWgradDesc* d, const WgPlan& p, hipStream_t stream)
     MIS_REQUIRE(grid < (1ll << 31), MIS_EUNSUPPORTED, "wgrad: grid too large");
     hipLaunchKernelGGL((wgrad_kernel<T, G, USE_TR>), dim3((unsigned)grid), dim3(256), lds, stream, a);
     MIS_LAUNCH_CHECK("wgrad");
+    if (d->reduce_stream != nullptr && d->reduce_stream != (void*)stream) {   // reductions go to the side stream, after the MFMA kernel
+        hipEvent_t ev;
+        MIS_REQUIRE(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, MIS_EHIP, "wgrad: hipEventCreate failed");
+        const hipStream_t side = reinterpret_cast<hipStream_t>(d->reduce_stream);
+        const bool ok = hipEventRecord(ev, stream) == hipSuccess && hipStreamWaitEvent(side, ev, 0) == hipSuccess;
+        (void)hipEventDestroy(ev);          // released by the runtime once it has completed
+        MIS_REQUIRE(ok, MIS_EHIP, "wgrad: could not order the reduction stream after the MFMA kernel");
+        stream = side;
+    }
     int nslab = p.nsplit;
     const size_t E = (size_t)p.TT * d->Cin * d->Cout;     // multiple of 4 (channel tiles are multiples of 32)
     if (nslab > 4) {

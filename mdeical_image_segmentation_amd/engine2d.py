@@ -17,6 +17,8 @@ PyTorch is only the allocator and stream provider here.  No CPU fallback exists.
 """
 import math
 
+import os
+
 import torch
 
 from . import ops
@@ -105,6 +107,8 @@ class UNet2DEngine:
             raise MisError("out_channels must be 1..4")
         ops.load()
         self.cin, self.cout = in_channels, out_channels
+        # wgrad's slab reductions (HBM-bound) run on a second stream under the following dgrad kernel
+        self.side_reduce = os.environ.get("MISAMD_NO_SIDE_REDUCE") is None
         self.dtype = dtype
         self.device = torch.device(device)
         self.specs = unet2d_param_specs(in_channels, out_channels)
@@ -263,7 +267,7 @@ class UNet2DEngine:
     # ---- backward --------------------------------------------------------------------------------------
     def _bwd_conv(self, x, dy, name, cin, cout, dx=None, mask=None, dx1=None, cout0=None, dx_mode=OUT_PLAIN):
         """grads of y = relu(conv3x3(x) + b) given dy = dL/d(pre-activation)."""
-        ops.wgrad(x, dy, self.G[name + ".weight"], ksize=3, Cin=cin, Cout=cout, dbias=self.G[name + ".bias"])
+        ops.wgrad(x, dy, self.G[name + ".weight"], ksize=3, Cin=cin, Cout=cout, dbias=self.G[name + ".bias"], side=self.side_reduce)
         if dx is not None:
             ops.conv_igemm(dy, self.wd_[name], dx, ksize=3, Cin=cout, Cout=cin, mask=mask, y0_mode=dx_mode, y1=dx1,
                            Cout0=cout0)
@@ -272,7 +276,11 @@ class UNet2DEngine:
         """Run after forward(train=True): fills self.G (reference-layout fp32 grads).
         stage_cb(module_prefixes) is called as soon as the gradients of those modules have been enqueued
         (used by ddp.GradReducer to start their all-reduce while the rest of backward still runs)."""
-        cb = stage_cb if stage_cb is not None else (lambda names: None)
+        def cb(names):
+            if stage_cb is not None:
+                ops.wgrad_join(self.device)      # the stage's weight gradients are final only after their side-stream reductions
+                stage_cb(names)
+
         cb(["final_conv"])
         for j in range(3, -1, -1):
             l = 3 - j
@@ -286,7 +294,7 @@ class UNet2DEngine:
                            cout0=c, dx_mode=OUT_UNSHUFFLE2)
             up = f"up_sample.{j}.up"
             ops.wgrad(x_in, self.dys[j], self.G[up + ".weight"], ksize=1, Cin=2 * c, Cout=4 * c, dw_layout=1,
-                      dbias=self.G[up + ".bias"])
+                      dbias=self.G[up + ".bias"], side=self.side_reduce)
             ops.conv_igemm(self.dys[j], self.wd_[up], g_in, ksize=1, Cin=4 * c, Cout=2 * c, mask=x_in)
             cb([f"up_conv.{j}", f"up_sample.{j}"])
         self._bwd_conv(self.m1, self.g_m2, "middle_conv.second", 1024, 1024, dx=self.g_m1, mask=self.m1)
@@ -302,6 +310,7 @@ class UNet2DEngine:
             else:
                 ops.first_conv_wgrad(self._images, self.g_t1[0], self.G["down_conv.0.first.weight"], self.G["down_conv.0.first.bias"])
             cb([f"down_conv.{l}"])
+        ops.wgrad_join(self.device)
 
     # ---- optimizer -------------------------------------------------------------------------------------
     def optimizer_step(self, lr=None):

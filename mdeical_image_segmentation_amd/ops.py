@@ -117,7 +117,34 @@ def workspace(nbytes, device, tag="default"):
     return buf
 
 
-def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alpha=1.0, in_scale=None, in_shift=None, dbias=None):
+class _SideReduce:
+    """Second stream for the slab reductions of wgrad (HBM-bound) so that they run under the caller's next MFMA kernel.
+    Two workspaces alternate; a workspace is reused only after the reduction that read it has finished (event wait)."""
+
+    def __init__(self):
+        self.per_device = {}
+
+    def state(self, device):
+        st = self.per_device.get(str(device))
+        if st is None:
+            st = {"stream": torch.cuda.Stream(device=device), "events": [None, None], "n": 0}
+            self.per_device[str(device)] = st
+        return st
+
+
+_side = _SideReduce()
+
+
+def wgrad_join(device=None):
+    """Make the current stream wait for every side-stream reduction issued so far (before dw / dbias are read)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    st = _side.per_device.get(str(dev))
+    if st is not None:
+        torch.cuda.current_stream(dev).wait_stream(st["stream"])
+
+
+def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alpha=1.0, in_scale=None, in_shift=None, dbias=None, side=False):
+    """side=True: the reduction kernels go to a second stream (see _SideReduce); the caller must call wgrad_join() before using dw."""
     lib = load()
     x0 = _v(x0)
     dy = _v(dy)
@@ -142,13 +169,27 @@ def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alph
     need = lib.mis_wgrad_workspace_bytes(C.byref(d))
     if need == 0:
         check(-1, "mis_wgrad_workspace_bytes")
-    ws = workspace(need, dy.t.device, "wgrad")
+    st = None
+    if side:
+        st = _side.state(dy.t.device)
+        slot = st["n"] & 1
+        st["n"] += 1
+        ws = workspace(need, dy.t.device, f"wgrad{slot}")
+        if st["events"][slot] is not None:            # the reduction that last read this workspace must be done
+            torch.cuda.current_stream(dy.t.device).wait_event(st["events"][slot])
+        d.reduce_stream = st["stream"].cuda_stream
+    else:
+        ws = workspace(need, dy.t.device, "wgrad")
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     taps = 1 if ksize == 1 else (27 if d.is3d else 9)
     key = ("wgrad", "bf16" if d.dtype == MIS_BF16 else "f32", f"k{ksize}", "3d" if d.is3d else "2d", "",
            f"{d.N}x{d.D}x{d.H}x{d.W} {Cin}->{Cout}")
     with _Timed(key, 2.0 * d.N * d.D * d.H * d.W * taps * Cin * Cout):
         check(lib.mis_wgrad(C.byref(d), stream_ptr()), "mis_wgrad")
+    if st is not None:
+        ev = torch.cuda.Event()
+        ev.record(st["stream"])
+        st["events"][slot] = ev
 
 
 def first_conv_fwd(x_nchw, w, bias, y):
