@@ -13,7 +13,14 @@
 // (reference call sites: model/unet2d/layers.py:122,125,165; model/unet3d/buildingblocks.py:64-66).
 #include <stdlib.h>
 
+#include <utility>
+
 #include "common.hpp"
+
+template <typename F, int... I> __device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 struct WSrc {
     const void* p;
@@ -132,28 +139,32 @@ template <typename T, typename G> struct WgStager {
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-__device__ __forceinline__ s16x4 tr_read(const char* lds_generic, int byte_off) {
-    // generic -> LDS address space: the low 32 bits of a generic LDS pointer are the LDS offset
-    const uint32_t addr = (uint32_t)(uintptr_t)(lds_generic) + (uint32_t)byte_off;
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>(addr));
+typedef __attribute__((address_space(3))) char lds_char_t;
+// var_off: per-lane part (a VGPR), const_off: compile-time part - kept as pointer arithmetic in the LDS address space so that it
+// lands in the instruction's 16-bit offset field instead of costing a v_add per read
+__device__ __forceinline__ s16x4 tr_read(const char* lds_generic, int var_off, int const_off) {
+    lds_char_t* p = reinterpret_cast<lds_char_t*>((uint32_t)(uintptr_t)(lds_generic) + (uint32_t)var_off);
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>(p + const_off));
 }
 
 __device__ __forceinline__ uint32_t ld_u16(const char* base, int off) { return *reinterpret_cast<const uint16_t*>(base + off); }
 
 // bf16 operand fragment for lane (i = lane & 15, g = lane >> 4): 8 pixels (k = 8g + 4s + e) of channel cbase + i
 template <bool USE_TR>
-__device__ __forceinline__ bf16x8_t wg_frag_bf16(const char* img, int off_s0, int off_s1, int lane) {
+__device__ __forceinline__ bf16x8_t wg_frag_bf16(const char* img, int off_s0, int off_s1, int coff, int lane) {
     // off_s*: for USE_TR the per-lane tr address (row q = (lane&15)>>2, 8-byte piece (lane&3));
     //         for !USE_TR the byte offset of pixel (g, s, e = 0), channel cbase (then + e*PSTR + i*2)
     if constexpr (USE_TR) {
-        const s16x4 lo = tr_read(img, off_s0);
-        const s16x4 hi = tr_read(img, off_s1);
+        const s16x4 lo = tr_read(img, off_s0, coff);
+        const s16x4 hi = tr_read(img, off_s1, coff);
         typedef __attribute__((ext_vector_type(8))) short s16x8;
         s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8_t, r);
     } else {
         const int i = lane & 15;
         u32x4 r;
+        off_s0 += coff;
+        off_s1 += coff;
         r[0] = ld_u16(img, off_s0 + 0 * PSTR + i * 2) | (ld_u16(img, off_s0 + 1 * PSTR + i * 2) << 16);
         r[1] = ld_u16(img, off_s0 + 2 * PSTR + i * 2) | (ld_u16(img, off_s0 + 3 * PSTR + i * 2) << 16);
         r[2] = ld_u16(img, off_s1 + 0 * PSTR + i * 2) | (ld_u16(img, off_s1 + 1 * PSTR + i * 2) << 16);
@@ -263,22 +274,21 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 1 : 2)) void wgrad_kernel(co
                         offQ[s] = m0 * PSTR;
                     }
                 }
+                // (hand software-pipelining of the fragment reads - tap t+1's reads before tap t's MFMAs, two register sets, pinned with
+                //  sched_group_barrier - measured 25-30 % SLOWER than hipcc's own read -> wait -> 4 MFMAs per tap; what did pay off is
+                //  keeping every tap / fragment offset in the ds_read immediate so that the loop carries no address VALU)
                 bf16x8_t B[FR];
+                const int qv0 = offQ[0] + wj * FR * 32, qv1 = offQ[1] + wj * FR * 32;
+                const int pv0 = offP[0] + wi * FR * 32, pv1 = offP[1] + wi * FR * 32;
 #pragma unroll
-                for (int fj = 0; fj < FR; ++fj) {
-                    const int cb = (wj * FR + fj) * 32;   // byte offset of the 16-channel fragment
-                    B[fj] = wg_frag_bf16<USE_TR>(lds_q, offQ[0] + cb, offQ[1] + cb, lane);
-                }
+                for (int fj = 0; fj < FR; ++fj) B[fj] = wg_frag_bf16<USE_TR>(lds_q, qv0, qv1, fj * 32, lane);
 #pragma unroll
                 for (int tap = 0; tap < TAPS2; ++tap) {
                     const int kh = tap / G::KS, kw = tap % G::KS;
                     const int toff = (kh * G::PHW + kw) * PSTR;
                     bf16x8_t A[FR];
 #pragma unroll
-                    for (int fi = 0; fi < FR; ++fi) {
-                        const int cb = (wi * FR + fi) * 32;
-                        A[fi] = wg_frag_bf16<USE_TR>(lds_p, offP[0] + cb + toff, offP[1] + cb + toff, lane);
-                    }
+                    for (int fi = 0; fi < FR; ++fi) A[fi] = wg_frag_bf16<USE_TR>(lds_p, pv0, pv1, fi * 32 + toff, lane);
 #pragma unroll
                     for (int fi = 0; fi < FR; ++fi)
 #pragma unroll
