@@ -152,6 +152,17 @@ def main():
                                "frac": round(ach / peak, 4), "traffic": None, "kernel": "/".join(k for k in key if k),
                                "launches": cnt, "avg_launch_ms": round(sec / cnt * 1e3, 4),
                                "alg_gflop_per_launch": round(fl / cnt / 1e9, 2)}
+            # HBM traffic of the dominant kernel cannot be counted from inside this process: it comes from the committed rocprofv3 PMC
+            # passes of this same command (profiles/README.md), per launch like `achieved`
+            try:
+                import json as _json
+                tr = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_e_traffic.json")))
+                t = tr.get(out["roofline"]["kernel"])
+                if t is not None and args.batch == 32 and args.size == 512:
+                    out["roofline"]["traffic"] = t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"]
+                    out["roofline"]["traffic_unit"] = "bytes/launch (PMC: FETCH_SIZE x2 + WRITE_SIZE)"
+            except (OSError, ValueError, KeyError):
+                pass
             out["kernels"] = {"/".join(k for k in key if k): {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / args.steps * 1e3, 3),
                                                              "launches_per_step": v[2] // args.steps}
                               for key, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}

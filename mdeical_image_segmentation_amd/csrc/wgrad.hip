@@ -453,7 +453,8 @@ static int wg_plan(const MisWgradDesc* d, WgPlan* p) {
     p->KDn = (p->is3d && d->ksize == 3) ? 3 : 1;
     p->TT = d->ksize == 3 ? (p->is3d ? 27 : 9) : 1;
     const long long base = (long long)p->nCi * p->nCo * p->KDn;
-    long long want = (1024 + base - 1) / base;     // aim for >= ~1024 blocks (2 per CU x 2 rounds)
+    static const int target_blocks = getenv("MIS_WGRAD_BLOCKS") ? atoi(getenv("MIS_WGRAD_BLOCKS")) : 1024;
+    long long want = (target_blocks + base - 1) / base;     // aim for >= ~1024 blocks (2 per CU x 2 rounds)
     if (want < 1) want = 1;
     if (want > nt) want = nt;
     // keep the slab traffic bounded: at most 64 MiB of partials per layer unless a single split already exceeds it
