@@ -179,8 +179,9 @@ int mis_gn_bwd_apply(int dtype, const void* dy, int dy_ld, const void* x, int x_
 int mis_first3d_fwd(int dtype, const float* x, const float* scale, const float* shift, int sstride, int N, int D, int H, int W, const float* w,
                     int Cout, void* y, int y_ld, int Cpad, void* stream);
 size_t mis_first3d_bwd_workspace_bytes(void);
-int mis_first3d_bwd(int dtype, const float* x, const float* scale, const float* shift, int sstride, int N, int D, int H, int W, const void* dy,
-                    int dy_ld, int Cpad, const float* w, int Cout, float* workspace, float* dw, float* dxn, void* stream);
+int mis_first3d_bwd(int dtype, const float* x, const float* mean /*[N]*/, const float* rstd /*[N]*/, const float* gamma /*[1]*/,
+                    const float* beta /*[1]*/, int N, int D, int H, int W, const void* dy, int dy_ld, int Cpad, const float* w, int Cout,
+                    float* workspace, float* dw, float* dgamma /*[1]*/, float* dbeta /*[1]*/, float* dxn /*optional (N,D,H,W) or NULL*/, void* stream);
 int mis_relu_mask(int dtype, const void* dy, int dy_ld, const void* y, int y_ld, void* dx, int dx_ld, long long npix, int C, void* stream);
 
 /* 'deconv' upsampling of the 3-D decoders: ConvTranspose3d(k3, s2, p1, no bias) then nearest resize 2n-1 -> 2n

@@ -146,7 +146,7 @@ def load():
         "mis_gn_bwd_finalize": [vp, vp, vp, vp, vp, i, i, i, dbl, vp, vp, vp, vp, vp, vp],
         "mis_gn_bwd_apply": [i, vp, i, vp, i, i, i, i, i, i, i, vp, vp, vp, i, i, i, vp, i, vp, i, vp],
         "mis_first3d_fwd": [i, vp, vp, vp, i, i, i, i, i, vp, i, vp, i, i, vp],
-        "mis_first3d_bwd": [i, vp, vp, vp, i, i, i, i, i, vp, i, i, vp, i, vp, vp, vp, vp],
+        "mis_first3d_bwd": [i, vp, vp, vp, vp, vp, i, i, i, i, vp, i, i, vp, i, vp, vp, vp, vp, vp, vp],
         "mis_relu_mask": [i, vp, i, vp, i, vp, i, ll, i, vp],
         "mis_convt3_col2im": [i, vp, vp, i, i, i, i, i, i, vp],
         "mis_convt3_im2col": [i, vp, i, vp, i, i, i, i, i, vp],

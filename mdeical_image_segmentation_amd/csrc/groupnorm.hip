@@ -397,31 +397,34 @@ extern "C" int mis_first3d_fwd(int dtype, const float* x, const float* scale, co
     return MIS_OK;
 }
 
-// backward of the first 3-D layer given dy = dL/d(pre-activation) [voxel][Cpad]:
-//   dW[co][tap] = sum_v xn[v+tap] * dy[v][co]   (xn = a*x+b in bounds, 0 outside)         blockIdx.y = kd slab (9 taps)
-//   dxn[v]      = sum_{tap,co} dy[v-tap][co] * W[co][tap]                                   (needed only for the GroupNorm grads)
+// backward of the first 3-D layer given dy = dL/d(pre-activation) [voxel][Cpad].  With xn = gamma*xh + beta inside the volume (xh = the
+// per-sample standardised input) and 0 outside, everything the layer needs follows from two correlation sums per (co, tap):
+//   G[co][tap] = sum_v xh[v+tap] * dy[v][co],   S[co][tap] = sum_v [v+tap inside] * dy[v][co]           blockIdx.y = kd slab (9 taps)
+//   dW = gamma*G + beta*S,   dgamma = sum_{co,tap} W*G,   dbeta = sum_{co,tap} W*S
+// (dgamma/dbeta are sum_v dxn*xh and sum_v dxn with dxn = the transposed conv of dy - which therefore never has to be formed;
+//  the optional first3d_dgrad_kernel below still produces it for callers that want dL/d(normalised input) itself).
 constexpr int F3_BLOCKS = 512;
 template <typename T>
-__global__ __launch_bounds__(256) void first3d_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            int sstride, int N, int D, int H, int W, const T* __restrict__ dy, int dy_ld, int Cpad,
-                                                            float* __restrict__ partial /*[blocks][3][9][64]*/) {
+__global__ __launch_bounds__(256) void first3d_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            int N, int D, int H, int W, const T* __restrict__ dy, int dy_ld, int Cpad,
+                                                            float* __restrict__ partial /*[blocks][3][2][9][64]*/) {
     __shared__ float red[4][9 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lpv = Cpad / 8, vpb = 256 / lpv, cg = tid % lpv;
     const int kd = blockIdx.y;
     const long long DHW = (long long)D * H * W, total = (long long)N * DHW;
-    float acc[9][8];
+    float accG[9][8], accS[9][8];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+        for (int j = 0; j < 8; ++j) accG[t][j] = accS[t][j] = 0.f;
     for (long long v = (long long)blockIdx.x * vpb + tid / lpv; v < total; v += (long long)gridDim.x * vpb) {
         const int n = (int)(v / DHW);
         const long long rem = v - (long long)n * DHW;
         const int xx = (int)(rem % W);
         const long long t = rem / W;
         const int yy = (int)(t % H), zz = (int)(t / H);
-        const float a = scale[n * sstride], b = shift[n * sstride];
+        const float a = rstd[n], b = -mean[n] * rstd[n];
         const float* xp = x + (long long)n * DHW;
         float g[8];
         const T* src = dy + (size_t)v * dy_ld + cg * 8;
@@ -435,43 +438,88 @@ __global__ __launch_bounds__(256) void first3d_wgrad_kernel(const float* __restr
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
             const int sy = yy + tp / 3 - 1, sx = xx + tp % 3 - 1;
-            float xv = 0.f;
-            if (sz >= 0 && sz < D && sy >= 0 && sy < H && sx >= 0 && sx < W) xv = fmaf(xp[((long long)sz * H + sy) * W + sx], a, b);
+            float xv = 0.f, in = 0.f;
+            if (sz >= 0 && sz < D && sy >= 0 && sy < H && sx >= 0 && sx < W) {
+                xv = fmaf(xp[((long long)sz * H + sy) * W + sx], a, b);
+                in = 1.f;
+            }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[tp][j] = fmaf(xv, g[j], acc[tp][j]);
+            for (int j = 0; j < 8; ++j) {
+                accG[tp][j] = fmaf(xv, g[j], accG[tp][j]);
+                accS[tp][j] = fmaf(in, g[j], accS[tp][j]);
+            }
         }
     }
     // lanes with equal (lane % lpv) hold the same channels
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float vsum = acc[t][j];
-            for (int o = lpv; o < 64; o <<= 1) vsum += __shfl_xor(vsum, o, 64);
-            acc[t][j] = vsum;
-        }
-    for (int i = tid; i < 4 * 9 * 64; i += 256) (&red[0][0])[i] = 0.f;
-    __syncthreads();
-    if (lane < lpv) {
+    for (int which = 0; which < 2; ++which) {
+        float (*acc)[8] = which == 0 ? accG : accS;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) red[wave][t * 64 + lane * 8 + j] = acc[t][j];
+            for (int j = 0; j < 8; ++j) {
+                float vsum = acc[t][j];
+                for (int o = lpv; o < 64; o <<= 1) vsum += __shfl_xor(vsum, o, 64);
+                acc[t][j] = vsum;
+            }
+        __syncthreads();
+        for (int i = tid; i < 4 * 9 * 64; i += 256) (&red[0][0])[i] = 0.f;
+        __syncthreads();
+        if (lane < lpv) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[wave][t * 64 + lane * 8 + j] = acc[t][j];
+        }
+        __syncthreads();
+        float* out = partial + (((size_t)blockIdx.x * 3 + kd) * 2 + which) * 576;
+        for (int i = tid; i < 576; i += 256) out[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
     }
-    __syncthreads();
-    float* out = partial + ((size_t)blockIdx.x * 3 + kd) * 576;
-    for (int i = tid; i < 576; i += 256) out[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
 }
 
-__global__ void first3d_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, int Cout, float* __restrict__ dw) {
+// dW = gamma*G + beta*S in the reference layout; G and S totals go to gs[2][3*576] for the finalize kernel
+__global__ void first3d_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, int Cout, const float* __restrict__ gamma,
+                                            const float* __restrict__ beta, float* __restrict__ dw, float* __restrict__ gs) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (kd, tp, co)
     if (idx >= 3 * 576) return;
     const int kd = idx / 576, r = idx - kd * 576;
     const int tp = r >> 6, co = r & 63;
-    if (co >= Cout) return;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[((size_t)b * 3 + kd) * 576 + r];
-    dw[co * 27 + kd * 9 + tp] = s;
+    float G = 0.f, S = 0.f;
+    if (co < Cout) {
+        for (int b = 0; b < nblocks; ++b) {
+            G += partial[(((size_t)b * 3 + kd) * 2 + 0) * 576 + r];
+            S += partial[(((size_t)b * 3 + kd) * 2 + 1) * 576 + r];
+        }
+        dw[co * 27 + kd * 9 + tp] = fmaf(gamma[0], G, beta[0] * S);
+    }
+    gs[idx] = G;
+    gs[3 * 576 + idx] = S;
+}
+
+__global__ __launch_bounds__(256) void first3d_gn_finalize_kernel(const float* __restrict__ gs, const float* __restrict__ w /*[Cout][27]*/, int Cout,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double red[2][4];
+    double dg = 0.0, db = 0.0;
+    for (int idx = threadIdx.x; idx < 3 * 576; idx += 256) {
+        const int kd = idx / 576, r = idx - kd * 576;
+        const int tp = r >> 6, co = r & 63;
+        if (co < Cout) {
+            const double wv = w[co * 27 + kd * 9 + tp];
+            dg += wv * (double)gs[idx];
+            db += wv * (double)gs[3 * 576 + idx];
+        }
+    }
+    dg = wave_sum_d(dg);
+    db = wave_sum_d(db);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = dg;
+        red[1][threadIdx.x >> 6] = db;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        dgamma[0] = (float)((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+        dbeta[0] = (float)((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    }
 }
 
 template <typename T>
@@ -509,35 +557,43 @@ __global__ __launch_bounds__(256) void first3d_dgrad_kernel(const T* __restrict_
     }
 }
 
-extern "C" size_t mis_first3d_bwd_workspace_bytes(void) { return (size_t)F3_BLOCKS * 3 * 576 * sizeof(float); }
+extern "C" size_t mis_first3d_bwd_workspace_bytes(void) { return ((size_t)F3_BLOCKS * 3 * 2 * 576 + 2 * 3 * 576) * sizeof(float); }
 
-extern "C" int mis_first3d_bwd(int dtype, const float* x, const float* scale, const float* shift, int sstride, int N, int D, int H, int W,
-                               const void* dy, int dy_ld, int Cpad, const float* w, int Cout, float* workspace, float* dw, float* dxn,
-                               void* stream) {
+extern "C" int mis_first3d_bwd(int dtype, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int N, int D,
+                               int H, int W, const void* dy, int dy_ld, int Cpad, const float* w, int Cout, float* workspace, float* dw,
+                               float* dgamma, float* dbeta, float* dxn, void* stream) {
     (void)hipGetLastError();
-    MIS_REQUIRE(x && scale && shift && dy && w && workspace && dw && dxn, MIS_EINVAL, "first3d_bwd: null pointer");
+    MIS_REQUIRE(x && mean && rstd && gamma && beta && dy && w && workspace && dw && dgamma && dbeta, MIS_EINVAL, "first3d_bwd: null pointer");
     MIS_REQUIRE(Cout > 0 && Cout <= Cpad && Cout % 8 == 0 && (Cpad == 32 || Cpad == 64) && dy_ld % 8 == 0, MIS_EUNSUPPORTED, "first3d_bwd: sizes");
     const long long total = (long long)N * D * H * W;
     const int vpb = 256 / (Cpad / 8);
     long long blocks = (total + vpb - 1) / vpb;
     if (blocks > F3_BLOCKS) blocks = F3_BLOCKS;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    long long dblocks = (total + 255) / 256;
-    if (dblocks > 8192) dblocks = 8192;
-    if (dtype == MIS_BF16) {
-        hipLaunchKernelGGL(first3d_wgrad_kernel<__bf16>, dim3((unsigned)blocks, 3), dim3(256), 0, s, x, scale, shift, sstride, N, D, H, W, (const __bf16*)dy,
-                           dy_ld, Cpad, workspace);
-        MIS_LAUNCH_CHECK("first3d_wgrad");
-        hipLaunchKernelGGL(first3d_dgrad_kernel<__bf16>, dim3((unsigned)dblocks), dim3(256), 0, s, (const __bf16*)dy, dy_ld, Cpad, N, D, H, W, w, Cout, dxn);
-    } else {
-        hipLaunchKernelGGL(first3d_wgrad_kernel<float>, dim3((unsigned)blocks, 3), dim3(256), 0, s, x, scale, shift, sstride, N, D, H, W, (const float*)dy,
-                           dy_ld, Cpad, workspace);
-        MIS_LAUNCH_CHECK("first3d_wgrad");
-        hipLaunchKernelGGL(first3d_dgrad_kernel<float>, dim3((unsigned)dblocks), dim3(256), 0, s, (const float*)dy, dy_ld, Cpad, N, D, H, W, w, Cout, dxn);
-    }
-    MIS_LAUNCH_CHECK("first3d_dgrad");
-    hipLaunchKernelGGL(first3d_wgrad_reduce_kernel, dim3((3 * 576 + 255) / 256), dim3(256), 0, s, (const float*)workspace, (int)blocks, Cout, dw);
+    float* gs = workspace + (size_t)F3_BLOCKS * 3 * 2 * 576;
+    if (dtype == MIS_BF16)
+        hipLaunchKernelGGL(first3d_wgrad_kernel<__bf16>, dim3((unsigned)blocks, 3), dim3(256), 0, s, x, mean, rstd, N, D, H, W, (const __bf16*)dy, dy_ld,
+                           Cpad, workspace);
+    else
+        hipLaunchKernelGGL(first3d_wgrad_kernel<float>, dim3((unsigned)blocks, 3), dim3(256), 0, s, x, mean, rstd, N, D, H, W, (const float*)dy, dy_ld,
+                           Cpad, workspace);
+    MIS_LAUNCH_CHECK("first3d_wgrad");
+    hipLaunchKernelGGL(first3d_wgrad_reduce_kernel, dim3((3 * 576 + 255) / 256), dim3(256), 0, s, (const float*)workspace, (int)blocks, Cout, gamma,
+                       beta, dw, gs);
     MIS_LAUNCH_CHECK("first3d_wgrad_reduce");
+    hipLaunchKernelGGL(first3d_gn_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)gs, w, Cout, dgamma, dbeta);
+    MIS_LAUNCH_CHECK("first3d_gn_finalize");
+    if (dxn != nullptr) {       // optional: dL/d(normalised input) itself
+        long long dblocks = (total + 255) / 256;
+        if (dblocks > 8192) dblocks = 8192;
+        if (dtype == MIS_BF16)
+            hipLaunchKernelGGL(first3d_dgrad_kernel<__bf16>, dim3((unsigned)dblocks), dim3(256), 0, s, (const __bf16*)dy, dy_ld, Cpad, N, D, H, W, w, Cout,
+                               dxn);
+        else
+            hipLaunchKernelGGL(first3d_dgrad_kernel<float>, dim3((unsigned)dblocks), dim3(256), 0, s, (const float*)dy, dy_ld, Cpad, N, D, H, W, w, Cout,
+                               dxn);
+        MIS_LAUNCH_CHECK("first3d_dgrad");
+    }
     return MIS_OK;
 }
 

@@ -233,7 +233,6 @@ class UNet3DEngine:
         if self.deconv:     # one column buffer (N, d, h, w, 27*Cout) shared by all levels and by forward / backward
             self.cols_elems = max(N * (D >> (l + 1)) * (H >> (l + 1)) * (W >> (l + 1)) * 27 * fm[l] for l in range(L - 1))
             self.cols = torch.empty(self.cols_elems, dtype=dt, device=dev)
-        self.dxn0 = torch.empty(N, D, H, W, dtype=torch.float32, device=dev)
         self.logits = torch.empty(N, self.cout, D, H, W, dtype=torch.float32, device=dev)
         self.argmax = torch.empty(N, D, H, W, dtype=torch.uint8, device=dev)
         self._shape = (N, D, H, W)
@@ -398,14 +397,10 @@ class UNet3DEngine:
         x = self._x
         N, _, D, H, W = x.shape
         npix = D * H * W
-        ops.first3d_bwd(x, s.scale, s.shift, 4, self.g_t_enc[0], self.c1p, self.P[s.name + ".conv.weight"], self.c1,
-                        self.Gr[s.name + ".conv.weight"], self.dxn0)
-        dv = self.dxn0.view(N, 1, 1, npix // 4, 4)
-        xv = x.view(N, 1, 1, npix // 4, 4)
-        ops.gn_bwd_stats(dv, xv, 4, False, (N, 1, 1, npix // 4), s.S1, s.S2, 4, 0)
-        ops.gn_bwd_finalize(s.S1, s.S2, s.mean, s.rstd, s.g4, N, 4, 1, npix // 4, s.p, s.q, s.r, s.dgam, s.dbet)
-        self.Gr[s.name + ".groupnorm.weight"].copy_(s.dgam.sum().reshape(1))
-        self.Gr[s.name + ".groupnorm.bias"].copy_(s.dbet.sum().reshape(1))
+        # dW plus the 1-channel GroupNorm's dgamma / dbeta straight from the correlation sums (no dL/d(input) pass)
+        ops.first3d_bwd(x, s.mean, s.rstd, self.P[s.name + ".groupnorm.weight"], self.P[s.name + ".groupnorm.bias"], self.g_t_enc[0], self.c1p,
+                        self.P[s.name + ".conv.weight"], self.c1, self.Gr[s.name + ".conv.weight"], self.Gr[s.name + ".groupnorm.weight"],
+                        self.Gr[s.name + ".groupnorm.bias"])
         cb(["encoders.0"])
 
     # ---- optimizer -------------------------------------------------------------------------------------

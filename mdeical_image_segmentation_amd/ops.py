@@ -373,13 +373,15 @@ def first3d_fwd(x, scale, shift, sstride, w, Cout, y, Cpad):
                               y.ptr, y.ld, Cpad, stream_ptr()), "mis_first3d_fwd")
 
 
-def first3d_bwd(x, scale, shift, sstride, dy, Cpad, w, Cout, dw, dxn):
+def first3d_bwd(x, mean, rstd, gamma, beta, dy, Cpad, w, Cout, dw, dgamma, dbeta, dxn=None):
+    """first 3-D layer backward: dW, and the 1-channel GroupNorm's dgamma / dbeta (device scalars); dxn optional."""
     lib = load()
     dy = _v(dy)
     N, D, H, W = x.shape[0], x.shape[-3], x.shape[-2], x.shape[-1]
     ws = workspace(lib.mis_first3d_bwd_workspace_bytes(), x.device, "first3d")
-    check(lib.mis_first3d_bwd(dtype_code(dy.dtype), x.data_ptr(), scale.data_ptr(), shift.data_ptr(), sstride, N, D, H, W, dy.ptr, dy.ld, Cpad,
-                              w.data_ptr(), Cout, ws.data_ptr(), dw.data_ptr(), dxn.data_ptr(), stream_ptr()), "mis_first3d_bwd")
+    check(lib.mis_first3d_bwd(dtype_code(dy.dtype), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, D, H, W,
+                              dy.ptr, dy.ld, Cpad, w.data_ptr(), Cout, ws.data_ptr(), dw.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                              None if dxn is None else dxn.data_ptr(), stream_ptr()), "mis_first3d_bwd")
 
 
 def relu_mask(dy, y, dx):

@@ -197,11 +197,20 @@ def test_first3d_layer_kernels(dtype):
     gd[..., Co:] = 7.0          # padding channels may hold anything: they must not leak into dW / dxn
     dw = torch.zeros(Co, 1, 3, 3, 3, device=DEV)
     dxn = torch.zeros(N, D, H, W, device=DEV)
-    ops.first3d_bwd(xd, scale, shift, 4, gd, Cp, w.detach().to(DEV), Co, dw, dxn)
+    dg, db = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    ops.first3d_bwd(xd, mean, rstd, gamma.detach().to(DEV), beta.detach().to(DEV), gd, Cp, w.detach().to(DEV), Co, dw, dg, db, dxn)
     wt = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=0.3)
     assert torch.allclose(dw.cpu(), w.grad, **wt), (dw.cpu() - w.grad).abs().max()
     xt = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
     assert torch.allclose(dxn.cpu(), xn.grad[:, 0], **xt), (dxn.cpu() - xn.grad[:, 0]).abs().max()
+    # the 1-channel GroupNorm's parameter gradients come from the correlation sums, not from dxn
+    gt = dict(rtol=2e-4, atol=2e-3) if dtype == torch.float32 else dict(rtol=3e-2, atol=1.0)
+    assert torch.allclose(dg.cpu(), gamma.grad, **gt), (dg.item(), gamma.grad.item())
+    assert torch.allclose(db.cpu(), beta.grad, **gt), (db.item(), beta.grad.item())
+    # and without the optional dxn output
+    dg2, db2 = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    ops.first3d_bwd(xd, mean, rstd, gamma.detach().to(DEV), beta.detach().to(DEV), gd, Cp, w.detach().to(DEV), Co, dw, dg2, db2)
+    assert torch.equal(dg2, dg) and torch.equal(db2, db)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
