@@ -11,6 +11,8 @@
 //   dx = p[n,c]*dy + q[n,c]*x + r[n,c]  with  p = rstd*gamma, q = -rstd^2*B/m, r = -q*mean - rstd*A/m,
 //        A = sum_{c in g} gamma*S1, B = sum_{c in g} gamma*rstd*(S2 - mean*S1)     (gn_bwd_apply; optional ReLU mask of x,
 //   optional accumulate, and for the upsampled source the 8 children of a coarse voxel are summed here)
+#include <stdlib.h>
+
 #include "common.hpp"
 
 // ---------------------------------------------------------------------------------------------------------
@@ -376,6 +378,95 @@ __global__ __launch_bounds__(256) void first3d_fwd_kernel(const float* __restric
     }
 }
 
+// Tiled variant for Cout = 32 (the reference's default first layer): one block = a 1 x 4 x 64 voxel tile whose normalised input halo
+// (3 x 6 x 66 floats, zero outside the volume) is staged once in LDS; a thread owns 4 consecutive voxels x 8 channels, so one row of 6
+// halo values feeds 3 taps x 4 voxels and every weight vector read from LDS is used 4 times: 864 FMAs per thread against ~60 LDS reads,
+// no per-tap global loads or bounds checks.  Padding channels [32, Cpad) are written as zeros.
+template <typename T>
+__global__ __launch_bounds__(256) void first3d_fwd_tiled_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                int sstride, int N, int D, int H, int W, const float* __restrict__ w /*[32][27]*/, T* y,
+                                                                int y_ld, int Cpad) {
+    constexpr int TH = 4, TW = 64, HH = TH + 2, HW = TW + 2, CO = 32;
+    __shared__ __attribute__((aligned(16))) float wl[27 * CO];
+    __shared__ __attribute__((aligned(16))) float xs[3][HH][HW + 2];      // +2: rows stay 16-byte aligned (68 floats)
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 27 * CO; i += 256) wl[i] = w[(i % CO) * 27 + i / CO];       // [tap][co]
+    const int tilesW = (W + TW - 1) / TW, tilesH = (H + TH - 1) / TH;
+    long long b = blockIdx.x;
+    const int tw = (int)(b % tilesW);
+    b /= tilesW;
+    const int th = (int)(b % tilesH);
+    b /= tilesH;
+    const int z = (int)(b % D);
+    const int n = (int)(b / D);
+    const int h0 = th * TH, w0 = tw * TW;
+    const float a = scale[n * sstride], sh = shift[n * sstride];
+    const float* xp = x + (long long)n * D * H * W;
+    for (int i = tid; i < 3 * HH * HW; i += 256) {
+        const int px = i % HW, r = i / HW;
+        const int py = r % HH, pz = r / HH;
+        const int sz = z + pz - 1, sy = h0 + py - 1, sx = w0 + px - 1;
+        float v = 0.f;
+        if (sz >= 0 && sz < D && sy >= 0 && sy < H && sx >= 0 && sx < W) v = fmaf(xp[((long long)sz * H + sy) * W + sx], a, sh);
+        xs[pz][py][px] = v;
+    }
+    __syncthreads();
+    const int cg = tid & 3, gq = tid >> 2;          // 4 channel groups of 8, 64 voxel groups
+    const int r = gq >> 4, wq = (gq & 15) * 4;      // tile row, first of 4 voxels
+    float acc[4][8];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[v][j] = 0.f;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            float xr[6];
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(&xs[kd][r + kh][wq]);
+            xr[0] = lo[0]; xr[1] = lo[1]; xr[2] = lo[2]; xr[3] = lo[3];
+            xr[4] = xs[kd][r + kh][wq + 4];
+            xr[5] = xs[kd][r + kh][wq + 5];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const float* wr = &wl[((kd * 3 + kh) * 3 + kw) * CO + cg * 8];
+                const f32x4 w0v = *reinterpret_cast<const f32x4*>(wr), w1v = *reinterpret_cast<const f32x4*>(wr + 4);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float xv = xr[v + kw];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[v][j] = fmaf(xv, w0v[j], acc[v][j]);
+                        acc[v][4 + j] = fmaf(xv, w1v[j], acc[v][4 + j]);
+                    }
+                }
+            }
+        }
+    const int yy = h0 + r;
+    if (yy < H) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int xx = w0 + wq + v;
+            if (xx >= W) break;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[v][j] = fmaxf(acc[v][j], 0.f);
+            T* dst = y + ((((size_t)n * D + z) * H + yy) * W + xx) * y_ld + cg * 8;
+            float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if constexpr (sizeof(T) == 2) {
+                *reinterpret_cast<u32x4*>(dst) = pack_chunk<__bf16>(acc[v]);
+                if (Cpad > CO) *reinterpret_cast<u32x4*>(dst + CO) = pack_chunk<__bf16>(zero);
+            } else {
+                *reinterpret_cast<u32x4*>(dst) = pack_chunk<float>(acc[v]);
+                *reinterpret_cast<u32x4*>(dst + 4) = pack_chunk<float>(acc[v] + 4);
+                if (Cpad > CO) {
+                    *reinterpret_cast<u32x4*>(dst + CO) = pack_chunk<float>(zero);
+                    *reinterpret_cast<u32x4*>(dst + CO + 4) = pack_chunk<float>(zero);
+                }
+            }
+        }
+    }
+}
+
 extern "C" int mis_first3d_fwd(int dtype, const float* x, const float* scale, const float* shift, int sstride, int N, int D, int H, int W,
                                const float* w, int Cout, void* y, int y_ld, int Cpad, void* stream) {
     (void)hipGetLastError();
@@ -383,10 +474,22 @@ extern "C" int mis_first3d_fwd(int dtype, const float* x, const float* scale, co
     MIS_REQUIRE(Cout > 0 && Cout <= Cpad && (Cpad == 32 || Cpad == 64) && y_ld >= Cpad && y_ld % 8 == 0, MIS_EUNSUPPORTED,
                 "first3d_fwd: Cout %d / Cpad %d", Cout, Cpad);
     const long long total = (long long)N * D * H * W;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static const int tiled = getenv("MIS_FIRST3D_UNTILED") == nullptr;
+    const long long tiles = (long long)N * D * ((H + 3) / 4) * ((W + 63) / 64);
+    if (tiled && Cout == 32 && tiles < (1ll << 31)) {
+        if (dtype == MIS_BF16)
+            hipLaunchKernelGGL(first3d_fwd_tiled_kernel<__bf16>, dim3((unsigned)tiles), dim3(256), 0, s, x, scale, shift, sstride, N, D, H, W, w, (__bf16*)y,
+                               y_ld, Cpad);
+        else
+            hipLaunchKernelGGL(first3d_fwd_tiled_kernel<float>, dim3((unsigned)tiles), dim3(256), 0, s, x, scale, shift, sstride, N, D, H, W, w, (float*)y, y_ld,
+                               Cpad);
+        MIS_LAUNCH_CHECK("first3d_fwd(tiled)");
+        return MIS_OK;
+    }
     const int vpb = 256 / (Cpad / 8);
     long long blocks = (total + vpb - 1) / vpb;
     if (blocks > 8192) blocks = 8192;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIS_BF16)
         hipLaunchKernelGGL(first3d_fwd_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, x, scale, shift, sstride, N, D, H, W, w, Cout, (__bf16*)y,
                            y_ld, Cpad);
@@ -466,6 +569,113 @@ __global__ __launch_bounds__(256) void first3d_wgrad_kernel(const float* __restr
         for (int i = tid; i < 4 * 9 * 64; i += 256) (&red[0][0])[i] = 0.f;
         __syncthreads();
         if (lane < lpv) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[wave][t * 64 + lane * 8 + j] = acc[t][j];
+        }
+        __syncthreads();
+        float* out = partial + (((size_t)blockIdx.x * 3 + kd) * 2 + which) * 576;
+        for (int i = tid; i < 576; i += 256) out[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    }
+}
+
+// Tiled variant for Cout = 32: a persistent block walks 1 x 4 x 64 voxel tiles; the standardised input row halo (6 x 66 values of the
+// plane z + kd - 1, plus the matching inside-the-volume flags) is staged in LDS, a thread owns 4 consecutive voxels x 8 channels of dy,
+// so one halo row of 6 values feeds 3 taps x 4 voxels: no per-tap global loads or bounds checks.  Same partial layout as above.
+template <typename T>
+__global__ __launch_bounds__(256) void first3d_wgrad_tiled_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  int N, int D, int H, int W, const T* __restrict__ dy, int dy_ld,
+                                                                  float* __restrict__ partial /*[blocks][3][2][9][64]*/) {
+    constexpr int TH = 4, TW = 64, HH = TH + 2, HW = TW + 2;
+    __shared__ __attribute__((aligned(16))) float xs[HH][HW + 2], ins[HH][HW + 2];
+    __shared__ float red[4][9 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kd = blockIdx.y;
+    const int cg = tid & 3, gq = tid >> 2;
+    const int r = gq >> 4, wq = (gq & 15) * 4;
+    const int tilesW = (W + TW - 1) / TW, tilesH = (H + TH - 1) / TH;
+    const long long ntiles = (long long)N * D * tilesH * tilesW;
+    float accG[9][8], accS[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) accG[t][j] = accS[t][j] = 0.f;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        long long b = tile;
+        const int tw = (int)(b % tilesW);
+        b /= tilesW;
+        const int th = (int)(b % tilesH);
+        b /= tilesH;
+        const int z = (int)(b % D);
+        const int n = (int)(b / D);
+        const int sz = z + kd - 1;
+        if (sz < 0 || sz >= D) continue;                 // block-uniform: this tap plane lies outside the volume
+        const int h0 = th * TH, w0 = tw * TW;
+        const float a = rstd[n], sh = -mean[n] * rstd[n];
+        const float* xp = x + ((long long)n * D + sz) * H * W;
+        __syncthreads();                                 // the previous tile's readers are done
+        for (int i = tid; i < HH * HW; i += 256) {
+            const int px = i % HW, py = i / HW;
+            const int sy = h0 + py - 1, sx = w0 + px - 1;
+            const bool in = sy >= 0 && sy < H && sx >= 0 && sx < W;
+            xs[py][px] = in ? fmaf(xp[(long long)sy * W + sx], a, sh) : 0.f;
+            ins[py][px] = in ? 1.f : 0.f;
+        }
+        float g[4][8];
+        const int yy = h0 + r;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int xx = w0 + wq + v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[v][j] = 0.f;
+            if (yy < H && xx < W) {
+                const T* src = dy + ((((size_t)n * D + z) * H + yy) * W + xx) * dy_ld + cg * 8;
+                if constexpr (sizeof(T) == 2) {
+                    unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(src), g[v]);
+                } else {
+                    unpack_chunk<float>(*reinterpret_cast<const u32x4*>(src), g[v]);
+                    unpack_chunk<float>(*reinterpret_cast<const u32x4*>(src + 4), g[v] + 4);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            float xr[6], ir[6];
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(&xs[r + kh][wq]);
+            const f32x4 li4 = *reinterpret_cast<const f32x4*>(&ins[r + kh][wq]);
+            xr[0] = lo[0]; xr[1] = lo[1]; xr[2] = lo[2]; xr[3] = lo[3];
+            ir[0] = li4[0]; ir[1] = li4[1]; ir[2] = li4[2]; ir[3] = li4[3];
+            xr[4] = xs[r + kh][wq + 4]; xr[5] = xs[r + kh][wq + 5];
+            ir[4] = ins[r + kh][wq + 4]; ir[5] = ins[r + kh][wq + 5];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        accG[kh * 3 + kw][j] = fmaf(xr[v + kw], g[v][j], accG[kh * 3 + kw][j]);
+                        accS[kh * 3 + kw][j] = fmaf(ir[v + kw], g[v][j], accS[kh * 3 + kw][j]);
+                    }
+        }
+    }
+    // lanes with equal (lane & 3) hold the same channels
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        float (*acc)[8] = which == 0 ? accG : accS;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float vsum = acc[t][j];
+                for (int o = 4; o < 64; o <<= 1) vsum += __shfl_xor(vsum, o, 64);
+                acc[t][j] = vsum;
+            }
+        __syncthreads();
+        for (int i = tid; i < 4 * 9 * 64; i += 256) (&red[0][0])[i] = 0.f;
+        __syncthreads();
+        if (lane < 4) {
 #pragma unroll
             for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -571,7 +781,17 @@ extern "C" int mis_first3d_bwd(int dtype, const float* x, const float* mean, con
     if (blocks > F3_BLOCKS) blocks = F3_BLOCKS;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* gs = workspace + (size_t)F3_BLOCKS * 3 * 2 * 576;
-    if (dtype == MIS_BF16)
+    static const int tiled = getenv("MIS_FIRST3D_UNTILED") == nullptr;
+    if (tiled && Cout == 32) {
+        const long long tiles = (long long)N * D * ((H + 3) / 4) * ((W + 63) / 64);
+        blocks = tiles < F3_BLOCKS ? tiles : F3_BLOCKS;
+        if (dtype == MIS_BF16)
+            hipLaunchKernelGGL(first3d_wgrad_tiled_kernel<__bf16>, dim3((unsigned)blocks, 3), dim3(256), 0, s, x, mean, rstd, N, D, H, W, (const __bf16*)dy,
+                               dy_ld, workspace);
+        else
+            hipLaunchKernelGGL(first3d_wgrad_tiled_kernel<float>, dim3((unsigned)blocks, 3), dim3(256), 0, s, x, mean, rstd, N, D, H, W, (const float*)dy,
+                               dy_ld, workspace);
+    } else if (dtype == MIS_BF16)
         hipLaunchKernelGGL(first3d_wgrad_kernel<__bf16>, dim3((unsigned)blocks, 3), dim3(256), 0, s, x, mean, rstd, N, D, H, W, (const __bf16*)dy, dy_ld,
                            Cpad, workspace);
     else
