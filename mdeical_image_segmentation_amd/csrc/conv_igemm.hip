@@ -744,6 +744,10 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
             return launch_cfg<T, Geom<1, 16, 16, 3, false>, 1, 4>(d, s);
         }
         if (wide) return launch_cfg<T, Geom<4, 4, 8, 3, true>, 2, 4>(d, s);
+        // bf16, Cout not a multiple of 128 (the 64- and 192-column layers at full resolution): 8 waves on a 4x8x8 voxel tile, LDS-DMA weight
+        // tiles, 3 taps per barrier (+6...11 % over the 4-wave 4x4x8 config; the same tile with 1 tap per barrier or 4 waves was slower)
+        static const int bn64v2 = getenv("MIS_CONV3D_BN64V1") == nullptr;
+        if (bn64v2 && sizeof(T) == 2) return launch_cfg<T, Geom<4, 8, 8, 3, true>, 2, 2, 512, 3, 4, false, true>(d, s);
         return launch_cfg<T, Geom<4, 4, 8, 3, true>, 2, 2>(d, s);
     }
     if (!is3d) {
