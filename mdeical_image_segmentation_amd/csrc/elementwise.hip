@@ -1,6 +1,8 @@
 // HBM-bound kernels of the U-Net hot path (gfx950): first-layer direct conv (fwd + wgrad), per-channel sums
 // (bias gradients, GroupNorm statistics), 2x max-pool fwd / fused bwd, weight repack, layout converts.
 // All global accesses are 16 bytes per lane along the channel axis (NHWC), grids are capped and grid-strided.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 // =========================================================================================================
@@ -55,6 +57,94 @@ __global__ __launch_bounds__(256) void first_conv_fwd_kernel(const float* __rest
     }
 }
 
+// Tiled variant: a persistent block walks 2 x 64 pixel tiles whose input halo (Cin x 4 x 66 floats, zero outside the image) is staged in
+// LDS; a thread owns 4 consecutive pixels x 8 channels, so one halo row of 6 values feeds 3 taps x 4 pixels and every weight vector read
+// from LDS is used 4 times.  No per-tap global loads or bounds checks; the kernel is bound by its 128-byte-per-pixel output stream.
+template <typename T>
+__global__ __launch_bounds__(256) void first_conv_fwd_tiled_kernel(const float* __restrict__ x, int N, int Cin, int H, int W,
+                                                                   const float* __restrict__ w, const float* __restrict__ bias, T* y, int y_ld) {
+    constexpr int TH = 2, TW = 64, HH = TH + 2, HW = TW + 2;
+    __shared__ __attribute__((aligned(16))) float wl[36 * 64];
+    __shared__ __attribute__((aligned(16))) float bl[64];
+    __shared__ __attribute__((aligned(16))) float xs[4][HH][HW + 2];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 9 * Cin * 64; i += 256) {
+        const int co = i & 63, r = i >> 6;   // r = tap*Cin + ci
+        const int tap = r / Cin, ci = r - tap * Cin;
+        wl[i] = w[(co * Cin + ci) * 9 + tap];
+    }
+    if (tid < 64) bl[tid] = bias ? bias[tid] : 0.f;
+    const int cg = tid & 7, gq = tid >> 3;
+    const int r = gq >> 4, wq = (gq & 15) * 4;
+    const int tilesW = (W + TW - 1) / TW, tilesH = (H + TH - 1) / TH;
+    const long long ntiles = (long long)N * tilesH * tilesW;
+    const long long HWp = (long long)H * W;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        long long b = tile;
+        const int tw = (int)(b % tilesW);
+        b /= tilesW;
+        const int th = (int)(b % tilesH);
+        const int n = (int)(b / tilesH);
+        const int h0 = th * TH, w0 = tw * TW;
+        __syncthreads();                      // previous tile's readers are done (first time: weights are visible after the next barrier)
+        for (int i = tid; i < Cin * HH * HW; i += 256) {
+            const int px = i % HW, t2 = i / HW;
+            const int py = t2 % HH, ci = t2 / HH;
+            const int sy = h0 + py - 1, sx = w0 + px - 1;
+            float v = 0.f;
+            if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = x[((long long)n * Cin + ci) * HWp + (long long)sy * W + sx];
+            xs[ci][py][px] = v;
+        }
+        __syncthreads();
+        float acc[4][8];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[v][j] = bl[cg * 8 + j];
+        for (int ci = 0; ci < Cin; ++ci) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                float xr[6];
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(&xs[ci][r + kh][wq]);
+                xr[0] = lo[0]; xr[1] = lo[1]; xr[2] = lo[2]; xr[3] = lo[3];
+                xr[4] = xs[ci][r + kh][wq + 4];
+                xr[5] = xs[ci][r + kh][wq + 5];
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float* wr = &wl[((kh * 3 + kw) * Cin + ci) * 64 + cg * 8];
+                    const f32x4 w0v = *reinterpret_cast<const f32x4*>(wr), w1v = *reinterpret_cast<const f32x4*>(wr + 4);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float xv = xr[v + kw];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc[v][j] = fmaf(xv, w0v[j], acc[v][j]);
+                            acc[v][4 + j] = fmaf(xv, w1v[j], acc[v][4 + j]);
+                        }
+                    }
+                }
+            }
+        }
+        const int yy = h0 + r;
+        if (yy < H) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int xx = w0 + wq + v;
+                if (xx >= W) break;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[v][j] = fmaxf(acc[v][j], 0.f);
+                T* dst = y + (((size_t)n * H + yy) * W + xx) * y_ld + cg * 8;
+                if constexpr (sizeof(T) == 2) {
+                    *reinterpret_cast<u32x4*>(dst) = pack_chunk<__bf16>(acc[v]);
+                } else {
+                    *reinterpret_cast<u32x4*>(dst) = pack_chunk<float>(acc[v]);
+                    *reinterpret_cast<u32x4*>(dst + 4) = pack_chunk<float>(acc[v] + 4);
+                }
+            }
+        }
+    }
+}
+
 extern "C" int mis_conv3x3_first_fwd(int dtype, const float* x, int N, int Cin, int H, int W, const float* w, const float* bias, void* y,
                                      int y_ld, int Cout, void* stream) {
     (void)hipGetLastError();   // drop any stale (already handled) error of this thread
@@ -63,9 +153,20 @@ extern "C" int mis_conv3x3_first_fwd(int dtype, const float* x, int N, int Cin, 
     MIS_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0, MIS_EINVAL, "first_fwd: bad argument");
     MIS_REQUIRE(y_ld % 8 == 0, MIS_EINVAL, "first_fwd: y_ld alignment");
     const long long npix = (long long)N * H * W;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static const int tiled = getenv("MIS_FIRST2D_UNTILED") == nullptr;
+    if (tiled) {
+        long long tiles = (long long)N * ((H + 1) / 2) * ((W + 63) / 64);
+        if (tiles > 4096) tiles = 4096;
+        if (dtype == MIS_BF16)
+            hipLaunchKernelGGL(first_conv_fwd_tiled_kernel<__bf16>, dim3((unsigned)tiles), dim3(256), 0, s, x, N, Cin, H, W, w, bias, (__bf16*)y, y_ld);
+        else
+            hipLaunchKernelGGL(first_conv_fwd_tiled_kernel<float>, dim3((unsigned)tiles), dim3(256), 0, s, x, N, Cin, H, W, w, bias, (float*)y, y_ld);
+        MIS_LAUNCH_CHECK("first_conv_fwd(tiled)");
+        return MIS_OK;
+    }
     long long blocks = (npix + 31) / 32;
     if (blocks > 16384) blocks = 16384;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIS_BF16)
         hipLaunchKernelGGL(first_conv_fwd_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, x, N, Cin, H, W, w, bias, (__bf16*)y, y_ld);
     else
@@ -136,15 +237,113 @@ __global__ __launch_bounds__(256) void first_conv_wgrad_kernel(const float* __re
     for (int i = tid; i < 640; i += 256) out[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
 }
 
+// Tiled variant (same 2 x 64 pixel tiles, halo of input channel blockIdx.y in LDS, 4 pixels x 8 channels of dy per thread).
+template <typename T>
+__global__ __launch_bounds__(256) void first_conv_wgrad_tiled_kernel(const float* __restrict__ x, int N, int Cin, int H, int W, const T* dy, int dy_ld,
+                                                                     float* __restrict__ partial /*[blocks][Cin][10][64]*/) {
+    constexpr int TH = 2, TW = 64, HH = TH + 2, HW = TW + 2;
+    __shared__ __attribute__((aligned(16))) float xs[HH][HW + 2];
+    __shared__ float red[4][10 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = tid & 7, gq = tid >> 3;
+    const int r = gq >> 4, wq = (gq & 15) * 4;
+    const int ci = blockIdx.y;
+    const int tilesW = (W + TW - 1) / TW, tilesH = (H + TH - 1) / TH;
+    const long long ntiles = (long long)N * tilesH * tilesW;
+    const long long HWp = (long long)H * W;
+    float acc[10][8];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        long long b = tile;
+        const int tw = (int)(b % tilesW);
+        b /= tilesW;
+        const int th = (int)(b % tilesH);
+        const int n = (int)(b / tilesH);
+        const int h0 = th * TH, w0 = tw * TW;
+        __syncthreads();
+        for (int i = tid; i < HH * HW; i += 256) {
+            const int px = i % HW, py = i / HW;
+            const int sy = h0 + py - 1, sx = w0 + px - 1;
+            float v = 0.f;
+            if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = x[((long long)n * Cin + ci) * HWp + (long long)sy * W + sx];
+            xs[py][px] = v;
+        }
+        float g[4][8];
+        const int yy = h0 + r;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int xx = w0 + wq + v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[v][j] = 0.f;
+            if (yy < H && xx < W) {
+                const T* src = dy + (((size_t)n * H + yy) * W + xx) * dy_ld + cg * 8;
+                if constexpr (sizeof(T) == 2) {
+                    unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(src), g[v]);
+                } else {
+                    unpack_chunk<float>(*reinterpret_cast<const u32x4*>(src), g[v]);
+                    unpack_chunk<float>(*reinterpret_cast<const u32x4*>(src + 4), g[v] + 4);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            float xr[6];
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(&xs[r + kh][wq]);
+            xr[0] = lo[0]; xr[1] = lo[1]; xr[2] = lo[2]; xr[3] = lo[3];
+            xr[4] = xs[r + kh][wq + 4];
+            xr[5] = xs[r + kh][wq + 5];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[kh * 3 + kw][j] = fmaf(xr[v + kw], g[v][j], acc[kh * 3 + kw][j]);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[9][j] += g[v][j];
+    }
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[t][j];
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[t][j] = v;
+        }
+    __syncthreads();
+    if (lane < 8) {
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[wave][t * 64 + lane * 8 + j] = acc[t][j];
+    }
+    __syncthreads();
+    float* out = partial + ((size_t)blockIdx.x * Cin + ci) * 640;
+    for (int i = tid; i < 640; i += 256) out[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+
 __global__ void first_conv_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, int Cin, float* __restrict__ dw,
                                                float* __restrict__ db) {
-    // one thread per (ci, t, co)
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= Cin * 640) return;
-    const int ci = idx / 640, r = idx - ci * 640;
+    // 4 lanes per (ci, t, co): each sums every 4th block slab in a fixed order, then two shuffles
+    const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = gidx >> 2, part = gidx & 3;
+    const bool live = idx < Cin * 640;
+    const int ci = live ? idx / 640 : 0, r = live ? idx - ci * 640 : 0;
     const int t = r >> 6, co = r & 63;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[((size_t)b * Cin + ci) * 640 + r];
+    if (live)
+        for (int b = part; b < nblocks; b += 4) s += partial[((size_t)b * Cin + ci) * 640 + r];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (!live || part != 0) return;
     if (t < 9) dw[(co * Cin + ci) * 9 + t] = s;
     else if (ci == 0 && db != nullptr) db[co] = s;
 }
@@ -165,14 +364,24 @@ extern "C" int mis_conv3x3_first_wgrad(int dtype, const float* x, int N, int Cin
     long long blocks = (npix + 31) / 32;
     if (blocks > FW_BLOCKS) blocks = FW_BLOCKS;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MIS_BF16)
+    static const int tiled = getenv("MIS_FIRST2D_UNTILED") == nullptr;
+    if (tiled) {
+        const long long tiles = (long long)N * ((H + 1) / 2) * ((W + 63) / 64);
+        blocks = tiles < FW_BLOCKS ? tiles : FW_BLOCKS;
+        if (dtype == MIS_BF16)
+            hipLaunchKernelGGL(first_conv_wgrad_tiled_kernel<__bf16>, dim3((unsigned)blocks, Cin), dim3(256), 0, s, x, N, Cin, H, W, (const __bf16*)dy,
+                               dy_ld, workspace);
+        else
+            hipLaunchKernelGGL(first_conv_wgrad_tiled_kernel<float>, dim3((unsigned)blocks, Cin), dim3(256), 0, s, x, N, Cin, H, W, (const float*)dy,
+                               dy_ld, workspace);
+    } else if (dtype == MIS_BF16)
         hipLaunchKernelGGL(first_conv_wgrad_kernel<__bf16>, dim3((unsigned)blocks, Cin), dim3(256), 0, s, x, N, Cin, H, W, (const __bf16*)dy,
                            dy_ld, workspace);
     else
         hipLaunchKernelGGL(first_conv_wgrad_kernel<float>, dim3((unsigned)blocks, Cin), dim3(256), 0, s, x, N, Cin, H, W, (const float*)dy,
                            dy_ld, workspace);
     MIS_LAUNCH_CHECK("first_conv_wgrad");
-    hipLaunchKernelGGL(first_conv_wgrad_reduce_kernel, dim3((Cin * 640 + 255) / 256), dim3(256), 0, s, (const float*)workspace, (int)blocks,
+    hipLaunchKernelGGL(first_conv_wgrad_reduce_kernel, dim3((Cin * 640 * 4 + 255) / 256), dim3(256), 0, s, (const float*)workspace, (int)blocks,
                        Cin, dw, db);
     MIS_LAUNCH_CHECK("first_conv_wgrad_reduce");
     return MIS_OK;
