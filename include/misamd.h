@@ -217,6 +217,16 @@ int mis_aug_pointwise(const float* src, float* dst, long long n, float a, float 
                       unsigned long long seed, void* stream);
 int mis_aug_contrast(const float* src, float* dst, long long n, float mean, float alpha, void* stream);
 
+/* Stand-alone BCE + Dice loss on logits (model/unet3d/losses.py:7-33,83-129,167-178): x, t fp32 (N, C, S).
+ * fwd: out[0] = alpha*mean(BCEWithLogits) + beta*(1 - mean_c dice_c), out[1] = the BCE mean, out[2+4c..] = {sum s*t, sum s^2, sum t^2, dice_c}
+ *      (s = sigmoid(x)); out must hold 2 + 4*C floats and is the `sums` input of bwd.
+ * bwd: dx = grad_out[0] * dLoss/dx (grad_out: device scalar). */
+size_t mis_bcedice_workspace_bytes(int C);
+int mis_bcedice_fwd(const float* x, const float* t, int N, int C, long long S, float alpha, float beta, int normalize /*1: s = sigmoid(x), 0: s = x*/,
+                    void* workspace, float* out, void* stream);
+int mis_bcedice_bwd(const float* x, const float* t, int N, int C, long long S, float alpha, float beta, int normalize, const float* sums,
+                    const float* grad_out, float* dx, void* stream);
+
 /* Evaluation metrics of the 2-D trainer (trainer/metrcis.py:61-109,153-168 `compute_metrics`): sigmoid with +1e-6 in the denominator,
  * threshold = global mean probability, per-sample IoU / Dice, mean over samples.  values, labels: fp32 (N, npix); out[3] = {iou, dice, threshold}.
  * values_are_logits = 0 with a given threshold gives compute_iou / compute_dice on ready-made predictions. */

@@ -1,25 +1,64 @@
-"""Mirror of the hot-path part of model/unet3d/losses.py (:7-33, :83-129, :167-178, :258-306) as stand-alone torch
-modules (compatibility surface for an EXTERNAL loss on the logits of the fused UNet3D; the fused train step computes
-BCE+Dice inside the head kernel instead - engine3d.UNet3DEngine)."""
+"""Mirror of the hot-path part of the reference's model/unet3d/losses.py (`flatten` :258-270, `compute_per_channel_dice` :7-33,
+`_AbstractDiceLoss` :83-116, `DiceLoss` :119-129, `BCEDiceLoss` :167-178, `get_loss_criterion` :273-306) as nn.Modules whose forward and
+backward are the stand-alone HIP loss kernels (csrc/losses.hip, `mis_bcedice_fwd/_bwd`): two reduction passes + one elementwise pass.
+
+This is the surface for an EXTERNAL criterion applied to the logits of the fused UNet3D (and for the HF wrapper's double-sigmoid quirk);
+the fused train step computes the same BCE+Dice inside the 1x1-head kernel instead (engine3d.UNet3DEngine).  CUDA tensors only."""
 import torch
 from torch import nn
 
+from ... import ops
+from ..._lib import MisError, check, load, stream_ptr
+
 
 def flatten(tensor):
+    """(N, C, D, H, W) -> (C, N * D * H * W)   [tensor plumbing, losses.py:258-270]"""
     C = tensor.size(1)
     axis_order = (1, 0) + tuple(range(2, tensor.dim()))
     return tensor.permute(axis_order).contiguous().view(C, -1)
 
 
+def _prep(input, target):
+    if input.size() != target.size():
+        raise MisError("'input' and 'target' must have the same shape")
+    if input.device.type != "cuda":
+        raise MisError(f"the loss kernels run on MI355X only: got a tensor on {input.device} (no CPU fallback)")
+    x = input.contiguous().float()
+    t = target.to(device=x.device).contiguous().float()
+    N, C = x.shape[0], x.shape[1]
+    S = x[0, 0].numel()
+    return x, t, N, C, S
+
+
+class _BCEDice(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, target, alpha, beta, normalize):
+        x, t, N, C, S = _prep(input, target)
+        lib = load()
+        ws = ops.workspace(lib.mis_bcedice_workspace_bytes(C), x.device, "bcedice")
+        out = torch.empty(2 + 4 * C, dtype=torch.float32, device=x.device)
+        check(lib.mis_bcedice_fwd(x.data_ptr(), t.data_ptr(), N, C, S, float(alpha), float(beta), 1 if normalize else 0, ws.data_ptr(),
+                                  out.data_ptr(), stream_ptr()), "mis_bcedice_fwd")
+        ctx.save_for_backward(x, t, out)
+        ctx.cfg = (N, C, S, float(alpha), float(beta), 1 if normalize else 0, input.shape, input.dtype)
+        return out[0].clone(), out[2:].view(C, 4)[:, 3].clone()
+
+    @staticmethod
+    def backward(ctx, g, g_dice):
+        x, t, out = ctx.saved_tensors
+        N, C, S, alpha, beta, normalize, shape, dtype = ctx.cfg
+        dx = torch.empty_like(x)
+        gg = g.contiguous().float().reshape(1)
+        check(load().mis_bcedice_bwd(x.data_ptr(), t.data_ptr(), N, C, S, alpha, beta, normalize, out.data_ptr(), gg.data_ptr(), dx.data_ptr(),
+                                     stream_ptr()), "mis_bcedice_bwd")
+        return dx.view(shape).to(dtype), None, None, None, None
+
+
 def compute_per_channel_dice(input, target, epsilon=1e-6, weight=None):
-    assert input.size() == target.size(), "'input' and 'target' must have the same shape"
-    input = flatten(input)
-    target = flatten(target).float()
-    intersect = (input * target).sum(-1)
-    if weight is not None:
-        intersect = weight * intersect
-    denominator = (input * input).sum(-1) + (target * target).sum(-1)
-    return 2 * (intersect / denominator.clamp(min=epsilon))
+    """per-channel Dice of already normalised probabilities: 2 * sum(p*t) / clamp(sum(p^2) + sum(t^2), eps)   [losses.py:7-33]"""
+    if weight is not None or epsilon != 1e-6:
+        raise NotImplementedError("compute_per_channel_dice on MI355X: weight=None, epsilon=1e-6 (the reference's defaults) are built")
+    return _BCEDice.apply(input, target, 0.0, 1.0, False)[1]
 
 
 class _AbstractDiceLoss(nn.Module):
@@ -27,19 +66,17 @@ class _AbstractDiceLoss(nn.Module):
         super().__init__()
         self.register_buffer("weight", weight)
         assert normalization in ["sigmoid", "softmax", "none"]
-        if normalization == "sigmoid":
-            self.normalization = nn.Sigmoid()
-        elif normalization == "softmax":
-            self.normalization = nn.Softmax(dim=1)
-        else:
-            self.normalization = lambda x: x
+        if normalization == "softmax" or weight is not None:
+            raise NotImplementedError("Dice loss on MI355X: normalization 'sigmoid' (default) or 'none', weight=None are built")
+        self.normalization_name = normalization
+        self.normalization = nn.Sigmoid() if normalization == "sigmoid" else (lambda x: x)     # attribute kept for interface parity
 
     def dice(self, input, target, weight):
         raise NotImplementedError
 
     def forward(self, input, target):
-        input = self.normalization(input)
-        return 1. - torch.mean(self.dice(input, target, weight=self.weight))
+        # 1 - mean_c dice_c with the normalisation fused into the kernel
+        return _BCEDice.apply(input, target, 0.0, 1.0, self.normalization_name == "sigmoid")[0]
 
 
 class DiceLoss(_AbstractDiceLoss):
@@ -48,20 +85,27 @@ class DiceLoss(_AbstractDiceLoss):
 
 
 class BCEDiceLoss(nn.Module):
+    """alpha * BCEWithLogits + beta * Dice (sigmoid normalisation), one fused forward / backward"""
+
     def __init__(self, alpha, beta):
         super().__init__()
         self.alpha = alpha
-        self.bce = nn.BCEWithLogitsLoss()
+        self.bce = nn.BCEWithLogitsLoss()      # attributes kept for interface parity (reference :172-175)
         self.beta = beta
         self.dice = DiceLoss()
 
     def forward(self, input, target):
-        return self.alpha * self.bce(input, target) + self.beta * self.dice(input, target)
+        return _BCEDice.apply(input, target, self.alpha, self.beta, True)[0]
+
+
+class _BCEOnly(nn.Module):
+    def forward(self, input, target):
+        return _BCEDice.apply(input, target, 1.0, 0.0, True)[0]
 
 
 def get_loss_criterion(config):
-    """losses.py:273-306 (mutates config['loss'] via pop, like the reference); BCEDiceLoss / DiceLoss / BCEWithLogitsLoss /
-    CrossEntropyLoss are built, the rest of the factory is out of scope."""
+    """losses.py:273-306 (mutates config['loss'] via pop, like the reference); BCEDiceLoss / DiceLoss / BCEWithLogitsLoss are built on the
+    HIP loss kernels, the rest of the factory is out of scope."""
     assert "loss" in config, "Could not find loss function configuration"
     loss_config = config["loss"]
     name = loss_config.pop("name")
@@ -74,9 +118,7 @@ def get_loss_criterion(config):
     elif name == "DiceLoss":
         loss = DiceLoss(normalization=loss_config.get("normalization", "sigmoid"))
     elif name == "BCEWithLogitsLoss":
-        loss = nn.BCEWithLogitsLoss()
-    elif name == "CrossEntropyLoss":
-        loss = nn.CrossEntropyLoss()
+        loss = _BCEOnly()
     else:
         raise NotImplementedError(f"Unsupported loss function on the accelerated path: '{name}'")
     if torch.cuda.is_available():
