@@ -70,7 +70,7 @@ class _Conv3x3ReLU(torch.autograd.Function):
         dt = y.dtype
         g = _to_nhwc(gy, dt)
         # dL/d(pre-activation) = gy * (y > 0)
-        g = torch.where(y > 0, g, torch.zeros_like(g))
+        ops.relu_mask(g, y, g)
         dw = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=gy.device)
         db = torch.empty(Cout, dtype=torch.float32, device=gy.device)
         if Cin <= 4:
