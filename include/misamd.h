@@ -227,6 +227,14 @@ int mis_bcedice_fwd(const float* x, const float* t, int N, int C, long long S, f
 int mis_bcedice_bwd(const float* x, const float* t, int N, int C, long long S, float alpha, float beta, int normalize, const float* sums,
                     const float* grad_out, float* dx, void* stream);
 
+/* UNet 3+ skip paths (model/unet2d/unet.py:136-446): nn.MaxPool2d(k, k, ceil_mode=True) and nn.Upsample(scale_factor=s, mode='bilinear')
+ * (align_corners=False), NHWC, forward and backward.  Pool output grid = ceil(H/k) x ceil(W/k); bilinear output grid = H*s x W*s. */
+int mis_maxpoolk_fwd(int dtype, const void* x, int x_ld, void* y, int y_ld, int N, int H, int W, int C, int k, void* stream);
+int mis_maxpoolk_bwd(int dtype, const void* x, int x_ld, const void* dy, int dy_ld, void* dx, int dx_ld, int N, int H, int W, int C, int k, void* stream);
+int mis_bilinear_up_fwd(int dtype, const void* x, int x_ld, void* y, int y_ld, int N, int H, int W, int C, int scale, void* stream);
+size_t mis_bilinear_up_bwd_workspace_bytes(int N, int H, int W, int C, int scale);
+int mis_bilinear_up_bwd(int dtype, const void* dy, int dy_ld, void* dx, int dx_ld, int N, int H, int W, int C, int scale, float* workspace, void* stream);
+
 /* Evaluation metrics of the 2-D trainer (trainer/metrcis.py:61-109,153-168 `compute_metrics`): sigmoid with +1e-6 in the denominator,
  * threshold = global mean probability, per-sample IoU / Dice, mean over samples.  values, labels: fp32 (N, npix); out[3] = {iou, dice, threshold}.
  * values_are_logits = 0 with a given threshold gives compute_iou / compute_dice on ready-made predictions. */

@@ -270,6 +270,95 @@ class _Conv3x3BNReLU(torch.autograd.Function):
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None
 
 
+class _MaxPoolCeil(torch.autograd.Function):
+    """nn.MaxPool2d(k, k, ceil_mode=True) - reference unet.py:170-171 etc. (UNet 3+ encoder-to-decoder skips)"""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        _need_cuda(x)
+        dt = _compute_dtype()
+        N, C, H, W = x.shape
+        xin = _to_nhwc(x, dt)
+        y = torch.empty(N, (H + k - 1) // k, (W + k - 1) // k, C, dtype=dt, device=x.device)
+        ops.maxpoolk_fwd(xin, y, k)
+        ctx.save_for_backward(xin)
+        ctx.k = k
+        return _to_nchw(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (xin,) = ctx.saved_tensors
+        dx = torch.empty_like(xin)
+        ops.maxpoolk_bwd(xin, _to_nhwc(gy, xin.dtype), dx, ctx.k)
+        return _to_nchw(dx), None
+
+
+class _BilinearUp(torch.autograd.Function):
+    """nn.Upsample(scale_factor=s, mode='bilinear') (align_corners=False) - reference unet.py:190 etc."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        _need_cuda(x)
+        dt = _compute_dtype()
+        N, C, H, W = x.shape
+        y = torch.empty(N, H * s, W * s, C, dtype=dt, device=x.device)
+        ops.bilinear_up_fwd(_to_nhwc(x, dt), y, s)
+        ctx.cfg = (N, C, H, W, s, dt)
+        return _to_nchw(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, H, W, s, dt = ctx.cfg
+        dx = torch.empty(N, H, W, C, dtype=dt, device=gy.device)
+        ops.bilinear_up_bwd(_to_nhwc(gy, dt), dx, s)
+        return _to_nchw(dx), None
+
+
+class _Conv3x3Plain(torch.autograd.Function):
+    """y = conv2d(x, w, b, padding=1) with ANY number of output channels (the 3x3 output head of UNet 3+, unet.py:325): the filter bank is
+    zero-padded to 64 output channels for the MFMA kernels and the result sliced."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _need_cuda(x)
+        dt = _compute_dtype()
+        dev = x.device
+        N, Cin, H, W = x.shape
+        Cout, Cp, Op = w.shape[0], _pad64(Cin), _pad64(w.shape[0])
+        xin = torch.zeros(N, H, W, Cp, dtype=dt, device=dev) if Cp != Cin else torch.empty(N, H, W, Cp, dtype=dt, device=dev)
+        ops.nchw_to_nhwc(x.contiguous().float(), ops.View(xin, 0, Cin))
+        wpad = torch.zeros(Op, Cp, 3, 3, dtype=torch.float32, device=dev)
+        wpad[:Cout, :Cin] = w.detach()
+        bpad = torch.zeros(Op, dtype=torch.float32, device=dev)
+        bpad[:Cout] = b.detach()
+        wf = torch.empty(9, Op, Cp, dtype=dt, device=dev)
+        wd = torch.empty(9, Cp, Op, dtype=dt, device=dev)
+        ops.pack_conv_weight(wpad, wf, wd)
+        y = torch.empty(N, H, W, Op, dtype=dt, device=dev)
+        ops.conv_igemm(xin, wf, y, ksize=3, Cin=Cp, Cout=Op, bias=bpad)
+        ctx.save_for_backward(xin)
+        ctx.wd = wd
+        ctx.shape = (N, Cin, H, W, Cout, Cp, Op)
+        return _to_nchw(y)[:, :Cout].contiguous()                    # channel slice of the padded result (tensor plumbing)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (xin,) = ctx.saved_tensors
+        N, Cin, H, W, Cout, Cp, Op = ctx.shape
+        dt, dev = xin.dtype, gy.device
+        gfull = torch.zeros(N, Op, H, W, dtype=torch.float32, device=dev)
+        gfull[:, :Cout] = gy
+        g = _to_nhwc(gfull, dt)
+        dwp = torch.empty(Op, Cp, 3, 3, dtype=torch.float32, device=dev)
+        dbp = torch.empty(Op, dtype=torch.float32, device=dev)
+        ops.wgrad(xin, g, dwp, ksize=3, Cin=Cp, Cout=Op, dbias=dbp)
+        dxp = torch.empty(N, H, W, Cp, dtype=dt, device=dev)
+        ops.conv_igemm(g, ctx.wd, dxp, ksize=3, Cin=Op, Cout=Cp)
+        dx = torch.empty(N, Cin, H, W, dtype=torch.float32, device=dev)
+        ops.nhwc_to_nchw(ops.View(dxp, 0, Cin), dx)
+        return dx, dwp[:Cout, :Cin].contiguous(), dbp[:Cout].contiguous()
+
+
 class unetConv2(nn.Module):
     """n x [Conv2d(ks 3, s 1, p 1, bias) -> BatchNorm2d -> ReLU] (or without the norm), kaiming-normal init - the reference's
     "BN" double-conv block (model/unet2d/layers.py:8-46).  Containers are stock nn.Sequential(Conv2d, BatchNorm2d, ReLU) named
@@ -300,13 +389,16 @@ class unetConv2(nn.Module):
             if not self.is_batchnorm:
                 x = _Conv3x3ReLU.apply(x, conv.weight, conv.bias)
                 continue
-            bn = seq[1]
-            training = self.training or not bn.track_running_stats
-            if self.training and bn.track_running_stats:
-                bn.num_batches_tracked += 1
-            x = _Conv3x3BNReLU.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
-                                     bn.eps, bn.momentum)
+            x = conv_bn_relu(x, conv, seq[1], self.training)
         return x
+
+
+def conv_bn_relu(x, conv, bn, module_training):
+    """relu(bn(conv3x3(x))) through the HIP path with nn.BatchNorm2d's train / eval semantics (running statistics, num_batches_tracked)"""
+    training = module_training or not bn.track_running_stats
+    if module_training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    return _Conv3x3BNReLU.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, bn.momentum)
 
 
 unetUp = _out_of_scope("unetUp", "model/unet2d/layers.py:49-74")

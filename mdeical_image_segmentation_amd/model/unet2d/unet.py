@@ -17,7 +17,9 @@ from transformers.utils import ModelOutput
 from ... import ops
 from ..._lib import MisError
 from ...engine2d import UNet2DEngine
-from .layers import CropAndConcat, DoubleConvolution, DownSample, UpSample
+from .init_weights import init_weights
+from .layers import (CropAndConcat, DoubleConvolution, DownSample, UpSample, _BilinearUp, _Conv3x3Plain, _MaxPool2, _MaxPoolCeil, conv_bn_relu,
+                     unetConv2)
 
 
 def _dtype_from(name):
@@ -146,6 +148,73 @@ class UNetModel(PreTrainedModel):
         return UNetModelOutput(loss=loss, logits=logits, labels=labels)
 
 
+_FILTERS = [64, 128, 256, 512, 1024]
+
+
+class UNet_3Plus(nn.Module):
+    """UNet 3+ (reference model/unet2d/unet.py:136-446): 5 `unetConv2` encoder blocks; every decoder stage d = 4..1 fuses five 64-channel
+    branches - encoder maps h_i (i < d) through MaxPool2d(2^(d-i), ceil_mode=True), h_d itself, and the deeper decoder maps hd_j (j > d)
+    through bilinear up-sampling by 2^(j-d) - each through Conv3x3 + BatchNorm + ReLU, concatenated (320 channels) and fused by another
+    Conv3x3 + BN + ReLU; a 3x3 conv produces the logits.  Same module names, registration order (hence state-dict keys and seeded
+    kaiming init) as the reference; every operator runs on the HIP kernels through the per-layer autograd functions of layers.py."""
+
+    def __init__(self, in_channels=3, n_classes=1, feature_scale=4, is_deconv=True, is_batchnorm=True):
+        super().__init__()
+        self.is_deconv, self.in_channels, self.is_batchnorm, self.feature_scale = is_deconv, in_channels, is_batchnorm, feature_scale
+        f = _FILTERS
+        for i in range(5):
+            setattr(self, f"conv{i + 1}", unetConv2(in_channels if i == 0 else f[i - 1], f[i], is_batchnorm))
+            if i < 4:
+                setattr(self, f"maxpool{i + 1}", nn.MaxPool2d(kernel_size=2))
+        self.CatChannels, self.CatBlocks = f[0], 5
+        self.UpChannels = self.CatChannels * self.CatBlocks
+        for d in (4, 3, 2, 1):
+            for i in range(1, 6):
+                name, cin = self._branch(d, i)
+                if i < d:
+                    setattr(self, name, nn.MaxPool2d(2 ** (d - i), 2 ** (d - i), ceil_mode=True))
+                elif i > d:
+                    setattr(self, name, nn.Upsample(scale_factor=2 ** (i - d), mode="bilinear"))
+                setattr(self, name + "_conv", nn.Conv2d(cin, self.CatChannels, 3, padding=1))
+                setattr(self, name + "_bn", nn.BatchNorm2d(self.CatChannels))
+                setattr(self, name + "_relu", nn.ReLU(inplace=True))
+            setattr(self, f"conv{d}d_1", nn.Conv2d(self.UpChannels, self.UpChannels, 3, padding=1))
+            setattr(self, f"bn{d}d_1", nn.BatchNorm2d(self.UpChannels))
+            setattr(self, f"relu{d}d_1", nn.ReLU(inplace=True))
+        self.outconv1 = nn.Conv2d(self.UpChannels, n_classes, 3, padding=1)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.BatchNorm2d)):
+                init_weights(m, init_type="kaiming")
+
+    def _branch(self, d, i):
+        if i < d:
+            return f"h{i}_PT_hd{d}", _FILTERS[i - 1]
+        if i == d:
+            return f"h{i}_Cat_hd{d}", _FILTERS[i - 1]
+        return f"hd{i}_UT_hd{d}", (_FILTERS[4] if i == 5 else self.UpChannels)
+
+    def forward(self, inputs):
+        if inputs.device.type != "cuda":
+            raise MisError(f"UNet_3Plus runs on MI355X only: got input on {inputs.device} (no CPU fallback)")
+        h = {1: self.conv1(inputs)}
+        for i in range(2, 6):
+            h[i] = getattr(self, f"conv{i}")(_MaxPool2.apply(h[i - 1]))
+        hd = {5: h[5]}
+        for d in (4, 3, 2, 1):
+            parts = []
+            for i in range(1, 6):
+                name, _ = self._branch(d, i)
+                if i < d:
+                    src = _MaxPoolCeil.apply(h[i], 2 ** (d - i))
+                elif i == d:
+                    src = h[i]
+                else:
+                    src = _BilinearUp.apply(hd[i], 2 ** (i - d))
+                parts.append(conv_bn_relu(src, getattr(self, name + "_conv"), getattr(self, name + "_bn"), self.training))
+            hd[d] = conv_bn_relu(torch.cat(parts, 1), getattr(self, f"conv{d}d_1"), getattr(self, f"bn{d}d_1"), self.training)
+        return _Conv3x3Plain.apply(hd[1], self.outconv1.weight, self.outconv1.bias)
+
+
 def _stub(name):
     class _S(nn.Module):
         def __init__(self, *a, **k):
@@ -154,6 +223,5 @@ def _stub(name):
     return _S
 
 
-UNet_3Plus = _stub("UNet_3Plus")
 UNet_3Plus_DeepSup = _stub("UNet_3Plus_DeepSup")
 UNet_3Plus_DeepSup_CGM = _stub("UNet_3Plus_DeepSup_CGM")

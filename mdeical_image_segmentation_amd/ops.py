@@ -425,3 +425,29 @@ def convt3_im2col(gu, gcols):
     gu = _v(gu)
     N, d, h, w = gcols.shape[:4]
     check(lib.mis_convt3_im2col(dtype_code(gcols.dtype), gu.ptr, gu.ld, gcols.data_ptr(), N, d, h, w, gu.C, stream_ptr()), "mis_convt3_im2col")
+
+
+def maxpoolk_fwd(x, y, k):
+    lib = load()
+    x, y = _v(x), _v(y)
+    check(lib.mis_maxpoolk_fwd(dtype_code(x.dtype), x.ptr, x.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, k, stream_ptr()), "mis_maxpoolk_fwd")
+
+
+def maxpoolk_bwd(x, dy, dx, k):
+    lib = load()
+    x, dy, dx = _v(x), _v(dy), _v(dx)
+    check(lib.mis_maxpoolk_bwd(dtype_code(x.dtype), x.ptr, x.ld, dy.ptr, dy.ld, dx.ptr, dx.ld, x.N, x.H, x.W, x.C, k, stream_ptr()), "mis_maxpoolk_bwd")
+
+
+def bilinear_up_fwd(x, y, scale):
+    lib = load()
+    x, y = _v(x), _v(y)
+    check(lib.mis_bilinear_up_fwd(dtype_code(x.dtype), x.ptr, x.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, scale, stream_ptr()), "mis_bilinear_up_fwd")
+
+
+def bilinear_up_bwd(dy, dx, scale):
+    lib = load()
+    dy, dx = _v(dy), _v(dx)
+    ws = workspace(lib.mis_bilinear_up_bwd_workspace_bytes(dx.N, dx.H, dx.W, dx.C, scale), dx.t.device, "bilinear")
+    check(lib.mis_bilinear_up_bwd(dtype_code(dx.dtype), dy.ptr, dy.ld, dx.ptr, dx.ld, dx.N, dx.H, dx.W, dx.C, scale, ws.data_ptr(), stream_ptr()),
+          "mis_bilinear_up_bwd")

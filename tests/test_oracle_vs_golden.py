@@ -224,3 +224,31 @@ def test_patch_tiled_predictor_oracle():
     top2 = np.sort(res, axis=0)[-2:]
     near = (top2[1] - top2[0]) < 1e-4
     assert np.array_equal(seg[~near], g["seg"][~near])
+
+
+def test_unet3plus_oracle():
+    """oracle.unet3plus_oracle against the real reference UNet_3Plus (g9_unet3plus.npz); parameters regenerated from the seed by the mirror
+    module (bit-identical seeded init is asserted), which is a plain container here (no kernels run on the CPU)."""
+    from oracle import unet3plus_oracle as o3p
+    from mdeical_image_segmentation_amd.model.unet2d.unet import UNet_3Plus
+    g = load_golden("g9_unet3plus.npz")
+    torch.manual_seed(3)
+    m = UNet_3Plus(3, 1)
+    assert [k for k, _ in m.named_parameters()] == [str(n) for n in g["names"]]
+    assert list(m.state_dict().keys()) == [str(k) for k in g["state_keys"]]
+    ps = np.stack([stat(p) for _, p in m.named_parameters()])
+    assert np.array_equal(ps[:, 3:], g["param_stats"][:, 3:]), "seeded init differs from the reference"
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    for k in sd:
+        if sd[k].is_floating_point() and "running" not in k:
+            sd[k].requires_grad_(True)
+    x = T(g["x"]).requires_grad_(True)
+    y = o3p.forward(sd, x, training=True)
+    assert torch.allclose(y, T(g["y"]), atol=2e-5), (y - T(g["y"])).abs().max()
+    y.backward(T(g["gy"]))
+    assert torch.allclose(x.grad, T(g["gx"]), rtol=1e-3, atol=1e-6)
+    assert torch.allclose(sd["outconv1.weight"].grad, T(g["g_outconv_w"]), rtol=1e-3, atol=1e-5)
+    assert torch.allclose(sd["conv1.conv1.1.running_mean"], T(g["rm_conv1"]), atol=1e-6)
+    with torch.no_grad():
+        ye = o3p.forward({k: v.detach() for k, v in sd.items()}, T(g["xe"]), training=False)
+    assert torch.allclose(ye, T(g["ye"]), atol=2e-5)
