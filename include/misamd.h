@@ -235,6 +235,16 @@ int mis_bilinear_up_fwd(int dtype, const void* x, int x_ld, void* y, int y_ld, i
 size_t mis_bilinear_up_bwd_workspace_bytes(int N, int H, int W, int C, int scale);
 int mis_bilinear_up_bwd(int dtype, const void* dy, int dy_ld, void* dx, int dx_ld, int N, int H, int W, int C, int scale, float* workspace, void* stream);
 
+/* SegmentationLoss of the UNet 3+ path (model/unet2d/loss.py:21-70): F1Loss + MSSSIMLoss (pytorch_msssim 1.0.0 MS_SSIM, data_range 1, 5 scales,
+ * 11-tap Gaussian) + IoULoss on single-channel (logits, targets) fp32 (N, H, W); min(H, W) > 160.
+ * fwd: out[0] = w_f1*F1 + w_msssim*MSSSIM + w_iou*IoU (SegmentationLoss: all 1), out[1..3] = the three terms, out[4..5] internal;
+ *      the workspace keeps the state for bwd.
+ * bwd (same workspace / out): dlogits = grad_out[0] * dLoss/dlogits. */
+size_t mis_segloss_workspace_bytes(int N, int H, int W);
+int mis_segloss_fwd(const float* logits, const float* target, int N, int H, int W, float w_f1, float w_msssim, float w_iou, void* workspace,
+                    float* out /*[8]*/, void* stream);
+int mis_segloss_bwd(const float* target, int N, int H, int W, void* workspace, const float* out, const float* grad_out, float* dlogits, void* stream);
+
 /* Evaluation metrics of the 2-D trainer (trainer/metrcis.py:61-109,153-168 `compute_metrics`): sigmoid with +1e-6 in the denominator,
  * threshold = global mean probability, per-sample IoU / Dice, mean over samples.  values, labels: fp32 (N, npix); out[3] = {iou, dice, threshold}.
  * values_are_logits = 0 with a given threshold gives compute_iou / compute_dice on ready-made predictions. */

@@ -111,7 +111,7 @@ class UNetModelOutput(ModelOutput):
 
 class UNetConfig(PretrainedConfig):
     def __init__(self, in_channels=1, out_channels=1, unet_type="UNet", compute_dtype=None, **kwargs):
-        """unet_type: only "UNet" is accelerated (UNet_3Plus* are SURVEY.md §8f "next" rows).
+        """unet_type: "UNet" (fused engine) or "UNet_3Plus" (per-layer HIP path + SegmentationLoss kernels); the DeepSup variants raise.
         compute_dtype: "f32" (default, the parity mode) or "bf16"; env MISAMD_DTYPE overrides the default."""
         super().__init__(**kwargs)
         self.in_channels = in_channels
@@ -134,13 +134,21 @@ class UNetModel(PreTrainedModel):
             self.unet = UNet(config.in_channels, config.out_channels, compute_dtype=getattr(config, "compute_dtype", None))
             # kept for interface parity (reference unet.py:1184-1188); the loss itself is computed in the head kernel
             self.criterion = nn.CrossEntropyLoss() if config.out_channels > 1 else nn.BCEWithLogitsLoss()
+        elif config.unet_type == "UNet_3Plus":
+            from .loss import SegmentationLoss
+            self.unet = UNet_3Plus(config.in_channels, config.out_channels)
+            self.criterion = SegmentationLoss()
         else:
-            raise NotImplementedError(f"unet_type={config.unet_type!r}: only 'UNet' is built (UNet_3Plus* are out of the hot-path scope)")
+            raise NotImplementedError(f"unet_type={config.unet_type!r}: 'UNet' and 'UNet_3Plus' are built (the deep-supervision variants are not)")
 
     def _init_weights(self, module):   # PyTorch default init already applied by the containers (as in the reference)
         return
 
     def forward(self, images: torch.Tensor, labels: torch.Tensor = None, **kwargs):
+        if self.config.unet_type == "UNet_3Plus":          # per-layer HIP path + the fused SegmentationLoss kernels (reference :1209-1213)
+            logits = self.unet(images)
+            loss = self.criterion(logits, labels) if labels is not None else None
+            return UNetModelOutput(loss=loss, logits=logits, labels=labels)
         if labels is None:
             logits = self.unet(images, None)
             return UNetModelOutput(loss=None, logits=logits, labels=None)
