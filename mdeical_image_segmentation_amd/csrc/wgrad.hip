@@ -494,11 +494,18 @@ static int wg_launch(const MisWgradDesc* d, const WgPlan& p, hipStream_t stream)
     hipLaunchKernelGGL((wgrad_kernel<T, G, USE_TR>), dim3((unsigned)grid), dim3(256), lds, stream, a);
     MIS_LAUNCH_CHECK("wgrad");
     if (d->reduce_stream != nullptr && d->reduce_stream != (void*)stream) {   // reductions go to the side stream, after the MFMA kernel
-        hipEvent_t ev;
-        MIS_REQUIRE(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, MIS_EHIP, "wgrad: hipEventCreate failed");
+        // events come from a small ring that lives as long as the process: an event destroyed right after hipStreamWaitEvent was observed
+        // to let the waiting stream run ahead of the recorded work now and then (nondeterministic gradients)
+        static hipEvent_t ring[64];
+        static bool ring_ok[64] = {false};
+        static unsigned ring_pos = 0;
+        const unsigned slot = ring_pos++ % 64u;
+        if (!ring_ok[slot]) {
+            MIS_REQUIRE(hipEventCreateWithFlags(&ring[slot], hipEventDisableTiming) == hipSuccess, MIS_EHIP, "wgrad: hipEventCreate failed");
+            ring_ok[slot] = true;
+        }
         const hipStream_t side = reinterpret_cast<hipStream_t>(d->reduce_stream);
-        const bool ok = hipEventRecord(ev, stream) == hipSuccess && hipStreamWaitEvent(side, ev, 0) == hipSuccess;
-        (void)hipEventDestroy(ev);          // released by the runtime once it has completed
+        const bool ok = hipEventRecord(ring[slot], stream) == hipSuccess && hipStreamWaitEvent(side, ring[slot], 0) == hipSuccess;
         MIS_REQUIRE(ok, MIS_EHIP, "wgrad: could not order the reduction stream after the MFMA kernel");
         stream = side;
     }

@@ -125,6 +125,9 @@ class _SideReduce:
         self.per_device = {}
 
     def state(self, device):
+        device = torch.device(device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         st = self.per_device.get(str(device))
         if st is None:
             st = {"stream": torch.cuda.Stream(device=device), "events": [None, None], "n": 0}
@@ -138,6 +141,8 @@ _side = _SideReduce()
 def wgrad_join(device=None):
     """Make the current stream wait for every side-stream reduction issued so far (before dw / dbias are read)."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:                      # "cuda" and "cuda:0" are the same device: the table is keyed by the indexed form
+        dev = torch.device("cuda", torch.cuda.current_device())
     st = _side.per_device.get(str(dev))
     if st is not None:
         torch.cuda.current_stream(dev).wait_stream(st["stream"])
@@ -174,6 +179,9 @@ def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alph
         st = _side.state(dy.t.device)
         slot = st["n"] & 1
         st["n"] += 1
+        cur = _ws_cache.get((f"wgrad{slot}", str(dy.t.device)))
+        if cur is None or cur.numel() * 4 < need:     # growing = freeing the old buffer: no side-stream reduction may still be reading it
+            st["stream"].synchronize()
         ws = workspace(need, dy.t.device, f"wgrad{slot}")
         if st["events"][slot] is not None:            # the reduction that last read this workspace must be done
             torch.cuda.current_stream(dy.t.device).wait_event(st["events"][slot])
