@@ -202,6 +202,11 @@ def _pad64(c):
     return (c + 63) // 64 * 64
 
 
+def _pad_chunk(c, dt):
+    e = 8 if dt == torch.bfloat16 else 4
+    return (c + e - 1) // e * e
+
+
 class _Conv3x3BNReLU(torch.autograd.Function):
     """y = relu(batch_norm(conv2d(x, w, b, padding=1))) - reference layers.py:17-25 (one `conv%d` Sequential of unetConv2).
     Input channels are zero-padded to a multiple of 64 (the K tile of the MFMA kernels); running statistics are updated in place."""
@@ -301,17 +306,26 @@ class _BilinearUp(torch.autograd.Function):
         _need_cuda(x)
         dt = _compute_dtype()
         N, C, H, W = x.shape
-        y = torch.empty(N, H * s, W * s, C, dtype=dt, device=x.device)
-        ops.bilinear_up_fwd(_to_nhwc(x, dt), y, s)
-        ctx.cfg = (N, C, H, W, s, dt)
-        return _to_nchw(y)
+        Cp = _pad_chunk(C, dt)                  # the kernels move 16-byte channel chunks: few-channel maps (deep-supervision logits) are padded
+        xin = torch.zeros(N, H, W, Cp, dtype=dt, device=x.device) if Cp != C else torch.empty(N, H, W, Cp, dtype=dt, device=x.device)
+        ops.nchw_to_nhwc(x.contiguous().float(), ops.View(xin, 0, C))
+        y = torch.empty(N, H * s, W * s, Cp, dtype=dt, device=x.device)
+        ops.bilinear_up_fwd(xin, y, s)
+        ctx.cfg = (N, C, Cp, H, W, s, dt)
+        out = torch.empty(N, C, H * s, W * s, dtype=torch.float32, device=x.device)
+        ops.nhwc_to_nchw(ops.View(y, 0, C), out)
+        return out
 
     @staticmethod
     def backward(ctx, gy):
-        N, C, H, W, s, dt = ctx.cfg
-        dx = torch.empty(N, H, W, C, dtype=dt, device=gy.device)
-        ops.bilinear_up_bwd(_to_nhwc(gy, dt), dx, s)
-        return _to_nchw(dx), None
+        N, C, Cp, H, W, s, dt = ctx.cfg
+        g = torch.zeros(N, H * s, W * s, Cp, dtype=dt, device=gy.device) if Cp != C else torch.empty(N, H * s, W * s, Cp, dtype=dt, device=gy.device)
+        ops.nchw_to_nhwc(gy.contiguous().float(), ops.View(g, 0, C))
+        dxp = torch.empty(N, H, W, Cp, dtype=dt, device=gy.device)
+        ops.bilinear_up_bwd(g, dxp, s)
+        dx = torch.empty(N, C, H, W, dtype=torch.float32, device=gy.device)
+        ops.nhwc_to_nchw(ops.View(dxp, 0, C), dx)
+        return dx, None
 
 
 class _Conv3x3Plain(torch.autograd.Function):

@@ -111,7 +111,7 @@ class UNetModelOutput(ModelOutput):
 
 class UNetConfig(PretrainedConfig):
     def __init__(self, in_channels=1, out_channels=1, unet_type="UNet", compute_dtype=None, **kwargs):
-        """unet_type: "UNet" (fused engine) or "UNet_3Plus" (per-layer HIP path + SegmentationLoss kernels); the DeepSup variants raise.
+        """unet_type: "UNet" (fused engine), "UNet_3Plus" / "UNet_3Plus_DeepSup" (per-layer HIP path + SegmentationLoss kernels); the CGM variant raises.
         compute_dtype: "f32" (default, the parity mode) or "bf16"; env MISAMD_DTYPE overrides the default."""
         super().__init__(**kwargs)
         self.in_channels = in_channels
@@ -134,21 +134,25 @@ class UNetModel(PreTrainedModel):
             self.unet = UNet(config.in_channels, config.out_channels, compute_dtype=getattr(config, "compute_dtype", None))
             # kept for interface parity (reference unet.py:1184-1188); the loss itself is computed in the head kernel
             self.criterion = nn.CrossEntropyLoss() if config.out_channels > 1 else nn.BCEWithLogitsLoss()
-        elif config.unet_type == "UNet_3Plus":
+        elif config.unet_type in ("UNet_3Plus", "UNet_3Plus_DeepSup"):
             from .loss import SegmentationLoss
-            self.unet = UNet_3Plus(config.in_channels, config.out_channels)
+            cls = UNet_3Plus if config.unet_type == "UNet_3Plus" else UNet_3Plus_DeepSup
+            self.unet = cls(config.in_channels, config.out_channels)
             self.criterion = SegmentationLoss()
         else:
-            raise NotImplementedError(f"unet_type={config.unet_type!r}: 'UNet' and 'UNet_3Plus' are built (the deep-supervision variants are not)")
+            raise NotImplementedError(f"unet_type={config.unet_type!r}: 'UNet', 'UNet_3Plus' and 'UNet_3Plus_DeepSup' are built")
 
     def _init_weights(self, module):   # PyTorch default init already applied by the containers (as in the reference)
         return
 
     def forward(self, images: torch.Tensor, labels: torch.Tensor = None, **kwargs):
-        if self.config.unet_type == "UNet_3Plus":          # per-layer HIP path + the fused SegmentationLoss kernels (reference :1209-1213)
-            logits = self.unet(images)
-            loss = self.criterion(logits, labels) if labels is not None else None
-            return UNetModelOutput(loss=loss, logits=logits, labels=labels)
+        if self.config.unet_type != "UNet":                # per-layer HIP path + the fused SegmentationLoss kernels (reference :1199-1213)
+            out = self.unet(images)
+            if isinstance(out, tuple):                        # deep supervision: the loss is summed over the five maps, logits = d1
+                loss = sum(self.criterion(d, labels) for d in out) if labels is not None else None
+                return UNetModelOutput(loss=loss, logits=out[0], labels=labels)
+            loss = self.criterion(out, labels) if labels is not None else None
+            return UNetModelOutput(loss=loss, logits=out, labels=labels)
         if labels is None:
             logits = self.unet(images, None)
             return UNetModelOutput(loss=None, logits=logits, labels=None)
@@ -159,12 +163,15 @@ class UNetModel(PreTrainedModel):
 _FILTERS = [64, 128, 256, 512, 1024]
 
 
-class UNet_3Plus(nn.Module):
-    """UNet 3+ (reference model/unet2d/unet.py:136-446): 5 `unetConv2` encoder blocks; every decoder stage d = 4..1 fuses five 64-channel
-    branches - encoder maps h_i (i < d) through MaxPool2d(2^(d-i), ceil_mode=True), h_d itself, and the deeper decoder maps hd_j (j > d)
-    through bilinear up-sampling by 2^(j-d) - each through Conv3x3 + BatchNorm + ReLU, concatenated (320 channels) and fused by another
-    Conv3x3 + BN + ReLU; a 3x3 conv produces the logits.  Same module names, registration order (hence state-dict keys and seeded
-    kaiming init) as the reference; every operator runs on the HIP kernels through the per-layer autograd functions of layers.py."""
+class _UNet3PlusBase(nn.Module):
+    """UNet 3+ (reference model/unet2d/unet.py:136-446 and, with deep supervision, :454-787): 5 `unetConv2` encoder blocks; every decoder
+    stage d = 4..1 fuses five 64-channel branches - encoder maps h_i (i < d) through MaxPool2d(2^(d-i), ceil_mode=True), h_d itself, and the
+    deeper decoder maps hd_j (j > d) through bilinear up-sampling by 2^(j-d) - each through Conv3x3 + BatchNorm + ReLU, concatenated (320
+    channels) and fused by another Conv3x3 + BN + ReLU; 3x3 convs produce the logits (one, or one per decoder stage up-sampled to full
+    resolution).  Same module names, registration order (hence state-dict keys and seeded kaiming init) as the reference; every operator runs
+    on the HIP kernels through the per-layer autograd functions of layers.py."""
+
+    _deep_supervision = False
 
     def __init__(self, in_channels=3, n_classes=1, feature_scale=4, is_deconv=True, is_batchnorm=True):
         super().__init__()
@@ -189,7 +196,13 @@ class UNet_3Plus(nn.Module):
             setattr(self, f"conv{d}d_1", nn.Conv2d(self.UpChannels, self.UpChannels, 3, padding=1))
             setattr(self, f"bn{d}d_1", nn.BatchNorm2d(self.UpChannels))
             setattr(self, f"relu{d}d_1", nn.ReLU(inplace=True))
-        self.outconv1 = nn.Conv2d(self.UpChannels, n_classes, 3, padding=1)
+        if self._deep_supervision:
+            for k in (6, 5, 4, 3, 2):                                   # reference :643-648 (upscore6 is registered but never used)
+                setattr(self, f"upscore{k}", nn.Upsample(scale_factor=2 ** (k - 1), mode="bilinear"))
+            for k in range(1, 6):
+                setattr(self, f"outconv{k}", nn.Conv2d(f[4] if k == 5 else self.UpChannels, n_classes, 3, padding=1))
+        else:
+            self.outconv1 = nn.Conv2d(self.UpChannels, n_classes, 3, padding=1)
         for m in self.modules():
             if isinstance(m, (nn.Conv2d, nn.BatchNorm2d)):
                 init_weights(m, init_type="kaiming")
@@ -201,9 +214,9 @@ class UNet_3Plus(nn.Module):
             return f"h{i}_Cat_hd{d}", _FILTERS[i - 1]
         return f"hd{i}_UT_hd{d}", (_FILTERS[4] if i == 5 else self.UpChannels)
 
-    def forward(self, inputs):
+    def _decode(self, inputs):
         if inputs.device.type != "cuda":
-            raise MisError(f"UNet_3Plus runs on MI355X only: got input on {inputs.device} (no CPU fallback)")
+            raise MisError(f"{type(self).__name__} runs on MI355X only: got input on {inputs.device} (no CPU fallback)")
         h = {1: self.conv1(inputs)}
         for i in range(2, 6):
             h[i] = getattr(self, f"conv{i}")(_MaxPool2.apply(h[i - 1]))
@@ -220,7 +233,28 @@ class UNet_3Plus(nn.Module):
                     src = _BilinearUp.apply(hd[i], 2 ** (i - d))
                 parts.append(conv_bn_relu(src, getattr(self, name + "_conv"), getattr(self, name + "_bn"), self.training))
             hd[d] = conv_bn_relu(torch.cat(parts, 1), getattr(self, f"conv{d}d_1"), getattr(self, f"bn{d}d_1"), self.training)
-        return _Conv3x3Plain.apply(hd[1], self.outconv1.weight, self.outconv1.bias)
+        return hd
+
+    def _head(self, hd, k):
+        conv = getattr(self, f"outconv{k}")
+        return _Conv3x3Plain.apply(hd[k], conv.weight, conv.bias)
+
+
+class UNet_3Plus(_UNet3PlusBase):
+    def forward(self, inputs):
+        return self._head(self._decode(inputs), 1)
+
+
+class UNet_3Plus_DeepSup(_UNet3PlusBase):
+    """five logit maps d1..d5 at full resolution (reference :768-787): outconv_k on decoder stage k, bilinear up-sampling by 2^(k-1)"""
+    _deep_supervision = True
+
+    def forward(self, inputs):
+        hd = self._decode(inputs)
+        outs = [self._head(hd, 1)]
+        for k in range(2, 6):
+            outs.append(_BilinearUp.apply(self._head(hd, k), 2 ** (k - 1)))
+        return tuple(outs)
 
 
 def _stub(name):
@@ -231,5 +265,4 @@ def _stub(name):
     return _S
 
 
-UNet_3Plus_DeepSup = _stub("UNet_3Plus_DeepSup")
 UNet_3Plus_DeepSup_CGM = _stub("UNet_3Plus_DeepSup_CGM")

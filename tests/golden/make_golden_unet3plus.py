@@ -43,6 +43,20 @@ def main():
     with torch.no_grad():
         xe = torch.randn(1, 3, 32, 32, generator=g)
         out["xe"], out["ye"] = xe, net(xe)
+    # deep supervision (unet.py:454-787): five full-resolution logit maps
+    torch.manual_seed(4)
+    ds = U.UNet_3Plus_DeepSup(3, 1).train()
+    xd = torch.randn(1, 3, 32, 48, generator=g)
+    outs = ds(xd)
+    sum(o.sum() * (i + 1) for i, o in enumerate(outs)).backward()
+    out["ds_x"] = xd
+    out["ds_names"] = np.array([k for k, _ in ds.named_parameters()])
+    out["ds_state_keys"] = np.array(list(ds.state_dict().keys()))
+    out["ds_param_stats"] = np.stack([stat(p) for _, p in ds.named_parameters()])
+    for i, o in enumerate(outs):
+        out[f"ds_d{i + 1}"] = o
+    for k in range(1, 6):
+        out[f"ds_g_outconv{k}_w"] = getattr(ds, f"outconv{k}").weight.grad
     out = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()}
     np.savez_compressed(os.path.join(HERE, "g9_unet3plus.npz"), **out)
     print("wrote g9_unet3plus.npz", sum(a.nbytes for a in out.values()) // 1024, "KiB;", len(names), "parameters")

@@ -45,7 +45,7 @@ def test_cpu_input_fails_loudly(surface):
     with pytest.raises(MisError):
         m(images=torch.zeros(1, 1, 16, 16), labels=torch.zeros(1, 16, 16, dtype=torch.long))
     with pytest.raises(NotImplementedError):
-        unet2d.UNetModel(unet2d.UNetConfig(1, 1, "UNet_3Plus_DeepSup"))
+        unet2d.UNetModel(unet2d.UNetConfig(1, 1, "UNet_3Plus_DeepSup_CGM"))
 
 
 @pytest.mark.gpu

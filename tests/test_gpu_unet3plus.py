@@ -109,3 +109,26 @@ def test_unet3plus_matches_reference_golden():
     de = (ye.cpu() - T(g["ye"])).abs().max().item()
     assert de < 2e-4 * max(1.0, float(np.abs(g["ye"]).max())), de
     print(f"UNet 3+: train logits max|diff| {d:.3g}, worst (HIP err / reference-fp32 err) vs fp64 {worst:.2f}, eval max|diff| {de:.3g}")
+
+
+def test_unet3plus_deepsup_matches_reference_golden():
+    from mdeical_image_segmentation_amd.model.unet2d.unet import UNet_3Plus_DeepSup
+    g = load_golden("g9_unet3plus.npz")
+    torch.manual_seed(4)
+    m = UNet_3Plus_DeepSup(3, 1)
+    assert [k for k, _ in m.named_parameters()] == [str(n) for n in g["ds_names"]]
+    assert list(m.state_dict().keys()) == [str(k) for k in g["ds_state_keys"]]
+    ps = np.stack([stat(p) for _, p in m.named_parameters()])
+    assert np.array_equal(ps[:, 3:], g["ds_param_stats"][:, 3:]), "seeded init differs from the reference"
+    m = m.cuda().train()
+    outs = m(T(g["ds_x"]).cuda())
+    assert len(outs) == 5
+    for i, o in enumerate(outs):
+        ref = T(g[f"ds_d{i + 1}"])
+        assert o.shape == ref.shape
+        assert (o.detach().cpu() - ref).abs().max().item() < 3e-4 * max(1.0, ref.abs().max().item()), i
+    sum(o.sum() * (i + 1) for i, o in enumerate(outs)).backward()
+    for k in range(1, 6):
+        ref = T(g[f"ds_g_outconv{k}_w"])
+        got = getattr(m, f"outconv{k}").weight.grad.cpu()
+        assert (got - ref).norm().item() <= 5e-3 * ref.norm().item() + 1e-6, k
