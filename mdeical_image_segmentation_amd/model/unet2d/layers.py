@@ -1,7 +1,8 @@
 """Mirror of the reference's 2-D building blocks (model/unet2d/layers.py:103-192) on the HIP kernels.
 
 Each module keeps stock parameter containers (nn.Conv2d / nn.ConvTranspose2d: identical state-dict keys and
-shapes) but its forward/backward run through libmisamd: NCHW fp32 at the module boundary, NHWC inside.
+shapes) but its forward/backward run through libmisamd.  Inputs are (N, C, H, W) tensors of any layout; outputs are (N, C, H, W)-shaped
+channels_last tensors in the compute dtype, i.e. NHWC memory, so that chained layers hand activations over without a layout pass.
 The fused whole-network path (engine2d.UNet2DEngine, used by UNet / UNetModel) does not go through these
 per-layer functions; they exist so that the blocks remain usable on their own.
 CUDA tensors only - there is no CPU fallback."""
@@ -24,18 +25,28 @@ def _need_cuda(x):
         raise MisError("mdeical_image_segmentation_amd runs on MI355X only: got a tensor on %s (no CPU fallback)" % x.device)
 
 
-def _to_nhwc(x, dtype):
+def _to_nhwc(x, dtype, Cp=None):
+    """(N, C, H, W) tensor -> contiguous (N, H, W, Cp) tensor of the compute dtype (Cp >= C: zero-padded channels).
+    A channels_last tensor that already has the compute dtype - what every function below RETURNS - is used as it is (a free view):
+    activations cross layer boundaries in NHWC memory, only the network input (NCHW fp32) is converted by a kernel."""
     N, C, H, W = x.shape
-    y = torch.empty(N, H, W, C, dtype=dtype, device=x.device)
-    ops.nchw_to_nhwc(x.contiguous().float(), y)
+    Cp = C if Cp is None else Cp
+    if Cp == C and x.dtype == dtype:
+        v = x.permute(0, 2, 3, 1)
+        if v.is_contiguous():
+            return v
+    y = torch.zeros(N, H, W, Cp, dtype=dtype, device=x.device) if Cp != C else torch.empty(N, H, W, Cp, dtype=dtype, device=x.device)
+    if x.is_contiguous() and x.dtype == torch.float32:
+        ops.nchw_to_nhwc(x, ops.View(y, 0, C))              # NCHW fp32 (the network input): layout kernel
+    else:
+        y[..., :C].copy_(x.permute(0, 2, 3, 1))             # any other stride pattern (e.g. a channel slice handed back by torch.cat's backward)
     return y
 
 
-def _to_nchw(y):
-    N, H, W, C = y.shape
-    x = torch.empty(N, C, H, W, dtype=torch.float32, device=y.device)
-    ops.nhwc_to_nchw(y, x)
-    return x
+def _to_nchw(y, C=None):
+    """NHWC buffer -> (N, C, H, W)-shaped channels_last VIEW of its first C channels (no copy, same dtype)"""
+    v = y.permute(0, 3, 1, 2)
+    return v if C is None or C == y.shape[-1] else v[:, :C]
 
 
 class _Conv3x3ReLU(torch.autograd.Function):
@@ -49,7 +60,7 @@ class _Conv3x3ReLU(torch.autograd.Function):
         Cout = w.shape[0]
         y = torch.empty(N, H, W, Cout, dtype=dt, device=x.device)
         if Cin <= 4:
-            xin = x.contiguous().float()
+            xin = x.contiguous(memory_format=torch.contiguous_format).float()
             ops.first_conv_fwd(xin, w.detach().contiguous(), b.detach(), y)
             wd = None
         else:
@@ -68,9 +79,9 @@ class _Conv3x3ReLU(torch.autograd.Function):
         xin, y = ctx.saved_tensors
         N, Cin, H, W, Cout = ctx.shape
         dt = y.dtype
-        g = _to_nhwc(gy, dt)
-        # dL/d(pre-activation) = gy * (y > 0)
-        ops.relu_mask(g, y, g)
+        # dL/d(pre-activation) = gy * (y > 0)   (never in place: gy may be a view of autograd's own buffer)
+        g = torch.empty_like(y)
+        ops.relu_mask(_to_nhwc(gy, dt), y, g)
         dw = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=gy.device)
         db = torch.empty(Cout, dtype=torch.float32, device=gy.device)
         if Cin <= 4:
@@ -130,7 +141,7 @@ class _ConvT2x2(torch.autograd.Function):
         N, Cin, H, W, Cq = ctx.shape
         dt = xin.dtype
         # pixel-unshuffle the incoming gradient: (N, Cq, 2H, 2W) -> (N, H, W, 4*Cq) with column ab*Cq + c
-        g = gy.contiguous().float().view(N, Cq, H, 2, W, 2).permute(0, 2, 4, 3, 5, 1).reshape(N, H, W, 4 * Cq).to(dt).contiguous()
+        g = gy.contiguous(memory_format=torch.contiguous_format).float().view(N, Cq, H, 2, W, 2).permute(0, 2, 4, 3, 5, 1).reshape(N, H, W, 4 * Cq).to(dt).contiguous()
         dw = torch.empty(Cin, Cq, 2, 2, dtype=torch.float32, device=gy.device)
         db = torch.empty(Cq, dtype=torch.float32, device=gy.device)
         ops.wgrad(xin, g, dw, ksize=1, Cin=Cin, Cout=4 * Cq, dw_layout=1)
@@ -220,8 +231,7 @@ class _Conv3x3BNReLU(torch.autograd.Function):
         Cout, Cp = w.shape[0], _pad64(Cin)
         if Cout % 64:
             raise MisError(f"unetConv2: out_size {Cout} must be a multiple of 64")
-        xin = torch.zeros(N, H, W, Cp, dtype=dt, device=dev) if Cp != Cin else torch.empty(N, H, W, Cp, dtype=dt, device=dev)
-        ops.nchw_to_nhwc(x.contiguous().float(), ops.View(xin, 0, Cin))
+        xin = _to_nhwc(x, dt, Cp)
         wpad = w.detach().float()
         if Cp != Cin:
             wpad = torch.zeros(Cout, Cp, 3, 3, dtype=torch.float32, device=dev)
@@ -253,8 +263,8 @@ class _Conv3x3BNReLU(torch.autograd.Function):
         N, Cin, H, W, Cout, Cp = ctx.shape
         dt, dev = y.dtype, gy.device
         f32 = dict(dtype=torch.float32, device=dev)
-        g = _to_nhwc(gy, dt)
-        ops.relu_mask(g, y, g)                                   # g = gy * (y > 0)
+        g = torch.empty_like(y)
+        ops.relu_mask(_to_nhwc(gy, dt), y, g)                    # g = gy * (y > 0)
         S1, S2 = torch.empty(N, Cout, **f32), torch.empty(N, Cout, **f32)
         ops.gn_bwd_stats(g, z, Cout, False, (N, 1, H, W), S1, S2, Cout, 0)
         p, q, r = (torch.empty(N, Cout, **f32) for _ in range(3))
@@ -270,8 +280,7 @@ class _Conv3x3BNReLU(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dxp = torch.empty(N, H, W, Cp, dtype=dt, device=dev)
             ops.conv_igemm(dz, ctx.wd, dxp, ksize=3, Cin=Cout, Cout=Cp)
-            dx = torch.empty(N, Cin, H, W, **f32)
-            ops.nhwc_to_nchw(ops.View(dxp, 0, Cin), dx)
+            dx = _to_nchw(dxp, Cin)
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None
 
 
@@ -307,25 +316,17 @@ class _BilinearUp(torch.autograd.Function):
         dt = _compute_dtype()
         N, C, H, W = x.shape
         Cp = _pad_chunk(C, dt)                  # the kernels move 16-byte channel chunks: few-channel maps (deep-supervision logits) are padded
-        xin = torch.zeros(N, H, W, Cp, dtype=dt, device=x.device) if Cp != C else torch.empty(N, H, W, Cp, dtype=dt, device=x.device)
-        ops.nchw_to_nhwc(x.contiguous().float(), ops.View(xin, 0, C))
         y = torch.empty(N, H * s, W * s, Cp, dtype=dt, device=x.device)
-        ops.bilinear_up_fwd(xin, y, s)
+        ops.bilinear_up_fwd(_to_nhwc(x, dt, Cp), y, s)
         ctx.cfg = (N, C, Cp, H, W, s, dt)
-        out = torch.empty(N, C, H * s, W * s, dtype=torch.float32, device=x.device)
-        ops.nhwc_to_nchw(ops.View(y, 0, C), out)
-        return out
+        return _to_nchw(y, C)
 
     @staticmethod
     def backward(ctx, gy):
         N, C, Cp, H, W, s, dt = ctx.cfg
-        g = torch.zeros(N, H * s, W * s, Cp, dtype=dt, device=gy.device) if Cp != C else torch.empty(N, H * s, W * s, Cp, dtype=dt, device=gy.device)
-        ops.nchw_to_nhwc(gy.contiguous().float(), ops.View(g, 0, C))
         dxp = torch.empty(N, H, W, Cp, dtype=dt, device=gy.device)
-        ops.bilinear_up_bwd(g, dxp, s)
-        dx = torch.empty(N, C, H, W, dtype=torch.float32, device=gy.device)
-        ops.nhwc_to_nchw(ops.View(dxp, 0, C), dx)
-        return dx, None
+        ops.bilinear_up_bwd(_to_nhwc(gy, dt, Cp), dxp, s)
+        return _to_nchw(dxp, C), None
 
 
 class _Conv3x3Plain(torch.autograd.Function):
@@ -339,8 +340,7 @@ class _Conv3x3Plain(torch.autograd.Function):
         dev = x.device
         N, Cin, H, W = x.shape
         Cout, Cp, Op = w.shape[0], _pad64(Cin), _pad64(w.shape[0])
-        xin = torch.zeros(N, H, W, Cp, dtype=dt, device=dev) if Cp != Cin else torch.empty(N, H, W, Cp, dtype=dt, device=dev)
-        ops.nchw_to_nhwc(x.contiguous().float(), ops.View(xin, 0, Cin))
+        xin = _to_nhwc(x, dt, Cp)
         wpad = torch.zeros(Op, Cp, 3, 3, dtype=torch.float32, device=dev)
         wpad[:Cout, :Cin] = w.detach()
         bpad = torch.zeros(Op, dtype=torch.float32, device=dev)
@@ -353,24 +353,20 @@ class _Conv3x3Plain(torch.autograd.Function):
         ctx.save_for_backward(xin)
         ctx.wd = wd
         ctx.shape = (N, Cin, H, W, Cout, Cp, Op)
-        return _to_nchw(y)[:, :Cout].contiguous()                    # channel slice of the padded result (tensor plumbing)
+        return _to_nchw(y, Cout).float().contiguous()                # the logits leave as fp32 NCHW (tiny: Cout channels of the padded result)
 
     @staticmethod
     def backward(ctx, gy):
         (xin,) = ctx.saved_tensors
         N, Cin, H, W, Cout, Cp, Op = ctx.shape
         dt, dev = xin.dtype, gy.device
-        gfull = torch.zeros(N, Op, H, W, dtype=torch.float32, device=dev)
-        gfull[:, :Cout] = gy
-        g = _to_nhwc(gfull, dt)
+        g = _to_nhwc(gy, dt, Op)
         dwp = torch.empty(Op, Cp, 3, 3, dtype=torch.float32, device=dev)
         dbp = torch.empty(Op, dtype=torch.float32, device=dev)
         ops.wgrad(xin, g, dwp, ksize=3, Cin=Cp, Cout=Op, dbias=dbp)
         dxp = torch.empty(N, H, W, Cp, dtype=dt, device=dev)
         ops.conv_igemm(g, ctx.wd, dxp, ksize=3, Cin=Op, Cout=Cp)
-        dx = torch.empty(N, Cin, H, W, dtype=torch.float32, device=dev)
-        ops.nhwc_to_nchw(ops.View(dxp, 0, Cin), dx)
-        return dx, dwp[:Cout, :Cin].contiguous(), dbp[:Cout].contiguous()
+        return _to_nchw(dxp, Cin), dwp[:Cout, :Cin].contiguous(), dbp[:Cout].contiguous()
 
 
 class unetConv2(nn.Module):
