@@ -141,6 +141,9 @@ class UNetModel(PreTrainedModel):
             self.criterion = SegmentationLoss()
         else:
             raise NotImplementedError(f"unet_type={config.unet_type!r}: 'UNet', 'UNet_3Plus' and 'UNet_3Plus_DeepSup' are built")
+        # transformers >= 5 needs post_init() for from_pretrained / tied-weight bookkeeping (the 4.40-era reference does not call it);
+        # _init_weights is a no-op, so the seeded PyTorch / kaiming initialisation above is left untouched
+        self.post_init()
 
     def _init_weights(self, module):   # PyTorch default init already applied by the containers (as in the reference)
         return

@@ -53,6 +53,7 @@ class UNet3DForMedicalSegmentation(PreTrainedModel):
         else:
             self.activation = None
         self.loss_criterion = get_loss_criterion({"loss": dict(config.loss_config["loss"])})
+        self.post_init()          # transformers >= 5: needed by from_pretrained; _init_weights is a no-op
 
     def _init_weights(self, module):
         return

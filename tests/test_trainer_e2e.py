@@ -41,8 +41,25 @@ def test_custom_trainer_reproduces_reference_run():
         args = TrainingArguments(output_dir=out, per_device_train_batch_size=2, max_steps=4, learning_rate=5e-3, weight_decay=1e-3,
                                  logging_steps=1, save_strategy="no", report_to=[], remove_unused_columns=False, label_names=["labels"],
                                  seed=42, dataloader_num_workers=0, max_grad_norm=1.0, lr_scheduler_type="linear", warmup_steps=0)
-        tr = CustomTrainer(model=model, args=args, train_dataset=SynthDataset(), data_collator=collate)
+        from trainer import compute_metrics
+        tr = CustomTrainer(model=model, args=args, train_dataset=SynthDataset(), eval_dataset=SynthDataset(n=4, seed=6), data_collator=collate,
+                           compute_metrics=compute_metrics)
         tr.train()
+        # trainer.evaluate() (train.py:160): eval-mode forward through the engine, logits gathered by HF, metrics by the device kernel
+        ev = tr.evaluate()
+        assert "eval_iou" in ev and "eval_dice" in ev and 0.0 <= ev["eval_iou"] <= 1.0 and 0.0 <= ev["eval_dice"] <= 1.0
+        from oracle import metrics_oracle as mo
+        eds = SynthDataset(n=4, seed=6)
+        with torch.no_grad():
+            lg = model(images=eds.images.cuda(), labels=eds.labels.cuda()).logits.cpu().numpy()
+        ref = mo.compute_metrics(lg, eds.labels.numpy())
+        assert abs(ev["eval_iou"] - float(ref["iou"])) < 2e-3 and abs(ev["eval_dice"] - float(ref["dice"])) < 2e-3, (ev, ref)
+        # checkpoint round trip with the reference's key layout (save_pretrained -> from_pretrained)
+        model.save_pretrained(out + "/ckpt")
+        m2 = UNetModel.from_pretrained(out + "/ckpt").cuda().eval()
+        with torch.no_grad():
+            lg2 = m2(images=eds.images.cuda(), labels=eds.labels.cuda()).logits.cpu().numpy()
+        assert np.array_equal(lg, lg2), "logits differ after the checkpoint round trip"
     losses = [h["loss"] for h in tr.state.log_history if "loss" in h]
     gnorm = [h["grad_norm"] for h in tr.state.log_history if "loss" in h]
     ref_l, ref_g = g["losses"], g["grad_norm"]
