@@ -17,6 +17,10 @@
 
 #include "common.hpp"
 
+#ifndef MIS_WG_F32_UNROLL
+#define MIS_WG_F32_UNROLL 8   /* 32-step pixel loop of the f32 path: unroll 1 / 2 / 4 / 8 / 16 measured 8.52 / 8.56 / 8.78 / 8.82 / 8.83 vol/s on the 3-D fp32 step */
+#endif
+
 template <typename F, int... I> __device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);
 }
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 1 : 2)) void wgrad_kernel(co
                 }
             }
         } else {
-#pragma unroll 1
+#pragma unroll MIS_WG_F32_UNROLL
             for (int kk = 0; kk < 32; ++kk) {
                 const int m = (kk >> 1) * 8 + (kk & 1) + 2 * lg;
                 const int dz = m / (G::TH * G::TW);
