@@ -17,6 +17,9 @@
 
 #include "common.hpp"
 
+#ifndef MIS_WG_BF16_UNROLL
+#define MIS_WG_BF16_UNROLL 1
+#endif
 #ifndef MIS_WG_F32_UNROLL
 #define MIS_WG_F32_UNROLL 8   /* 32-step pixel loop of the f32 path: unroll 1 / 2 / 4 / 8 / 16 measured 8.52 / 8.56 / 8.78 / 8.82 / 8.83 vol/s on the 3-D fp32 step */
 #endif
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 1 : 2)) void wgrad_kernel(co
 
         if constexpr (BF) {
             const int q = li >> 2, pp = li & 3;
-#pragma unroll 1
+#pragma unroll MIS_WG_BF16_UNROLL
             for (int ks = 0; ks < 4; ++ks) {
                 int offP[2], offQ[2];
 #pragma unroll
