@@ -245,6 +245,14 @@ int mis_segloss_fwd(const float* logits, const float* target, int N, int H, int 
                     float* out /*[8]*/, void* stream);
 int mis_segloss_bwd(const float* target, int N, int H, int W, void* workspace, const float* out, const float* grad_out, float* dlogits, void* stream);
 
+/* Residual 3-D U-Net pieces (model/unet3d/buildingblocks.py:255-325 ResNetBlock; model.py:197-232): y = [relu](a + b) for the residual join and the
+ * decoder's sum-joining; the first block's 1x1x1 conv from ONE input channel on the raw fp32 volume, y[v][c] = w[c]*x[v] + b[c], and its
+ * weight / bias gradients dw[c] = sum x*dy, db[c] = sum dy. */
+int mis_add_act(int dtype, const void* a, int a_ld, const void* b, int b_ld, void* y, int y_ld, long long npix, int C, int relu, void* stream);
+int mis_expand1_fwd(int dtype, const float* x, const float* w, const float* b, void* y, int y_ld, long long nvox, int C, void* stream);
+size_t mis_expand1_bwd_workspace_bytes(int C);
+int mis_expand1_bwd(int dtype, const float* x, const void* dy, int dy_ld, long long nvox, int C, float* workspace, float* dw, float* db, void* stream);
+
 /* Evaluation metrics of the 2-D trainer (trainer/metrcis.py:61-109,153-168 `compute_metrics`): sigmoid with +1e-6 in the denominator,
  * threshold = global mean probability, per-sample IoU / Dice, mean over samples.  values, labels: fp32 (N, npix); out[3] = {iou, dice, threshold}.
  * values_are_logits = 0 with a given threshold gives compute_iou / compute_dice on ready-made predictions. */

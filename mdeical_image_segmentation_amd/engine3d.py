@@ -258,7 +258,7 @@ class UNet3DEngine:
         s.src0, s.c0, s.src1, s.c1 = src0, c0, src1, c1
         grid = (src0.shape[0], src0.shape[1], src0.shape[2], src0.shape[3])
         ops.conv_igemm(View(src0, 0, src0.shape[-1] if src1 is None else c0), s.wf, y, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid,
-                       x1=None if src1 is None else View(src1, 0, c1), relu=True, in_scale=s.scale, in_shift=s.shift)
+                       x1=None if src1 is None else View(src1, 0, c1), relu=getattr(s, "relu", True), in_scale=s.scale, in_shift=s.shift)
 
     def _cols_view(self, low, cout):
         n, d, h, w = low.shape[:4]

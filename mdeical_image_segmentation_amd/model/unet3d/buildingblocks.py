@@ -9,15 +9,17 @@ from torch import nn
 
 
 def create_conv(in_channels, out_channels, kernel_size, order, num_groups, padding, dropout_prob, is3d):
-    """buildingblocks.py:14-113 for order 'gcr' (GroupNorm -> Conv3d(no bias) -> ReLU)."""
-    if order != "gcr" or not is3d or kernel_size != 3 or padding != 1:
-        raise NotImplementedError("only layer_order='gcr', 3-D, kernel 3, padding 1 is built (SURVEY.md §8a-8)")
+    """buildingblocks.py:14-113 for order 'gcr' (GroupNorm -> Conv3d(no bias) -> ReLU) and 'gc' (the last conv of a ResNetBlock)."""
+    if order not in ("gcr", "gc") or not is3d or kernel_size != 3 or padding != 1:
+        raise NotImplementedError("only layer_order='gcr' (and its 'gc' tail), 3-D, kernel 3, padding 1 is built (SURVEY.md §8a-8)")
     if in_channels < num_groups:
         num_groups = 1
     assert in_channels % num_groups == 0
-    return [("groupnorm", nn.GroupNorm(num_groups=num_groups, num_channels=in_channels)),
-            ("conv", nn.Conv3d(in_channels, out_channels, kernel_size, padding=padding, bias=False)),
-            ("ReLU", nn.ReLU(inplace=True))]
+    mods = [("groupnorm", nn.GroupNorm(num_groups=num_groups, num_channels=in_channels)),
+            ("conv", nn.Conv3d(in_channels, out_channels, kernel_size, padding=padding, bias=False))]
+    if "r" in order:
+        mods.append(("ReLU", nn.ReLU(inplace=True)))
+    return mods
 
 
 class _ContainerOnly:
@@ -49,6 +51,23 @@ class DoubleConv(_ContainerOnly, nn.Sequential):
             c2_in, c2_out = out_channels, out_channels
         self.add_module("SingleConv1", SingleConv(c1_in, c1_out, kernel_size, order, num_groups, padding, dropout_prob, is3d))
         self.add_module("SingleConv2", SingleConv(c2_in, c2_out, kernel_size, order, num_groups, padding, dropout_prob, is3d))
+
+
+class ResNetBlock(_ContainerOnly, nn.Module):
+    """buildingblocks.py:255-325 (order 'gcr'): conv1 = 1x1x1 conv when the channel count changes, conv2 = SingleConv(order), conv3 = SingleConv
+    without the non-linearity, which follows the residual add.  Parameter container; computed by engine3d_res.ResidualUNet3DEngine."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, order="gcr", num_groups=8, is3d=True, **kwargs):
+        super().__init__()
+        if order != "gcr" or not is3d:
+            raise NotImplementedError("ResNetBlock on MI355X: layer_order='gcr' (ResidualUNet3D's default), 3-D")
+        self.conv1 = nn.Conv3d(in_channels, out_channels, 1) if in_channels != out_channels else nn.Identity()
+        self.conv2 = SingleConv(out_channels, out_channels, kernel_size=kernel_size, order=order, num_groups=num_groups, is3d=is3d)
+        n_order = order
+        for c in "rel":
+            n_order = n_order.replace(c, "")
+        self.conv3 = SingleConv(out_channels, out_channels, kernel_size=kernel_size, order=n_order, num_groups=num_groups, is3d=is3d)
+        self.non_linearity = nn.ReLU(inplace=True)
 
 
 class Encoder(_ContainerOnly, nn.Module):
@@ -90,6 +109,14 @@ class Decoder(_ContainerOnly, nn.Module):
     def __init__(self, in_channels, out_channels, conv_kernel_size=3, scale_factor=2, basic_module=DoubleConv, conv_layer_order="gcr",
                  num_groups=8, padding=1, upsample="default", dropout_prob=0.1, is3d=True):
         super().__init__()
+        if basic_module is ResNetBlock:
+            # buildingblocks.py:486-534: 'default' -> transposed-conv upsampling, SUM joining, the block sees out_channels
+            if upsample not in ("default", "deconv"):
+                raise NotImplementedError("ResNetBlock decoders: transposed-conv upsampling + sum joining (the reference's default) is built")
+            self.upsampling = TransposeConvUpsampling(in_channels, out_channels, kernel_size=conv_kernel_size, scale_factor=scale_factor, is3d=is3d)
+            self.basic_module = basic_module(out_channels, out_channels, encoder=False, kernel_size=conv_kernel_size, order=conv_layer_order,
+                                             num_groups=num_groups, padding=padding, dropout_prob=dropout_prob, is3d=is3d)
+            return
         if upsample not in ("default", "nearest", "deconv") or basic_module is not DoubleConv:
             raise NotImplementedError("only DoubleConv decoders with nearest or 'deconv' upsampling + concat are built (SURVEY.md §8a-11)")
         if upsample == "deconv":
@@ -115,7 +142,7 @@ def create_decoders(f_maps, basic_module, conv_kernel_size, conv_padding, layer_
     decoders = []
     rf = list(reversed(f_maps))
     for i in range(len(rf) - 1):
-        in_feature_num = rf[i] + rf[i + 1] if upsample != "deconv" else rf[i]
+        in_feature_num = rf[i] + rf[i + 1] if (basic_module is DoubleConv and upsample != "deconv") else rf[i]
         decoders.append(Decoder(in_feature_num, rf[i + 1], basic_module=basic_module, conv_layer_order=layer_order,
                                 conv_kernel_size=conv_kernel_size, num_groups=num_groups, padding=conv_padding, upsample=upsample,
                                 dropout_prob=dropout_prob, is3d=is3d))

@@ -459,3 +459,24 @@ def bilinear_up_bwd(dy, dx, scale):
     ws = workspace(lib.mis_bilinear_up_bwd_workspace_bytes(dx.N, dx.H, dx.W, dx.C, scale), dx.t.device, "bilinear")
     check(lib.mis_bilinear_up_bwd(dtype_code(dx.dtype), dy.ptr, dy.ld, dx.ptr, dx.ld, dx.N, dx.H, dx.W, dx.C, scale, ws.data_ptr(), stream_ptr()),
           "mis_bilinear_up_bwd")
+
+
+def add_act(a, b, y, relu=False):
+    lib = load()
+    a, b, y = _v(a), _v(b), _v(y)
+    check(lib.mis_add_act(dtype_code(y.dtype), a.ptr, a.ld, b.ptr, b.ld, y.ptr, y.ld, y.npix, y.C, 1 if relu else 0, stream_ptr()), "mis_add_act")
+
+
+def expand1_fwd(x, w, b, y):
+    """x: fp32 (N, 1, D, H, W) volume; y: NDHWC view; y[v][c] = w[c] * x[v] + b[c]"""
+    lib = load()
+    y = _v(y)
+    check(lib.mis_expand1_fwd(dtype_code(y.dtype), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.ptr, y.ld, y.npix, y.C, stream_ptr()), "mis_expand1_fwd")
+
+
+def expand1_bwd(x, dy, dw, db):
+    lib = load()
+    dy = _v(dy)
+    ws = workspace(lib.mis_expand1_bwd_workspace_bytes(dy.C), x.device, "expand1")
+    check(lib.mis_expand1_bwd(dtype_code(dy.dtype), x.data_ptr(), dy.ptr, dy.ld, dy.npix, dy.C, ws.data_ptr(), dw.data_ptr(), db.data_ptr(), stream_ptr()),
+          "mis_expand1_bwd")

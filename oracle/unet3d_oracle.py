@@ -152,3 +152,31 @@ def loss_and_grads(p, x, target, num_levels=4, num_groups=8, upsample="default")
     loss = bce_dice_loss(logits, target)
     loss.backward()
     return loss.detach(), logits.detach(), {k: v.grad.detach() for k, v in ps.items()}
+
+
+def _res_block(x, p, pre, num_groups=8):
+    """ResNetBlock with order 'gcr' (buildingblocks.py:255-325): optional 1x1x1 conv, SingleConv 'gcr', SingleConv 'gc', += residual, ReLU"""
+    r = F.conv3d(x, p[f"{pre}.conv1.weight"], p[f"{pre}.conv1.bias"]) if f"{pre}.conv1.weight" in p else x
+    g = _groups(r.shape[1], num_groups)
+    t = F.group_norm(r, g, p[f"{pre}.conv2.groupnorm.weight"], p[f"{pre}.conv2.groupnorm.bias"], eps=1e-5)
+    t = F.relu(F.conv3d(t, p[f"{pre}.conv2.conv.weight"], None, padding=1))
+    u = F.group_norm(t, g, p[f"{pre}.conv3.groupnorm.weight"], p[f"{pre}.conv3.groupnorm.bias"], eps=1e-5)
+    u = F.conv3d(u, p[f"{pre}.conv3.conv.weight"], None, padding=1)
+    return F.relu(u + r)
+
+
+def resunet3d_forward(p, x, num_levels, num_groups=8):
+    """ResidualUNet3D (model.py:197-232): ResNetBlock encoders with MaxPool3d, decoders = ConvTranspose3d(k3, s2, p1) resized to the encoder grid,
+    SUM joining, ResNetBlock; 1x1x1 head."""
+    feats = []
+    for i in range(num_levels):
+        if i > 0:
+            x = F.max_pool3d(x, 2)
+        x = _res_block(x, p, f"encoders.{i}.basic_module", num_groups)
+        feats.insert(0, x)
+    feats = feats[1:]
+    for i, enc in enumerate(feats):
+        x = F.conv_transpose3d(x, p[f"decoders.{i}.upsampling.upsample.conv_transposed.weight"], None, stride=2, padding=1)
+        x = F.interpolate(x, size=enc.shape[2:], mode="nearest")
+        x = _res_block(enc + x, p, f"decoders.{i}.basic_module", num_groups)
+    return F.conv3d(x, p["final_conv.weight"], p["final_conv.bias"])
