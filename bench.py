@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print a per-layer table of the MFMA kernels to stderr")
+    ap.add_argument("--net", default="1x2", choices=["1x2", "3x4"],
+                    help="2-D net: 1-channel -> 2 classes (BASELINE configs[1], default at every N) or 3 -> 4 (configs[2])")
     ap.add_argument("--workload", default="2d", choices=["2d", "3d"],
                     help="2d = BASELINE configs[1] (headline); 3d = configs[3]: UNet3D(1,3) bs=2 128^3 (use --dtype f32)")
     args = ap.parse_args()
@@ -81,11 +83,12 @@ def main():
         return bench3d(args, rank, world, dev, dist)
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    eng = UNet2DEngine(1, 2, dtype=dtype, device=dev, seed=0)       # identical init on every rank
+    cin, ncls = (1, 2) if args.net == "1x2" else (3, 4)
+    eng = UNet2DEngine(cin, ncls, dtype=dtype, device=dev, seed=0)  # identical init on every rank
     reducer = GradReducer(eng.flat) if world > 1 else None
     g = torch.Generator().manual_seed(1000 + rank)                    # per-rank data shard
-    images = torch.randn(args.batch, 1, args.size, args.size, generator=g).to(dev)
-    labels = torch.randint(0, 2, (args.batch, args.size, args.size), generator=g).to(dev)
+    images = torch.randn(args.batch, cin, args.size, args.size, generator=g).to(dev)
+    labels = torch.randint(0, ncls, (args.batch, args.size, args.size), generator=g).to(dev)
 
     def step():
         eng.forward(images, labels, train=True, grad_scale=1.0 / world)
@@ -126,7 +129,7 @@ def main():
             "metric": "images/sec (2D 512x512 U-Net train step)", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"unet2d 1-ch->2-class, bs={args.batch}/GPU {args.size}x{args.size}, "
+            "config": {"workload": f"unet2d {cin}-ch->{ncls}-class, bs={args.batch}/GPU {args.size}x{args.size}, "
                                    "fwd+CE loss+bwd+clip_grad_norm(1.0)+AdamW, random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(loss, 5)},
         }
