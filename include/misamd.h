@@ -213,6 +213,12 @@ int mis_aug_rotate0(const void* src, void* dst, long long nvol, int D, int H, in
 size_t mis_aug_rotate3_workspace_bytes(long long nvol, int D, int H, int W);
 int mis_aug_rotate3(const float* src, float* dst, double* workspace, long long nvol, int D, int H, int W, int a0, int a1,
                     const double* m4 /*host*/, const double* off2 /*host*/, void* stream);
+/* ElasticDeformation (transforms.py:138-191): one axis of scipy.ndimage.gaussian_filter(mode='reflect') on float64 fields (weights = the
+ * normalised kernel of radius int(4*sigma+0.5), on the device), and scipy.ndimage.map_coordinates(order 0 | 3, mode='reflect') at the voxel
+ * grid displaced by alpha * (fz, fy, fx) (fz may be NULL). */
+int mis_aug_gauss1d(const double* src, double* dst, long long nvol, int D, int H, int W, int axis, const double* weights, int radius, void* stream);
+int mis_aug_map_coordinates(const void* src, void* dst, double* workspace, long long nvol, int D, int H, int W, const double* fz, const double* fy,
+                            const double* fx, double alpha, int order, int elem_size, void* stream);
 int mis_aug_pointwise(const float* src, float* dst, long long n, float a, float b, int do_clip, float lo, float hi, float noise_std,
                       unsigned long long seed, void* stream);
 int mis_aug_contrast(const float* src, float* dst, long long n, float mean, float alpha, void* stream);

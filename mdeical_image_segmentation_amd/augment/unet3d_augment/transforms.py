@@ -11,7 +11,8 @@ outputs are CUDA tensors.  Differences, all loud or documented:
   * AdditiveGaussianNoise draws the decision and the std from the reference stream but the noise FIELD comes from an
     on-device counter-based generator (same distribution, different values); `exact=True` generates the field with
     numpy on the host instead;
-  * ElasticDeformation, Poisson noise, GaussianBlur3D, label->boundary transforms: out of scope.
+  * ElasticDeformation: spline_order 0 and 3 (fields from the reference's stream, smoothing + resampling on the device);
+  * Poisson noise, GaussianBlur3D (needs skimage), label->boundary transforms: out of scope.
 """
 import ctypes as C
 import importlib
@@ -161,6 +162,64 @@ class RandomContrast:
         return m
 
 
+class ElasticDeformation:
+    """transforms.py:138-191: with probability p, three (two when apply_3d=False) random fields randn(volume) are smoothed with
+    scipy.ndimage.gaussian_filter(sigma, mode='reflect'), scaled by alpha and added to the voxel grid; the volume is resampled there with
+    scipy.ndimage.map_coordinates(order=spline_order, mode='reflect').  The fields are drawn on the host from the reference's RandomState
+    stream (same draw order) and uploaded as float64; smoothing (3 separable passes per field) and resampling run on the device
+    (csrc/augment.hip).  spline_order 0 (labels; exact gather) and 3 (raw; float64 spline coefficients like scipy) are built."""
+
+    def __init__(self, random_state, spline_order, alpha=2000, sigma=50, execution_probability=0.1, apply_3d=True, **kwargs):
+        if spline_order not in (0, 3):
+            raise NotImplementedError("on-device ElasticDeformation: spline_order 0 and 3 are built")
+        self.random_state = random_state
+        self.spline_order = spline_order
+        self.alpha = alpha
+        self.sigma = sigma
+        self.execution_probability = execution_probability
+        self.apply_3d = apply_3d
+
+    def _field(self, shape, dev, wdev, radius):
+        lib = load()
+        a = torch.from_numpy(self.random_state.randn(*shape)).to(dev)                 # float64, the reference's stream
+        b = torch.empty_like(a)
+        D, H, W = shape
+        for ax in range(3):                                                               # gaussian_filter: axis 0, 1, 2
+            check(lib.mis_aug_gauss1d(a.data_ptr(), b.data_ptr(), 1, D, H, W, ax, wdev.data_ptr(), radius, stream_ptr()), "mis_aug_gauss1d")
+            a, b = b, a
+        return a
+
+    def __call__(self, m):
+        if self.random_state.uniform() < self.execution_probability:
+            m = _dev(m)
+            assert m.dim() in (3, 4)
+            shape = tuple(m.shape[-3:])
+            D, H, W = shape
+            # scipy.ndimage.gaussian_filter1d: radius int(4*sigma + 0.5), normalised exp(-x^2 / (2 sigma^2)) in float64
+            sd = float(self.sigma)
+            radius = int(4.0 * sd + 0.5)
+            xs = np.arange(-radius, radius + 1)
+            phi = np.exp(-0.5 / (sd * sd) * xs ** 2)
+            phi = (phi / phi.sum())[::-1].copy()
+            wdev = torch.from_numpy(phi).to(m.device)
+            fz = self._field(shape, m.device, wdev, radius) if self.apply_3d else None
+            fy = self._field(shape, m.device, wdev, radius)
+            fx = self._field(shape, m.device, wdev, radius)
+            if self.spline_order == 3 and m.dtype != torch.float32:
+                raise MisError("ElasticDeformation(spline_order=3): fp32 volumes only (labels use order 0)")
+            out = torch.empty_like(m)
+            nvol = m.numel() // (D * H * W)
+            lib = load()
+            ws = None
+            if self.spline_order == 3:
+                ws = ops.workspace(nvol * D * H * W * 8, m.device, "elastic")
+            check(lib.mis_aug_map_coordinates(m.data_ptr(), out.data_ptr(), None if ws is None else ws.data_ptr(), nvol, D, H, W,
+                                              None if fz is None else fz.data_ptr(), fy.data_ptr(), fx.data_ptr(), float(self.alpha),
+                                              self.spline_order, m.element_size(), stream_ptr()), "mis_aug_map_coordinates")
+            return out
+        return m
+
+
 class Standardize:
     """transforms.py:495-523: (m - mean) / clip(std, eps). Volume statistics are reduced on the device when not given."""
 
@@ -268,7 +327,6 @@ def _unbuilt(name):
     return _U
 
 
-ElasticDeformation = _unbuilt("ElasticDeformation")
 AdditivePoissonNoise = _unbuilt("AdditivePoissonNoise")
 GaussianBlur3D = _unbuilt("GaussianBlur3D")
 PercentileNormalizer = _unbuilt("PercentileNormalizer")

@@ -55,15 +55,12 @@ __device__ __forceinline__ double refl_coord(double x, int n) {
     return x;
 }
 __device__ __forceinline__ int refl_idx(long long k, int n) {
+    // half-sample symmetric ('reflect') extension d c b a | a b c d | d c b a, periodic with 2n: valid for ANY k (the Gaussian of
+    // ElasticDeformation reaches hundreds of samples beyond a 10..128-voxel line)
     const long long sz2 = 2LL * n;
-    if (k < 0) {
-        if (k < -sz2) k = sz2 * (-k / sz2) + k;
-        k = k < -n ? k + sz2 : -k - 1;
-    } else if (k > n - 1) {
-        k -= sz2 * (k / sz2);
-        if (k >= n) k = sz2 - k - 1;
-    }
-    return (int)k;
+    long long m = k % sz2;
+    if (m < 0) m += sz2;
+    return (int)(m < n ? m : sz2 - 1 - m);
 }
 
 struct RotArgs {
@@ -260,6 +257,128 @@ extern "C" int mis_aug_rotate3(const float* src, float* dst, double* workspace, 
                        W, a1, z, pow(z, (double)dims[a1]));
     hipLaunchKernelGGL(aug_rotate3_kernel, dim3(aug_grid(vox)), dim3(256), 0, s, (const double*)workspace, dst, nvol, D, H, W, a0, a1, ra);
     MIS_LAUNCH_CHECK("aug_rotate3");
+    return MIS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ElasticDeformation (reference transforms.py:138-191): three smooth random displacement fields
+//   d = scipy.ndimage.gaussian_filter(randn(volume), sigma, mode='reflect') * alpha      (float64; fields drawn on the host from the reference's stream)
+// and scipy.ndimage.map_coordinates(m, (z + dz, y + dy, x + dx), order, mode='reflect') with order 0 (labels) or 3 (raw).
+//   aug_gauss1d_kernel : one axis of the separable Gaussian as scipy's correlate1d evaluates a symmetric kernel,
+//                        centre tap first, then (x[l-k] + x[l+k]) * w[k] from the far end inwards, 'reflect' extension (any radius)
+//   aug_mapcoord*_kernel: coordinate reflect, order 0 = round-half-up gather, order 3 = 4x4x4 cubic B-spline taps on float64 coefficients
+//                        (the prefilter is the per-axis aug_spline3_filter_kernel above, run over all three axes)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void aug_gauss1d_kernel(const double* __restrict__ src, double* __restrict__ dst, long long nvol, int D, int H, int W, int ax,
+                                                          const double* __restrict__ wgt /*[2r+1], already reversed (symmetric)*/, int radius) {
+    const long long per = (long long)D * H * W, total = nvol * per;
+    const int dims[3] = {D, H, W};
+    const long long strides[3] = {(long long)H * W, (long long)W, 1};
+    const int n = dims[ax];
+    const long long st = strides[ax];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i % per;
+        int c[3];
+        c[2] = (int)(r % W);
+        c[1] = (int)((r / W) % H);
+        c[0] = (int)(r / ((long long)H * W));
+        const int l = c[ax];
+        const double* line = src + (i - (long long)l * st);
+        double t = line[(long long)l * st] * wgt[radius];
+        for (int k = -radius; k < 0; ++k) t += (line[(long long)refl_idx(l + k, n) * st] + line[(long long)refl_idx(l - k, n) * st]) * wgt[k + radius];
+        dst[i] = t;
+    }
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void aug_mapcoord0_kernel(const E* __restrict__ src, E* __restrict__ dst, long long nvol, int D, int H, int W,
+                                                            const double* __restrict__ fz, const double* __restrict__ fy, const double* __restrict__ fx,
+                                                            double alpha) {
+    const long long per = (long long)D * H * W, total = nvol * per;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long v = i / per, r = i - v * per;
+        const int x = (int)(r % W), y = (int)((r / W) % H), z = (int)(r / ((long long)H * W));
+        const double cz = refl_coord(fz != nullptr ? (double)z + fz[r] * alpha : (double)z, D);
+        const double cy = refl_coord((double)y + fy[r] * alpha, H);
+        const double cx = refl_coord((double)x + fx[r] * alpha, W);
+        const int iz = refl_idx((long long)floor(cz + 0.5), D), iy = refl_idx((long long)floor(cy + 0.5), H), ix = refl_idx((long long)floor(cx + 0.5), W);
+        dst[i] = src[((v * D + iz) * H + iy) * W + ix];
+    }
+}
+
+__global__ __launch_bounds__(256) void aug_mapcoord3_kernel(const double* __restrict__ coef, float* __restrict__ dst, long long nvol, int D, int H, int W,
+                                                            const double* __restrict__ fz, const double* __restrict__ fy, const double* __restrict__ fx,
+                                                            double alpha) {
+    const long long per = (long long)D * H * W, total = nvol * per;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long v = i / per, r = i - v * per;
+        const int x = (int)(r % W), y = (int)((r / W) % H), z = (int)(r / ((long long)H * W));
+        const double cz = refl_coord(fz != nullptr ? (double)z + fz[r] * alpha : (double)z, D);
+        const double cy = refl_coord((double)y + fy[r] * alpha, H);
+        const double cx = refl_coord((double)x + fx[r] * alpha, W);
+        long long sz, sy, sx;
+        double wz[4], wy[4], wx[4];
+        spline3_weights(cz, sz, wz);
+        spline3_weights(cy, sy, wy);
+        spline3_weights(cx, sx, wx);
+        long long ox[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ox[c] = refl_idx(sx + c, W);
+        const double* cv = coef + v * per;
+        double t = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const long long oz = (long long)refl_idx(sz + a, D) * H;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const long long row = (oz + refl_idx(sy + b, H)) * W;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) t += ((cv[row + ox[c]] * wz[a]) * wy[b]) * wx[c];
+            }
+        }
+        dst[i] = (float)t;
+    }
+}
+
+extern "C" int mis_aug_gauss1d(const double* src, double* dst, long long nvol, int D, int H, int W, int axis, const double* weights /*device, 2r+1*/,
+                               int radius, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(src && dst && src != dst && weights && nvol > 0 && D > 0 && H > 0 && W > 0 && axis >= 0 && axis <= 2 && radius >= 0, MIS_EINVAL,
+                "aug_gauss1d: bad argument");
+    hipLaunchKernelGGL(aug_gauss1d_kernel, dim3(aug_grid(nvol * D * H * W)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, nvol, D, H, W, axis,
+                       weights, radius);
+    MIS_LAUNCH_CHECK("aug_gauss1d");
+    return MIS_OK;
+}
+
+// fields: float64 (D, H, W) displacement fields BEFORE the multiplication by alpha; fz may be NULL (apply_3d=False: no displacement along z).
+// order 0: src / dst of 4- or 8-byte elements;  order 3: fp32, workspace = nvol*D*H*W doubles (spline coefficients).
+extern "C" int mis_aug_map_coordinates(const void* src, void* dst, double* workspace, long long nvol, int D, int H, int W, const double* fz, const double* fy,
+                                       const double* fx, double alpha, int order, int elem_size, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(src && dst && src != dst && fy && fx && nvol > 0 && D > 0 && H > 0 && W > 0, MIS_EINVAL, "aug_map_coordinates: bad argument");
+    MIS_REQUIRE(order == 0 || order == 3, MIS_EUNSUPPORTED, "aug_map_coordinates: spline order %d (0 and 3 are built)", order);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long long vox = nvol * D * H * W;
+    if (order == 0) {
+        MIS_REQUIRE(elem_size == 4 || elem_size == 8, MIS_EUNSUPPORTED, "aug_map_coordinates: element size %d", elem_size);
+        if (elem_size == 4)
+            hipLaunchKernelGGL(aug_mapcoord0_kernel<uint32_t>, dim3(aug_grid(vox)), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, nvol, D, H, W, fz, fy, fx, alpha);
+        else
+            hipLaunchKernelGGL(aug_mapcoord0_kernel<uint64_t>, dim3(aug_grid(vox)), dim3(256), 0, s, (const uint64_t*)src, (uint64_t*)dst, nvol, D, H, W, fz, fy, fx, alpha);
+        MIS_LAUNCH_CHECK("aug_map_coordinates(order 0)");
+        return MIS_OK;
+    }
+    MIS_REQUIRE(workspace != nullptr && elem_size == 4, MIS_EINVAL, "aug_map_coordinates: order 3 needs fp32 data and a workspace");
+    const int dims[3] = {D, H, W};
+    const double z = sqrt(3.0) - 2.0;
+    hipLaunchKernelGGL(aug_spline3_filter_kernel<float>, dim3(aug_grid(vox / dims[0])), dim3(256), 0, s, (const float*)src, workspace, nvol, D, H, W, 0, z,
+                       pow(z, (double)dims[0]));
+    for (int ax = 1; ax < 3; ++ax)
+        hipLaunchKernelGGL(aug_spline3_filter_kernel<double>, dim3(aug_grid(vox / dims[ax])), dim3(256), 0, s, (const double*)workspace, workspace, nvol, D, H, W,
+                           ax, z, pow(z, (double)dims[ax]));
+    hipLaunchKernelGGL(aug_mapcoord3_kernel, dim3(aug_grid(vox)), dim3(256), 0, s, (const double*)workspace, (float*)dst, nvol, D, H, W, fz, fy, fx, alpha);
+    MIS_LAUNCH_CHECK("aug_map_coordinates(order 3)");
     return MIS_OK;
 }
 

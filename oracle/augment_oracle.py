@@ -143,6 +143,20 @@ def rotate3(m, angle, axes):
     return np.moveaxis(out, (0, 1), (a0, a1)).astype(m.dtype)
 
 
+def elastic(m, rs, spline_order, alpha=2000, sigma=50, apply_3d=True):
+    """ElasticDeformation.__call__ after the execution-probability draw (transforms.py:167-189): the smoothing and the resampling ARE scipy
+    calls in the reference (scipy is present in this container, so the oracle calls the same functions); draws randn fields from `rs`."""
+    from scipy.ndimage import gaussian_filter, map_coordinates
+    shape = m.shape if m.ndim == 3 else m[0].shape
+    dz = gaussian_filter(rs.randn(*shape), sigma, mode="reflect") * alpha if apply_3d else np.zeros(shape)
+    dy, dx = [gaussian_filter(rs.randn(*shape), sigma, mode="reflect") * alpha for _ in range(2)]
+    z, y, x = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), np.arange(shape[2]), indexing="ij")
+    idx = z + dz, y + dy, x + dx
+    if m.ndim == 3:
+        return map_coordinates(m, idx, order=spline_order, mode="reflect")
+    return np.stack([map_coordinates(c, idx, order=spline_order, mode="reflect") for c in m], axis=0)
+
+
 def contrast(m, mean, alpha):
     return np.clip(mean + alpha * (m - mean), -1, 1)
 

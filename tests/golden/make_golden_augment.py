@@ -62,6 +62,14 @@ def main():
         rr = tr.RandomRotate(np.random.RandomState(400 + s), angle_spectrum=30, mode="reflect", order=3)
         out[f"rot3_{s}"] = np.ascontiguousarray(rr(v))
     out["c4_rot3"] = np.ascontiguousarray(tr.RandomRotate(np.random.RandomState(8), axes=[(2, 1)], order=3)(c4))
+    # (4) elastic deformation (order 3 on raw, order 0 on labels, same seed -> same fields); small sigma so the field varies over the volume
+    ev = rng.rand(10, 12, 14).astype(np.float32)
+    el = (rng.rand(10, 12, 14) * 5).astype(np.int64)
+    out["el_raw"], out["el_label"] = ev, el
+    out["el_raw_out"] = np.ascontiguousarray(tr.ElasticDeformation(np.random.RandomState(500), spline_order=3, alpha=15, sigma=3, execution_probability=1.0)(ev))
+    out["el_label_out"] = np.ascontiguousarray(tr.ElasticDeformation(np.random.RandomState(500), spline_order=0, alpha=15, sigma=3, execution_probability=1.0)(el))
+    out["el_raw_2d"] = np.ascontiguousarray(tr.ElasticDeformation(np.random.RandomState(501), spline_order=3, alpha=2000, sigma=50, execution_probability=1.0,
+                                                                   apply_3d=False)(ev))
     np.savez_compressed(os.path.join(HERE, "g5_augment.npz"), **out)
     print("wrote g5_augment.npz", sum(a.nbytes for a in out.values()) // 1024, "KiB; seed", t.seed)
 

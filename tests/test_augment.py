@@ -45,6 +45,11 @@ def test_oracle_matches_reference_goldens():
     rs = np.random.RandomState(9)
     rs.uniform()
     assert np.array_equal(ao.contrast(g["v"], 0.05, rs.uniform(0.5, 1.5)), g["contrast"])
+    for key, src, order, seed, kw in (("el_raw_out", "el_raw", 3, 500, dict(alpha=15, sigma=3)), ("el_label_out", "el_label", 0, 500, dict(alpha=15, sigma=3)),
+                                      ("el_raw_2d", "el_raw", 3, 501, dict(alpha=2000, sigma=50, apply_3d=False))):
+        rs = np.random.RandomState(seed)
+        rs.uniform()
+        assert np.array_equal(ao.elastic(g[src], rs, order, **kw), g[key]), key
 
 
 @pytest.mark.gpu
@@ -65,6 +70,15 @@ def test_device_transforms_match_reference_goldens():
         out = tr.RandomRotate(np.random.RandomState(400 + s), angle_spectrum=30, mode="reflect", order=3)(v)
         assert np.allclose(out.cpu().numpy(), g[f"rot3_{s}"], rtol=0, atol=5e-7), f"rot3_{s}"
     assert np.allclose(tr.RandomRotate(np.random.RandomState(8), axes=[(2, 1)], order=3)(g["c4"]).cpu().numpy(), g["c4_rot3"], rtol=0, atol=5e-7)
+    # elastic deformation: labels (order 0) exact, raw (order 3) up to fp32 rounding of float64 spline arithmetic
+    el = tr.ElasticDeformation(np.random.RandomState(500), spline_order=0, alpha=15, sigma=3, execution_probability=1.0)(g["el_label"])
+    assert np.array_equal(el.cpu().numpy(), g["el_label_out"])
+    er = tr.ElasticDeformation(np.random.RandomState(500), spline_order=3, alpha=15, sigma=3, execution_probability=1.0)(g["el_raw"])
+    assert np.abs(er.cpu().numpy() - g["el_raw_out"]).max() < 1e-6
+    e2 = tr.ElasticDeformation(np.random.RandomState(501), spline_order=3, alpha=2000, sigma=50, execution_probability=1.0, apply_3d=False)(g["el_raw"])
+    assert np.abs(e2.cpu().numpy() - g["el_raw_2d"]).max() < 1e-6
+    keep = tr.ElasticDeformation(np.random.RandomState(1), spline_order=3, execution_probability=0.0)(g["el_raw"])
+    assert np.array_equal(np.asarray(keep if isinstance(keep, np.ndarray) else keep.cpu().numpy()), g["el_raw"])
     assert np.array_equal(tr.RandomContrast(np.random.RandomState(9), mean=0.05, execution_probability=1.0)(v).cpu().numpy(), g["contrast"])
     assert np.allclose(tr.Standardize()(v).cpu().numpy(), g["std_auto"], atol=2e-6)
     assert np.allclose(tr.Standardize(mean=0.1, std=0.5)(v).cpu().numpy(), g["std_fixed"], atol=1e-6)
