@@ -241,6 +241,14 @@ int mis_bilinear_up_fwd(int dtype, const void* x, int x_ld, void* y, int y_ld, i
 size_t mis_bilinear_up_bwd_workspace_bytes(int N, int H, int W, int C, int scale);
 int mis_bilinear_up_bwd(int dtype, const void* dy, int dy_ld, void* dx, int dx_ld, int N, int H, int W, int C, int scale, float* workspace, void* stream);
 
+/* conv3x3(pad 1)(bilinear_upsample_s(x)) of the UNet 3+ decoder-to-decoder branches (model/unet2d/unet.py:190-192, 229-236, 273-285, 322-339) without
+ * the upsampled tensor: the channel contraction runs on the low-resolution grid (mis_conv_igemm, ksize 1, column tap*C + co of z), then
+ *   fwd: y[N][h*s][w*s][C] = bias + sum over the 3x3 taps inside the upsampled image of bilinear(z[..][tap*C + c]) at (o + tap - 1)
+ *   bwd: dz[N][h][w][9*C]  = the adjoint of that gather applied to dy
+ * z / dz are dense (row stride 9*C); y / dy have a row stride.  C % (16 bytes / element) == 0, 1 <= scale <= 32. */
+int mis_upconv_gather_fwd(int dtype, const void* z, void* y, int y_ld, const float* bias, int N, int h, int w, int scale, int C, void* stream);
+int mis_upconv_gather_bwd(int dtype, const void* dy, int dy_ld, void* dz, int N, int h, int w, int scale, int C, void* stream);
+
 /* SegmentationLoss of the UNet 3+ path (model/unet2d/loss.py:21-70): F1Loss + MSSSIMLoss (pytorch_msssim 1.0.0 MS_SSIM, data_range 1, 5 scales,
  * 11-tap Gaussian) + IoULoss on single-channel (logits, targets) fp32 (N, H, W); min(H, W) > 160.
  * fwd: out[0] = w_f1*F1 + w_msssim*MSSSIM + w_iou*IoU (SegmentationLoss: all 1), out[1..3] = the three terms, out[4..5] internal;

@@ -6,6 +6,8 @@ channels_last tensors in the compute dtype, i.e. NHWC memory, so that chained la
 The fused whole-network path (engine2d.UNet2DEngine, used by UNet / UNetModel) does not go through these
 per-layer functions; they exist so that the blocks remain usable on their own.
 CUDA tensors only - there is no CPU fallback."""
+import os
+
 import torch
 from torch import nn
 
@@ -327,6 +329,93 @@ class _BilinearUp(torch.autograd.Function):
         dxp = torch.empty(N, H, W, Cp, dtype=dt, device=gy.device)
         ops.bilinear_up_bwd(_to_nhwc(gy, dt, Cp), dxp, s)
         return _to_nchw(dxp, C), None
+
+
+class _UpConv3x3BNReLU(torch.autograd.Function):
+    """y = relu(batch_norm(conv2d(upsample_bilinear_s(x), w, b, padding=1))) - the decoder-to-decoder branches of UNet 3+ (reference unet.py:190-192 etc.)
+    WITHOUT the upsampled tensor: the channel contraction commutes with the interpolation, so it runs at the low resolution as a 1x1 GEMM with
+    9*Cout columns (s^2 x fewer FLOPs than the reference's order) and mis_upconv_gather_fwd/bwd interpolate the nine tap products (csrc/upconv.hip).
+    Same arithmetic up to fp32 summation order."""
+
+    @staticmethod
+    def forward(ctx, x, s, w, b, gamma, beta, running_mean, running_var, training, eps, momentum):
+        _need_cuda(x)
+        dt = _compute_dtype()
+        dev = x.device
+        N, Cin, h, wl = x.shape
+        Cout, Cp = w.shape[0], _pad64(Cin)
+        if Cout % 64:
+            raise MisError(f"up-branch conv: out channels {Cout} must be a multiple of 64")
+        H, W = h * s, wl * s
+        xin = _to_nhwc(x, dt, Cp)
+        wpad = w.detach().float()
+        if Cp != Cin:
+            wpad = torch.zeros(Cout, Cp, 3, 3, dtype=torch.float32, device=dev)
+            wpad[:, :Cin] = w.detach()
+        wf = torch.empty(9, Cout, Cp, dtype=dt, device=dev)             # [tap][co][ci] = the 1x1 filter bank of the 9*Cout-column GEMM
+        ops.pack_conv_weight(wpad.contiguous(), wf)
+        zt = torch.empty(N, h, wl, 9 * Cout, dtype=dt, device=dev)
+        ops.conv_igemm(xin, wf, zt, ksize=1, Cin=Cp, Cout=9 * Cout)
+        z = torch.empty(N, H, W, Cout, dtype=dt, device=dev)
+        ops.upconv_gather_fwd(zt, z, s, Cout, bias=b.detach().float())
+        del zt
+        f32 = dict(dtype=torch.float32, device=dev)
+        scale, shift = torch.empty(N, Cout, **f32), torch.empty(N, Cout, **f32)
+        mean, rstd = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
+        sm = sq = None
+        if training:
+            sm, sq = torch.empty(N, Cout, **f32), torch.empty(N, Cout, **f32)
+            ops.chanstats(z, sm, sq)
+        ops.bn_fwd_finalize(sm, sq, N, Cout, N * H * W, gamma.detach().float(), beta.detach().float(), running_mean, running_var, training,
+                            scale, shift, mean, rstd, eps=eps, momentum=momentum)
+        y = torch.empty_like(z)
+        ops.affine_act(z, y, scale, shift, relu=True)
+        ctx.save_for_backward(xin, z, y, mean, rstd, gamma.detach().float(), wpad)
+        ctx.training = training
+        ctx.shape = (N, Cin, h, wl, Cout, Cp, s)
+        return _to_nchw(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xin, z, y, mean, rstd, gamma, wpad = ctx.saved_tensors
+        N, Cin, h, wl, Cout, Cp, s = ctx.shape
+        H, W = h * s, wl * s
+        dt, dev = y.dtype, gy.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        g = torch.empty_like(y)
+        ops.relu_mask(_to_nhwc(gy, dt), y, g)
+        S1, S2 = torch.empty(N, Cout, **f32), torch.empty(N, Cout, **f32)
+        ops.gn_bwd_stats(g, z, Cout, False, (N, 1, H, W), S1, S2, Cout, 0)
+        p, q, r = (torch.empty(N, Cout, **f32) for _ in range(3))
+        dgamma, dbeta = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
+        ops.bn_bwd_finalize(S1, S2, mean, rstd, gamma, N, Cout, N * H * W, ctx.training, p, q, r, dgamma, dbeta)
+        dz = torch.empty_like(z)
+        ops.gn_bwd_apply(g, z, Cout, False, (N, 1, H, W), p, q, r, Cout, 0, dz)
+        del g
+        db = torch.empty(Cout, **f32)
+        ops.colsum(dz, db)
+        dzt = torch.empty(N, h, wl, 9 * Cout, dtype=dt, device=dev)
+        ops.upconv_gather_bwd(dz, dzt, s, Cout)
+        dwk = torch.empty(9 * Cout, Cp, 1, 1, **f32)
+        ops.wgrad(xin, dzt, dwk, ksize=1, Cin=Cp, Cout=9 * Cout)
+        dw = dwk.view(3, 3, Cout, Cp).permute(2, 3, 0, 1)[:, :Cin].contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wd = wpad.permute(1, 2, 3, 0).reshape(Cp, 9 * Cout).to(dt).contiguous()     # [ci][tap*Cout + co]: filter bank of the transposed GEMM
+            dxp = torch.empty(N, h, wl, Cp, dtype=dt, device=dev)
+            ops.conv_igemm(dzt, wd, dxp, ksize=1, Cin=9 * Cout, Cout=Cp)
+            dx = _to_nchw(dxp, Cin)
+        return dx, None, dw, db, dgamma, dbeta, None, None, None, None, None
+
+
+def up_conv_bn_relu(x, s, conv, bn, module_training):
+    """relu(bn(conv3x3(upsample_bilinear(x, s)))) - fused form (default) or, with MISAMD_UPCONV_UNFUSED=1, the reference's literal order"""
+    if os.environ.get("MISAMD_UPCONV_UNFUSED") == "1":
+        return conv_bn_relu(_BilinearUp.apply(x, s), conv, bn, module_training)
+    training = module_training or not bn.track_running_stats
+    if module_training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    return _UpConv3x3BNReLU.apply(x, s, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, bn.momentum)
 
 
 class _Conv3x3Plain(torch.autograd.Function):

@@ -18,7 +18,7 @@ from ... import ops
 from ..._lib import MisError
 from ...engine2d import UNet2DEngine
 from .init_weights import init_weights
-from .layers import (CropAndConcat, DoubleConvolution, DownSample, UpSample, _BilinearUp, _Conv3x3Plain, _MaxPool2, _MaxPoolCeil, conv_bn_relu,
+from .layers import (CropAndConcat, DoubleConvolution, DownSample, UpSample, _BilinearUp, _Conv3x3Plain, _MaxPool2, _MaxPoolCeil, conv_bn_relu, up_conv_bn_relu,
                      unetConv2)
 
 
@@ -228,12 +228,10 @@ class _UNet3PlusBase(nn.Module):
             parts = []
             for i in range(1, 6):
                 name, _ = self._branch(d, i)
-                if i < d:
-                    src = _MaxPoolCeil.apply(h[i], 2 ** (d - i))
-                elif i == d:
-                    src = h[i]
-                else:
-                    src = _BilinearUp.apply(hd[i], 2 ** (i - d))
+                if i > d:           # bilinear upsample -> conv -> BN -> ReLU, contracted at the low resolution (layers._UpConv3x3BNReLU)
+                    parts.append(up_conv_bn_relu(hd[i], 2 ** (i - d), getattr(self, name + "_conv"), getattr(self, name + "_bn"), self.training))
+                    continue
+                src = _MaxPoolCeil.apply(h[i], 2 ** (d - i)) if i < d else h[i]
                 parts.append(conv_bn_relu(src, getattr(self, name + "_conv"), getattr(self, name + "_bn"), self.training))
             hd[d] = conv_bn_relu(torch.cat(parts, 1), getattr(self, f"conv{d}d_1"), getattr(self, f"bn{d}d_1"), self.training)
         return hd

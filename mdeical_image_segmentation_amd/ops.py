@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (MIS_BF16, MIS_F32, OUT_PLAIN, OUT_SHUFFLE2, OUT_UNSHUFFLE2, ConvDesc, HeadDesc, WgradDesc, check,
+from ._lib import (MIS_BF16, MIS_F32, OUT_PLAIN, OUT_SHUFFLE2, OUT_UNSHUFFLE2, ConvDesc, HeadDesc, MisError, WgradDesc, check,
                    dtype_code, load, stream_ptr)
 
 
@@ -459,6 +459,26 @@ def bilinear_up_bwd(dy, dx, scale):
     ws = workspace(lib.mis_bilinear_up_bwd_workspace_bytes(dx.N, dx.H, dx.W, dx.C, scale), dx.t.device, "bilinear")
     check(lib.mis_bilinear_up_bwd(dtype_code(dx.dtype), dy.ptr, dy.ld, dx.ptr, dx.ld, dx.N, dx.H, dx.W, dx.C, scale, ws.data_ptr(), stream_ptr()),
           "mis_bilinear_up_bwd")
+
+
+def upconv_gather_fwd(z, y, scale, C, bias=None):
+    """z (N, h, w, 9*C) dense -> y (N, h*s, w*s, C): the 3x3 taps of conv3x3(bilinear_up_s(x)) gathered from the low-resolution tap products"""
+    lib = load()
+    y = _v(y)
+    N, h, w, c9 = z.shape
+    if c9 != 9 * C or not z.is_contiguous() or y.H != h * scale or y.W != w * scale or y.C != C:
+        raise MisError(f"upconv_gather_fwd: z {tuple(z.shape)} / y ({y.N},{y.H},{y.W},{y.C}) do not match scale {scale}, C {C}")
+    check(lib.mis_upconv_gather_fwd(dtype_code(z.dtype), z.data_ptr(), y.ptr, y.ld, None if bias is None else bias.data_ptr(), N, h, w, scale, C,
+                                    stream_ptr()), "mis_upconv_gather_fwd")
+
+
+def upconv_gather_bwd(dy, dz, scale, C):
+    lib = load()
+    dy = _v(dy)
+    N, h, w, c9 = dz.shape
+    if c9 != 9 * C or not dz.is_contiguous() or dy.H != h * scale or dy.W != w * scale or dy.C != C:
+        raise MisError(f"upconv_gather_bwd: dz {tuple(dz.shape)} / dy ({dy.N},{dy.H},{dy.W},{dy.C}) do not match scale {scale}, C {C}")
+    check(lib.mis_upconv_gather_bwd(dtype_code(dz.dtype), dy.ptr, dy.ld, dz.data_ptr(), N, h, w, scale, C, stream_ptr()), "mis_upconv_gather_bwd")
 
 
 def add_act(a, b, y, relu=False):

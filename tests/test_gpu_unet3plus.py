@@ -53,6 +53,43 @@ def test_bilinear_up_fwd_bwd(s, shape):
     assert (xd.grad.cpu() - xr.grad).abs().max().item() < 1e-5 * max(1.0, xr.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("s,shape,dtype", [(2, (2, 70, 6, 5), "f32"), (4, (1, 128, 3, 5), "f32"), (16, (2, 64, 2, 3), "f32"), (8, (2, 96, 3, 2), "bf16")])
+def test_upconv_bn_relu_matches_upsample_then_conv(s, shape, dtype, monkeypatch):
+    """relu(bn(conv3x3(upsample_bilinear(x)))) contracted at the low resolution (csrc/upconv.hip) against the reference's literal order in fp64:
+    output, running statistics and every gradient."""
+    from mdeical_image_segmentation_amd.model.unet2d.layers import _UpConv3x3BNReLU
+    monkeypatch.setenv("MISAMD_DTYPE", dtype)
+    gen = torch.Generator().manual_seed(100 + s)
+    N, Cin, h, w = shape
+    x = torch.randn(*shape, generator=gen)
+    wt = torch.randn(64, Cin, 3, 3, generator=gen) * (1.0 / (3.0 * Cin ** 0.5))
+    b = torch.randn(64, generator=gen) * 0.1
+    ga = 1.0 + 0.1 * torch.randn(64, generator=gen)
+    be = 0.1 * torch.randn(64, generator=gen)
+    gy = torch.randn(N, 64, h * s, w * s, generator=gen)
+    ref = [t.double().requires_grad_(True) for t in (x, wt, b, ga, be)]
+    rm, rv = torch.zeros(64, dtype=torch.float64), torch.ones(64, dtype=torch.float64)
+    yr = F.relu(F.batch_norm(F.conv2d(F.interpolate(ref[0], scale_factor=s, mode="bilinear"), ref[1], ref[2], padding=1), rm, rv, ref[3], ref[4], True, 0.1, 1e-5))
+    yr.backward(gy.double())
+    dev = [t.cuda().requires_grad_(True) for t in (x, wt, b, ga, be)]
+    drm, drv = torch.zeros(64, device="cuda"), torch.ones(64, device="cuda")
+    yd = _UpConv3x3BNReLU.apply(dev[0], s, dev[1], dev[2], dev[3], dev[4], drm, drv, True, 1e-5, 0.1)
+    yd.backward(gy.cuda())
+    tol = 6e-2 if dtype == "bf16" else 2e-4        # bf16: z, dz and the tap products are rounded to 8 bits of mantissa; the f32 cases pin the arithmetic
+
+    def rel(a, r):
+        return ((a.detach().double().cpu() - r).norm() / r.norm().clamp_min(1e-30)).item()
+
+    assert yd.shape == yr.shape
+    assert rel(yd, yr.detach()) < tol
+    assert rel(drm, rm) < tol and rel(drv, rv) < tol
+    for name, d, r in zip(("dx", "dw", "db", "dgamma", "dbeta"), dev, ref):
+        if name == "db":        # the conv bias cancels in train-mode batch norm: its gradient is rounding noise around zero
+            assert d.grad.abs().max().item() < tol * max(1.0, gy.abs().sum().item() ** 0.5)
+            continue
+        assert rel(d.grad, r.grad) < tol, name
+
+
 def test_unet3plus_matches_reference_golden():
     from mdeical_image_segmentation_amd.model.unet2d.unet import UNet_3Plus
     g = load_golden("g9_unet3plus.npz")
