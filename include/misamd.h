@@ -200,6 +200,13 @@ int mis_bn_fwd_finalize(const float* sum, const float* sumsq, int N, int C, doub
                         float* mean, float* rstd, void* stream);
 int mis_bn_bwd_finalize(const float* S1, const float* S2, const float* mean, const float* rstd, const float* gamma, int N, int C,
                         double count_total, int training, float* p, float* q, float* r, float* dgamma, float* dbeta, void* stream);
+/* fused form of the first and last backward passes: the ReLU mask is recomputed from z (fma(z, scale, shift) > 0, the forward's expression), so no
+ * g tensor is written:  S1 = sum m*dy, S2 = sum m*dy*z;  dz = p*(m*dy) + q*z + r.  scale/shift/p/q/r: [N][C] fp32. */
+size_t mis_bn_bwd_stats_workspace_bytes(int N, int C);
+int mis_bn_bwd_stats(int dtype, const void* dy, int dy_ld, const void* z, int z_ld, int N, long long npix, int C, const float* scale,
+                     const float* shift, float* workspace, float* S1, float* S2, void* stream);
+int mis_bn_bwd_apply(int dtype, const void* dy, int dy_ld, const void* z, int z_ld, int N, long long npix, int C, const float* scale,
+                     const float* shift, const float* p, const float* q, const float* r, void* dz, int dz_ld, void* stream);
 int mis_affine_act(int dtype, const void* x, int x_ld, void* y, int y_ld, int N, long long npix, int C, const float* scale,
                    const float* shift, int relu, void* stream);
 

@@ -445,16 +445,25 @@ __global__ __launch_bounds__(256) void chansum_kernel(const T* __restrict__ x, i
     }
 }
 
-// out[n][c % Cq] = alpha * sum over slabs and folds
-__global__ void chansum_reduce_kernel(const float* __restrict__ part, int nslabs, int N, int C, int fold, float alpha, float* __restrict__ out) {
+// out[n][c % Cq] = alpha * sum over slabs and folds.  16 outputs per block, 16 slab lanes per output (fixed order: lane partials, then lanes 0..15)
+__global__ __launch_bounds__(256) void chansum_reduce_kernel(const float* __restrict__ part, int nslabs, int N, int C, int fold, float alpha,
+                                                             float* __restrict__ out) {
+    __shared__ double red[256];
     const int Cq = C / fold;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N * Cq) return;
-    const int n = idx / Cq, c = idx - n * Cq;
+    const int o = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + o;
     double s = 0.0;
-    for (int f = 0; f < fold; ++f)
-        for (int k = 0; k < nslabs; ++k) s += (double)part[((size_t)n * nslabs + k) * C + f * Cq + c];
-    out[idx] = (float)(alpha * s);
+    if (idx < N * Cq) {
+        const int n = idx / Cq, c = idx - n * Cq;
+        for (int f = 0; f < fold; ++f)
+            for (int k = lane; k < nslabs; k += 16) s += (double)part[((size_t)n * nslabs + k) * C + f * Cq + c];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (lane == 0 && idx < N * Cq) {
+        for (int l = 1; l < 16; ++l) s += red[l * 16 + o];
+        out[idx] = (float)(alpha * s);
+    }
 }
 
 static int chansum_slabs(long long npix, int C, int EPC) {
@@ -480,12 +489,150 @@ static int chansum_launch(const void* x, int ld, int N, long long npix, int C, f
     hipLaunchKernelGGL((chansum_kernel<T, SQ>), dim3(nslabs, ngroups, N), dim3(256), 0, s, (const T*)x, ld, npix, C, ps, pq);
     MIS_LAUNCH_CHECK("chansum");
     const int Cq = C / fold;
-    hipLaunchKernelGGL(chansum_reduce_kernel, dim3((N * Cq + 255) / 256), dim3(256), 0, s, (const float*)ps, nslabs, N, C, fold, alpha, sum);
+    hipLaunchKernelGGL(chansum_reduce_kernel, dim3((N * Cq + 15) / 16), dim3(256), 0, s, (const float*)ps, nslabs, N, C, fold, alpha, sum);
     MIS_LAUNCH_CHECK("chansum_reduce");
     if (SQ) {
-        hipLaunchKernelGGL(chansum_reduce_kernel, dim3((N * Cq + 255) / 256), dim3(256), 0, s, (const float*)pq, nslabs, N, C, fold, alpha, sumsq);
+        hipLaunchKernelGGL(chansum_reduce_kernel, dim3((N * Cq + 15) / 16), dim3(256), 0, s, (const float*)pq, nslabs, N, C, fold, alpha, sumsq);
         MIS_LAUNCH_CHECK("chansum_reduce_sq");
     }
+    return MIS_OK;
+}
+
+// BatchNorm2d + ReLU backward without a materialised g = dy * (y > 0): the mask is recomputed from z as fma(z, scale, shift) > 0 (the expression
+// mis_affine_act evaluated in the forward), so the two passes read dy and z only.
+//   stats: S1[n][c] = sum_pix m * dy,  S2[n][c] = sum_pix m * dy * z           apply: dz = p * (m * dy) + q * z + r
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__ dy, int dy_ld, const T* __restrict__ z, int z_ld, long long npix, int C,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           float* __restrict__ part1, float* __restrict__ part2) {
+    constexpr int EPC = Tr<T>::EPC;
+    __shared__ float red[256 * 8];
+    __shared__ float red2[256 * 8];
+    const int nchunks = C / EPC;
+    const int chb = nchunks < 256 ? nchunks : 256;
+    const int rows = 256 / chb;
+    const int tid = threadIdx.x;
+    const int cl = tid % chb, r = tid / chb;
+    const int chunk = blockIdx.y * chb + cl;
+    const int n = blockIdx.z;
+    const int nslabs = gridDim.x;
+    float s[EPC], q[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s[e] = q[e] = 0.f;
+    if (chunk < nchunks && r < rows) {
+        float sc[EPC], sh[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            sc[e] = scale[(size_t)n * C + chunk * EPC + e];
+            sh[e] = shift[(size_t)n * C + chunk * EPC + e];
+        }
+        const T* gb = dy + (size_t)n * npix * dy_ld + (size_t)chunk * EPC;
+        const T* zb = z + (size_t)n * npix * z_ld + (size_t)chunk * EPC;
+        for (long long p = (long long)blockIdx.x * rows + r; p < npix; p += (long long)nslabs * rows) {
+            float g[EPC], f[EPC];
+            unpack_chunk<T>(*reinterpret_cast<const u32x4*>(gb + p * dy_ld), g);
+            unpack_chunk<T>(*reinterpret_cast<const u32x4*>(zb + p * z_ld), f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float m = fmaf(f[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
+                s[e] += m;
+                q[e] = fmaf(m, f[e], q[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        red[tid * EPC + e] = s[e];
+        red2[tid * EPC + e] = q[e];
+    }
+    __syncthreads();
+    if (r == 0 && chunk < nchunks) {
+        for (int k = 1; k < rows; ++k)
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                s[e] += red[(k * chb + cl) * EPC + e];
+                q[e] += red2[(k * chb + cl) * EPC + e];
+            }
+        float* o = part1 + ((size_t)n * nslabs + blockIdx.x) * C + (size_t)chunk * EPC;
+        float* o2 = part2 + ((size_t)n * nslabs + blockIdx.x) * C + (size_t)chunk * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            o[e] = s[e];
+            o2[e] = q[e];
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, int dy_ld, const T* __restrict__ z, int z_ld, int N, long long npix, int C,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ p,
+                                                           const float* __restrict__ q, const float* __restrict__ r, T* __restrict__ dz, int dz_ld) {
+    constexpr int EPC = Tr<T>::EPC;
+    const int nch = C / EPC;
+    const long long total = (long long)N * npix * nch;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        const long long pp = i / nch;
+        const size_t nc = (size_t)(pp / npix) * C + (size_t)ch * EPC;
+        float g[EPC], f[EPC], o[EPC];
+        unpack_chunk<T>(*reinterpret_cast<const u32x4*>(dy + (size_t)pp * dy_ld + (size_t)ch * EPC), g);
+        unpack_chunk<T>(*reinterpret_cast<const u32x4*>(z + (size_t)pp * z_ld + (size_t)ch * EPC), f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float m = fmaf(f[e], scale[nc + e], shift[nc + e]) > 0.f ? g[e] : 0.f;
+            o[e] = fmaf(p[nc + e], m, fmaf(q[nc + e], f[e], r[nc + e]));
+        }
+        *reinterpret_cast<u32x4*>(dz + (size_t)pp * dz_ld + (size_t)ch * EPC) = pack_chunk<T>(o);
+    }
+}
+
+extern "C" size_t mis_bn_bwd_stats_workspace_bytes(int N, int C) { return (size_t)2 * N * CS_SLABS * C * sizeof(float); }
+
+extern "C" int mis_bn_bwd_stats(int dtype, const void* dy, int dy_ld, const void* z, int z_ld, int N, long long npix, int C, const float* scale,
+                                const float* shift, float* workspace, float* S1, float* S2, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, MIS_EINVAL, "bn_bwd_stats: bad dtype %d", dtype);
+    const int EPC = dtype == MIS_BF16 ? 8 : 4;
+    MIS_REQUIRE(dy && z && scale && shift && workspace && S1 && S2 && npix > 0 && N > 0, MIS_EINVAL, "bn_bwd_stats: bad argument");
+    MIS_REQUIRE(C > 0 && C % EPC == 0 && dy_ld % EPC == 0 && z_ld % EPC == 0 && dy_ld >= C && z_ld >= C, MIS_EINVAL, "bn_bwd_stats: C / ld alignment");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nchunks = C / EPC;
+    const int chb = nchunks < 256 ? nchunks : 256;
+    const int ngroups = (nchunks + chb - 1) / chb;
+    const int nslabs = chansum_slabs(npix, C, EPC);
+    float* p1 = workspace;
+    float* p2 = workspace + (size_t)N * CS_SLABS * C;
+    if (dtype == MIS_BF16)
+        hipLaunchKernelGGL(bn_bwd_stats_kernel<__bf16>, dim3(nslabs, ngroups, N), dim3(256), 0, s, (const __bf16*)dy, dy_ld, (const __bf16*)z, z_ld, npix, C,
+                           scale, shift, p1, p2);
+    else
+        hipLaunchKernelGGL(bn_bwd_stats_kernel<float>, dim3(nslabs, ngroups, N), dim3(256), 0, s, (const float*)dy, dy_ld, (const float*)z, z_ld, npix, C, scale,
+                           shift, p1, p2);
+    MIS_LAUNCH_CHECK("bn_bwd_stats");
+    hipLaunchKernelGGL(chansum_reduce_kernel, dim3((N * C + 15) / 16), dim3(256), 0, s, (const float*)p1, nslabs, N, C, 1, 1.f, S1);
+    hipLaunchKernelGGL(chansum_reduce_kernel, dim3((N * C + 15) / 16), dim3(256), 0, s, (const float*)p2, nslabs, N, C, 1, 1.f, S2);
+    MIS_LAUNCH_CHECK("bn_bwd_stats_reduce");
+    return MIS_OK;
+}
+
+extern "C" int mis_bn_bwd_apply(int dtype, const void* dy, int dy_ld, const void* z, int z_ld, int N, long long npix, int C, const float* scale,
+                                const float* shift, const float* p, const float* q, const float* r, void* dz, int dz_ld, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, MIS_EINVAL, "bn_bwd_apply: bad dtype %d", dtype);
+    const int EPC = dtype == MIS_BF16 ? 8 : 4;
+    MIS_REQUIRE(dy && z && scale && shift && p && q && r && dz && npix > 0 && N > 0, MIS_EINVAL, "bn_bwd_apply: bad argument");
+    MIS_REQUIRE(C > 0 && C % EPC == 0 && dy_ld % EPC == 0 && z_ld % EPC == 0 && dz_ld % EPC == 0 && dy_ld >= C && z_ld >= C && dz_ld >= C, MIS_EINVAL,
+                "bn_bwd_apply: C / ld alignment");
+    long long blocks = ((long long)N * npix * (C / EPC) + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIS_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, (const __bf16*)dy, dy_ld, (const __bf16*)z, z_ld, N, npix, C,
+                           scale, shift, p, q, r, (__bf16*)dz, dz_ld);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, dy_ld, (const float*)z, z_ld, N, npix, C, scale,
+                           shift, p, q, r, (float*)dz, dz_ld);
+    MIS_LAUNCH_CHECK("bn_bwd_apply");
     return MIS_OK;
 }
 

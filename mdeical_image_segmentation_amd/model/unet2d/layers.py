@@ -45,6 +45,20 @@ def _to_nhwc(x, dtype, Cp=None):
     return y
 
 
+def _grad_nhwc(gy, dtype):
+    """Incoming gradient (N, C, H, W) -> NHWC kernel operand.  torch.cat's backward hands every branch a channel slice (narrow) of one
+    channels_last gradient: such a slice is passed to the kernels as a strided ops.View of its base (row stride = all channels), without a copy."""
+    base = gy._base
+    if base is not None and base.dim() == 4 and gy.dtype == dtype and base.dtype == dtype and gy.stride() == base.stride():
+        N, C, H, W = gy.shape
+        full = base.permute(0, 2, 3, 1)
+        c0 = gy.storage_offset() - base.storage_offset()
+        if full.is_contiguous() and tuple(full.shape[:3]) == (N, H, W) and 0 <= c0 and c0 + C <= full.shape[3] \
+                and (c0 * gy.element_size()) % 16 == 0 and (full.shape[3] * gy.element_size()) % 16 == 0:
+            return ops.View(full, c0, C)
+    return _to_nhwc(gy, dtype)
+
+
 def _to_nchw(y, C=None):
     """NHWC buffer -> (N, C, H, W)-shaped channels_last VIEW of its first C channels (no copy, same dtype)"""
     v = y.permute(0, 3, 1, 2)
@@ -254,26 +268,25 @@ class _Conv3x3BNReLU(torch.autograd.Function):
                             scale, shift, mean, rstd, eps=eps, momentum=momentum)
         y = torch.empty_like(z)
         ops.affine_act(z, y, scale, shift, relu=True)
-        ctx.save_for_backward(xin, z, y, mean, rstd, gamma.detach().float())
+        ctx.save_for_backward(xin, z, scale, shift, mean, rstd, gamma.detach().float())
         ctx.wd, ctx.training = wd, training
         ctx.shape = (N, Cin, H, W, Cout, Cp)
         return _to_nchw(y)
 
     @staticmethod
     def backward(ctx, gy):
-        xin, z, y, mean, rstd, gamma = ctx.saved_tensors
+        xin, z, scale, shift, mean, rstd, gamma = ctx.saved_tensors
         N, Cin, H, W, Cout, Cp = ctx.shape
-        dt, dev = y.dtype, gy.device
+        dt, dev = z.dtype, gy.device
         f32 = dict(dtype=torch.float32, device=dev)
-        g = torch.empty_like(y)
-        ops.relu_mask(_to_nhwc(gy, dt), y, g)                    # g = gy * (y > 0)
+        g = _grad_nhwc(gy, dt)
         S1, S2 = torch.empty(N, Cout, **f32), torch.empty(N, Cout, **f32)
-        ops.gn_bwd_stats(g, z, Cout, False, (N, 1, H, W), S1, S2, Cout, 0)
+        ops.bn_bwd_stats(g, z, scale, shift, S1, S2)            # the ReLU mask (y > 0) is recomputed from z: no masked copy of the gradient
         p, q, r = (torch.empty(N, Cout, **f32) for _ in range(3))
         dgamma, dbeta = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
         ops.bn_bwd_finalize(S1, S2, mean, rstd, gamma, N, Cout, N * H * W, ctx.training, p, q, r, dgamma, dbeta)
         dz = torch.empty_like(z)
-        ops.gn_bwd_apply(g, z, Cout, False, (N, 1, H, W), p, q, r, Cout, 0, dz)
+        ops.bn_bwd_apply(g, z, scale, shift, p, q, r, dz)
         dwp = torch.empty(Cout, Cp, 3, 3, **f32)
         db = torch.empty(Cout, **f32)
         ops.wgrad(xin, dz, dwp, ksize=3, Cin=Cp, Cout=Cout, dbias=db)
@@ -370,27 +383,26 @@ class _UpConv3x3BNReLU(torch.autograd.Function):
                             scale, shift, mean, rstd, eps=eps, momentum=momentum)
         y = torch.empty_like(z)
         ops.affine_act(z, y, scale, shift, relu=True)
-        ctx.save_for_backward(xin, z, y, mean, rstd, gamma.detach().float(), wpad)
+        ctx.save_for_backward(xin, z, scale, shift, mean, rstd, gamma.detach().float(), wpad)
         ctx.training = training
         ctx.shape = (N, Cin, h, wl, Cout, Cp, s)
         return _to_nchw(y)
 
     @staticmethod
     def backward(ctx, gy):
-        xin, z, y, mean, rstd, gamma, wpad = ctx.saved_tensors
+        xin, z, scale, shift, mean, rstd, gamma, wpad = ctx.saved_tensors
         N, Cin, h, wl, Cout, Cp, s = ctx.shape
         H, W = h * s, wl * s
-        dt, dev = y.dtype, gy.device
+        dt, dev = z.dtype, gy.device
         f32 = dict(dtype=torch.float32, device=dev)
-        g = torch.empty_like(y)
-        ops.relu_mask(_to_nhwc(gy, dt), y, g)
+        g = _grad_nhwc(gy, dt)
         S1, S2 = torch.empty(N, Cout, **f32), torch.empty(N, Cout, **f32)
-        ops.gn_bwd_stats(g, z, Cout, False, (N, 1, H, W), S1, S2, Cout, 0)
+        ops.bn_bwd_stats(g, z, scale, shift, S1, S2)
         p, q, r = (torch.empty(N, Cout, **f32) for _ in range(3))
         dgamma, dbeta = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
         ops.bn_bwd_finalize(S1, S2, mean, rstd, gamma, N, Cout, N * H * W, ctx.training, p, q, r, dgamma, dbeta)
         dz = torch.empty_like(z)
-        ops.gn_bwd_apply(g, z, Cout, False, (N, 1, H, W), p, q, r, Cout, 0, dz)
+        ops.bn_bwd_apply(g, z, scale, shift, p, q, r, dz)
         del g
         db = torch.empty(Cout, **f32)
         ops.colsum(dz, db)

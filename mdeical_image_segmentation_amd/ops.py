@@ -461,6 +461,24 @@ def bilinear_up_bwd(dy, dx, scale):
           "mis_bilinear_up_bwd")
 
 
+def bn_bwd_stats(dy, z, scale, shift, S1, S2):
+    """S1[n][c] = sum m*dy, S2 = sum m*dy*z with the ReLU mask m = (z*scale + shift > 0) recomputed from z"""
+    lib = load()
+    dy, z = _v(dy), _v(z)
+    npix = z.D * z.H * z.W
+    ws = workspace(lib.mis_bn_bwd_stats_workspace_bytes(z.N, z.C), z.t.device, "bn_bwd")
+    check(lib.mis_bn_bwd_stats(dtype_code(z.dtype), dy.ptr, dy.ld, z.ptr, z.ld, z.N, npix, z.C, scale.data_ptr(), shift.data_ptr(), ws.data_ptr(),
+                               S1.data_ptr(), S2.data_ptr(), stream_ptr()), "mis_bn_bwd_stats")
+
+
+def bn_bwd_apply(dy, z, scale, shift, p, q, r, dz):
+    lib = load()
+    dy, z, dz = _v(dy), _v(z), _v(dz)
+    npix = z.D * z.H * z.W
+    check(lib.mis_bn_bwd_apply(dtype_code(z.dtype), dy.ptr, dy.ld, z.ptr, z.ld, z.N, npix, z.C, scale.data_ptr(), shift.data_ptr(), p.data_ptr(),
+                               q.data_ptr(), r.data_ptr(), dz.ptr, dz.ld, stream_ptr()), "mis_bn_bwd_apply")
+
+
 def upconv_gather_fwd(z, y, scale, C, bias=None):
     """z (N, h, w, 9*C) dense -> y (N, h*s, w*s, C): the 3x3 taps of conv3x3(bilinear_up_s(x)) gathered from the low-resolution tap products"""
     lib = load()
