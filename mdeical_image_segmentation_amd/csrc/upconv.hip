@@ -21,6 +21,24 @@ __device__ __forceinline__ void upc_src(int dst, float inv_scale, int n, int& i0
     lam = src - (float)i0;
 }
 
+// per axis and tap offset k in {0,1,2}: the two source indices and their weights for upsampled position o + k - 1 (weights 0 when that position is
+// in the zero padding of the 3x3 convolution) - branch-free, so that all 36 chunk loads of an output element are independent and issued together
+struct UpcAxis {
+    int i0[3], i1[3];
+    float w0[3], w1[3];
+};
+__device__ __forceinline__ void upc_axis(int o, float inv, int n, int n_up, UpcAxis& a) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int p = o + k - 1;
+        const bool ok = p >= 0 && p < n_up;
+        float lam;
+        upc_src(ok ? p : 0, inv, n, a.i0[k], a.i1[k], lam);
+        a.w0[k] = ok ? 1.f - lam : 0.f;
+        a.w1[k] = ok ? lam : 0.f;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void upconv_gather_fwd_kernel(const T* __restrict__ Z, T* __restrict__ y, int y_ld, const float* __restrict__ bias, int N,
                                                                 int h, int w, int s, int C) {
@@ -31,35 +49,30 @@ __global__ __launch_bounds__(256) void upconv_gather_fwd_kernel(const T* __restr
     const long long total = (long long)N * H * W * nch;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int ch = (int)(i % nch);
-        long long r = i / nch;
+        const long long r = i / nch;
         const int ox = (int)(r % W);
-        r /= W;
-        const int oy = (int)(r % H);
-        const int n = (int)(r / H);
+        const int rr = (int)(r / W);
+        const int oy = rr % H;
+        const int n = rr / H;
+        UpcAxis ay, ax;
+        upc_axis(oy, inv, h, H, ay);
+        upc_axis(ox, inv, w, W, ax);
         float acc[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[e] = bias ? bias[ch * EPC + e] : 0.f;
         const T* img = Z + (size_t)n * h * w * zld + (size_t)ch * EPC;
+#pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const int py = oy + ky - 1;
-            if (py < 0 || py >= H) continue;
-            int y0, y1;
-            float ly;
-            upc_src(py, inv, h, y0, y1, ly);
-            const float hy = 1.f - ly;
+            const T* r0 = img + (size_t)ay.i0[ky] * w * zld + (size_t)(ky * 3) * C;
+            const T* r1 = img + (size_t)ay.i1[ky] * w * zld + (size_t)(ky * 3) * C;
+#pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int px = ox + kx - 1;
-                if (px < 0 || px >= W) continue;
-                int x0, x1;
-                float lx;
-                upc_src(px, inv, w, x0, x1, lx);
-                const float hx = 1.f - lx;
-                const T* base = img + (size_t)(ky * 3 + kx) * C;
                 float a[EPC], b[EPC], c[EPC], d[EPC];
-                unpack_chunk<T>(*reinterpret_cast<const u32x4*>(base + ((size_t)y0 * w + x0) * zld), a);
-                unpack_chunk<T>(*reinterpret_cast<const u32x4*>(base + ((size_t)y0 * w + x1) * zld), b);
-                unpack_chunk<T>(*reinterpret_cast<const u32x4*>(base + ((size_t)y1 * w + x0) * zld), c);
-                unpack_chunk<T>(*reinterpret_cast<const u32x4*>(base + ((size_t)y1 * w + x1) * zld), d);
+                unpack_chunk<T>(*reinterpret_cast<const u32x4*>(r0 + (size_t)ax.i0[kx] * zld + kx * C), a);
+                unpack_chunk<T>(*reinterpret_cast<const u32x4*>(r0 + (size_t)ax.i1[kx] * zld + kx * C), b);
+                unpack_chunk<T>(*reinterpret_cast<const u32x4*>(r1 + (size_t)ax.i0[kx] * zld + kx * C), c);
+                unpack_chunk<T>(*reinterpret_cast<const u32x4*>(r1 + (size_t)ax.i1[kx] * zld + kx * C), d);
+                const float hx = ax.w0[kx], lx = ax.w1[kx], hy = ay.w0[ky], ly = ay.w1[ky];
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) acc[e] += hy * (hx * a[e] + lx * b[e]) + ly * (hx * c[e] + lx * d[e]);
             }
@@ -124,6 +137,114 @@ __global__ __launch_bounds__(256) void upconv_gather_bwd_kernel(const T* __restr
     }
 }
 
+// weight with which upsampled position q references low-resolution index j (0 when q lies in the zero padding)
+__device__ __forceinline__ float upc_coef(int q, int j, float inv, int n, int n_up) {
+    const bool ok = q >= 0 && q < n_up;
+    int i0, i1;
+    float lam;
+    upc_src(ok ? q : 0, inv, n, i0, i1, lam);
+    const float wgt = (i0 == j ? 1.f - lam : 0.f) + (i1 == j ? lam : 0.f);
+    return ok ? wgt : 0.f;
+}
+
+// C == 64: one thread per (low-resolution pixel, 16-byte chunk, row part) accumulates ALL nine taps from one pass over the (2s+3)^2 window of dY
+// (each dY chunk is loaded once instead of once per tap); for large scales the window rows are dealt round-robin to R threads whose partial sums
+// are added in a fixed order through LDS.
+template <typename T, int R>
+__global__ __launch_bounds__(256) void upconv_gather_bwd64_kernel(const T* __restrict__ dY, int dy_ld, T* __restrict__ dZ, int N, int h, int w, int s) {
+    constexpr int EPC = Tr<T>::EPC, NCH = 64 / EPC, JPB = 256 / (NCH * R);
+    __shared__ float red[R > 1 ? 256 * 3 * EPC : 1];
+    const int H = h * s, W = w * s;
+    const float inv = 1.0f / (float)s;
+    const int ch = threadIdx.x % NCH;
+    const int part = (threadIdx.x / NCH) % R;
+    const int jl = threadIdx.x / (NCH * R);
+    const long long jtot = (long long)N * h * w;
+    for (long long jb = (long long)blockIdx.x * JPB; jb < jtot; jb += (long long)gridDim.x * JPB) {
+        const long long j = jb + jl;
+        const bool live = j < jtot;
+        float acc[9][EPC];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[t][e] = 0.f;
+        if (live) {
+            const int jx = (int)(j % w);
+            const int rr = (int)(j / w);
+            const int jy = rr % h;
+            const int n = rr / h;
+            int oylo = s * (jy - 1) - 2, oyhi = s * (jy + 2) + 1, oxlo = s * (jx - 1) - 2, oxhi = s * (jx + 2) + 1;
+            if (oylo < 0) oylo = 0;
+            if (oyhi > H - 1) oyhi = H - 1;
+            if (oxlo < 0) oxlo = 0;
+            if (oxhi > W - 1) oxhi = W - 1;
+            const T* img = dY + (size_t)n * H * W * dy_ld + (size_t)ch * EPC;
+            for (int oy = oylo + part; oy <= oyhi; oy += R) {
+                float wy[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) wy[k] = upc_coef(oy + k - 1, jy, inv, h, H);
+                if (wy[0] == 0.f && wy[1] == 0.f && wy[2] == 0.f) continue;
+                const T* row = img + (size_t)oy * W * dy_ld;
+#pragma unroll 2
+                for (int ox = oxlo; ox <= oxhi; ++ox) {
+                    float g[EPC], wx[3];
+                    unpack_chunk<T>(*reinterpret_cast<const u32x4*>(row + (size_t)ox * dy_ld), g);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) wx[k] = upc_coef(ox + k - 1, jx, inv, w, W);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const float cw = wy[ky] * wx[kx];
+#pragma unroll
+                            for (int e = 0; e < EPC; ++e) acc[ky * 3 + kx][e] = fmaf(cw, g[e], acc[ky * 3 + kx][e]);
+                        }
+                }
+            }
+        }
+        if (R > 1) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) red[(threadIdx.x * 3 + kx) * EPC + e] = acc[ky * 3 + kx][e];
+                __syncthreads();
+                if (part == 0)
+                    for (int pp = 1; pp < R; ++pp)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                            for (int e = 0; e < EPC; ++e) acc[ky * 3 + kx][e] += red[((threadIdx.x + pp * NCH) * 3 + kx) * EPC + e];
+                __syncthreads();
+            }
+        }
+        if (live && part == 0) {
+            T* dst = dZ + (size_t)j * 9 * 64 + (size_t)ch * EPC;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) *reinterpret_cast<u32x4*>(dst + t * 64) = pack_chunk<T>(acc[t]);
+        }
+    }
+}
+
+template <typename T, int R>
+static void upc_launch_bwd64(const void* dy, int dy_ld, void* dz, int N, int h, int w, int s, hipStream_t st) {
+    constexpr int JPB = 256 / ((64 / Tr<T>::EPC) * R);
+    long long blocks = ((long long)N * h * w + JPB - 1) / JPB;
+    if (blocks > 262144) blocks = 262144;
+    hipLaunchKernelGGL((upconv_gather_bwd64_kernel<T, R>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)dy, dy_ld, (T*)dz, N, h, w, s);
+}
+
+template <typename T>
+static void upc_dispatch_bwd64(const void* dy, int dy_ld, void* dz, int N, int h, int w, int s, hipStream_t st) {
+    if (s <= 4)
+        upc_launch_bwd64<T, 1>(dy, dy_ld, dz, N, h, w, s, st);
+    else if (s <= 8)
+        upc_launch_bwd64<T, 4>(dy, dy_ld, dz, N, h, w, s, st);
+    else
+        upc_launch_bwd64<T, 8>(dy, dy_ld, dz, N, h, w, s, st);
+}
+
 static int upc_check(const char* what, int dtype, const void* a, const void* b, int ld, int N, int h, int w, int s, int C) {
     MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, MIS_EINVAL, "%s: bad dtype %d", what, dtype);
     const int EPC = dtype == MIS_BF16 ? 8 : 4;
@@ -159,8 +280,16 @@ extern "C" int mis_upconv_gather_bwd(int dtype, const void* dy, int dy_ld, void*
     (void)hipGetLastError();
     if (int rc = upc_check("upconv_gather_bwd", dtype, dy, dz, dy_ld, N, h, w, scale, C)) return rc;
     const int EPC = dtype == MIS_BF16 ? 8 : 4;
-    const unsigned g = upc_grid((long long)N * h * w * 9 * (C / EPC));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (C == 64 && getenv("MIS_UPCONV_BWD_GENERIC") == nullptr) {
+        if (dtype == MIS_BF16)
+            upc_dispatch_bwd64<__bf16>(dy, dy_ld, dz, N, h, w, scale, st);
+        else
+            upc_dispatch_bwd64<float>(dy, dy_ld, dz, N, h, w, scale, st);
+        MIS_LAUNCH_CHECK("upconv_gather_bwd64");
+        return MIS_OK;
+    }
+    const unsigned g = upc_grid((long long)N * h * w * 9 * (C / EPC));
     if (dtype == MIS_BF16)
         hipLaunchKernelGGL(upconv_gather_bwd_kernel<__bf16>, dim3(g), dim3(256), 0, st, (const __bf16*)dy, dy_ld, (__bf16*)dz, N, h, w, scale, C);
     else

@@ -90,6 +90,23 @@ def test_upconv_bn_relu_matches_upsample_then_conv(s, shape, dtype, monkeypatch)
         assert rel(d.grad, r.grad) < tol, name
 
 
+@pytest.mark.parametrize("s,C", [(2, 64), (8, 64), (16, 64), (4, 128), (16, 32)])
+def test_upconv_gathers_are_adjoint(s, C):
+    """<gather_fwd(z), dy> == <z, gather_bwd(dy)> for the all-taps C=64 kernels (every row-split factor) and the generic ones"""
+    from mdeical_image_segmentation_amd import ops
+    gen = torch.Generator().manual_seed(s * 1000 + C)
+    N, h, w = 2, 3, 5
+    z = torch.randn(N, h, w, 9 * C, generator=gen).cuda()
+    dy = torch.randn(N, h * s, w * s, C, generator=gen).cuda()
+    y = torch.empty_like(dy)
+    dz = torch.empty_like(z)
+    ops.upconv_gather_fwd(z, y, s, C)
+    ops.upconv_gather_bwd(dy, dz, s, C)
+    a = (y.double() * dy.double()).sum().item()
+    b = (z.double() * dz.double()).sum().item()
+    assert abs(a - b) < 1e-5 * max(1.0, abs(a)), (a, b)
+
+
 def test_unet3plus_matches_reference_golden():
     from mdeical_image_segmentation_amd.model.unet2d.unet import UNet_3Plus
     g = load_golden("g9_unet3plus.npz")
