@@ -214,6 +214,9 @@ int mis_affine_act(int dtype, const void* x, int x_ld, void* y, int y_ld, int N,
  * 4- or 8-byte elements for the geometric ops (raw fp32 / int64 labels), fp32 for the intensity ops; src != dst. */
 int mis_aug_flip_rot90(const void* src, void* dst, long long nvol, int D, int H, int W, int flipmask /*bit0 D, bit1 H, bit2 W*/, int k,
                        int elem_size, void* stream);
+/* CropToFixed (augment/unet3d_augment/transforms.py:194-247) on (nslices, H, W) planes: dst (nslices, CH, CW)[i][j] = src[r(y0+i)][r(x0+j)],
+ * r = numpy.pad(mode='reflect') index rule; elem_size 4 or 8 (raw fp32 / int64 labels). */
+int mis_aug_crop_reflect(const void* src, void* dst, long long nslices, int H, int W, int y0, int x0, int CH, int CW, int elem_size, void* stream);
 int mis_aug_rotate0(const void* src, void* dst, long long nvol, int D, int H, int W, int a0, int a1, const double* m4 /*host*/,
                     const double* off2 /*host*/, int elem_size, void* stream);
 /* order-3 (cubic spline) variant, fp32 volumes: workspace = nvol*D*H*W doubles (the float64 spline coefficients scipy keeps) */

@@ -12,7 +12,9 @@ outputs are CUDA tensors.  Differences, all loud or documented:
     on-device counter-based generator (same distribution, different values); `exact=True` generates the field with
     numpy on the host instead;
   * ElasticDeformation: spline_order 0 and 3 (fields from the reference's stream, smoothing + resampling on the device);
-  * Poisson noise, GaussianBlur3D (needs skimage), label->boundary transforms: out of scope.
+  * AdditivePoissonNoise: the integer field comes from the reference's stream on the host (uploaded, added on the device: bit-exact);
+  * CropToFixed: window / mirror padding as one gather kernel, start positions from the reference's stream;
+  * GaussianBlur3D (needs skimage), PercentileNormalizer, label->boundary transforms: out of scope.
 """
 import ctypes as C
 import importlib
@@ -327,10 +329,62 @@ def _unbuilt(name):
     return _U
 
 
-AdditivePoissonNoise = _unbuilt("AdditivePoissonNoise")
+class AdditivePoissonNoise:
+    """transforms.py:622-633: if uniform() < p: lam = uniform(lam range); m + Poisson(lam) field.  The field is drawn from the reference's
+    own stream on the host (keeps every later draw aligned) and added on the device; fp32 result = the reference's float64 sum rounded once."""
+
+    def __init__(self, random_state, lam=(0.0, 1.0), execution_probability=0.1, **kwargs):
+        self.execution_probability = execution_probability
+        self.random_state = random_state
+        self.lam = lam
+
+    def __call__(self, m):
+        if self.random_state.uniform() < self.execution_probability:
+            lam = self.random_state.uniform(self.lam[0], self.lam[1])
+            m = _dev(m).to(torch.float32)
+            noise = torch.from_numpy(self.random_state.poisson(lam, size=tuple(m.shape)).astype(np.float32)).to(m.device)
+            if m.numel() % 4 == 0:
+                out = torch.empty_like(m)
+                ops.add_act(m.view(1, 1, -1, 4), noise.view(1, 1, -1, 4), out.view(1, 1, -1, 4))
+                return out
+            return m + noise
+        return m
+
+
+class CropToFixed:
+    """transforms.py:194-247: random (or centred) (crop_y, crop_x) window of the last two axes; an axis shorter than the crop is taken whole
+    and mirror-padded (numpy 'reflect') to the crop size.  One gather kernel (mis_aug_crop_reflect); raw fp32 and int64 labels alike."""
+
+    def __init__(self, random_state, size=(256, 256), centered=False, **kwargs):
+        self.random_state = random_state
+        self.crop_y, self.crop_x = size
+        self.centered = centered
+
+    @staticmethod
+    def _start_pad(crop_size, max_size, rs):
+        if crop_size < max_size:
+            return (rs.randint(max_size - crop_size) if rs is not None else (max_size - crop_size) // 2), 0
+        if rs is not None:
+            rs.randint(1)                                   # the reference still draws (range 1) - keeps the stream aligned
+        return 0, (crop_size - max_size) // 2
+
+    def __call__(self, m):
+        m = _dev(m)
+        y, x = m.shape[-2:]
+        rs = None if self.centered else self.random_state
+        y_start, y_lo = self._start_pad(self.crop_y, y, rs)
+        x_start, x_lo = self._start_pad(self.crop_x, x, rs)
+        es = m.element_size()
+        if es not in (4, 8):
+            raise MisError(f"augment: unsupported element size {es} ({m.dtype})")
+        out = torch.empty(tuple(m.shape[:-2]) + (self.crop_y, self.crop_x), dtype=m.dtype, device=m.device)
+        check(load().mis_aug_crop_reflect(m.data_ptr(), out.data_ptr(), m.numel() // (y * x), y, x, y_start - y_lo, x_start - x_lo,
+                                          self.crop_y, self.crop_x, es, stream_ptr()), "mis_aug_crop_reflect")
+        return out
+
+
 GaussianBlur3D = _unbuilt("GaussianBlur3D")
 PercentileNormalizer = _unbuilt("PercentileNormalizer")
-CropToFixed = _unbuilt("CropToFixed")
 
 
 class Transformer:

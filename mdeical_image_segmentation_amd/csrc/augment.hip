@@ -116,6 +116,42 @@ extern "C" int mis_aug_flip_rot90(const void* src, void* dst, long long nvol, in
     return MIS_OK;
 }
 
+// CropToFixed (transforms.py:194-247): out[v][z][i][j] = src[v][z][r(y0 + i)][r(x0 + j)], r = numpy 'reflect' (edge not repeated, periodic):
+// a plain window when the crop is smaller than the plane, the whole plane mirror-padded to the crop size otherwise
+template <typename E>
+__global__ __launch_bounds__(256) void aug_crop_reflect_kernel(const E* __restrict__ src, E* __restrict__ dst, long long nslices, int H, int W, int y0, int x0,
+                                                               int CH, int CW) {
+    const long long total = nslices * CH * CW;
+    const int ph = H > 1 ? 2 * H - 2 : 1, pw = W > 1 ? 2 * W - 2 : 1;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int j = (int)(i % CW);
+        long long r = i / CW;
+        const int ii = (int)(r % CH);
+        const long long sl = r / CH;
+        int y = (y0 + ii) % ph, x = (x0 + j) % pw;
+        if (y < 0) y += ph;
+        if (x < 0) x += pw;
+        if (y >= H) y = ph - y;
+        if (x >= W) x = pw - x;
+        dst[i] = src[(sl * H + y) * W + x];
+    }
+}
+
+extern "C" int mis_aug_crop_reflect(const void* src, void* dst, long long nslices, int H, int W, int y0, int x0, int CH, int CW, int elem_size,
+                                    void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(src && dst && src != dst && nslices > 0 && H > 0 && W > 0 && CH > 0 && CW > 0, MIS_EINVAL, "aug_crop_reflect: bad argument");
+    MIS_REQUIRE(elem_size == 4 || elem_size == 8, MIS_EUNSUPPORTED, "aug_crop_reflect: element size %d", elem_size);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned g = aug_grid(nslices * CH * CW);
+    if (elem_size == 4)
+        hipLaunchKernelGGL(aug_crop_reflect_kernel<uint32_t>, dim3(g), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, nslices, H, W, y0, x0, CH, CW);
+    else
+        hipLaunchKernelGGL(aug_crop_reflect_kernel<uint64_t>, dim3(g), dim3(256), 0, s, (const uint64_t*)src, (uint64_t*)dst, nslices, H, W, y0, x0, CH, CW);
+    MIS_LAUNCH_CHECK("aug_crop_reflect");
+    return MIS_OK;
+}
+
 extern "C" int mis_aug_rotate0(const void* src, void* dst, long long nvol, int D, int H, int W, int a0, int a1, const double* m4,
                                const double* off2, int elem_size, void* stream) {
     (void)hipGetLastError();

@@ -196,3 +196,37 @@ class Pipeline:
 
     def label(self, m):
         return self._geo(m, self.rs["lflip"], self.rs["lrot90"], self.rs["lrot"])
+
+
+def crop_to_fixed(m, rs, size, centered=False):
+    """CropToFixed (transforms.py:194-247) as index arithmetic: window start from the stream (a draw even when the range is 1), then
+    out[..., i, j] = m[..., r(y0 - pad_lo_y + i), r(x0 - pad_lo_x + j)] with numpy's 'reflect' rule r (period 2n-2)."""
+    cy, cx = size
+    y, x = m.shape[-2:]
+
+    def start_pad(crop, mx):
+        if crop < mx:
+            return (mx - crop) // 2 if centered else None, 0
+        return 0, (crop - mx) // 2
+
+    (ys, ylo), (xs, xlo) = start_pad(cy, y), start_pad(cx, x)
+    if not centered:
+        ys = rs.randint(y - cy if cy < y else 1)
+        xs = rs.randint(x - cx if cx < x else 1)
+
+    def refl(idx, n):
+        if n == 1:
+            return np.zeros_like(idx)
+        p = 2 * n - 2
+        idx = np.mod(idx, p)
+        return np.where(idx < n, idx, p - idx)
+
+    iy = refl(ys - ylo + np.arange(cy), y)
+    ix = refl(xs - xlo + np.arange(cx), x)
+    return m[..., iy[:, None], ix[None, :]]
+
+
+def poisson_noise(m, rs, lam_range):
+    """AdditivePoissonNoise (transforms.py:622-633) after the execution draw: lam = uniform(range); m + poisson(lam) (float64 like numpy's promotion)."""
+    lam = rs.uniform(lam_range[0], lam_range[1])
+    return m + rs.poisson(lam, size=m.shape)

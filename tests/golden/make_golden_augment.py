@@ -70,6 +70,11 @@ def main():
     out["el_label_out"] = np.ascontiguousarray(tr.ElasticDeformation(np.random.RandomState(500), spline_order=0, alpha=15, sigma=3, execution_probability=1.0)(el))
     out["el_raw_2d"] = np.ascontiguousarray(tr.ElasticDeformation(np.random.RandomState(501), spline_order=3, alpha=2000, sigma=50, execution_probability=1.0,
                                                                    apply_3d=False)(ev))
+    # (5) CropToFixed (window, mirror-padded, mixed, centred; 3-D and 4-D; int64 labels) and Poisson noise
+    for s_, (size, cen, src) in enumerate([((8, 9), False, "v"), ((13, 20), False, "v"), ((7, 19), False, "v"), ((6, 6), True, "v"), ((12, 31), True, "v"),
+                                           ((4, 9), False, "c4"), ((8, 8), False, "label")]):
+        out[f"crop_{s_}"] = np.ascontiguousarray(tr.CropToFixed(np.random.RandomState(600 + s_), size=size, centered=cen)(out[src]))
+    out["poisson"] = tr.AdditivePoissonNoise(np.random.RandomState(700), lam=(0.5, 3.0), execution_probability=1.0)(v)
     np.savez_compressed(os.path.join(HERE, "g5_augment.npz"), **out)
     print("wrote g5_augment.npz", sum(a.nbytes for a in out.values()) // 1024, "KiB; seed", t.seed)
 

@@ -7,6 +7,9 @@ import torch
 from conftest import load_golden
 from oracle import augment_oracle as ao
 
+CROPS = [((8, 9), False, "v"), ((13, 20), False, "v"), ((7, 19), False, "v"), ((6, 6), True, "v"), ((12, 31), True, "v"), ((4, 9), False, "c4"),
+         ((8, 8), False, "label")]
+
 
 def _replay_single(g):
     """replays the explicit-seed single-transform goldens with the oracle"""
@@ -50,6 +53,24 @@ def test_oracle_matches_reference_goldens():
         rs = np.random.RandomState(seed)
         rs.uniform()
         assert np.array_equal(ao.elastic(g[src], rs, order, **kw), g[key]), key
+    for s_, (size, cen, src) in enumerate(CROPS):
+        assert np.array_equal(ao.crop_to_fixed(g[src], np.random.RandomState(600 + s_), size, cen), g[f"crop_{s_}"]), f"crop_{s_}"
+    rs = np.random.RandomState(700)
+    rs.uniform()
+    assert np.array_equal(ao.poisson_noise(g["v"], rs, (0.5, 3.0)), g["poisson"])
+
+
+@pytest.mark.gpu
+def test_device_crop_and_poisson_match_reference_goldens():
+    from mdeical_image_segmentation_amd.augment.unet3d_augment import transforms as tr
+    g = load_golden("g5_augment.npz")
+    for s_, (size, cen, src) in enumerate(CROPS):
+        out = tr.CropToFixed(np.random.RandomState(600 + s_), size=size, centered=cen)(g[src])
+        assert out.dtype == torch.from_numpy(g[src]).dtype and np.array_equal(out.cpu().numpy(), g[f"crop_{s_}"]), f"crop_{s_}"
+    out = tr.AdditivePoissonNoise(np.random.RandomState(700), lam=(0.5, 3.0), execution_probability=1.0)(g["v"])
+    assert np.array_equal(out.cpu().numpy(), g["poisson"].astype(np.float32))
+    keep = tr.AdditivePoissonNoise(np.random.RandomState(700), execution_probability=0.0)(g["v"])
+    assert np.array_equal(np.asarray(keep if isinstance(keep, np.ndarray) else keep.cpu().numpy()), g["v"])
 
 
 @pytest.mark.gpu
