@@ -70,6 +70,11 @@ template <typename T, typename G> struct WgStager {
     static constexpr int QI = G::M * 8 / 256;
     u32x4 pv[PI], qv[QI];
     uint32_t okmask;
+    // f32 path: the GroupNorm affine of this thread's channel chunk (tid & 7) is fetched WITH the tile, so that its latency hides under the previous
+    // tile's MFMAs (+2.7 % on the 3-D fp32 step).  The bf16 kernels keep the fetch in store(): prefetching there measured -15 % (3-D) and even slowed
+    // the affine-free 2-D kernel by 11 % through its effect on the register allocation.
+    static constexpr bool PREFETCH_AFFINE = sizeof(T) == 4;
+    float sc[PREFETCH_AFFINE ? EPC : 1], sh[PREFETCH_AFFINE ? EPC : 1];
 
     __device__ __forceinline__ void load(const WgArgs& a, int n, int d0, int h0, int w0, int kd, int ci0, int co0, int tid) {
         {
@@ -79,6 +84,20 @@ template <typename T, typename G> struct WgStager {
             const int shd = (s.D != a.D), shh = (s.H != a.H), shw = (s.W != a.W);   // exact 2x nearest-upsample addressing
             const T* base = reinterpret_cast<const T*>(s.p) + (size_t)n * s.D * s.H * s.W * s.ld + cl;
             okmask = 0u;
+            if constexpr (PREFETCH_AFFINE) if (a.in_scale != nullptr) {
+                const float* psc = a.in_scale + (size_t)n * a.Cin + ci0 + (tid & 7) * EPC;
+                const float* psh = a.in_shift + (size_t)n * a.Cin + ci0 + (tid & 7) * EPC;
+#pragma unroll
+                for (int e = 0; e < EPC; e += 4) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(psc + e);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(psh + e);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        sc[e + k] = v0[k];
+                        sh[e + k] = v1[k];
+                    }
+                }
+            }
 #pragma unroll
             for (int b = 0; b < PI; ++b) {
                 const int it = b * 256 + tid;
@@ -125,12 +144,17 @@ template <typename T, typename G> struct WgStager {
                 const int p = it >> 3, c16 = it & 7;
                 u32x4 val = pv[b];
                 if (a.in_scale != nullptr && ((okmask >> b) & 1u)) {
-                    const float* sc = a.in_scale + (size_t)n * a.Cin + ci0 + c16 * EPC;
-                    const float* sh = a.in_shift + (size_t)n * a.Cin + ci0 + c16 * EPC;
                     float f[EPC];
                     unpack_chunk<T>(val, f);
+                    if constexpr (PREFETCH_AFFINE) {
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
+                        for (int e = 0; e < EPC; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
+                    } else {
+                        const float* gsc = a.in_scale + (size_t)n * a.Cin + ci0 + c16 * EPC;
+                        const float* gsh = a.in_shift + (size_t)n * a.Cin + ci0 + c16 * EPC;
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) f[e] = fmaf(f[e], gsc[e], gsh[e]);
+                    }
                     val = pack_chunk<T>(f);
                 }
                 lds_write_b128(lds_p, p * PSTR + c16 * 16, val);
