@@ -14,6 +14,8 @@ the ReLU mask, accumulates skip gradients and sums the 8 children of each coarse
 """
 import math
 
+import os
+
 import torch
 
 from . import ops
@@ -98,6 +100,8 @@ class UNet3DEngine:
         ops.load()
         self.cin, self.cout, self.f_maps, self.G = in_channels, out_channels, f_maps, num_groups
         self.dtype, self.device = dtype, torch.device(device)
+        # split-K slab reductions of the weight-gradient kernels run on a second stream under the next MFMA kernel (joined per DDP stage / at the end)
+        self.side_reduce = os.environ.get("MISAMD_NO_SIDE_REDUCE") is None
         self.levels = len(f_maps)
         self.specs = unet3d_param_specs(in_channels, out_channels, f_maps, upsample)
         self.flat = FlatParams(self.specs, self.device, lambda n: not n.endswith("bias"))
@@ -348,7 +352,8 @@ class UNet3DEngine:
         x0v = View(src0, 0, src0.shape[-1] if src1 is None else c0)
         x1v = None if src1 is None else View(src1, 0, c1)
         dw = self.Gr[s.name + ".conv.weight"] if s.dwpad is None else s.dwpad
-        ops.wgrad(x0v, g_y, dw, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid, x1=x1v, in_scale=s.scale, in_shift=s.shift)
+        ops.wgrad(x0v, g_y, dw, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid, x1=x1v, in_scale=s.scale, in_shift=s.shift,
+                  side=self.side_reduce and s.dwpad is None)
         if s.dwpad is not None:
             self.Gr[s.name + ".conv.weight"].copy_(s.dwpad[:, :s.cin])
         dyn = self.dyn[(self._level(s.name), s.cin_pad)]
@@ -364,8 +369,17 @@ class UNet3DEngine:
             # nearest source = a ReLU output on the half grid (mask here); 'deconv' source = the linear transposed-conv output
             ops.gn_bwd_apply(dyn, View(src1, 0, c1), c1, up1, grid, s.p, s.q, s.r, ctot, c0, dx1, relu_mask=up1)
 
+    def _stage_cb(self, stage_cb):
+        if stage_cb is None:
+            return lambda names: None
+
+        def cb(names):
+            ops.wgrad_join(self.device)      # a stage's weight gradients are final only after their side-stream reductions
+            stage_cb(names)
+        return cb
+
     def backward(self, stage_cb=None):
-        cb = stage_cb if stage_cb is not None else (lambda names: None)
+        cb = self._stage_cb(stage_cb)
         L = self.levels
         cb(["final_conv"])
         for j in range(L - 2, -1, -1):
@@ -402,6 +416,7 @@ class UNet3DEngine:
                         self.P[s.name + ".conv.weight"], self.c1, self.Gr[s.name + ".conv.weight"], self.Gr[s.name + ".groupnorm.weight"],
                         self.Gr[s.name + ".groupnorm.bias"])
         cb(["encoders.0"])
+        ops.wgrad_join(self.device)
 
     # ---- optimizer -------------------------------------------------------------------------------------
     def optimizer_step(self, lr=None):

@@ -8,6 +8,8 @@ Reuses the GroupNorm-folded conv / wgrad machinery, the transposed-conv GEMM + g
 are the residual joins (`mis_add_act`) and the first block's single-input-channel 1x1x1 conv (`mis_expand1_*`)."""
 import math
 
+import os
+
 import torch
 
 from . import ops
@@ -73,6 +75,7 @@ class ResidualUNet3DEngine(UNet3DEngine):
         self.deconv = True
         self.cin, self.cout, self.f_maps, self.G = in_channels, out_channels, f_maps, num_groups
         self.dtype, self.device = dtype, torch.device(device)
+        self.side_reduce = os.environ.get("MISAMD_NO_SIDE_REDUCE") is None
         self.levels = len(f_maps)
         self.specs = resunet3d_param_specs(in_channels, out_channels, f_maps)
         self.flat = FlatParams(self.specs, self.device, lambda n: not n.endswith("bias"))
@@ -219,7 +222,7 @@ class ResidualUNet3DEngine(UNet3DEngine):
         self._sc_bwd(self.sc[pre + ".conv2"], g_t, g_r, mask0=False, add0=g_pre)   # r is not a ReLU output; + residual branch
 
     def backward(self, stage_cb=None):
-        cb = stage_cb if stage_cb is not None else (lambda names: None)
+        cb = self._stage_cb(stage_cb)
         L = self.levels
         cb(["final_conv"])
         for j in range(L - 2, -1, -1):
@@ -242,3 +245,4 @@ class ResidualUNet3DEngine(UNet3DEngine):
                 ops.expand1_bwd(self._x, self.g_r[0], self.Gr["encoders.0.basic_module.conv1.weight"].view(-1),
                                 self.Gr["encoders.0.basic_module.conv1.bias"])
             cb([f"encoders.{l}"])
+        ops.wgrad_join(self.device)
