@@ -284,6 +284,12 @@ size_t mis_seg_metrics_workspace_bytes(int N, long long npix);
 int mis_seg_metrics(const float* values, const float* labels, int N, long long npix, int values_are_logits, int auto_threshold, float threshold,
                     void* workspace, float* out, void* stream);
 
+/* MeanIoU of the 3-D validation loop (model/unet3d/metrics.py:33-103, expand_as_one_hot model/unet3d/utils.py:222-254): counts[n][c] = {sum(pred & tgt),
+ * sum(pred | tgt)} with pred = one-hot of the first channel maximum (C == 1: prob > 0.5), tgt = one-hot fp32 (N, C, S) cast to uint8 or int64 labels
+ * (N, S); ignore_index zeroes pred and tgt where the target equals it.  probs fp32 (N, C, S), C <= 16; counts: N*C*2 uint64 (zeroed here). */
+int mis_iou3d_counts(const float* probs, const void* target, int target_is_labels, int N, int C, long long S, int has_ignore, long long ignore_index,
+                     unsigned long long* counts, void* stream);
+
 /* Patch-tiled volume prediction (model/unet3d/predictor.py:85-168; dataset/unet3d_dataset/utils.py:85-125,314-361).
  * gather: patches[p] (C, PD, PH, PW) = the volume window starting at origins[p] - halo, np.pad(mode='reflect') outside the volume
  *         (origins: device int32 (NP, 3) positions of the patch INTERIORS in the unpadded volume; PD = interior + 2*hd, ...);

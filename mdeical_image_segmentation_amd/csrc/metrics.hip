@@ -111,3 +111,94 @@ extern "C" int mis_seg_metrics(const float* logits, const float* labels, int N, 
     MIS_LAUNCH_CHECK("seg_metrics");
     return MIS_OK;
 }
+
+// ---- MeanIoU of the 3-D validation loop (model/unet3d/metrics.py:33-103; expand_as_one_hot model/unet3d/utils.py:222-254) -------------------------
+// Per sample n and channel c:  I = sum(pred & tgt), U = sum(pred | tgt) over the S voxels, with
+//   pred = one-hot of the FIRST maximum over channels (C == 1: probability > 0.5)                     [_binarize_predictions :87-98]
+//   tgt  = the one-hot float target cast to uint8, or (label == c) for an integer label volume         [expand_as_one_hot]
+//   ignore_index: voxels whose target equals it are zeroed in pred and tgt (a label volume carries it into every channel) [:63-68]
+// Integer counts accumulated with 64-bit atomic adds (order-independent, exact); the ratio / means are the caller's few scalars.
+constexpr int IOU_MAXC = 16;
+
+template <bool LABELS>
+__global__ __launch_bounds__(256) void iou3d_counts_kernel(const float* __restrict__ probs, const void* __restrict__ target, int N, int C, long long S,
+                                                           int has_ignore, long long ignore_index, unsigned long long* __restrict__ counts) {
+    const int n = blockIdx.y;
+    unsigned long long inter[IOU_MAXC], uni[IOU_MAXC];
+#pragma unroll
+    for (int c = 0; c < IOU_MAXC; ++c) inter[c] = uni[c] = 0ull;
+    const float* pb = probs + (size_t)n * C * S;
+    for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < S; s += (long long)gridDim.x * 256) {
+        int best = 0;
+        float bv = pb[s];
+        for (int c = 1; c < C; ++c) {
+            const float v = pb[(size_t)c * S + s];
+            if (v > bv) {
+                bv = v;
+                best = c;
+            }
+        }
+        long long lbl = 0;
+        bool ign_all = false;
+        if (LABELS) {
+            lbl = reinterpret_cast<const long long*>(target)[(size_t)n * S + s];
+            ign_all = has_ignore && lbl == ignore_index;
+        }
+#pragma unroll
+        for (int c = 0; c < IOU_MAXC; ++c) {
+            if (c >= C) continue;
+            unsigned p = (C == 1) ? (bv > 0.5f ? 1u : 0u) : (c == best ? 1u : 0u);
+            unsigned t;
+            if (LABELS) {
+                t = (!ign_all && lbl == c) ? 1u : 0u;
+                if (ign_all) p = 0u;
+            } else {
+                const float tv = reinterpret_cast<const float*>(target)[((size_t)n * C + c) * S + s];
+                if (has_ignore && tv == (float)ignore_index) {
+                    p = 0u;
+                    t = 0u;
+                } else {
+                    t = (unsigned)(unsigned char)(long long)tv;      // .byte() of a float tensor
+                }
+            }
+            inter[c] += p & t;
+            uni[c] += p | t;
+        }
+    }
+    __shared__ unsigned long long red[2 * IOU_MAXC];
+    if (threadIdx.x < 2 * IOU_MAXC) red[threadIdx.x] = 0ull;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < IOU_MAXC; ++c) {
+        if (c >= C) continue;             // uniform across the block
+        unsigned long long a = inter[c], b = uni[c];
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_down(a, off, 64);
+            b += __shfl_down(b, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&red[2 * c], a);
+            atomicAdd(&red[2 * c + 1], b);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * C) atomicAdd(&counts[(size_t)n * 2 * C + threadIdx.x], red[threadIdx.x]);
+}
+
+extern "C" int mis_iou3d_counts(const float* probs, const void* target, int target_is_labels, int N, int C, long long S, int has_ignore,
+                                long long ignore_index, unsigned long long* counts, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(probs && target && counts, MIS_EINVAL, "iou3d_counts: null pointer");
+    MIS_REQUIRE(N > 0 && S > 0 && C >= 1 && C <= IOU_MAXC, MIS_EUNSUPPORTED, "iou3d_counts: N %d, C %d (1..%d), S %lld", N, C, IOU_MAXC, S);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(counts, 0, (size_t)N * C * 2 * sizeof(unsigned long long), st) != hipSuccess) return MIS_EHIP;
+    long long bx = (S + 256 * 8 - 1) / (256 * 8);
+    if (bx > 2048) bx = 2048;
+    if (bx < 1) bx = 1;
+    if (target_is_labels)
+        hipLaunchKernelGGL(iou3d_counts_kernel<true>, dim3((unsigned)bx, N), dim3(256), 0, st, probs, target, N, C, S, has_ignore, ignore_index, counts);
+    else
+        hipLaunchKernelGGL(iou3d_counts_kernel<false>, dim3((unsigned)bx, N), dim3(256), 0, st, probs, target, N, C, S, has_ignore, ignore_index, counts);
+    MIS_LAUNCH_CHECK("iou3d_counts");
+    return MIS_OK;
+}

@@ -203,6 +203,19 @@ def test_eval_metrics_oracle():
         assert abs(mo.compute_dice(lg, lb, 0.5) - float(g[f"{tag}_dice05"])) < 1e-7
 
 
+def test_eval_metrics3d_oracle():
+    from oracle import metrics_oracle as mo
+    g = load_golden("g11_metrics3d.npz")
+    assert mo.mean_iou3d(g["probs"], g["onehot"]) == g["miou_onehot"]
+    assert mo.mean_iou3d(g["probs"], g["labels"]) == g["miou_labels"]
+    assert mo.mean_iou3d(g["probs"], g["labels"], skip_channels=(0,)) == g["miou_skip0"]
+    assert mo.mean_iou3d(g["probs"], g["lab_ign"], ignore_index=-1) == g["miou_lab_ign"]
+    assert mo.mean_iou3d(g["probs"], g["oh_ign"], ignore_index=-1) == g["miou_oh_ign"]
+    assert mo.mean_iou3d(g["p1"], g["t1"]) == g["miou_c1"]
+    assert abs(mo.dice_coefficient3d(g["probs"], g["onehot"]) - float(g["dice"])) < 1e-6
+    assert abs(mo.dice_coefficient3d(g["p1"], g["t1"]) - float(g["dice_c1"])) < 1e-6
+
+
 def test_patch_tiled_predictor_oracle():
     """oracle.predictor_oracle + the 3-D oracle net against the replay of the reference's predictor loop on its own SliceBuilder /
     mirror_pad / remove_padding / UNet3D (g8_predictor.npz)."""
