@@ -277,6 +277,26 @@ int mis_expand1_fwd(int dtype, const float* x, const float* w, const float* b, v
 size_t mis_expand1_bwd_workspace_bytes(int C);
 int mis_expand1_bwd(int dtype, const float* x, const void* dy, int dy_ld, long long nvox, int C, float* workspace, float* dw, float* db, void* stream);
 
+/* Squeeze & excitation of the residual 3-D blocks: `ResNetBlockSE` with se_module 'scse' (model/unet3d/buildingblocks.py:326-362; model/unet3d/se.py:18-116
+ * ChannelSELayer3D with reduction_ratio 1, SpatialSELayer3D, ChannelSpatialSELayer3D = elementwise max of the two).  e, y, g, de: (N, S, C) channels-last
+ * with a row stride, C % 64 == 0; everything else fp32.
+ *   fwd: mis_chanstats(e) -> mis_se_fc_fwd (mean, z1 = W1 mean + b1, a = sigmoid(W2 relu(z1) + b2), all [N][C]) -> mis_se_apply_fwd
+ *        (bgate[n][v] = sigmoid(w . e[n][v] + b0), y = max(e*a, e*bgate)).
+ *   bwd: mis_se_bwd_reduce (dq [N][S], da [N][C], dw [C], db0 [1]) -> mis_se_fc_bwd (dW1, db1, dW2, db2 [C][C] / [C], cross [N][C]) ->
+ *        mis_se_bwd_apply (de = [e > 0] * (g * (selected gate) + cross + dq * w); e is a ReLU output and its mask is fused; de may alias g).
+ * workspace: mis_se_bwd_workspace_bytes(N, C), shared by mis_se_bwd_reduce and mis_se_fc_bwd of one block. */
+int mis_se_fc_fwd(const float* chan_sum, double count, const float* W1, const float* b1, const float* W2, const float* b2, int N, int C, float* mean,
+                  float* z1, float* a, void* stream);
+int mis_se_apply_fwd(int dtype, const void* e, int e_ld, int N, long long S, int C, const float* a, const float* w, const float* b0, float* bgate,
+                     void* y, int y_ld, void* stream);
+size_t mis_se_bwd_workspace_bytes(int N, int C);
+int mis_se_bwd_reduce(int dtype, const void* g, int g_ld, const void* e, int e_ld, int N, long long S, int C, const float* a, const float* bgate,
+                      float* workspace, float* dq, float* da, float* dw, float* db0, void* stream);
+int mis_se_fc_bwd(const float* da, const float* a, const float* z1, const float* mean, const float* W1, const float* W2, int N, int C, double count,
+                  float* workspace, float* dW1, float* db1, float* dW2, float* db2, float* cross, void* stream);
+int mis_se_bwd_apply(int dtype, const void* g, int g_ld, const void* e, int e_ld, int N, long long S, int C, const float* a, const float* bgate,
+                     const float* dq, const float* w, const float* cross, void* de, int de_ld, void* stream);
+
 /* Evaluation metrics of the 2-D trainer (trainer/metrcis.py:61-109,153-168 `compute_metrics`): sigmoid with +1e-6 in the denominator,
  * threshold = global mean probability, per-sample IoU / Dice, mean over samples.  values, labels: fp32 (N, npix); out[3] = {iou, dice, threshold}.
  * values_are_logits = 0 with a given threshold gives compute_iou / compute_dice on ready-made predictions. */

@@ -19,7 +19,14 @@ from .engine3d import UNet3DEngine, _SC, _ct_name
 from .ops import View
 
 
-def resunet3d_param_specs(in_channels, out_channels, f_maps):
+def _se_specs(pre, co):
+    """parameters of `se_module` = ChannelSpatialSELayer3D(co, reduction_ratio=1) in registration order (se.py:18-116)"""
+    m = f"{pre}.se_module"
+    return [(f"{m}.cSE.fc1.weight", (co, co)), (f"{m}.cSE.fc1.bias", (co,)), (f"{m}.cSE.fc2.weight", (co, co)), (f"{m}.cSE.fc2.bias", (co,)),
+            (f"{m}.sSE.conv.weight", (1, co, 1, 1, 1)), (f"{m}.sSE.conv.bias", (1,))]
+
+
+def resunet3d_param_specs(in_channels, out_channels, f_maps, se=False):
     specs = []
     for i, co in enumerate(f_maps):
         ci = in_channels if i == 0 else f_maps[i - 1]
@@ -27,6 +34,8 @@ def resunet3d_param_specs(in_channels, out_channels, f_maps):
         specs += [(f"{pre}.conv1.weight", (co, ci, 1, 1, 1)), (f"{pre}.conv1.bias", (co,))]
         for k in (2, 3):
             specs += [(f"{pre}.conv{k}.groupnorm.weight", (co,)), (f"{pre}.conv{k}.groupnorm.bias", (co,)), (f"{pre}.conv{k}.conv.weight", (co, co, 3, 3, 3))]
+        if se:
+            specs += _se_specs(pre, co)
     rf = list(reversed(f_maps))
     for j in range(len(rf) - 1):
         co = rf[j + 1]
@@ -34,6 +43,8 @@ def resunet3d_param_specs(in_channels, out_channels, f_maps):
         pre = f"decoders.{j}.basic_module"
         for k in (2, 3):
             specs += [(f"{pre}.conv{k}.groupnorm.weight", (co,)), (f"{pre}.conv{k}.groupnorm.bias", (co,)), (f"{pre}.conv{k}.conv.weight", (co, co, 3, 3, 3))]
+        if se:
+            specs += _se_specs(pre, co)
     specs += [("final_conv.weight", (out_channels, f_maps[0], 1, 1, 1)), ("final_conv.bias", (out_channels,))]
     return specs
 
@@ -62,6 +73,8 @@ def default_init_res_(params, seed=None):
 
 
 class ResidualUNet3DEngine(UNet3DEngine):
+    SE = False
+
     def __init__(self, in_channels=1, out_channels=3, f_maps=(64, 128, 256, 512, 1024), num_groups=8, dtype=torch.float32, device="cuda", seed=None,
                  lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3, max_grad_norm=1.0, alpha=1.0, beta=1.0):
         if in_channels != 1:
@@ -77,7 +90,7 @@ class ResidualUNet3DEngine(UNet3DEngine):
         self.dtype, self.device = dtype, torch.device(device)
         self.side_reduce = os.environ.get("MISAMD_NO_SIDE_REDUCE") is None
         self.levels = len(f_maps)
-        self.specs = resunet3d_param_specs(in_channels, out_channels, f_maps)
+        self.specs = resunet3d_param_specs(in_channels, out_channels, f_maps, se=self.SE)
         self.flat = FlatParams(self.specs, self.device, lambda n: not n.endswith("bias"))
         self.P, self.Gr = self.flat.param, self.flat.grad
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
@@ -246,3 +259,45 @@ class ResidualUNet3DEngine(UNet3DEngine):
                                 self.Gr["encoders.0.basic_module.conv1.bias"])
             cb([f"encoders.{l}"])
         ops.wgrad_join(self.device)
+
+
+class ResidualUNetSE3DEngine(ResidualUNet3DEngine):
+    """The reference's `ResidualUNetSE3D` (model/unet3d/model.py:235-280): ResidualUNet3D whose blocks end in a concurrent spatial-and-channel
+    squeeze & excitation (`ResNetBlockSE`, se_module 'scse', buildingblocks.py:326-362) - csrc/se3d.hip.  The block's ReLU output goes to a side
+    buffer and the SE output takes its place, so every consumer (pooling, joins, transposed convs, head) is unchanged; in the backward the
+    consumers' masked gradient is turned into the block's pre-activation gradient in place before the residual block's own backward."""
+    SE = True
+
+    def _alloc(self, N, D, H, W):
+        if self._shape == (N, D, H, W):
+            return
+        super()._alloc(N, D, H, W)
+        L, fm, dev = self.levels, self.f_maps, self.device
+        self.se = {}
+        blocks = [(f"encoders.{l}.basic_module", l, fm[l]) for l in range(L)] + [(f"decoders.{j}.basic_module", L - 2 - j, fm[L - 2 - j]) for j in range(L - 1)]
+        for pre, l, c in blocks:
+            st = _SC()
+            S = (D >> l) * (H >> l) * (W >> l)
+            st.raw = torch.empty(N, D >> l, H >> l, W >> l, c, dtype=self.dtype, device=dev)
+            for name in ("sum", "sq", "mean", "z1", "a", "da", "cross"):
+                setattr(st, name, torch.zeros(N, c, device=dev))
+            st.bgate, st.dq = torch.zeros(N, S, device=dev), torch.zeros(N, S, device=dev)
+            self.se[pre] = st
+
+    def _se_params(self, pre, table):
+        m = pre + ".se_module"
+        return (table[m + ".cSE.fc1.weight"], table[m + ".cSE.fc1.bias"], table[m + ".cSE.fc2.weight"], table[m + ".cSE.fc2.bias"],
+                table[m + ".sSE.conv.weight"].view(-1), table[m + ".sSE.conv.bias"])
+
+    def _block_fwd(self, pre, r, t, u, out):
+        st = self.se[pre]
+        super()._block_fwd(pre, r, t, u, st.raw)
+        W1, b1, W2, b2, w, b0 = self._se_params(pre, self.P)
+        ops.se_fwd(st.raw, out, W1, b1, W2, b2, w, b0, st)
+
+    def _block_bwd(self, pre, g_pre, g_t, g_r):
+        st = self.se[pre]
+        W1, _, W2, _, w, _ = self._se_params(pre, self.P)
+        dW1, db1, dW2, db2, dw, db0 = self._se_params(pre, self.Gr)
+        ops.se_bwd(g_pre, st.raw, W1, W2, w, st, dW1, db1, dW2, db2, dw, db0)
+        super()._block_bwd(pre, g_pre, g_t, g_r)

@@ -7,6 +7,8 @@ stand-alone blocks are not part of the accelerated path."""
 import torch
 from torch import nn
 
+from .se import ChannelSpatialSELayer3D
+
 
 def create_conv(in_channels, out_channels, kernel_size, order, num_groups, padding, dropout_prob, is3d):
     """buildingblocks.py:14-113 for order 'gcr' (GroupNorm -> Conv3d(no bias) -> ReLU) and 'gc' (the last conv of a ResNetBlock)."""
@@ -70,6 +72,18 @@ class ResNetBlock(_ContainerOnly, nn.Module):
         self.non_linearity = nn.ReLU(inplace=True)
 
 
+class ResNetBlockSE(ResNetBlock):
+    """buildingblocks.py:326-362: ResNetBlock followed by a squeeze-and-excitation module.  Only se_module='scse' (the one ResidualUNetSE3D can reach:
+    Encoder / Decoder never pass another) is built: ChannelSpatialSELayer3D with reduction_ratio 1 (csrc/se3d.hip)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, order="cge", num_groups=8, se_module="scse", **kwargs):
+        super().__init__(in_channels, out_channels, kernel_size=kernel_size, order=order, num_groups=num_groups, **kwargs)
+        assert se_module in ["scse", "cse", "sse"]
+        if se_module != "scse":
+            raise NotImplementedError("ResNetBlockSE on MI355X: se_module='scse'")
+        self.se_module = ChannelSpatialSELayer3D(num_channels=out_channels, reduction_ratio=1)
+
+
 class Encoder(_ContainerOnly, nn.Module):
     def __init__(self, in_channels, out_channels, conv_kernel_size=3, apply_pooling=True, pool_kernel_size=2, pool_type="max",
                  basic_module=DoubleConv, conv_layer_order="gcr", num_groups=8, padding=1, upscale=2, dropout_prob=0.1, is3d=True):
@@ -109,7 +123,7 @@ class Decoder(_ContainerOnly, nn.Module):
     def __init__(self, in_channels, out_channels, conv_kernel_size=3, scale_factor=2, basic_module=DoubleConv, conv_layer_order="gcr",
                  num_groups=8, padding=1, upsample="default", dropout_prob=0.1, is3d=True):
         super().__init__()
-        if basic_module is ResNetBlock:
+        if basic_module in (ResNetBlock, ResNetBlockSE):
             # buildingblocks.py:486-534: 'default' -> transposed-conv upsampling, SUM joining, the block sees out_channels
             if upsample not in ("default", "deconv"):
                 raise NotImplementedError("ResNetBlock decoders: transposed-conv upsampling + sum joining (the reference's default) is built")

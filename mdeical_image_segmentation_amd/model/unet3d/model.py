@@ -10,8 +10,8 @@ from torch import nn
 
 from ..._lib import MisError
 from ...engine3d import UNet3DEngine
-from ...engine3d_res import ResidualUNet3DEngine
-from .buildingblocks import DoubleConv, ResNetBlock, create_decoders, create_encoders
+from ...engine3d_res import ResidualUNet3DEngine, ResidualUNetSE3DEngine
+from .buildingblocks import DoubleConv, ResNetBlock, ResNetBlockSE, create_decoders, create_encoders
 from .utils import number_of_features_per_level
 
 
@@ -51,9 +51,10 @@ class AbstractUNet(nn.Module):
         if isinstance(f_maps, int):
             f_maps = number_of_features_per_level(f_maps, num_levels=num_levels)
         assert isinstance(f_maps, (list, tuple)) and len(f_maps) > 1, "Required at least 2 levels in the U-Net"
-        if not is3d or basic_module not in (DoubleConv, ResNetBlock):
-            raise NotImplementedError("the 3-D U-Nets with DoubleConv (UNet3D) or ResNetBlock (ResidualUNet3D) basic modules are built")
-        self._residual = basic_module is ResNetBlock
+        if not is3d or basic_module not in (DoubleConv, ResNetBlock, ResNetBlockSE):
+            raise NotImplementedError("the 3-D U-Nets with DoubleConv (UNet3D), ResNetBlock (ResidualUNet3D) or ResNetBlockSE basic modules are built")
+        self._residual = basic_module in (ResNetBlock, ResNetBlockSE)
+        self._se = basic_module is ResNetBlockSE
         self.encoders = create_encoders(in_channels, f_maps, basic_module, conv_kernel_size, conv_padding, conv_upscale, dropout_prob,
                                         layer_order, num_groups, pool_kernel_size, is3d)
         self.decoders = create_decoders(f_maps, basic_module, conv_kernel_size, conv_padding, layer_order, num_groups, upsample,
@@ -73,7 +74,7 @@ class AbstractUNet(nn.Module):
         if self._engine is None or self._engine.device != x.device:
             cin, cout, f_maps, groups, upsample = self._cfg
             if self._residual:
-                eng = ResidualUNet3DEngine(cin, cout, f_maps=f_maps, num_groups=groups, dtype=_dtype_from(self._compute_dtype), device=x.device)
+                eng = (ResidualUNetSE3DEngine if self._se else ResidualUNet3DEngine)(cin, cout, f_maps=f_maps, num_groups=groups, dtype=_dtype_from(self._compute_dtype), device=x.device)
             else:
                 eng = UNet3DEngine(cin, cout, f_maps=f_maps, num_groups=groups, dtype=_dtype_from(self._compute_dtype), device=x.device,
                                    upsample=upsample)
@@ -115,6 +116,17 @@ class ResidualUNet3D(AbstractUNet):
                          dropout_prob=dropout_prob, is3d=True, compute_dtype=kwargs.get("compute_dtype"))
 
 
+class ResidualUNetSE3D(AbstractUNet):
+    """model.py:235-280: ResidualUNet3D with `ResNetBlockSE` blocks (squeeze & excitation 'scse' after every residual block)"""
+
+    def __init__(self, in_channels, out_channels, final_sigmoid=True, f_maps=64, layer_order="gcr", num_groups=8, num_levels=5,
+                 is_segmentation=True, conv_padding=1, conv_upscale=2, upsample="default", dropout_prob=0.1, **kwargs):
+        super().__init__(in_channels=in_channels, out_channels=out_channels, final_sigmoid=final_sigmoid, basic_module=ResNetBlockSE,
+                         f_maps=f_maps, layer_order=layer_order, num_groups=num_groups, num_levels=num_levels,
+                         is_segmentation=is_segmentation, conv_padding=conv_padding, conv_upscale=conv_upscale, upsample=upsample,
+                         dropout_prob=dropout_prob, is3d=True, compute_dtype=kwargs.get("compute_dtype"))
+
+
 def _stub(name):
     class _S(nn.Module):
         def __init__(self, *a, **k):
@@ -123,7 +135,6 @@ def _stub(name):
     return _S
 
 
-ResidualUNetSE3D = _stub("ResidualUNetSE3D")
 UNet2D = _stub("UNet2D")
 ResidualUNet2D = _stub("ResidualUNet2D")
 
@@ -135,4 +146,6 @@ def get_model(model_config):
         return UNet3D(**cfg)
     if name == "ResidualUNet3D":
         return ResidualUNet3D(**cfg)
-    raise NotImplementedError(f"get_model: UNet3D and ResidualUNet3D are built, got {name}")
+    if name == "ResidualUNetSE3D":
+        return ResidualUNetSE3D(**cfg)
+    raise NotImplementedError(f"get_model: UNet3D, ResidualUNet3D and ResidualUNetSE3D are built, got {name}")

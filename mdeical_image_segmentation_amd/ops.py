@@ -479,6 +479,33 @@ def bn_bwd_apply(dy, z, scale, shift, p, q, r, dz):
                                q.data_ptr(), r.data_ptr(), dz.ptr, dz.ld, stream_ptr()), "mis_bn_bwd_apply")
 
 
+def se_fwd(e, y, W1, b1, W2, b2, w, b0, st):
+    """scSE forward (csrc/se3d.hip) on a channels-last activation e -> y; `st` carries the per-block buffers sum, sq, mean, z1, a [N][C], bgate [N][S]"""
+    lib = load()
+    e, y = _v(e), _v(y)
+    S = e.D * e.H * e.W
+    chanstats(e, st.sum, st.sq)
+    check(lib.mis_se_fc_fwd(st.sum.data_ptr(), float(S), W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), e.N, e.C, st.mean.data_ptr(),
+                            st.z1.data_ptr(), st.a.data_ptr(), stream_ptr()), "mis_se_fc_fwd")
+    check(lib.mis_se_apply_fwd(dtype_code(e.dtype), e.ptr, e.ld, e.N, S, e.C, st.a.data_ptr(), w.data_ptr(), b0.data_ptr(), st.bgate.data_ptr(), y.ptr, y.ld,
+                               stream_ptr()), "mis_se_apply_fwd")
+
+
+def se_bwd(g, e, W1, W2, w, st, dW1, db1, dW2, db2, dw, db0):
+    """scSE backward + the ReLU mask of e, in place on g (dL/d(out) -> dL/d(pre-activation of e)); parameter gradients are written (not accumulated)"""
+    lib = load()
+    g, e = _v(g), _v(e)
+    S = e.D * e.H * e.W
+    ws = workspace(lib.mis_se_bwd_workspace_bytes(e.N, e.C), e.t.device, "se_bwd")
+    dt = dtype_code(e.dtype)
+    check(lib.mis_se_bwd_reduce(dt, g.ptr, g.ld, e.ptr, e.ld, e.N, S, e.C, st.a.data_ptr(), st.bgate.data_ptr(), ws.data_ptr(), st.dq.data_ptr(),
+                                st.da.data_ptr(), dw.data_ptr(), db0.data_ptr(), stream_ptr()), "mis_se_bwd_reduce")
+    check(lib.mis_se_fc_bwd(st.da.data_ptr(), st.a.data_ptr(), st.z1.data_ptr(), st.mean.data_ptr(), W1.data_ptr(), W2.data_ptr(), e.N, e.C, float(S),
+                            ws.data_ptr(), dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(), st.cross.data_ptr(), stream_ptr()), "mis_se_fc_bwd")
+    check(lib.mis_se_bwd_apply(dt, g.ptr, g.ld, e.ptr, e.ld, e.N, S, e.C, st.a.data_ptr(), st.bgate.data_ptr(), st.dq.data_ptr(), w.data_ptr(),
+                               st.cross.data_ptr(), g.ptr, g.ld, stream_ptr()), "mis_se_bwd_apply")
+
+
 def upconv_gather_fwd(z, y, scale, C, bias=None):
     """z (N, h, w, 9*C) dense -> y (N, h*s, w*s, C): the 3x3 taps of conv3x3(bilinear_up_s(x)) gathered from the low-resolution tap products"""
     lib = load()

@@ -162,12 +162,19 @@ def _res_block(x, p, pre, num_groups=8):
     t = F.relu(F.conv3d(t, p[f"{pre}.conv2.conv.weight"], None, padding=1))
     u = F.group_norm(t, g, p[f"{pre}.conv3.groupnorm.weight"], p[f"{pre}.conv3.groupnorm.bias"], eps=1e-5)
     u = F.conv3d(u, p[f"{pre}.conv3.conv.weight"], None, padding=1)
-    return F.relu(u + r)
+    out = F.relu(u + r)
+    m = f"{pre}.se_module"
+    if f"{m}.cSE.fc1.weight" in p:          # ResNetBlockSE, se_module 'scse' (buildingblocks.py:326-362; se.py:18-116, reduction_ratio 1)
+        mean = out.mean(dim=(2, 3, 4))
+        a = torch.sigmoid(F.linear(F.relu(F.linear(mean, p[f"{m}.cSE.fc1.weight"], p[f"{m}.cSE.fc1.bias"])), p[f"{m}.cSE.fc2.weight"], p[f"{m}.cSE.fc2.bias"]))
+        b = torch.sigmoid(F.conv3d(out, p[f"{m}.sSE.conv.weight"], p[f"{m}.sSE.conv.bias"]))
+        out = torch.max(out * a[:, :, None, None, None], out * b)
+    return out
 
 
 def resunet3d_forward(p, x, num_levels, num_groups=8):
     """ResidualUNet3D (model.py:197-232): ResNetBlock encoders with MaxPool3d, decoders = ConvTranspose3d(k3, s2, p1) resized to the encoder grid,
-    SUM joining, ResNetBlock; 1x1x1 head."""
+    SUM joining, ResNetBlock; 1x1x1 head.  With `se_module` parameters in p: ResidualUNetSE3D (model.py:235-280)."""
     feats = []
     for i in range(num_levels):
         if i > 0:
