@@ -233,6 +233,13 @@ int mis_aug_pointwise(const float* src, float* dst, long long n, float a, float 
                       unsigned long long seed, void* stream);
 int mis_aug_contrast(const float* src, float* dst, long long n, float mean, float alpha, void* stream);
 
+/* 2-D sample pipeline of the reference's datasets (dataset/unet2d_dataset/MYDataset.py:127-157, albumentations 1.4.10 restated - the library is absent:
+ * parity unpinned): Resize(OH, OW, nearest) -> HorizontalFlip -> VerticalFlip -> rot90 (k counter-clockwise quarter turns) -> Transpose ->
+ * brightness/contrast table clip(v*alpha + beta*255) on the image -> CHW float / 255.  img: uint8 (H, W, C) in HBM, mask: uint8 (H, W) or NULL;
+ * out_img fp32 (C, FH, FW), out_mask fp32 (FH, FW); (FH, FW) = (OH, OW), swapped when exactly one of (rot_k odd, transpose) holds. */
+int mis_aug2d_u8(const unsigned char* img, const unsigned char* mask, int H, int W, int C, int OH, int OW, int hflip, int vflip, int rot_k, int transpose,
+                 int use_bc, float alpha, float beta, float* out_img, float* out_mask, void* stream);
+
 /* Stand-alone BCE + Dice loss on logits (model/unet3d/losses.py:7-33,83-129,167-178): x, t fp32 (N, C, S).
  * fwd: out[0] = alpha*mean(BCEWithLogits) + beta*(1 - mean_c dice_c), out[1] = the BCE mean, out[2+4c..] = {sum s*t, sum s^2, sum t^2, dice_c}
  *      (s = sigmoid(x)); out must hold 2 + 4*C floats and is the `sums` input of bwd.
