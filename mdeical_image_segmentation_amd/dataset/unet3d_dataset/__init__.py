@@ -1,0 +1,4 @@
+from . import utils
+from .utils import FilterSliceBuilder, SliceBuilder, VolumeDataset, calculate_stats, get_slice_builder
+
+__all__ = ["SliceBuilder", "FilterSliceBuilder", "VolumeDataset", "calculate_stats", "get_slice_builder", "utils"]
