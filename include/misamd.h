@@ -258,6 +258,12 @@ int mis_bilinear_up_fwd(int dtype, const void* x, int x_ld, void* y, int y_ld, i
 size_t mis_bilinear_up_bwd_workspace_bytes(int N, int H, int W, int C, int scale);
 int mis_bilinear_up_bwd(int dtype, const void* dy, int dy_ld, void* dx, int dx_ld, int N, int H, int W, int C, int scale, float* workspace, void* stream);
 
+/* Classification-guided module of UNet_3Plus_DeepSup_CGM (model/unet2d/unet.py:998-1003, 1012-1038, 1147-1153): per sample
+ * cls[n][k] = sigmoid(max over pixels of (w[k] . x[n][pix] + b[k])), k = 0, 1;  gate[n] = float(argmax_k cls[n][k]) (first maximum);
+ * mis_scale_sigmoid: out = sigmoid(x * gate[n]) (gy == NULL) or its backward gy * y(1-y) * gate[n].  x of mis_cgm_gate: (N, npix, C) channels-last. */
+int mis_cgm_gate(int dtype, const void* x, int x_ld, int N, long long npix, int C, const float* w, const float* b, float* cls, float* gate, void* stream);
+int mis_scale_sigmoid(const float* x, const float* gy, const float* gate, int N, long long per_sample, float* out, void* stream);
+
 /* conv3x3(pad 1)(bilinear_upsample_s(x)) of the UNet 3+ decoder-to-decoder branches (model/unet2d/unet.py:190-192, 229-236, 273-285, 322-339) without
  * the upsampled tensor: the channel contraction runs on the low-resolution grid (mis_conv_igemm, ksize 1, column tap*C + co of z), then
  *   fwd: y[N][h*s][w*s][C] = bias + sum over the 3x3 taps inside the upsampled image of bilinear(z[..][tap*C + c]) at (o + tap - 1)

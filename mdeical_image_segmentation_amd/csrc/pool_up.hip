@@ -247,3 +247,78 @@ extern "C" int mis_bilinear_up_bwd(int dtype, const void* dy, int dy_ld, void* d
     MIS_LAUNCH_CHECK("bilinear_up_bwd");
     return MIS_OK;
 }
+
+// ---- classification-guided module of UNet_3Plus_DeepSup_CGM (model/unet2d/unet.py:998-1003, 1012-1038, 1147-1153) --------------------------------
+// cls = Sigmoid(AdaptiveMaxPool2d(1)(Conv2d(C, 2, 1)(x))) per sample, gate = float(argmax over the two classes) (first maximum on ties, after the
+// sigmoid exactly like the reference: two saturated scores tie); the five segmentation maps are then sigmoid(d * gate).
+template <typename T>
+__global__ __launch_bounds__(256) void cgm_gate_kernel(const T* __restrict__ x, int x_ld, long long npix, int C, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float* __restrict__ cls, float* __restrict__ gate) {
+    constexpr int EPC = Tr<T>::EPC;
+    const int n = blockIdx.x;
+    const T* xb = x + (size_t)n * npix * x_ld;
+    float m0 = -INFINITY, m1 = -INFINITY;
+    for (long long p = threadIdx.x; p < npix; p += 256) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int c = 0; c < C; c += EPC) {
+            float f[EPC];
+            unpack_chunk<T>(*reinterpret_cast<const u32x4*>(xb + p * x_ld + c), f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                a0 = fmaf(f[e], w[c + e], a0);
+                a1 = fmaf(f[e], w[C + c + e], a1);
+            }
+        }
+        m0 = fmaxf(m0, a0 + b[0]);
+        m1 = fmaxf(m1, a1 + b[1]);
+    }
+    __shared__ float r0[256], r1[256];
+    r0[threadIdx.x] = m0;
+    r1[threadIdx.x] = m1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 256; ++k) {
+            m0 = fmaxf(m0, r0[k]);
+            m1 = fmaxf(m1, r1[k]);
+        }
+        const float s0 = 1.f / (1.f + expf(-m0)), s1 = 1.f / (1.f + expf(-m1));
+        cls[2 * n] = s0;
+        cls[2 * n + 1] = s1;
+        gate[n] = s1 > s0 ? 1.f : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_sigmoid_kernel(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ gate,
+                                                            long long per_sample, long long total, float* __restrict__ out, int backward) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const float g = gate[i / per_sample];
+        const float y = 1.f / (1.f + expf(-x[i] * g));
+        out[i] = backward ? gy[i] * y * (1.f - y) * g : y;
+    }
+}
+
+extern "C" int mis_cgm_gate(int dtype, const void* x, int x_ld, int N, long long npix, int C, const float* w, const float* b, float* cls, float* gate,
+                            void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, MIS_EINVAL, "cgm_gate: bad dtype %d", dtype);
+    const int EPC = dtype == MIS_BF16 ? 8 : 4;
+    MIS_REQUIRE(x && w && b && cls && gate && N > 0 && npix > 0 && C > 0 && C % EPC == 0 && x_ld >= C && x_ld % EPC == 0, MIS_EINVAL, "cgm_gate: arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIS_BF16)
+        hipLaunchKernelGGL(cgm_gate_kernel<__bf16>, dim3(N), dim3(256), 0, s, (const __bf16*)x, x_ld, npix, C, w, b, cls, gate);
+    else
+        hipLaunchKernelGGL(cgm_gate_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)x, x_ld, npix, C, w, b, cls, gate);
+    MIS_LAUNCH_CHECK("cgm_gate");
+    return MIS_OK;
+}
+
+/* forward: out = sigmoid(x * gate[n]);  backward (gy != NULL): out = gy * y (1 - y) * gate[n] with y recomputed from x */
+extern "C" int mis_scale_sigmoid(const float* x, const float* gy, const float* gate, int N, long long per_sample, float* out, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(x && gate && out && N > 0 && per_sample > 0, MIS_EINVAL, "scale_sigmoid: arguments");
+    const long long total = (long long)N * per_sample;
+    hipLaunchKernelGGL(scale_sigmoid_kernel, dim3(pu_grid(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, gy, gate, per_sample, total, out,
+                       gy != nullptr ? 1 : 0);
+    MIS_LAUNCH_CHECK("scale_sigmoid");
+    return MIS_OK;
+}

@@ -15,7 +15,7 @@ from transformers import PretrainedConfig, PreTrainedModel
 from transformers.utils import ModelOutput
 
 from ... import ops
-from ..._lib import MisError
+from ..._lib import MisError, check, load, stream_ptr
 from ...engine2d import UNet2DEngine
 from .init_weights import init_weights
 from .layers import (CropAndConcat, DoubleConvolution, DownSample, UpSample, _BilinearUp, _Conv3x3Plain, _MaxPool2, _MaxPoolCeil, conv_bn_relu, up_conv_bn_relu,
@@ -111,7 +111,7 @@ class UNetModelOutput(ModelOutput):
 
 class UNetConfig(PretrainedConfig):
     def __init__(self, in_channels=1, out_channels=1, unet_type="UNet", compute_dtype=None, **kwargs):
-        """unet_type: "UNet" (fused engine), "UNet_3Plus" / "UNet_3Plus_DeepSup" (per-layer HIP path + SegmentationLoss kernels); the CGM variant raises.
+        """unet_type: "UNet" (fused engine), "UNet_3Plus" / "UNet_3Plus_DeepSup" (per-layer HIP path + SegmentationLoss kernels); the reference's UNetModel has no branch for the CGM class either (it is used on its own).
         compute_dtype: "f32" (default, the parity mode) or "bf16"; env MISAMD_DTYPE overrides the default."""
         super().__init__(**kwargs)
         self.in_channels = in_channels
@@ -175,6 +175,7 @@ class _UNet3PlusBase(nn.Module):
     on the HIP kernels through the per-layer autograd functions of layers.py."""
 
     _deep_supervision = False
+    _cgm = False
 
     def __init__(self, in_channels=3, n_classes=1, feature_scale=4, is_deconv=True, is_batchnorm=True):
         super().__init__()
@@ -206,6 +207,8 @@ class _UNet3PlusBase(nn.Module):
                 setattr(self, f"outconv{k}", nn.Conv2d(f[4] if k == 5 else self.UpChannels, n_classes, 3, padding=1))
         else:
             self.outconv1 = nn.Conv2d(self.UpChannels, n_classes, 3, padding=1)
+        if self._cgm:                                                   # reference :998-1003
+            self.cls = nn.Sequential(nn.Dropout(p=0.5), nn.Conv2d(f[4], 2, 1), nn.AdaptiveMaxPool2d(1), nn.Sigmoid())
         for m in self.modules():
             if isinstance(m, (nn.Conv2d, nn.BatchNorm2d)):
                 init_weights(m, init_type="kaiming")
@@ -258,12 +261,57 @@ class UNet_3Plus_DeepSup(_UNet3PlusBase):
         return tuple(outs)
 
 
-def _stub(name):
-    class _S(nn.Module):
-        def __init__(self, *a, **k):
-            raise NotImplementedError(f"{name} is outside the accelerated hot path (SURVEY.md §8f3)")
-    _S.__name__ = name
-    return _S
+class _GateSigmoid(torch.autograd.Function):
+    """sigmoid(d * gate[n]) for one deep-supervision map d (N, n_classes, H, W) - reference dotProduct + F.sigmoid (:1012-1017, 1147-1153); the gate is
+    an arg-max (no gradient), so only d receives one"""
+
+    @staticmethod
+    def forward(ctx, d, gate):
+        x = d.float().contiguous()
+        out = torch.empty_like(x)
+        check(load().mis_scale_sigmoid(x.data_ptr(), None, gate.data_ptr(), x.shape[0], x[0].numel(), out.data_ptr(), stream_ptr()), "mis_scale_sigmoid")
+        ctx.save_for_backward(x, gate)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gate = ctx.saved_tensors
+        g = gy.float().contiguous()
+        gx = torch.empty_like(x)
+        check(load().mis_scale_sigmoid(x.data_ptr(), g.data_ptr(), gate.data_ptr(), x.shape[0], x[0].numel(), gx.data_ptr(), stream_ptr()), "mis_scale_sigmoid")
+        return gx, None
 
 
-UNet_3Plus_DeepSup_CGM = _stub("UNet_3Plus_DeepSup_CGM")
+class UNet_3Plus_DeepSup_CGM(_UNet3PlusBase):
+    """UNet 3+ with deep supervision and the classification-guided module (reference :795-1153): a 2-way classifier on the deepest feature map
+    (Dropout -> Conv1x1 -> global max -> sigmoid -> arg-max) gates all five maps, which are returned as PROBABILITIES sigmoid(d_k * gate).  The
+    classifier is evaluated by `mis_cgm_gate`; its arg-max carries no gradient (the reference trains it with no loss either).  n_classes must be 1
+    (the reference's einsum 'ijk,ij->ijk' needs it)."""
+    _deep_supervision = True
+    _cgm = True
+
+    def __init__(self, in_channels=3, n_classes=1, feature_scale=4, is_deconv=True, is_batchnorm=True):
+        if n_classes != 1:
+            raise MisError("UNet_3Plus_DeepSup_CGM: n_classes must be 1 (the class gate is broadcast over a single segmentation channel)")
+        super().__init__(in_channels, n_classes, feature_scale, is_deconv, is_batchnorm)
+        self.last_cls = None                            # (N, 2) classifier scores of the last forward
+
+    def forward(self, inputs):
+        hd = self._decode(inputs)
+        x = hd[5]
+        if self.training:                               # nn.Dropout(p=0.5) of the classifier branch (torch's generator, like the reference)
+            x = torch.nn.functional.dropout(x, 0.5, True)
+        conv = self.cls[1]
+        N, C, h, w = x.shape
+        xv = x.permute(0, 2, 3, 1)
+        if not xv.is_contiguous():
+            xv = xv.contiguous()
+        cls = torch.empty(N, 2, dtype=torch.float32, device=x.device)
+        gate = torch.empty(N, dtype=torch.float32, device=x.device)
+        check(load().mis_cgm_gate(ops.dtype_code(xv.dtype), xv.data_ptr(), C, N, h * w, C, conv.weight.detach().float().contiguous().data_ptr(),
+                                  conv.bias.detach().float().contiguous().data_ptr(), cls.data_ptr(), gate.data_ptr(), stream_ptr()), "mis_cgm_gate")
+        self.last_cls = cls
+        outs = [self._head(hd, 1)]
+        for k in range(2, 6):
+            outs.append(_BilinearUp.apply(self._head(hd, k), 2 ** (k - 1)))
+        return tuple(_GateSigmoid.apply(d, gate) for d in outs)
