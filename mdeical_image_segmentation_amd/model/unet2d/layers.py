@@ -234,6 +234,20 @@ def _pad_chunk(c, dt):
     return (c + e - 1) // e * e
 
 
+def _conv3x3_cols(x, w_tap_out_in, y, n_out, bias=None, **kw):
+    """3x3 convolution with the [tap][out][in] operand `w_tap_out_in`; an output width that is not a multiple of 128 (UNet 3+'s 320) is cut into
+    a 128-multiple part for the 256 px x 128 ch MFMA tiles (≈1.05 PFLOP/s) and a remainder for the 64-column tiles (≈0.86), instead of running all
+    of it on the narrow tiles.  MISAMD_NO_COL_SPLIT=1 disables the cut."""
+    cin = w_tap_out_in.shape[2]
+    c0 = (n_out // 128) * 128
+    if c0 == 0 or c0 == n_out or os.environ.get("MISAMD_NO_COL_SPLIT") == "1":
+        ops.conv_igemm(x, w_tap_out_in, y, ksize=3, Cin=cin, Cout=n_out, bias=bias, **kw)
+        return
+    for lo, hi in ((0, c0), (c0, n_out)):
+        ops.conv_igemm(x, w_tap_out_in[:, lo:hi].contiguous(), ops.View(y, lo, hi - lo), ksize=3, Cin=cin, Cout=hi - lo,
+                       bias=None if bias is None else bias[lo:hi].contiguous(), **kw)
+
+
 class _Conv3x3BNReLU(torch.autograd.Function):
     """y = relu(batch_norm(conv2d(x, w, b, padding=1))) - reference layers.py:17-25 (one `conv%d` Sequential of unetConv2).
     Input channels are zero-padded to a multiple of 64 (the K tile of the MFMA kernels); running statistics are updated in place."""
@@ -256,7 +270,7 @@ class _Conv3x3BNReLU(torch.autograd.Function):
         wd = torch.empty(9, Cp, Cout, dtype=dt, device=dev)
         ops.pack_conv_weight(wpad.contiguous(), wf, wd)
         z = torch.empty(N, H, W, Cout, dtype=dt, device=dev)
-        ops.conv_igemm(xin, wf, z, ksize=3, Cin=Cp, Cout=Cout, bias=b.detach().float())
+        _conv3x3_cols(xin, wf, z, Cout, bias=b.detach().float())
         f32 = dict(dtype=torch.float32, device=dev)
         scale, shift = torch.empty(N, Cout, **f32), torch.empty(N, Cout, **f32)
         mean, rstd = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
@@ -294,7 +308,7 @@ class _Conv3x3BNReLU(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dxp = torch.empty(N, H, W, Cp, dtype=dt, device=dev)
-            ops.conv_igemm(dz, ctx.wd, dxp, ksize=3, Cin=Cout, Cout=Cp)
+            _conv3x3_cols(dz, ctx.wd, dxp, Cp)
             dx = _to_nchw(dxp, Cin)
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None
 
@@ -466,7 +480,7 @@ class _Conv3x3Plain(torch.autograd.Function):
         dbp = torch.empty(Op, dtype=torch.float32, device=dev)
         ops.wgrad(xin, g, dwp, ksize=3, Cin=Cp, Cout=Op, dbias=dbp)
         dxp = torch.empty(N, H, W, Cp, dtype=dt, device=dev)
-        ops.conv_igemm(g, ctx.wd, dxp, ksize=3, Cin=Op, Cout=Cp)
+        _conv3x3_cols(g, ctx.wd, dxp, Cp)
         return _to_nchw(dxp, Cin), dwp[:Cout, :Cin].contiguous(), dbp[:Cout].contiguous()
 
 
