@@ -67,7 +67,9 @@ template <typename T, typename G> struct WgStager {
     static constexpr int EPC = Tr<T>::EPC;
     static constexpr int PITEMS = G::PHP * 8;
     static constexpr int PI = (PITEMS + 255) / 256;
-    static constexpr int QI = G::M * 8 / 256;
+    // dY tile: 64 output channels per pixel for both types = 8 (bf16) / 16 (f32) 16-byte chunks; f32 rows are 256 B + 32 B pad
+    static constexpr int QC = sizeof(T) == 2 ? 8 : 16, QSH = sizeof(T) == 2 ? 3 : 4, QSTR = sizeof(T) == 2 ? PSTR : 288;
+    static constexpr int QI = G::M * QC / 256;
     u32x4 pv[PI], qv[QI];
     uint32_t okmask;
     // f32 path: the GroupNorm affine of this thread's channel chunk (tid & 7) is fetched WITH the tile, so that its latency hides under the previous
@@ -122,7 +124,7 @@ template <typename T, typename G> struct WgStager {
 #pragma unroll
             for (int b = 0; b < QI; ++b) {
                 const int it = b * 256 + tid;
-                const int m = it >> 3, c16 = it & 7;
+                const int m = it >> QSH, c16 = it & (QC - 1);
                 const int dz = m / (G::TH * G::TW);
                 const int hy = (m / G::TW) % G::TH;
                 const int wx = m % G::TW;
@@ -163,7 +165,7 @@ template <typename T, typename G> struct WgStager {
 #pragma unroll
         for (int b = 0; b < QI; ++b) {
             const int it = b * 256 + tid;
-            lds_write_b128(lds_q, (it >> 3) * PSTR + (it & 7) * 16, qv[b]);
+            lds_write_b128(lds_q, (it >> QSH) * QSTR + (it & (QC - 1)) * 16, qv[b]);
         }
     }
 };
@@ -208,7 +210,9 @@ template <typename T, typename G, bool USE_TR>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 1 : 2)) void wgrad_kernel(const WgArgs a) {
     constexpr bool BF = sizeof(T) == 2;
     constexpr int FR = BF ? 2 : 1;          // 16x16 fragments per wave per dim
-    constexpr int CT = BF ? 64 : 32;        // channel tile (ci and co)
+    constexpr int CT = BF ? 64 : 32;        // input-channel tile
+    constexpr int FRJ = 2, CTJ = 64;        // output-channel fragments / tile: 64 columns for both types (f32: each pixel's input value feeds two MFMAs)
+    constexpr int QSTR = BF ? PSTR : 288;   // LDS bytes per dY pixel row
     constexpr int TAPS2 = G::TAPS2;
     static_assert(G::M == 128, "pixel tile must be 128");
 
@@ -228,20 +232,20 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 1 : 2)) void wgrad_kernel(co
     const int kd = v % a.KDn;
     const int split = v / a.KDn;
     const int ci_t = pair / a.nCo, co_t = pair - ci_t * a.nCo;
-    const int ci0 = ci_t * CT, co0 = co_t * CT;
+    const int ci0 = ci_t * CT, co0 = co_t * CTJ;
 
-    f32x4 acc[TAPS2][FR][FR];
+    f32x4 acc[TAPS2][FR][FRJ];
 #pragma unroll
     for (int t = 0; t < TAPS2; ++t)
 #pragma unroll
         for (int fi = 0; fi < FR; ++fi)
 #pragma unroll
-            for (int fj = 0; fj < FR; ++fj) acc[t][fi][fj] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int fj = 0; fj < FRJ; ++fj) acc[t][fi][fj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const bool do_bias = (a.bias_partial != nullptr) && (ci_t == 0) && (kd == 0);
     float bsum = 0.f;
-    const int bco = tid % CT, bpart = tid / CT;           // CT columns x (256/CT) pixel groups
-    constexpr int BPIX = G::M / (256 / CT);               // pixels per group
+    const int bco = tid % CTJ, bpart = tid / CTJ;         // CTJ columns x (256/CTJ) pixel groups
+    constexpr int BPIX = G::M / (256 / CTJ);              // pixels per group
 
     const int t_begin = split * a.tps;
     int t_end = t_begin + a.tps;
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 1 : 2)) void wgrad_kernel(co
 
         if (do_bias) {
 #pragma unroll 8
-            for (int i = 0; i < BPIX; ++i) bsum += ld_elem<T>(reinterpret_cast<const T*>(lds_q + (bpart * BPIX + i) * PSTR) + bco);
+            for (int i = 0; i < BPIX; ++i) bsum += ld_elem<T>(reinterpret_cast<const T*>(lds_q + (bpart * BPIX + i) * QSTR) + bco);
         }
 
         if constexpr (BF) {
@@ -335,13 +339,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 1 : 2)) void wgrad_kernel(co
                 const int hy = (m / G::TW) % G::TH;
                 const int wx = m % G::TW;
                 const int p0 = (dz * G::PHH + hy) * G::PHW + wx;
-                const float b = *reinterpret_cast<const float*>(lds_q + m * PSTR + (wj * 16 + li) * 4);
+                const float b0 = *reinterpret_cast<const float*>(lds_q + m * QSTR + (wj * 32 + li) * 4);
+                const float b1 = *reinterpret_cast<const float*>(lds_q + m * QSTR + (wj * 32 + 16 + li) * 4);
                 const char* pa = lds_p + p0 * PSTR + (wi * 16 + li) * 4;
 #pragma unroll
                 for (int tap = 0; tap < TAPS2; ++tap) {
                     const int kh = tap / G::KS, kw = tap % G::KS;
                     const float av = *reinterpret_cast<const float*>(pa + (kh * G::PHW + kw) * PSTR);
-                    acc[tap][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc[tap][0][0], 0, 0, 0);
+                    acc[tap][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[tap][0][0], 0, 0, 0);
+                    acc[tap][0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[tap][0][1], 0, 0, 0);
                 }
             }
         }
@@ -352,9 +358,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 1 : 2)) void wgrad_kernel(co
         float* red = reinterpret_cast<float*>(smem);
         red[tid] = bsum;
         __syncthreads();
-        if (tid < CT) {
+        if (tid < CTJ) {
             float s = 0.f;
-            for (int k = 0; k < 256 / CT; ++k) s += red[k * CT + tid];
+            for (int k = 0; k < 256 / CTJ; ++k) s += red[k * CTJ + tid];
             a.bias_partial[(size_t)split * a.Cout + co0 + tid] = s;
         }
     }
@@ -367,8 +373,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 1 : 2)) void wgrad_kernel(co
 #pragma unroll
         for (int fi = 0; fi < FR; ++fi)
 #pragma unroll
-            for (int fj = 0; fj < FR; ++fj) {
-                const int co = co0 + (wj * FR + fj) * 16 + li;
+            for (int fj = 0; fj < FRJ; ++fj) {
+                const int co = co0 + (wj * FRJ + fj) * 16 + li;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ci = ci0 + (wi * FR + fi) * 16 + lg * 4 + r;
@@ -468,8 +474,8 @@ static int wg_plan(const MisWgradDesc* d, WgPlan* p) {
     MIS_REQUIRE(d->ksize == 3 || d->ksize == 1, MIS_EUNSUPPORTED, "wgrad: ksize %d", d->ksize);
     MIS_REQUIRE(d->N > 0 && d->D > 0 && d->H > 0 && d->W > 0, MIS_EINVAL, "wgrad: empty grid");
     p->CT = d->dtype == MIS_BF16 ? 64 : 32;
-    MIS_REQUIRE(d->Cin > 0 && d->Cin % p->CT == 0 && d->Cout > 0 && d->Cout % p->CT == 0, MIS_EUNSUPPORTED,
-                "wgrad: Cin %d / Cout %d must be multiples of %d", d->Cin, d->Cout, p->CT);
+    MIS_REQUIRE(d->Cin > 0 && d->Cin % p->CT == 0 && d->Cout > 0 && d->Cout % 64 == 0, MIS_EUNSUPPORTED,
+                "wgrad: Cin %d must be a multiple of %d and Cout %d of 64", d->Cin, p->CT, d->Cout);
     p->is3d = d->is3d != 0;
     MIS_REQUIRE(d->is3d || d->D == 1, MIS_EINVAL, "wgrad: D must be 1 for a 2-D op");
     const int TD = 1, TH = 8, TW = 16;
@@ -480,7 +486,7 @@ static int wg_plan(const MisWgradDesc* d, WgPlan* p) {
     MIS_REQUIRE(nt < (1ll << 30), MIS_EUNSUPPORTED, "wgrad: too many pixel tiles");
     p->ntiles = (int)nt;
     p->nCi = d->Cin / p->CT;
-    p->nCo = d->Cout / p->CT;
+    p->nCo = d->Cout / 64;
     p->KDn = (p->is3d && d->ksize == 3) ? 3 : 1;
     p->TT = d->ksize == 3 ? (p->is3d ? 27 : 9) : 1;
     const long long base = (long long)p->nCi * p->nCo * p->KDn;
@@ -513,7 +519,7 @@ static int wg_launch(const MisWgradDesc* d, const WgPlan& p, hipStream_t stream)
     a.bias_partial = d->dbias != nullptr ? d->workspace + (size_t)p.nsplit * p.TT * d->Cin * d->Cout : nullptr;
     a.tilesD = p.tilesD; a.tilesH = p.tilesH; a.tilesW = p.tilesW; a.ntiles = p.ntiles; a.nsplit = p.nsplit; a.tps = p.tps;
     a.nCi = p.nCi; a.nCo = p.nCo; a.KDn = p.KDn; a.TT = p.TT;
-    const size_t lds = (size_t)(G::PHP + G::M) * PSTR;
+    const size_t lds = (size_t)G::PHP * PSTR + (size_t)G::M * (sizeof(T) == 2 ? PSTR : 288);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, G, USE_TR>),
