@@ -250,6 +250,16 @@ int mis_bcedice_fwd(const float* x, const float* t, int N, int C, long long S, f
 int mis_bcedice_bwd(const float* x, const float* t, int N, int C, long long S, float alpha, float beta, int normalize, const float* sums,
                     const float* grad_out, float* dx, void* stream);
 
+/* Further criteria of the reference's 3-D loss factory (model/unet3d/losses.py:309-346): nn.CrossEntropyLoss(ignore_index) on logits fp32 (N, C, S) with
+ * int64 labels (N, S), mean over the non-ignored voxels (out[2] = {loss, count}; all ignored -> nan like torch); nn.MSELoss / L1Loss / SmoothL1Loss
+ * (kind 0 / 1 / 2, beta 1), mean over n elements.  bwd: dx = grad_out[0] * dLoss/dx.  workspace: mis_loss_workspace_bytes(). */
+size_t mis_loss_workspace_bytes(void);
+int mis_ce3d_fwd(const float* logits, const long long* labels, int N, int C, long long S, long long ignore_index, void* workspace, float* out, void* stream);
+int mis_ce3d_bwd(const float* logits, const long long* labels, int N, int C, long long S, long long ignore_index, const float* fwd_out,
+                 const float* grad_out, float* dx, void* stream);
+int mis_pointloss_fwd(int kind, const float* x, const float* t, long long n, void* workspace, float* out, void* stream);
+int mis_pointloss_bwd(int kind, const float* x, const float* t, long long n, const float* grad_out, float* dx, void* stream);
+
 /* UNet 3+ skip paths (model/unet2d/unet.py:136-446): nn.MaxPool2d(k, k, ceil_mode=True) and nn.Upsample(scale_factor=s, mode='bilinear')
  * (align_corners=False), NHWC, forward and backward.  Pool output grid = ceil(H/k) x ceil(W/k); bilinear output grid = H*s x W*s. */
 int mis_maxpoolk_fwd(int dtype, const void* x, int x_ld, void* y, int y_ld, int N, int H, int W, int C, int k, void* stream);

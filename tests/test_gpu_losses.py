@@ -55,3 +55,40 @@ def test_hf_wrapper_double_sigmoid_quirk():
     assert torch.allclose(out.logits.cpu(), torch.sigmoid(T(g["logits"])), atol=1e-5)
     out.loss.backward()
     assert m.model.final_conv.weight.grad is not None and torch.isfinite(m.model.final_conv.weight.grad).all()
+
+
+def test_cross_entropy_and_pointwise_losses_match_torch():
+    """The factory's CrossEntropyLoss (ignore_index) and MSELoss / L1Loss / SmoothL1Loss are torch.nn criteria in the reference (losses.py:354-373):
+    value and gradient against torch on the same data (fp64), incl. ignored voxels, an upstream scale and the all-ignored nan case."""
+    import torch.nn.functional as F
+
+    from mdeical_image_segmentation_amd.model.unet3d import losses as L
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 5, 6, 7, 9, generator=gen) * 3
+    lab = torch.randint(0, 5, (2, 6, 7, 9), generator=gen)
+    lab[torch.rand(2, 6, 7, 9, generator=gen) < 0.15] = -1
+    for ign, cfg in ((-1, {"name": "CrossEntropyLoss", "ignore_index": -1}), (-100, {"name": "CrossEntropyLoss"})):
+        lab_i = lab if ign == -1 else lab.clamp_min(0)
+        xr = x.double().requires_grad_(True)
+        (F.cross_entropy(xr, lab_i, ignore_index=ign) * 1.7).backward()
+        xd = x.cuda().requires_grad_(True)
+        crit = L.get_loss_criterion({"loss": dict(cfg)})
+        loss = crit(xd, lab_i.cuda())
+        (loss * 1.7).backward()
+        assert abs(loss.item() - F.cross_entropy(x.double(), lab_i, ignore_index=ign).item()) < 2e-6
+        assert (xd.grad.cpu().double() - xr.grad).abs().max().item() < 1e-7 + 2e-6 * xr.grad.abs().max().item()
+    assert torch.isnan(L.CrossEntropyLoss(ignore_index=3)(x.cuda(), torch.full((2, 6, 7, 9), 3).cuda()))
+    t = torch.randn(2, 5, 6, 7, 9, generator=gen)
+    t[0, 0, 0, 0, :4] = x[0, 0, 0, 0, :4]                       # exact zeros of the difference (L1 sub-gradient 0)
+    for name, fn in (("MSELoss", F.mse_loss), ("L1Loss", F.l1_loss), ("SmoothL1Loss", F.smooth_l1_loss)):
+        xr = x.double().requires_grad_(True)
+        fn(xr, t.double()).backward()
+        xd = x.cuda().requires_grad_(True)
+        loss = L.get_loss_criterion({"loss": {"name": name}})(xd, t.cuda())
+        loss.backward()
+        assert abs(loss.item() - fn(x.double(), t.double()).item()) < 2e-6 * max(1.0, abs(loss.item())), name
+        assert (xd.grad.cpu().double() - xr.grad).abs().max().item() < 1e-9 + 2e-6 * xr.grad.abs().max().item(), name
+    with pytest.raises(NotImplementedError):
+        L.get_loss_criterion({"loss": {"name": "GeneralizedDiceLoss"}})
+    with pytest.raises(NotImplementedError):
+        L.get_loss_criterion({"loss": {"name": "BCEDiceLoss", "ignore_index": 0}})
