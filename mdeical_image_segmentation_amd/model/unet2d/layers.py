@@ -248,12 +248,41 @@ def _conv3x3_cols(x, w_tap_out_in, y, n_out, bias=None, **kw):
                        bias=None if bias is None else bias[lo:hi].contiguous(), **kw)
 
 
+def _bn_relu_out(z, scale, shift, out):
+    """y = relu(z * scale + shift): into a fresh buffer, or straight into a channel slice (ops.View) of a concatenation buffer, which makes the
+    reference's torch.cat of the five decoder branches (unet.py:237-243 etc.) a no-op; returns the (N, C, H, W) channels_last view of the result"""
+    if out is None:
+        y = torch.empty_like(z)
+        ops.affine_act(z, y, scale, shift, relu=True)
+        return _to_nchw(y)
+    ops.affine_act(z, out, scale, shift, relu=True)
+    return out.t[..., out.c0:out.c0 + out.C].permute(0, 3, 1, 2)
+
+
+class _CatSlices(torch.autograd.Function):
+    """torch.cat(parts, 1) when every part already IS its channel slice of `buf` (written there by _bn_relu_out): forward returns the buffer, backward
+    hands each branch its slice of the gradient as a view (read in place by _grad_nhwc)"""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        ctx.widths = [p.shape[1] for p in parts]
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, c = [], 0
+        for wdt in ctx.widths:
+            outs.append(g[:, c:c + wdt])
+            c += wdt
+        return (None, *outs)
+
+
 class _Conv3x3BNReLU(torch.autograd.Function):
     """y = relu(batch_norm(conv2d(x, w, b, padding=1))) - reference layers.py:17-25 (one `conv%d` Sequential of unetConv2).
     Input channels are zero-padded to a multiple of 64 (the K tile of the MFMA kernels); running statistics are updated in place."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, eps, momentum):
+    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, eps, momentum, out=None):
         _need_cuda(x)
         dt = _compute_dtype()
         dev = x.device
@@ -280,12 +309,10 @@ class _Conv3x3BNReLU(torch.autograd.Function):
             ops.chanstats(z, s, sq)
         ops.bn_fwd_finalize(s, sq, N, Cout, N * H * W, gamma.detach().float(), beta.detach().float(), running_mean, running_var, training,
                             scale, shift, mean, rstd, eps=eps, momentum=momentum)
-        y = torch.empty_like(z)
-        ops.affine_act(z, y, scale, shift, relu=True)
         ctx.save_for_backward(xin, z, scale, shift, mean, rstd, gamma.detach().float())
         ctx.wd, ctx.training = wd, training
         ctx.shape = (N, Cin, H, W, Cout, Cp)
-        return _to_nchw(y)
+        return _bn_relu_out(z, scale, shift, out)
 
     @staticmethod
     def backward(ctx, gy):
@@ -310,7 +337,7 @@ class _Conv3x3BNReLU(torch.autograd.Function):
             dxp = torch.empty(N, H, W, Cp, dtype=dt, device=dev)
             _conv3x3_cols(dz, ctx.wd, dxp, Cp)
             dx = _to_nchw(dxp, Cin)
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None
 
 
 class _MaxPoolCeil(torch.autograd.Function):
@@ -365,7 +392,7 @@ class _UpConv3x3BNReLU(torch.autograd.Function):
     Same arithmetic up to fp32 summation order."""
 
     @staticmethod
-    def forward(ctx, x, s, w, b, gamma, beta, running_mean, running_var, training, eps, momentum):
+    def forward(ctx, x, s, w, b, gamma, beta, running_mean, running_var, training, eps, momentum, out=None):
         _need_cuda(x)
         dt = _compute_dtype()
         dev = x.device
@@ -395,12 +422,10 @@ class _UpConv3x3BNReLU(torch.autograd.Function):
             ops.chanstats(z, sm, sq)
         ops.bn_fwd_finalize(sm, sq, N, Cout, N * H * W, gamma.detach().float(), beta.detach().float(), running_mean, running_var, training,
                             scale, shift, mean, rstd, eps=eps, momentum=momentum)
-        y = torch.empty_like(z)
-        ops.affine_act(z, y, scale, shift, relu=True)
         ctx.save_for_backward(xin, z, scale, shift, mean, rstd, gamma.detach().float(), wpad)
         ctx.training = training
         ctx.shape = (N, Cin, h, wl, Cout, Cp, s)
-        return _to_nchw(y)
+        return _bn_relu_out(z, scale, shift, out)
 
     @staticmethod
     def backward(ctx, gy):
@@ -431,17 +456,17 @@ class _UpConv3x3BNReLU(torch.autograd.Function):
             dxp = torch.empty(N, h, wl, Cp, dtype=dt, device=dev)
             ops.conv_igemm(dzt, wd, dxp, ksize=1, Cin=9 * Cout, Cout=Cp)
             dx = _to_nchw(dxp, Cin)
-        return dx, None, dw, db, dgamma, dbeta, None, None, None, None, None
+        return dx, None, dw, db, dgamma, dbeta, None, None, None, None, None, None
 
 
-def up_conv_bn_relu(x, s, conv, bn, module_training):
+def up_conv_bn_relu(x, s, conv, bn, module_training, out=None):
     """relu(bn(conv3x3(upsample_bilinear(x, s)))) - fused form (default) or, with MISAMD_UPCONV_UNFUSED=1, the reference's literal order"""
     if os.environ.get("MISAMD_UPCONV_UNFUSED") == "1":
-        return conv_bn_relu(_BilinearUp.apply(x, s), conv, bn, module_training)
+        return conv_bn_relu(_BilinearUp.apply(x, s), conv, bn, module_training, out)
     training = module_training or not bn.track_running_stats
     if module_training and bn.track_running_stats:
         bn.num_batches_tracked += 1
-    return _UpConv3x3BNReLU.apply(x, s, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, bn.momentum)
+    return _UpConv3x3BNReLU.apply(x, s, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, bn.momentum, out)
 
 
 class _Conv3x3Plain(torch.autograd.Function):
@@ -518,12 +543,12 @@ class unetConv2(nn.Module):
         return x
 
 
-def conv_bn_relu(x, conv, bn, module_training):
+def conv_bn_relu(x, conv, bn, module_training, out=None):
     """relu(bn(conv3x3(x))) through the HIP path with nn.BatchNorm2d's train / eval semantics (running statistics, num_batches_tracked)"""
     training = module_training or not bn.track_running_stats
     if module_training and bn.track_running_stats:
         bn.num_batches_tracked += 1
-    return _Conv3x3BNReLU.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, bn.momentum)
+    return _Conv3x3BNReLU.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, bn.momentum, out)
 
 
 unetUp = _out_of_scope("unetUp", "model/unet2d/layers.py:49-74")

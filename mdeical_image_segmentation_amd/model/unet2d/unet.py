@@ -18,7 +18,7 @@ from ... import ops
 from ..._lib import MisError, check, load, stream_ptr
 from ...engine2d import UNet2DEngine
 from .init_weights import init_weights
-from .layers import (CropAndConcat, DoubleConvolution, DownSample, UpSample, _BilinearUp, _Conv3x3Plain, _MaxPool2, _MaxPoolCeil, conv_bn_relu, up_conv_bn_relu,
+from .layers import (CropAndConcat, DoubleConvolution, DownSample, UpSample, _BilinearUp, _Conv3x3Plain, _MaxPool2, _CatSlices, _MaxPoolCeil, conv_bn_relu, up_conv_bn_relu,
                      unetConv2)
 
 
@@ -228,15 +228,20 @@ class _UNet3PlusBase(nn.Module):
             h[i] = getattr(self, f"conv{i}")(_MaxPool2.apply(h[i - 1]))
         hd = {5: h[5]}
         for d in (4, 3, 2, 1):
+            # the five 64-channel branches write straight into their slices of one NHWC buffer: the reference's torch.cat is free
+            N, _, Hd, Wd = h[d].shape
+            buf = torch.empty(N, Hd, Wd, self.UpChannels, dtype=h[d].dtype, device=inputs.device)
             parts = []
             for i in range(1, 6):
                 name, _ = self._branch(d, i)
+                out = ops.View(buf, self.CatChannels * (i - 1), self.CatChannels)
                 if i > d:           # bilinear upsample -> conv -> BN -> ReLU, contracted at the low resolution (layers._UpConv3x3BNReLU)
-                    parts.append(up_conv_bn_relu(hd[i], 2 ** (i - d), getattr(self, name + "_conv"), getattr(self, name + "_bn"), self.training))
+                    parts.append(up_conv_bn_relu(hd[i], 2 ** (i - d), getattr(self, name + "_conv"), getattr(self, name + "_bn"), self.training, out))
                     continue
                 src = _MaxPoolCeil.apply(h[i], 2 ** (d - i)) if i < d else h[i]
-                parts.append(conv_bn_relu(src, getattr(self, name + "_conv"), getattr(self, name + "_bn"), self.training))
-            hd[d] = conv_bn_relu(torch.cat(parts, 1), getattr(self, f"conv{d}d_1"), getattr(self, f"bn{d}d_1"), self.training)
+                parts.append(conv_bn_relu(src, getattr(self, name + "_conv"), getattr(self, name + "_bn"), self.training, out))
+            cat = _CatSlices.apply(buf.permute(0, 3, 1, 2), *parts)
+            hd[d] = conv_bn_relu(cat, getattr(self, f"conv{d}d_1"), getattr(self, f"bn{d}d_1"), self.training)
         return hd
 
     def _head(self, hd, k):
