@@ -279,7 +279,9 @@ int mis_scale_sigmoid(const float* x, const float* gy, const float* gate, int N,
  *   fwd: y[N][h*s][w*s][C] = bias + sum over the 3x3 taps inside the upsampled image of bilinear(z[..][tap*C + c]) at (o + tap - 1)
  *   bwd: dz[N][h][w][9*C]  = the adjoint of that gather applied to dy
  * z / dz are dense (row stride 9*C); y / dy have a row stride.  C % (16 bytes / element) == 0, 1 <= scale <= 32. */
-int mis_upconv_gather_fwd(int dtype, const void* z, void* y, int y_ld, const float* bias, int N, int h, int w, int scale, int C, void* stream);
+size_t mis_upconv_gather_fwd_workspace_bytes(int dtype, int N, int h, int w, int scale, int C);
+int mis_upconv_gather_fwd(int dtype, const void* z, void* y, int y_ld, const float* bias, int N, int h, int w, int scale, int C, void* workspace /* NULL: single pass */,
+                          void* stream);
 int mis_upconv_gather_bwd(int dtype, const void* dy, int dy_ld, void* dz, int N, int h, int w, int scale, int C, void* stream);
 
 /* SegmentationLoss of the UNet 3+ path (model/unet2d/loss.py:21-70): F1Loss + MSSSIMLoss (pytorch_msssim 1.0.0 MS_SSIM, data_range 1, 5 scales,

@@ -81,6 +81,75 @@ __global__ __launch_bounds__(256) void upconv_gather_fwd_kernel(const T* __restr
     }
 }
 
+// Two-pass (separable) form of the forward gather: the x-direction first, on the low-resolution ROWS only,
+//   V[n][jy][ox][ky][c] = sum_kx [ox+kx-1 inside] bilinear_x(Z[n][jy][.][(ky,kx)*C + c])(ox + kx - 1)          (6 chunk loads per element, 3/s of the output size)
+//   y[n][oy][ox][c]     = bias + sum_ky [oy+ky-1 inside] bilinear_y(V[n][.][ox][ky][c])(oy + ky - 1)             (6 chunk loads per element)
+// i.e. 6 + 18/s loads per output element instead of 36; V (3/s x the output) goes through HBM once.  Same arithmetic up to fp32 summation order.
+template <typename T>
+__global__ __launch_bounds__(256) void upconv_xpass_kernel(const T* __restrict__ Z, T* __restrict__ V, int N, int h, int w, int s, int C) {
+    constexpr int EPC = Tr<T>::EPC;
+    const int nch = C / EPC, W = w * s;
+    const float inv = 1.0f / (float)s;
+    const size_t zld = (size_t)9 * C;
+    const long long total = (long long)N * h * W * 3 * nch;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        long long r = i / nch;
+        const int ky = (int)(r % 3);
+        r /= 3;
+        const int ox = (int)(r % W);
+        const long long row = r / W;                  // n * h + jy
+        UpcAxis ax;
+        upc_axis(ox, inv, w, W, ax);
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+        const T* base = Z + (size_t)row * w * zld + (size_t)(ky * 3) * C + (size_t)ch * EPC;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            float a[EPC], b[EPC];
+            unpack_chunk<T>(*reinterpret_cast<const u32x4*>(base + (size_t)ax.i0[kx] * zld + kx * C), a);
+            unpack_chunk<T>(*reinterpret_cast<const u32x4*>(base + (size_t)ax.i1[kx] * zld + kx * C), b);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += ax.w0[kx] * a[e] + ax.w1[kx] * b[e];
+        }
+        *reinterpret_cast<u32x4*>(V + (size_t)i * EPC) = pack_chunk<T>(acc);      // V is dense in exactly this index order
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upconv_ypass_kernel(const T* __restrict__ V, T* __restrict__ y, int y_ld, const float* __restrict__ bias, int N, int h,
+                                                           int w, int s, int C) {
+    constexpr int EPC = Tr<T>::EPC;
+    const int nch = C / EPC, H = h * s, W = w * s;
+    const float inv = 1.0f / (float)s;
+    const size_t vrow = (size_t)W * 3 * C;            // one low-resolution row of V
+    const long long total = (long long)N * H * W * nch;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        const long long r = i / nch;
+        const int ox = (int)(r % W);
+        const int rr = (int)(r / W);
+        const int oy = rr % H;
+        const int n = rr / H;
+        UpcAxis ay;
+        upc_axis(oy, inv, h, H, ay);
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = bias ? bias[ch * EPC + e] : 0.f;
+        const T* base = V + (size_t)n * h * vrow + (size_t)ox * 3 * C + (size_t)ch * EPC;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            float a[EPC], b[EPC];
+            unpack_chunk<T>(*reinterpret_cast<const u32x4*>(base + (size_t)ay.i0[ky] * vrow + ky * C), a);
+            unpack_chunk<T>(*reinterpret_cast<const u32x4*>(base + (size_t)ay.i1[ky] * vrow + ky * C), b);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += ay.w0[ky] * a[e] + ay.w1[ky] * b[e];
+        }
+        *reinterpret_cast<u32x4*>(y + (((size_t)n * H + oy) * W + ox) * y_ld + (size_t)ch * EPC) = pack_chunk<T>(acc);
+    }
+}
+
 // one thread per (low-resolution pixel j, tap, 16-byte channel chunk): walks the <= (2s+1)^2 upsampled positions that reference j
 template <typename T>
 __global__ __launch_bounds__(256) void upconv_gather_bwd_kernel(const T* __restrict__ dY, int dy_ld, T* __restrict__ dZ, int N, int h, int w, int s, int C) {
@@ -262,12 +331,31 @@ static unsigned upc_grid(long long total) {
     return (unsigned)b;
 }
 
-extern "C" int mis_upconv_gather_fwd(int dtype, const void* z, void* y, int y_ld, const float* bias, int N, int h, int w, int scale, int C, void* stream) {
+extern "C" size_t mis_upconv_gather_fwd_workspace_bytes(int dtype, int N, int h, int w, int scale, int C) {
+    return (size_t)N * h * w * scale * 3 * C * (dtype == MIS_BF16 ? 2 : 4);
+}
+
+/* workspace == NULL: single-pass gather (36 chunk loads per output element); otherwise the two-pass separable form through V = workspace */
+extern "C" int mis_upconv_gather_fwd(int dtype, const void* z, void* y, int y_ld, const float* bias, int N, int h, int w, int scale, int C, void* workspace,
+                                     void* stream) {
     (void)hipGetLastError();
     if (int rc = upc_check("upconv_gather_fwd", dtype, z, y, y_ld, N, h, w, scale, C)) return rc;
     const int EPC = dtype == MIS_BF16 ? 8 : 4;
-    const unsigned g = upc_grid((long long)N * h * scale * w * scale * (C / EPC));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (workspace != nullptr) {
+        const unsigned g1 = upc_grid((long long)N * h * w * scale * 3 * (C / EPC));
+        const unsigned g2 = upc_grid((long long)N * h * scale * w * scale * (C / EPC));
+        if (dtype == MIS_BF16) {
+            hipLaunchKernelGGL(upconv_xpass_kernel<__bf16>, dim3(g1), dim3(256), 0, st, (const __bf16*)z, (__bf16*)workspace, N, h, w, scale, C);
+            hipLaunchKernelGGL(upconv_ypass_kernel<__bf16>, dim3(g2), dim3(256), 0, st, (const __bf16*)workspace, (__bf16*)y, y_ld, bias, N, h, w, scale, C);
+        } else {
+            hipLaunchKernelGGL(upconv_xpass_kernel<float>, dim3(g1), dim3(256), 0, st, (const float*)z, (float*)workspace, N, h, w, scale, C);
+            hipLaunchKernelGGL(upconv_ypass_kernel<float>, dim3(g2), dim3(256), 0, st, (const float*)workspace, (float*)y, y_ld, bias, N, h, w, scale, C);
+        }
+        MIS_LAUNCH_CHECK("upconv_gather_fwd (two-pass)");
+        return MIS_OK;
+    }
+    const unsigned g = upc_grid((long long)N * h * scale * w * scale * (C / EPC));
     if (dtype == MIS_BF16)
         hipLaunchKernelGGL(upconv_gather_fwd_kernel<__bf16>, dim3(g), dim3(256), 0, st, (const __bf16*)z, (__bf16*)y, y_ld, bias, N, h, w, scale, C);
     else

@@ -2,6 +2,8 @@
 every wrapper passes raw pointers + sizes and enqueues on torch's current HIP stream."""
 import ctypes as C
 
+import os as _os
+
 import torch
 
 from . import _lib
@@ -513,7 +515,10 @@ def upconv_gather_fwd(z, y, scale, C, bias=None):
     N, h, w, c9 = z.shape
     if c9 != 9 * C or not z.is_contiguous() or y.H != h * scale or y.W != w * scale or y.C != C:
         raise MisError(f"upconv_gather_fwd: z {tuple(z.shape)} / y ({y.N},{y.H},{y.W},{y.C}) do not match scale {scale}, C {C}")
-    check(lib.mis_upconv_gather_fwd(dtype_code(z.dtype), z.data_ptr(), y.ptr, y.ld, None if bias is None else bias.data_ptr(), N, h, w, scale, C,
+    ws = None
+    if _os.environ.get("MISAMD_UPCONV_SINGLE_PASS") != "1":
+        ws = workspace(lib.mis_upconv_gather_fwd_workspace_bytes(dtype_code(z.dtype), N, h, w, scale, C), z.device, "upconv_v").data_ptr()
+    check(lib.mis_upconv_gather_fwd(dtype_code(z.dtype), z.data_ptr(), y.ptr, y.ld, None if bias is None else bias.data_ptr(), N, h, w, scale, C, ws,
                                     stream_ptr()), "mis_upconv_gather_fwd")
 
 
