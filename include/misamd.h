@@ -153,6 +153,11 @@ int mis_adamw_step(float* p, const float* g, float* m, float* v, long long n, co
                    float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                    float* gradnorm_out, void* stream);
 int mis_sumsq_npartials(long long n);
+/* the same step with the optimizer state on the device, for captured (hipGraph) train steps: *step_dev is advanced by the kernel when `advance` != 0
+ * (once per optimizer step: the first of the decay / no-decay calls), lr is read from lr_dev[0]; hyper_ws: 3 floats of scratch per call */
+int mis_adamw_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* sumsq_partials, int npartials, float max_norm,
+                       const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, int* step_dev, int advance, float* hyper_ws,
+                       float* gradnorm_out, void* stream);
 
 /* GroupNorm statistics (per sample, per channel sums) and finalisation to a*x+b. buildingblocks.py:87-92 */
 size_t mis_chanstats_workspace_bytes(int N, long long npix, int C);

@@ -17,7 +17,7 @@ EXPORTS = [
     "mis_conv3x3_first_fwd", "mis_conv3x3_first_wgrad_workspace_bytes", "mis_conv3x3_first_wgrad",
     "mis_colsum_workspace_bytes", "mis_colsum", "mis_maxpool2_fwd", "mis_maxpool2_bwd",
     "mis_pack_conv_weight", "mis_pack_convt_weight", "mis_head_workspace_bytes", "mis_head_loss",
-    "mis_adamw_workspace_bytes", "mis_sumsq", "mis_adamw_step", "mis_sumsq_npartials",
+    "mis_adamw_workspace_bytes", "mis_sumsq", "mis_adamw_step", "mis_adamw_step_dev", "mis_sumsq_npartials",
     "mis_chanstats_workspace_bytes", "mis_chanstats", "mis_nchw_to_nhwc", "mis_nhwc_to_nchw", "mis_probe_mfma",
     "mis_gn_fwd_finalize", "mis_gn_bwd_stats_workspace_bytes", "mis_gn_bwd_stats", "mis_gn_bwd_finalize", "mis_gn_bwd_apply",
     "mis_first3d_fwd", "mis_first3d_bwd_workspace_bytes", "mis_first3d_bwd", "mis_relu_mask",
@@ -153,6 +153,7 @@ def load():
         "mis_head_loss": [vp, vp],
         "mis_sumsq": [vp, ll, vp, vp],
         "mis_adamw_step": [vp, vp, vp, vp, ll, vp, i, f, f, f, f, f, f, i, vp, vp],
+        "mis_adamw_step_dev": [vp, vp, vp, vp, ll, vp, i, f, vp, f, f, f, f, vp, i, vp, vp, vp],
         "mis_chanstats": [i, vp, i, i, ll, i, vp, vp, vp, vp],
         "mis_nchw_to_nhwc": [i, vp, vp, i, i, i, ll, vp],
         "mis_nhwc_to_nchw": [i, vp, i, vp, i, i, ll, vp],

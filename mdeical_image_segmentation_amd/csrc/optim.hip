@@ -50,7 +50,12 @@ extern "C" int mis_sumsq(const float* g, long long n, float* workspace, void* st
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                     long long n, const float* __restrict__ partials, int npartials, float max_norm, float lr,
                                                     float beta1, float beta2, float eps, float decay_mul, float step_size, float bc2_sqrt,
-                                                    float* __restrict__ gradnorm_out) {
+                                                    float* __restrict__ gradnorm_out, const float* __restrict__ hyper) {
+    if (hyper != nullptr) {      // step-dependent scalars from device memory (hipGraph replays: the host values would be frozen into the graph)
+        decay_mul = hyper[0];
+        step_size = hyper[1];
+        bc2_sqrt = hyper[2];
+    }
     __shared__ double red[4];
     __shared__ float coef_s;
     float coef = 1.f;
@@ -101,8 +106,39 @@ extern "C" int mis_adamw_step(float* p, const float* g, float* m, float* v, long
     long long blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n, sumsq_partials,
-                       npartials, max_norm, lr, beta1, beta2, eps, decay_mul, step_size, bc2_sqrt, gradnorm_out);
+                       npartials, max_norm, lr, beta1, beta2, eps, decay_mul, step_size, bc2_sqrt, gradnorm_out, (const float*)nullptr);
     MIS_LAUNCH_CHECK("adamw");
+    return MIS_OK;
+}
+
+// Device-resident optimizer state for captured (hipGraph) train steps: *step is advanced on the device, lr is read from device memory.
+__global__ void adamw_hyper_kernel(int* __restrict__ step, int advance, const float* __restrict__ lr, float beta1, float beta2, float weight_decay,
+                                   float* __restrict__ hyper) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int s = *step;
+    if (advance) {
+        s += 1;
+        *step = s;
+    }
+    const double l = (double)lr[0];
+    const double bc1 = 1.0 - pow((double)beta1, (double)s), bc2 = 1.0 - pow((double)beta2, (double)s);
+    hyper[0] = 1.f - lr[0] * weight_decay;
+    hyper[1] = (float)(l / bc1);
+    hyper[2] = (float)sqrt(bc2);
+}
+
+extern "C" int mis_adamw_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* sumsq_partials, int npartials, float max_norm,
+                                  const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, int* step_dev, int advance,
+                                  float* hyper_ws, float* gradnorm_out, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(p && g && m && v && n > 0 && lr_dev && step_dev && hyper_ws, MIS_EINVAL, "adamw_step_dev: bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(adamw_hyper_kernel, dim3(1), dim3(64), 0, st, step_dev, advance, lr_dev, beta1, beta2, weight_decay, hyper_ws);
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, sumsq_partials, npartials, max_norm, 0.f, beta1, beta2, eps,
+                       0.f, 0.f, 1.f, gradnorm_out, (const float*)hyper_ws);
+    MIS_LAUNCH_CHECK("adamw_step_dev");
     return MIS_OK;
 }
 

@@ -313,6 +313,23 @@ class UNet2DEngine:
         ops.wgrad_join(self.device)
 
     # ---- optimizer -------------------------------------------------------------------------------------
+    def optimizer_step_dev(self):
+        """optimizer_step with the step counter and the learning rate read from DEVICE memory (self.opt_step / self.lr_dev), so that the call can be
+        captured in a hipGraph and replayed (graph.GraphedTrainStep); the host-side step_count is advanced by the caller of the replay"""
+        f = self.flat
+        if not hasattr(self, "opt_step"):
+            self.opt_step = torch.full((1,), self.step_count, dtype=torch.int32, device=self.device)
+            self.lr_dev = torch.full((1,), float(self.lr), dtype=torch.float32, device=self.device)
+            self.opt_hyper = torch.zeros(8, dtype=torch.float32, device=self.device)
+        ops.sumsq(f.g, self.partials)
+        nd = f.n_decay
+        common = dict(partials=self.partials, max_norm=self.max_norm, lr_dev=self.lr_dev, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
+                      step_dev=self.opt_step)
+        ops.adamw_step_dev(f.p[:nd], f.g[:nd], f.m[:nd], f.v[:nd], weight_decay=self.wd, advance=True, hyper=self.opt_hyper[:4],
+                           gradnorm_out=self.gradnorm, **common)
+        ops.adamw_step_dev(f.p[nd:], f.g[nd:], f.m[nd:], f.v[nd:], weight_decay=0.0, advance=False, hyper=self.opt_hyper[4:], **common)
+        self.repack()
+
     def optimizer_step(self, lr=None):
         """clip_grad_norm_(max_norm) + AdamW (decay on weights only), then refresh the packed operands."""
         lr = self.lr if lr is None else lr

@@ -316,6 +316,15 @@ def adamw_step(p, g, m, v, *, partials, max_norm, lr, beta1, beta2, eps, weight_
                              None if gradnorm_out is None else gradnorm_out.data_ptr(), stream_ptr()), "mis_adamw_step")
 
 
+def adamw_step_dev(p, g, m, v, *, partials, max_norm, lr_dev, beta1, beta2, eps, weight_decay, step_dev, advance, hyper, gradnorm_out=None):
+    """AdamW with the step counter and the learning rate in device memory (captured train steps, graph.GraphedTrainStep)"""
+    lib = load()
+    check(lib.mis_adamw_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                                 None if partials is None else partials.data_ptr(), 0 if partials is None else partials.numel(), max_norm,
+                                 lr_dev.data_ptr(), beta1, beta2, eps, weight_decay, step_dev.data_ptr(), 1 if advance else 0, hyper.data_ptr(),
+                                 None if gradnorm_out is None else gradnorm_out.data_ptr(), stream_ptr()), "mis_adamw_step_dev")
+
+
 def nchw_to_nhwc(x, y):
     """x: fp32 (N, C, *spatial) -> y channels-last view (dtype of y)."""
     lib = load()
