@@ -43,6 +43,31 @@ def cpu_baseline(batch, size, steps=2, warmup=1):
     return batch / dt, dt
 
 
+def cpu_baseline3d(size, steps=1, warmup=1):
+    """The CPU oracle of the 3-D path (UNet3D(1,3) + BCE-Dice forward/backward + clip + AdamW in stock PyTorch) on ONE volume of the benchmark size."""
+    from oracle import unet3d_oracle as o3
+    p = o3.init_params(1, 3, seed=0)
+    params = [v.requires_grad_(True) for v in p.values()]
+    opt = torch.optim.AdamW(params, lr=5e-3, weight_decay=1e-3)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 1, size, size, size, generator=g)
+    t = (torch.rand(1, 3, size, size, size, generator=g) > 0.5).float()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        o3.bce_dice_loss(o3.unet3d_forward(p, x, 4), t).backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+
+    for _ in range(warmup):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    return 1.0 / dt, dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -273,6 +298,11 @@ def bench3d(args, rank, world, dev, dist):
             if args.layers:
                 for k, v in sorted(layers.items(), key=lambda kv: -kv[1][1]):
                     print(f"{v[1] / args.steps * 1e3:9.3f} ms/step {v[0] / v[1] / 1e12:7.1f} TF/s x{v[2] // args.steps}  {' '.join(x for x in k if x)}", file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            v, sdt = cpu_baseline3d(size)
+            out["cpu_baseline"] = {"value": round(v, 4), "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"oracle (stock PyTorch CPU restatement of the reference) fp32 train step on one {size}^3 volume, "
+                                             f"1 warm-up + 1 timed step, {sdt:.2f} s/step (no augmentation)"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
