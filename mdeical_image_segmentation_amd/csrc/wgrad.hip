@@ -63,12 +63,14 @@ constexpr int PSTR = 160;   // LDS bytes per pixel row (128 data + 32 pad)
 
 // Global -> registers (load) ... -> LDS (store) staging of one pixel tile: P = input halo slab, Q = dY tile.
 // Split so that tile t+1's loads are in flight while tile t's MFMAs run (the block is the only one on its CU in bf16).
-template <typename T, typename G> struct WgStager {
+template <typename T, typename G, bool WIDE = false> struct WgStager {
     static constexpr int EPC = Tr<T>::EPC;
-    static constexpr int PITEMS = G::PHP * 8;
+    // WIDE (bf16 1x1 layers): 128 input and 128 output channels per block = 16 chunks per pixel, 288-byte LDS rows
+    static constexpr int PC = WIDE ? 16 : 8, PSH = WIDE ? 4 : 3, PS = WIDE ? 288 : PSTR;
+    static constexpr int PITEMS = G::PHP * PC;
     static constexpr int PI = (PITEMS + 255) / 256;
     // dY tile: 64 output channels per pixel for both types = 8 (bf16) / 16 (f32) 16-byte chunks; f32 rows are 256 B + 32 B pad
-    static constexpr int QC = sizeof(T) == 2 ? 8 : 16, QSH = sizeof(T) == 2 ? 3 : 4, QSTR = sizeof(T) == 2 ? PSTR : 288;
+    static constexpr int QC = WIDE ? 16 : (sizeof(T) == 2 ? 8 : 16), QSH = WIDE ? 4 : (sizeof(T) == 2 ? 3 : 4), QSTR = WIDE ? 288 : (sizeof(T) == 2 ? PSTR : 288);
     static constexpr int QI = G::M * QC / 256;
     u32x4 pv[PI], qv[QI];
     uint32_t okmask;
@@ -105,7 +107,7 @@ template <typename T, typename G> struct WgStager {
                 const int it = b * 256 + tid;
                 pv[b] = u32x4{0u, 0u, 0u, 0u};
                 if (it < PITEMS) {
-                    const int p = it >> 3, c16 = it & 7;
+                    const int p = it >> PSH, c16 = it & (PC - 1);
                     const int pz = p / (G::PHH * G::PHW);
                     const int pr = p - pz * (G::PHH * G::PHW);
                     const int py = pr / G::PHW;
@@ -143,7 +145,7 @@ template <typename T, typename G> struct WgStager {
         for (int b = 0; b < PI; ++b) {
             const int it = b * 256 + tid;
             if (it < PITEMS) {
-                const int p = it >> 3, c16 = it & 7;
+                const int p = it >> PSH, c16 = it & (PC - 1);
                 u32x4 val = pv[b];
                 if (a.in_scale != nullptr && ((okmask >> b) & 1u)) {
                     float f[EPC];
@@ -159,7 +161,7 @@ template <typename T, typename G> struct WgStager {
                     }
                     val = pack_chunk<T>(f);
                 }
-                lds_write_b128(lds_p, p * PSTR + c16 * 16, val);
+                lds_write_b128(lds_p, p * PS + c16 * 16, val);
             }
         }
 #pragma unroll
@@ -206,19 +208,21 @@ __device__ __forceinline__ bf16x8_t wg_frag_bf16(const char* img, int off_s0, in
     }
 }
 
-template <typename T, typename G, bool USE_TR>
+template <typename T, typename G, bool USE_TR, bool WIDE = false>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 1 : 2)) void wgrad_kernel(const WgArgs a) {
     constexpr bool BF = sizeof(T) == 2;
-    constexpr int FR = BF ? 2 : 1;          // 16x16 fragments per wave per dim
-    constexpr int CT = BF ? 64 : 32;        // input-channel tile
-    constexpr int FRJ = 2, CTJ = 64;        // output-channel fragments / tile: 64 columns for both types (f32: each pixel's input value feeds two MFMAs)
-    constexpr int QSTR = BF ? PSTR : 288;   // LDS bytes per dY pixel row
+    static_assert(!WIDE || (BF && USE_TR && G::KS == 1), "the 128 x 128 channel tile exists for the bf16 1x1 layers (transposing LDS reads)");
+    constexpr int FR = WIDE ? 4 : (BF ? 2 : 1);          // 16x16 fragments per wave per dim
+    constexpr int CT = WIDE ? 128 : (BF ? 64 : 32);        // input-channel tile
+    constexpr int FRJ = WIDE ? 4 : 2, CTJ = WIDE ? 128 : 64;        // output-channel fragments / tile: 64 columns for both types (f32: each pixel's input value feeds two MFMAs)
+    constexpr int QSTR = WIDE ? 288 : (BF ? PSTR : 288);   // LDS bytes per dY pixel row
+    constexpr int PS = WIDE ? 288 : PSTR;                  // ... per input pixel row
     constexpr int TAPS2 = G::TAPS2;
     static_assert(G::M == 128, "pixel tile must be 128");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds_p = smem;
-    char* lds_q = smem + G::PHP * PSTR;
+    char* lds_q = smem + G::PHP * PS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 1 : 2)) void wgrad_kernel(co
         h0 = th * G::TH;
         w0 = tw * G::TW;
     };
-    WgStager<T, G> st;
+    WgStager<T, G, WIDE> st;
     int cn, cd0, ch0, cw0;
     if (t_begin < t_end) {
         tile_coords(t_begin, cn, cd0, ch0, cw0);
@@ -302,32 +306,32 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 1 : 2)) void wgrad_kernel(co
                     const int wx = m0 % G::TW;
                     const int p0 = (dz * G::PHH + hy) * G::PHW + wx;
                     if constexpr (USE_TR) {
-                        offP[s] = (p0 + q) * PSTR + (pp >> 1) * 16 + (pp & 1) * 8;
-                        offQ[s] = (m0 + q) * PSTR + (pp >> 1) * 16 + (pp & 1) * 8;
+                        offP[s] = (p0 + q) * PS + (pp >> 1) * 16 + (pp & 1) * 8;
+                        offQ[s] = (m0 + q) * QSTR + (pp >> 1) * 16 + (pp & 1) * 8;
                     } else {
-                        offP[s] = p0 * PSTR;
-                        offQ[s] = m0 * PSTR;
+                        offP[s] = p0 * PS;
+                        offQ[s] = m0 * QSTR;
                     }
                 }
                 // (hand software-pipelining of the fragment reads - tap t+1's reads before tap t's MFMAs, two register sets, pinned with
                 //  sched_group_barrier - measured 25-30 % SLOWER than hipcc's own read -> wait -> 4 MFMAs per tap; what did pay off is
                 //  keeping every tap / fragment offset in the ds_read immediate so that the loop carries no address VALU)
-                bf16x8_t B[FR];
-                const int qv0 = offQ[0] + wj * FR * 32, qv1 = offQ[1] + wj * FR * 32;
+                bf16x8_t B[FRJ];
+                const int qv0 = offQ[0] + wj * FRJ * 32, qv1 = offQ[1] + wj * FRJ * 32;
                 const int pv0 = offP[0] + wi * FR * 32, pv1 = offP[1] + wi * FR * 32;
 #pragma unroll
-                for (int fj = 0; fj < FR; ++fj) B[fj] = wg_frag_bf16<USE_TR>(lds_q, qv0, qv1, fj * 32, lane);
+                for (int fj = 0; fj < FRJ; ++fj) B[fj] = wg_frag_bf16<USE_TR>(lds_q, qv0, qv1, fj * 32, lane);
 #pragma unroll
                 for (int tap = 0; tap < TAPS2; ++tap) {
                     const int kh = tap / G::KS, kw = tap % G::KS;
-                    const int toff = (kh * G::PHW + kw) * PSTR;
+                    const int toff = (kh * G::PHW + kw) * PS;
                     bf16x8_t A[FR];
 #pragma unroll
                     for (int fi = 0; fi < FR; ++fi) A[fi] = wg_frag_bf16<USE_TR>(lds_p, pv0, pv1, fi * 32 + toff, lane);
 #pragma unroll
                     for (int fi = 0; fi < FR; ++fi)
 #pragma unroll
-                        for (int fj = 0; fj < FR; ++fj)
+                        for (int fj = 0; fj < FRJ; ++fj)
                             acc[tap][fi][fj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[fi], B[fj], acc[tap][fi][fj], 0, 0, 0);
                 }
             }
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __r
 // ---------------------------------------------------------------------------------------------------------
 struct WgPlan {
     int tilesD, tilesH, tilesW, ntiles, nsplit, tps, nCi, nCo, KDn, TT, CT;
-    bool is3d;
+    bool is3d, wide;
 };
 
 static int wg_plan(const MisWgradDesc* d, WgPlan* p) {
@@ -474,6 +478,14 @@ static int wg_plan(const MisWgradDesc* d, WgPlan* p) {
     MIS_REQUIRE(d->ksize == 3 || d->ksize == 1, MIS_EUNSUPPORTED, "wgrad: ksize %d", d->ksize);
     MIS_REQUIRE(d->N > 0 && d->D > 0 && d->H > 0 && d->W > 0, MIS_EINVAL, "wgrad: empty grid");
     p->CT = d->dtype == MIS_BF16 ? 64 : 32;
+    {   // bf16 1x1 layers (the GEMMs of the transposed convolutions): 128 x 128 channel tiles - twice the MFMA work per staged byte
+        static const bool no_wide = getenv("MIS_WGRAD_K1_NARROW") != nullptr;
+        const char* e = getenv("MIS_WGRAD_NO_TR");
+        const bool use_tr = !(e != nullptr && e[0] == '1');
+        p->wide = !no_wide && use_tr && d->dtype == MIS_BF16 && d->ksize == 1 && d->Cin % 128 == 0 && d->Cout % 128 == 0 && d->Cin0 % 128 == 0 &&
+                  d->in_scale == nullptr;
+        if (p->wide) p->CT = 128;
+    }
     MIS_REQUIRE(d->Cin > 0 && d->Cin % p->CT == 0 && d->Cout > 0 && d->Cout % 64 == 0, MIS_EUNSUPPORTED,
                 "wgrad: Cin %d must be a multiple of %d and Cout %d of 64", d->Cin, p->CT, d->Cout);
     p->is3d = d->is3d != 0;
@@ -486,7 +498,7 @@ static int wg_plan(const MisWgradDesc* d, WgPlan* p) {
     MIS_REQUIRE(nt < (1ll << 30), MIS_EUNSUPPORTED, "wgrad: too many pixel tiles");
     p->ntiles = (int)nt;
     p->nCi = d->Cin / p->CT;
-    p->nCo = d->Cout / 64;
+    p->nCo = d->Cout / (p->wide ? 128 : 64);
     p->KDn = (p->is3d && d->ksize == 3) ? 3 : 1;
     p->TT = d->ksize == 3 ? (p->is3d ? 27 : 9) : 1;
     const long long base = (long long)p->nCi * p->nCo * p->KDn;
@@ -508,7 +520,7 @@ extern "C" size_t mis_wgrad_workspace_bytes(const MisWgradDesc* d) {
     return ((size_t)p.nsplit * p.TT * d->Cin * d->Cout + (size_t)p.nsplit * d->Cout) * sizeof(float);
 }
 
-template <typename T, typename G, bool USE_TR>
+template <typename T, typename G, bool USE_TR, bool WIDE = false>
 static int wg_launch(const MisWgradDesc* d, const WgPlan& p, hipStream_t stream) {
     WgArgs a;
     a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cin0 = d->Cin0;
@@ -519,16 +531,16 @@ static int wg_launch(const MisWgradDesc* d, const WgPlan& p, hipStream_t stream)
     a.bias_partial = d->dbias != nullptr ? d->workspace + (size_t)p.nsplit * p.TT * d->Cin * d->Cout : nullptr;
     a.tilesD = p.tilesD; a.tilesH = p.tilesH; a.tilesW = p.tilesW; a.ntiles = p.ntiles; a.nsplit = p.nsplit; a.tps = p.tps;
     a.nCi = p.nCi; a.nCo = p.nCo; a.KDn = p.KDn; a.TT = p.TT;
-    const size_t lds = (size_t)G::PHP * PSTR + (size_t)G::M * (sizeof(T) == 2 ? PSTR : 288);
+    const size_t lds = WIDE ? (size_t)(G::PHP + G::M) * 288 : (size_t)G::PHP * PSTR + (size_t)G::M * (sizeof(T) == 2 ? PSTR : 288);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, G, USE_TR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, G, USE_TR, WIDE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const long long grid = (long long)p.nCi * p.nCo * p.KDn * p.nsplit;
     MIS_REQUIRE(grid < (1ll << 31), MIS_EUNSUPPORTED, "wgrad: grid too large");
-    hipLaunchKernelGGL((wgrad_kernel<T, G, USE_TR>), dim3((unsigned)grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((wgrad_kernel<T, G, USE_TR, WIDE>), dim3((unsigned)grid), dim3(256), lds, stream, a);
     MIS_LAUNCH_CHECK("wgrad");
     if (d->reduce_stream != nullptr && d->reduce_stream != (void*)stream) {   // reductions go to the side stream, after the MFMA kernel
         // events come from a small ring that lives as long as the process: an event destroyed right after hipStreamWaitEvent was observed
@@ -571,6 +583,12 @@ template <typename T, bool USE_TR> static int wg_dispatch(const MisWgradDesc* d,
     if (d->ksize == 3) {
         if (!p.is3d) return wg_launch<T, WGeom<1, 8, 16, 3, false>, USE_TR>(d, p, s);
         return wg_launch<T, WGeom<1, 8, 16, 3, true>, USE_TR>(d, p, s);   // one depth slice per tile: same register budget as 2-D
+    }
+    if constexpr (sizeof(T) == 2 && USE_TR) {
+        if (p.wide) {
+            if (!p.is3d) return wg_launch<T, WGeom<1, 8, 16, 1, false>, USE_TR, true>(d, p, s);
+            return wg_launch<T, WGeom<1, 8, 16, 1, true>, USE_TR, true>(d, p, s);
+        }
     }
     if (!p.is3d) return wg_launch<T, WGeom<1, 8, 16, 1, false>, USE_TR>(d, p, s);
     return wg_launch<T, WGeom<1, 8, 16, 1, true>, USE_TR>(d, p, s);
