@@ -452,7 +452,8 @@ class _UpConv3x3BNReLU(torch.autograd.Function):
         dw = dwk.view(3, 3, Cout, Cp).permute(2, 3, 0, 1)[:, :Cin].contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            wd = wpad.permute(1, 2, 3, 0).reshape(Cp, 9 * Cout).to(dt).contiguous()     # [ci][tap*Cout + co]: filter bank of the transposed GEMM
+            wd = torch.empty(Cp, 3, 3, Cout, dtype=dt, device=dev)                         # [ci][tap*Cout + co]: filter bank of the transposed GEMM
+            wd.copy_(wpad.permute(1, 2, 3, 0))                                             # one permuting + casting copy
             dxp = torch.empty(N, h, wl, Cp, dtype=dt, device=dev)
             ops.conv_igemm(dzt, wd, dxp, ksize=1, Cin=9 * Cout, Cout=Cp)
             dx = _to_nchw(dxp, Cin)
