@@ -14,7 +14,8 @@ outputs are CUDA tensors.  Differences, all loud or documented:
   * ElasticDeformation: spline_order 0 and 3 (fields from the reference's stream, smoothing + resampling on the device);
   * AdditivePoissonNoise: the integer field comes from the reference's stream on the host (uploaded, added on the device: bit-exact);
   * CropToFixed: window / mirror padding as one gather kernel, start positions from the reference's stream;
-  * GaussianBlur3D (needs skimage), PercentileNormalizer, label->boundary transforms: out of scope.
+  * PercentileNormalizer: the order statistics are selected with torch.kthvalue on the device, numpy's interpolation rule;
+  * GaussianBlur3D (needs skimage), label->boundary transforms: out of scope.
 """
 import ctypes as C
 import importlib
@@ -383,8 +384,43 @@ class CropToFixed:
         return out
 
 
+class PercentileNormalizer:
+    """transforms.py:526-543: (m - P_pmin) / (P_pmax - P_pmin + eps) with numpy's linear-interpolated percentiles.  The two order statistics each
+    percentile needs are SELECTED on the device (torch.kthvalue on the flattened volume - the one place where a library selection primitive is used),
+    the interpolation follows numpy's `_lerp`, the normalisation is one elementwise kernel."""
+
+    def __init__(self, pmin=1, pmax=99.6, channelwise=False, eps=1e-10, **kwargs):
+        if channelwise:
+            raise NotImplementedError("PercentileNormalizer(channelwise=True) is not built")
+        self.eps, self.pmin, self.pmax = eps, pmin, pmax
+
+    @staticmethod
+    def _percentile(flat, q):
+        n = flat.numel()
+        pos = (n - 1) * (q / 100.0)
+        lo = int(np.floor(pos))
+        hi = min(lo + 1, n - 1)
+        t = np.float32(pos - lo)
+        a = flat.kthvalue(lo + 1).values.item()
+        b = flat.kthvalue(hi + 1).values.item()
+        a, b = np.float32(a), np.float32(b)
+        d = b - a
+        return np.float32(b - d * (np.float32(1) - t)) if t >= 0.5 else np.float32(a + d * t)      # numpy _lerp
+
+    def __call__(self, m):
+        m = _dev(m)
+        if m.dtype != torch.float32:
+            raise MisError("PercentileNormalizer: fp32 volumes only")
+        flat = m.reshape(-1)
+        pmin, pmax = self._percentile(flat, self.pmin), self._percentile(flat, self.pmax)
+        a = np.float32(1.0) / np.float32(pmax - pmin + np.float32(self.eps))
+        out = torch.empty_like(m)
+        check(load().mis_aug_pointwise(m.data_ptr(), out.data_ptr(), m.numel(), float(a), float(-pmin * a), 0, 0.0, 0.0, 0.0, 0, stream_ptr()),
+              "mis_aug_pointwise")
+        return out
+
+
 GaussianBlur3D = _unbuilt("GaussianBlur3D")
-PercentileNormalizer = _unbuilt("PercentileNormalizer")
 
 
 class Transformer:

@@ -74,6 +74,8 @@ def main():
     for s_, (size, cen, src) in enumerate([((8, 9), False, "v"), ((13, 20), False, "v"), ((7, 19), False, "v"), ((6, 6), True, "v"), ((12, 31), True, "v"),
                                            ((4, 9), False, "c4"), ((8, 8), False, "label")]):
         out[f"crop_{s_}"] = np.ascontiguousarray(tr.CropToFixed(np.random.RandomState(600 + s_), size=size, centered=cen)(out[src]))
+    out["pnorm"] = tr.PercentileNormalizer()(v)
+    out["pnorm_5_90"] = tr.PercentileNormalizer(pmin=5, pmax=90)(v)
     out["poisson"] = tr.AdditivePoissonNoise(np.random.RandomState(700), lam=(0.5, 3.0), execution_probability=1.0)(v)
     np.savez_compressed(os.path.join(HERE, "g5_augment.npz"), **out)
     print("wrote g5_augment.npz", sum(a.nbytes for a in out.values()) // 1024, "KiB; seed", t.seed)

@@ -69,6 +69,9 @@ def test_device_crop_and_poisson_match_reference_goldens():
         assert out.dtype == torch.from_numpy(g[src]).dtype and np.array_equal(out.cpu().numpy(), g[f"crop_{s_}"]), f"crop_{s_}"
     out = tr.AdditivePoissonNoise(np.random.RandomState(700), lam=(0.5, 3.0), execution_probability=1.0)(g["v"])
     assert np.array_equal(out.cpu().numpy(), g["poisson"].astype(np.float32))
+    for key, kw in (("pnorm", {}), ("pnorm_5_90", dict(pmin=5, pmax=90))):
+        got = tr.PercentileNormalizer(**kw)(g["v"]).cpu().numpy()
+        assert np.abs(got - g[key]).max() < 2e-6 * max(1.0, np.abs(g[key]).max()), key
     keep = tr.AdditivePoissonNoise(np.random.RandomState(700), execution_probability=0.0)(g["v"])
     assert np.array_equal(np.asarray(keep if isinstance(keep, np.ndarray) else keep.cpu().numpy()), g["v"])
 
