@@ -420,7 +420,21 @@ class PercentileNormalizer:
         return out
 
 
+class Identity:
+    """transforms.py:686-691"""
+
+    def __init__(self, **kwargs):
+        pass
+
+    def __call__(self, m):
+        return m
+
+
 GaussianBlur3D = _unbuilt("GaussianBlur3D")
+# label -> boundary / affinity targets and connected-component relabelling need skimage (find_boundaries, measure.label): names kept, construction raises
+for _n in ("AbstractLabelToBoundary", "StandardLabelToBoundary", "BlobsToMask", "RandomLabelToAffinities", "LabelToAffinities", "LabelToZAffinities",
+           "LabelToBoundaryAndAffinities", "LabelToMaskAndAffinities", "Relabel", "RgbToLabel"):
+    globals()[_n] = _unbuilt(_n)
 
 
 class Transformer:
