@@ -753,6 +753,12 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
     if (!is3d) {
         static const int k1v2 = getenv("MIS_CONV_K1V1") == nullptr;
         static const int k1p = getenv("MIS_CONV_K1NOPERSIST") == nullptr;
+        if constexpr (sizeof(T) == 2) {
+            // deep 1x1 GEMMs (transposed-conv forward / dgrad): 256 output columns per block = twice the MFMA work per staged pixel tile and barrier
+            static const int k1nf8 = getenv("MIS_CONV_K1_NO256") == nullptr;
+            if (k1nf8 && k1v2 && d->Cout % 256 == 0 && d->Cin >= 4 * (int)Tr<T>::CK)
+                return launch_cfg<T, Geom<1, 16, 16, 1, false>, 2, 8, 512, 1, 4, false, true>(d, s);
+        }
         if (wide && k1v2 && k1p && d->Cin <= 4 * (int)Tr<T>::CK) return launch_cfg<T, Geom<1, 16, 16, 1, false>, 2, 4, 512, 1, 4, true, true>(d, s);
         if (wide && k1v2) return launch_cfg<T, Geom<1, 16, 16, 1, false>, 2, 4, 512, 1, 4, false, true>(d, s);
         if (wide) return launch_cfg<T, Geom<1, 8, 16, 1, false>, 2, 4>(d, s);
