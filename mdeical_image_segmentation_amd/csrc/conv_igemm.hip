@@ -41,6 +41,10 @@ struct ConvArgs {
     int tilesD, tilesH, tilesW, nSp, nCt;
 };
 
+#ifndef MIS_WDMA_EXPLICIT_DRAIN
+#define MIS_WDMA_EXPLICIT_DRAIN 1
+#endif
+
 template <int TD_, int TH_, int TW_, int KS_, bool IS3D_> struct Geom {
     static constexpr int TD = TD_, TH = TH_, TW = TW_, KS = KS_;
     static constexpr bool IS3D = IS3D_;
@@ -267,6 +271,11 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const ConvArgs a) {
             if constexpr (!WDMA) {
 #pragma unroll
                 for (int k = 0; k < WI; ++k) lds_write_b128(wb0, w_loff[k], wreg[k]);
+            }
+            if constexpr (WDMA && (NF == 8 || MIS_WDMA_EXPLICIT_DRAIN)) {
+                // the 256-column instantiations: drain this wave's LDS-DMA weight loads explicitly - with their register pressure hipcc no longer places
+                // the vmcnt(0) ahead of the barrier on its own (observed as run-to-run differences in the low bits of the deep layers' outputs)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();   // WDMA: hipcc drains the in-flight LDS-DMA (vmcnt(0)) before this barrier
             {
@@ -727,6 +736,13 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
         if (!is3d) {
             static const int v2 = getenv("MIS_CONV_V1") == nullptr;
             static const int v3 = getenv("MIS_CONV_V3") != nullptr;
+            if constexpr (sizeof(T) == 2) {
+                // deep layers: 256 output columns per block (wave tile 128 ch x 64 px, one tap per barrier): every staged halo pixel and every pixel
+                // fragment read from LDS feeds twice the MFMAs (+7...12 % per layer for Cin >= 256 despite 19 spilled VGPRs)
+                static const int k3w = getenv("MIS_CONV_K3_NO256") == nullptr;
+                static const int k3min = getenv("MIS_CONV_K3_256_MINCIN") ? atoi(getenv("MIS_CONV_K3_256_MINCIN")) : 256;
+                if (k3w && v2 && d->Cout % 256 == 0 && d->Cin >= k3min) return launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 8, 512, 1, 4, false, true>(d, s);
+            }
             if (wide && v3 && sizeof(T) == 2) return launch_cfg<T, Geom<1, 32, 16, 3, false>, 2, 4, 512, 1, 8>(d, s);   // 8 waves, wave tile 128 px x 64 ch
             // persistent tiles pay off when a tile has few K steps (prologue latency dominates); deep layers run ~5 % faster without
             const bool shallow = d->Cin <= 2 * (int)Tr<T>::CK;
