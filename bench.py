@@ -184,7 +184,7 @@ def main():
             # passes of this same command (profiles/README.md), per launch like `achieved`
             try:
                 import json as _json
-                tr = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_e_traffic.json")))
+                tr = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_h_traffic.json")))
                 t = tr.get(out["roofline"]["kernel"])
                 if t is not None and args.batch == 32 and args.size == 512:
                     out["roofline"]["traffic"] = t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"]
