@@ -72,3 +72,55 @@ def test_custom_trainer_reproduces_reference_run():
     # the checkpoint surface: the state dict round-trips through safetensors-style keys
     sd = model.state_dict()
     assert len(sd) == 46 and all(k.startswith("unet.") for k in sd)
+
+
+@pytest.mark.gpu
+def test_reference_train_py_block_runs_unchanged(tmp_path):
+    """The body of the reference's train.py:110-160 with its own argparse defaults (transformers 4.40 keyword spelling:
+    evaluation_strategy / warmup_ratio / logging_dir), a synthetic dataset instead of DRIVE, 2 optimizer steps + evaluate().
+    `dropin.install()` is the only line a user adds."""
+    import argparse
+
+    import mdeical_image_segmentation_amd.dropin as d
+    d.install()
+    from pathlib import Path
+
+    from trainer import CustomTrainer, compute_metrics
+    from transformers import TrainingArguments
+    from unet2d import UNetConfig, UNetModel
+
+    args = argparse.Namespace(output_dir=str(tmp_path), evaluation_strategy="steps", eval_steps=100, logging_steps=1, num_train_epochs=5000,
+                              per_device_train_batch_size=1, per_device_eval_batch_size=1, save_steps=1000, save_total_limit=5,
+                              warmup_ratio=0.001, learning_rate=0.005, weight_decay=0.001, metric_for_best_model="iou", in_channels=1,
+                              out_channels=1, unet_type="UNet")
+    output_dir = Path(args.output_dir).joinpath("run").joinpath(args.unet_type)
+    output_dir.mkdir(exist_ok=True, parents=True)
+    training_args = TrainingArguments(
+        output_dir=output_dir.joinpath("results"),
+        evaluation_strategy=args.evaluation_strategy,
+        eval_steps=args.eval_steps,
+        logging_dir=output_dir.joinpath("logs"),
+        logging_steps=args.logging_steps,
+        num_train_epochs=args.num_train_epochs,
+        per_device_train_batch_size=args.per_device_train_batch_size,
+        per_device_eval_batch_size=args.per_device_eval_batch_size,
+        save_steps=args.save_steps,
+        save_total_limit=args.save_total_limit,
+        remove_unused_columns=False,
+        label_names=["labels"],
+        warmup_ratio=args.warmup_ratio,
+        learning_rate=args.learning_rate,
+        weight_decay=args.weight_decay,
+        metric_for_best_model=args.metric_for_best_model,
+        max_steps=2, report_to=[],            # the only additions: stop after two steps, no tensorboard in the test
+    )
+    config = UNetConfig(in_channels=args.in_channels, out_channels=args.out_channels, unet_type=args.unet_type)
+    model = UNetModel(config)
+    trainer = CustomTrainer(model=model, args=training_args, train_dataset=SynthDataset(n=4), eval_dataset=SynthDataset(n=2, seed=6),
+                            data_collator=collate, compute_metrics=compute_metrics)
+    trainer.train()
+    ev = trainer.evaluate()
+    losses = [h["loss"] for h in trainer.state.log_history if "loss" in h]
+    assert len(losses) == 2 and all(np.isfinite(losses))
+    assert "eval_iou" in ev and "eval_dice" in ev
+    assert trainer.state.global_step == 2
