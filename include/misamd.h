@@ -69,6 +69,9 @@ typedef struct MisConvDesc {
     int Cout0;
 } MisConvDesc;
 int mis_conv_igemm(const MisConvDesc* d, void* stream);
+/* Name of the kernel configuration the calling thread's last mis_conv_igemm ran, e.g. "k3.2d.bn256.dma" (diagnostic: the parity tests assert
+ * that each case reaches the dispatch branch it is written for). */
+const char* mis_conv_last_dispatch(void);
 
 /* Weight-gradient GEMM: dW[tap][ci][co] = sum_pixels x[pixel+tap][ci] * dy[pixel][co]   (split-K over pixel tiles,
  * fp32 partial slabs + deterministic reduction).  Replaces the weight part of convolution_backward for
@@ -95,6 +98,9 @@ typedef struct MisWgradDesc {
 } MisWgradDesc;
 size_t mis_wgrad_workspace_bytes(const MisWgradDesc* d);
 int mis_wgrad(const MisWgradDesc* d, void* stream);
+/* Diagnostic twins of mis_conv_last_dispatch for mis_wgrad: configuration name and split-K factor of the calling thread's last call. */
+const char* mis_wgrad_last_dispatch(void);
+int mis_wgrad_last_nsplit(void);
 
 /* First layer (Cin = 1..4, fp32 NCHW image in, NHWC out): direct conv, forward and weight/bias gradient.
  * model/unet2d/layers.py:122 for down_conv.0.first. */

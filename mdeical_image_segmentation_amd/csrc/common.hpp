@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "misamd.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -30,6 +32,25 @@ void mis_set_error(const char* fmt, ...);
             return MIS_EHIP;                                                          \
         }                                                                             \
     } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: set it once per (kernel, device), thread-safe
+// (`done` = one bit per device ordinal, a function-local static of the launching template).
+static inline int mis_set_dyn_lds(std::atomic<unsigned long long>& done, const void* fn, size_t bytes, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        mis_set_error("%s: hipGetDevice failed", what);
+        return MIS_EHIP;
+    }
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return MIS_OK;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        mis_set_error("%s: cannot raise the dynamic LDS limit to %zu bytes: %s", what, bytes, hipGetErrorString(e));
+        return MIS_EHIP;
+    }
+    done.fetch_or(bit, std::memory_order_release);
+    return MIS_OK;
+}
 
 // ---- element traits: one K chunk is always 128 bytes of channels per pixel -------------------------
 template <typename T> struct Tr;

@@ -687,11 +687,8 @@ static int launch_ws64(const MisConvDesc* d, hipStream_t stream) {
     a.nSp = (int)nsp;
     a.nCt = 1;
     const size_t lds = (size_t)WS64::WBYTES + WS64::HBYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv64_ws_kernel), lds, "conv_igemm(ws64)")) return rc;
     hipLaunchKernelGGL(conv64_ws_kernel, dim3((unsigned)(nsp > 256 ? 256 : nsp)), dim3(WS64::NT), lds, stream, a);
     MIS_LAUNCH_CHECK("conv_igemm(ws64)");
     return MIS_OK;
@@ -718,16 +715,22 @@ static int launch_cfg(const MisConvDesc* d, hipStream_t stream) {
     MIS_REQUIRE(nsp * a.nCt < (1ll << 31), MIS_EUNSUPPORTED, "conv_igemm: grid too large");
     a.nSp = (int)nsp;
     const size_t lds = (size_t)G::HP * G::HSTR + 2 * (size_t)TPS * BN * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, G, WN, NF, NT, TPS, PF, PERSIST, WDMA>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv_igemm_kernel<T, G, WN, NF, NT, TPS, PF, PERSIST, WDMA>), lds, "conv_igemm"))
+        return rc;
     hipLaunchKernelGGL((conv_igemm_kernel<T, G, WN, NF, NT, TPS, PF, PERSIST, WDMA>), dim3((unsigned)((PERSIST && nsp * a.nCt > 256) ? 256 : nsp * a.nCt)), dim3(NT), lds, stream, a);
     MIS_LAUNCH_CHECK("conv_igemm");
     return MIS_OK;
 }
+
+// name of the kernel configuration the last mis_conv_igemm call of this thread ran (tests assert that a parity case reaches the branch it is meant for)
+static thread_local const char* g_conv_last = "";
+extern "C" const char* mis_conv_last_dispatch(void) { return g_conv_last; }
+#define RUN(tag, ...)          \
+    do {                       \
+        g_conv_last = (tag);   \
+        return __VA_ARGS__;    \
+    } while (0)
 
 template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
     const bool is3d = d->is3d != 0;
@@ -741,30 +744,30 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
                 // fragment read from LDS feeds twice the MFMAs (+7...12 % per layer for Cin >= 256 despite 19 spilled VGPRs)
                 static const int k3w = getenv("MIS_CONV_K3_NO256") == nullptr;
                 static const int k3min = getenv("MIS_CONV_K3_256_MINCIN") ? atoi(getenv("MIS_CONV_K3_256_MINCIN")) : 256;
-                if (k3w && v2 && d->Cout % 256 == 0 && d->Cin >= k3min) return launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 8, 512, 1, 4, false, true>(d, s);
+                if (k3w && v2 && d->Cout % 256 == 0 && d->Cin >= k3min) RUN("k3.2d.bn256.dma", launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 8, 512, 1, 4, false, true>(d, s));
             }
-            if (wide && v3 && sizeof(T) == 2) return launch_cfg<T, Geom<1, 32, 16, 3, false>, 2, 4, 512, 1, 8>(d, s);   // 8 waves, wave tile 128 px x 64 ch
+            if (wide && v3 && sizeof(T) == 2) RUN("k3.2d.bn128.v3", launch_cfg<T, Geom<1, 32, 16, 3, false>, 2, 4, 512, 1, 8>(d, s));   // 8 waves, wave tile 128 px x 64 ch
             // persistent tiles pay off when a tile has few K steps (prologue latency dominates); deep layers run ~5 % faster without
             const bool shallow = d->Cin <= 2 * (int)Tr<T>::CK;
-            if (wide && v2 && shallow) return launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3, 4, true, true>(d, s);
+            if (wide && v2 && shallow) RUN("k3.2d.bn128.persist.dma", launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3, 4, true, true>(d, s));
             static const int dma = getenv("MIS_CONV_NODMA") == nullptr;
-            if (wide && v2 && dma) return launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3, 4, false, true>(d, s);
-            if (wide && v2) return launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3, 4, false>(d, s);   // 8 waves, one filter row per barrier
-            if (wide) return launch_cfg<T, Geom<1, 8, 16, 3, false>, 2, 4>(d, s);
+            if (wide && v2 && dma) RUN("k3.2d.bn128.dma", launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3, 4, false, true>(d, s));
+            if (wide && v2) RUN("k3.2d.bn128.reg", launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3, 4, false>(d, s));   // 8 waves, one filter row per barrier
+            if (wide) RUN("k3.2d.bn128.v1", launch_cfg<T, Geom<1, 8, 16, 3, false>, 2, 4>(d, s));
             if constexpr (sizeof(T) == 2) {
                 static const int ws = getenv("MIS_CONV_NOWS64") == nullptr;
                 const bool plain = d->x1 == nullptr && d->in_scale == nullptr && d->y0_mode == MIS_OUT_PLAIN && d->x0_H == d->H && d->x0_W == d->W;
-                if (ws && plain && d->Cin == 64 && d->Cout == 64 && (long long)d->N * d->H * d->W >= 256ll * 512 && (d->mask == nullptr || d->mask_ld % 8 == 0)) return launch_ws64(d, s);
+                if (ws && plain && d->Cin == 64 && d->Cout == 64 && (long long)d->N * d->H * d->W >= 256ll * 512 && (d->mask == nullptr || d->mask_ld % 8 == 0)) RUN("k3.2d.ws64", launch_ws64(d, s));
             }
-            if (v2 && (long long)d->H * d->W >= 64 * 64) return launch_cfg<T, Geom<1, 32, 16, 3, false>, 1, 4, 512, 3, 4, true, true>(d, s);
-            return launch_cfg<T, Geom<1, 16, 16, 3, false>, 1, 4>(d, s);
+            if (v2 && (long long)d->H * d->W >= 64 * 64) RUN("k3.2d.bn64.persist.dma", launch_cfg<T, Geom<1, 32, 16, 3, false>, 1, 4, 512, 3, 4, true, true>(d, s));
+            RUN("k3.2d.bn64.v1", launch_cfg<T, Geom<1, 16, 16, 3, false>, 1, 4>(d, s));
         }
-        if (wide) return launch_cfg<T, Geom<4, 4, 8, 3, true>, 2, 4>(d, s);
+        if (wide) RUN("k3.3d.bn128", launch_cfg<T, Geom<4, 4, 8, 3, true>, 2, 4>(d, s));
         // bf16, Cout not a multiple of 128 (the 64- and 192-column layers at full resolution): 8 waves on a 4x8x8 voxel tile, LDS-DMA weight
         // tiles, 3 taps per barrier (+6...11 % over the 4-wave 4x4x8 config; the same tile with 1 tap per barrier or 4 waves was slower)
         static const int bn64v2 = getenv("MIS_CONV3D_BN64V1") == nullptr;
-        if (bn64v2 && sizeof(T) == 2) return launch_cfg<T, Geom<4, 8, 8, 3, true>, 2, 2, 512, 3, 4, false, true>(d, s);
-        return launch_cfg<T, Geom<4, 4, 8, 3, true>, 2, 2>(d, s);
+        if (bn64v2 && sizeof(T) == 2) RUN("k3.3d.bn64.dma", launch_cfg<T, Geom<4, 8, 8, 3, true>, 2, 2, 512, 3, 4, false, true>(d, s));
+        RUN("k3.3d.bn64.v1", launch_cfg<T, Geom<4, 4, 8, 3, true>, 2, 2>(d, s));
     }
     if (!is3d) {
         static const int k1v2 = getenv("MIS_CONV_K1V1") == nullptr;
@@ -773,15 +776,15 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
             // deep 1x1 GEMMs (transposed-conv forward / dgrad): 256 output columns per block = twice the MFMA work per staged pixel tile and barrier
             static const int k1nf8 = getenv("MIS_CONV_K1_NO256") == nullptr;
             if (k1nf8 && k1v2 && d->Cout % 256 == 0 && d->Cin >= 4 * (int)Tr<T>::CK)
-                return launch_cfg<T, Geom<1, 16, 16, 1, false>, 2, 8, 512, 1, 4, false, true>(d, s);
+                RUN("k1.2d.bn256.dma", launch_cfg<T, Geom<1, 16, 16, 1, false>, 2, 8, 512, 1, 4, false, true>(d, s));
         }
-        if (wide && k1v2 && k1p && d->Cin <= 4 * (int)Tr<T>::CK) return launch_cfg<T, Geom<1, 16, 16, 1, false>, 2, 4, 512, 1, 4, true, true>(d, s);
-        if (wide && k1v2) return launch_cfg<T, Geom<1, 16, 16, 1, false>, 2, 4, 512, 1, 4, false, true>(d, s);
-        if (wide) return launch_cfg<T, Geom<1, 8, 16, 1, false>, 2, 4>(d, s);
-        return launch_cfg<T, Geom<1, 16, 16, 1, false>, 1, 4>(d, s);
+        if (wide && k1v2 && k1p && d->Cin <= 4 * (int)Tr<T>::CK) RUN("k1.2d.bn128.persist.dma", launch_cfg<T, Geom<1, 16, 16, 1, false>, 2, 4, 512, 1, 4, true, true>(d, s));
+        if (wide && k1v2) RUN("k1.2d.bn128.dma", launch_cfg<T, Geom<1, 16, 16, 1, false>, 2, 4, 512, 1, 4, false, true>(d, s));
+        if (wide) RUN("k1.2d.bn128.v1", launch_cfg<T, Geom<1, 8, 16, 1, false>, 2, 4>(d, s));
+        RUN("k1.2d.bn64", launch_cfg<T, Geom<1, 16, 16, 1, false>, 1, 4>(d, s));
     }
-    if (wide) return launch_cfg<T, Geom<4, 4, 8, 1, true>, 2, 4>(d, s);
-    return launch_cfg<T, Geom<4, 4, 8, 1, true>, 2, 2>(d, s);
+    if (wide) RUN("k1.3d.bn128", launch_cfg<T, Geom<4, 4, 8, 1, true>, 2, 4>(d, s));
+    RUN("k1.3d.bn64", launch_cfg<T, Geom<4, 4, 8, 1, true>, 2, 2>(d, s));
 }
 
 extern "C" int mis_conv_igemm(const MisConvDesc* d, void* stream) {

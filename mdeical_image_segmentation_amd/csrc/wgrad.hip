@@ -532,12 +532,8 @@ static int wg_launch(const MisWgradDesc* d, const WgPlan& p, hipStream_t stream)
     a.tilesD = p.tilesD; a.tilesH = p.tilesH; a.tilesW = p.tilesW; a.ntiles = p.ntiles; a.nsplit = p.nsplit; a.tps = p.tps;
     a.nCi = p.nCi; a.nCo = p.nCo; a.KDn = p.KDn; a.TT = p.TT;
     const size_t lds = WIDE ? (size_t)(G::PHP + G::M) * 288 : (size_t)G::PHP * PSTR + (size_t)G::M * (sizeof(T) == 2 ? PSTR : 288);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, G, USE_TR, WIDE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&wgrad_kernel<T, G, USE_TR, WIDE>), lds, "wgrad")) return rc;
     const long long grid = (long long)p.nCi * p.nCo * p.KDn * p.nsplit;
     MIS_REQUIRE(grid < (1ll << 31), MIS_EUNSUPPORTED, "wgrad: grid too large");
     hipLaunchKernelGGL((wgrad_kernel<T, G, USE_TR, WIDE>), dim3((unsigned)grid), dim3(256), lds, stream, a);
@@ -579,19 +575,31 @@ static int wg_launch(const MisWgradDesc* d, const WgPlan& p, hipStream_t stream)
     return MIS_OK;
 }
 
+// kernel configuration / split count of this thread's last mis_wgrad call (tests assert that a parity case reaches the branch it is meant for)
+static thread_local const char* g_wgrad_last = "";
+static thread_local int g_wgrad_last_nsplit = 0;
+extern "C" const char* mis_wgrad_last_dispatch(void) { return g_wgrad_last; }
+extern "C" int mis_wgrad_last_nsplit(void) { return g_wgrad_last_nsplit; }
+#define WRUN(tag, ...)          \
+    do {                        \
+        g_wgrad_last = (tag);   \
+        return __VA_ARGS__;     \
+    } while (0)
+
 template <typename T, bool USE_TR> static int wg_dispatch(const MisWgradDesc* d, const WgPlan& p, hipStream_t s) {
+    g_wgrad_last_nsplit = p.nsplit;
     if (d->ksize == 3) {
-        if (!p.is3d) return wg_launch<T, WGeom<1, 8, 16, 3, false>, USE_TR>(d, p, s);
-        return wg_launch<T, WGeom<1, 8, 16, 3, true>, USE_TR>(d, p, s);   // one depth slice per tile: same register budget as 2-D
+        if (!p.is3d) WRUN(USE_TR ? "k3.2d.tr" : "k3.2d", wg_launch<T, WGeom<1, 8, 16, 3, false>, USE_TR>(d, p, s));
+        WRUN(USE_TR ? "k3.3d.tr" : "k3.3d", wg_launch<T, WGeom<1, 8, 16, 3, true>, USE_TR>(d, p, s));   // one depth slice per tile: same register budget as 2-D
     }
     if constexpr (sizeof(T) == 2 && USE_TR) {
         if (p.wide) {
-            if (!p.is3d) return wg_launch<T, WGeom<1, 8, 16, 1, false>, USE_TR, true>(d, p, s);
-            return wg_launch<T, WGeom<1, 8, 16, 1, true>, USE_TR, true>(d, p, s);
+            if (!p.is3d) WRUN("k1.2d.wide.tr", wg_launch<T, WGeom<1, 8, 16, 1, false>, USE_TR, true>(d, p, s));
+            WRUN("k1.3d.wide.tr", wg_launch<T, WGeom<1, 8, 16, 1, true>, USE_TR, true>(d, p, s));
         }
     }
-    if (!p.is3d) return wg_launch<T, WGeom<1, 8, 16, 1, false>, USE_TR>(d, p, s);
-    return wg_launch<T, WGeom<1, 8, 16, 1, true>, USE_TR>(d, p, s);
+    if (!p.is3d) WRUN(USE_TR ? "k1.2d.tr" : "k1.2d", wg_launch<T, WGeom<1, 8, 16, 1, false>, USE_TR>(d, p, s));
+    WRUN(USE_TR ? "k1.3d.tr" : "k1.3d", wg_launch<T, WGeom<1, 8, 16, 1, true>, USE_TR>(d, p, s));
 }
 
 extern "C" int mis_wgrad(const MisWgradDesc* d, void* stream) {

@@ -32,26 +32,63 @@ def _dtype_from(name):
 
 
 class _FusedUNet(torch.autograd.Function):
+    """One autograd node for the whole network.  The engine keeps ONE set of activations, so a backward is only valid for the engine's
+    LATEST forward: every forward stamps a generation counter and backward raises MisError on a mismatch (e.g. `l1 = m(a); l2 = m(b);
+    (l1 + l2).backward()`, or an eval forward between a forward and its backward) instead of silently using the wrong activations.
+    Gradients arriving through `logits` (auxiliary losses, custom compute_loss) are honoured: dL/dlogits of the fused criterion, scaled by
+    g_loss, plus g_logits goes through the head kernel's external-gradient entry (`mis_head_loss`, LOSS_EXTERNAL)."""
+
     @staticmethod
     def forward(ctx, images, labels, owner, train, *params):
         eng = owner._engine_for(images)
         owner._sync_params_to_engine()
         loss, logits, _ = eng.forward(images.contiguous().float(), labels, train=train)
+        eng.fwd_gen = getattr(eng, "fwd_gen", 0) + 1
+        ctx.gen = eng.fwd_gen
         ctx.owner = owner
         ctx.train = train and labels is not None
+        ctx.labels = labels
+        ctx.set_materialize_grads(False)         # an unused output arrives as None, not as a tensor of zeros
         out_loss = loss.clone().reshape(()) if loss is not None else images.new_zeros(())
-        return out_loss, logits.clone()
+        out_logits = logits.clone()
+        ctx.logits = out_logits if labels is not None else None
+        return out_loss, out_logits
 
     @staticmethod
     def backward(ctx, g_loss, g_logits):
-        if not ctx.train:
-            raise MisError("backward through UNet needs labels (the loss is fused into the head kernel)")
         owner = ctx.owner
         eng = owner._engine
-        eng.backward()
+        if getattr(eng, "fwd_gen", 0) != ctx.gen:
+            raise MisError("backward of a UNet forward that is no longer the engine's latest one: the fused engine keeps a single set of "
+                           "activations - call backward() before running the model again (or use one model call per loss)")
+        if g_loss is not None and not ctx.train:
+            raise MisError("backward through the UNet loss needs labels and grad mode (the loss is fused into the head kernel)")
+        if g_logits is None:
+            if g_loss is None:
+                return (None,) * (4 + len(list(owner.parameters())))
+            scale = g_loss
+            eng.backward()
+        else:
+            # rare path: something besides the fused criterion reads `logits`
+            d = g_logits.to(torch.float32)
+            if g_loss is not None:
+                lg, lb = ctx.logits, ctx.labels
+                if eng.cout > 1:      # CrossEntropyLoss(mean): (softmax - onehot) / (N*H*W)   (reference unet.py:1184-1188, :1208)
+                    dl = torch.softmax(lg, 1)
+                    dl.scatter_add_(1, lb.unsqueeze(1), torch.full_like(dl[:, :1], -1.0))
+                    dl /= lb.numel()
+                else:                 # BCEWithLogitsLoss(mean): (sigmoid - t) / numel
+                    dl = (torch.sigmoid(lg) - lb) / lb.numel()
+                d = d + g_loss * dl
+            eng.head_backward(d.contiguous())
+            scale = None
+            eng.backward()
         grads = []
         for name, p in owner.named_parameters():
-            grads.append(eng.G[name] * g_loss if p.requires_grad else None)
+            if not p.requires_grad:
+                grads.append(None)
+            else:
+                grads.append(eng.G[name] * scale if scale is not None else eng.G[name].clone())
         return (None, None, None, None, *grads)
 
 

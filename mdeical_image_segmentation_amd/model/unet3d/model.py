@@ -30,6 +30,8 @@ class _FusedUNet3D(torch.autograd.Function):
         eng = owner._engine_for(x)
         owner._sync_params_to_engine()
         _, logits, _ = eng.forward(x.contiguous().float(), None)
+        eng.fwd_gen = getattr(eng, "fwd_gen", 0) + 1      # the engine keeps ONE set of activations: backward is valid for its latest forward only
+        ctx.gen = eng.fwd_gen
         ctx.owner = owner
         return logits.clone()
 
@@ -37,6 +39,9 @@ class _FusedUNet3D(torch.autograd.Function):
     def backward(ctx, g):
         owner = ctx.owner
         eng = owner._engine
+        if getattr(eng, "fwd_gen", 0) != ctx.gen:
+            raise MisError("backward of a UNet3D forward that is no longer the engine's latest one: the fused engine keeps a single set of "
+                           "activations - call backward() before running the model again")
         eng.head_backward(g.contiguous().float())
         eng.backward()
         grads = [eng.Gr[name].clone() if p.requires_grad else None for name, p in owner.named_parameters()]

@@ -106,6 +106,17 @@ def conv_igemm(x0, w_packed, y0, *, ksize, Cin, Cout, grid=None, x1=None, bias=N
         check(lib.mis_conv_igemm(C.byref(d), stream_ptr()), "mis_conv_igemm")
 
 
+def conv_last_dispatch():
+    """name of the kernel configuration the last conv_igemm call of this thread ran (e.g. 'k3.2d.bn256.dma')"""
+    return load().mis_conv_last_dispatch().decode()
+
+
+def wgrad_last_dispatch():
+    """(configuration name, split-K factor) of this thread's last wgrad call"""
+    lib = load()
+    return lib.mis_wgrad_last_dispatch().decode(), lib.mis_wgrad_last_nsplit()
+
+
 _ws_cache = {}
 
 

@@ -54,8 +54,10 @@ def test_fp32_engine_matches_reference_goldens(tag, cin, cout):
     ref_am = T(g["argmax"])
     ref_am = ref_am if ref_am.dim() == 3 else ref_am[:, 0]
     nt = near_tie_mask(ref_logits)
-    flips = int((am.cpu().long() != ref_am)[~nt].sum())
-    assert flips == 0, f"{flips} argmax flips away from near-ties"
+    # the bar is BIT-EXACT argmax on the goldens: no pixel may be excused as a near-tie here (the mask only serves the non-golden shapes below)
+    assert int(nt.sum()) == 0, f"{int(nt.sum())} golden pixels lie within 1e-4 of a tie: regenerate the golden on structured inputs"
+    flips = int((am.cpu().long() != ref_am).sum())
+    assert flips == 0, f"{flips} argmax flips against the reference"
     assert torch.equal(am.cpu().long(), (logits.cpu().argmax(1) if cout > 1 else (logits.cpu()[:, 0] > 0).long()))
     print(f"[{tag}] logits max|diff| {d:.3g}; near-tie pixels excluded: {int(nt.sum())} of {nt.numel()}; "
           f"flips incl. near-ties: {int((am.cpu().long() != ref_am).sum())}")
@@ -99,10 +101,14 @@ def test_bf16_engine_close_to_oracle():
     eng.backward()
     p = o2.init_params(1, 2, seed=0)
     _, _, grads = o2.loss_and_grads(p, T(g["images"]), T(g["labels"]))
-    for n in ("final_conv.weight", "up_conv.3.second.weight", "middle_conv.first.weight", "down_conv.1.first.weight"):
-        a, b = eng.G[n].cpu().flatten(), grads[n].flatten()
-        cos = torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)
-        assert cos > 0.98, (n, cos.item())
+    worst = ("", 0.0)
+    for n, gref in grads.items():          # all 46 tensors: relative L2 error of the bf16 gradient against the fp32 oracle
+        a, b = eng.G[n].cpu().flatten().double(), gref.flatten().double()
+        rel = ((a - b).norm() / (b.norm() + 1e-30)).item()
+        if rel > worst[1]:
+            worst = (n, rel)
+        assert rel <= 2e-2, (n, rel)
+    print(f"bf16: worst gradient rel-L2 {worst[1]:.3g} ({worst[0]})")
 
 
 def test_larger_batch_vs_oracle_fp32():
