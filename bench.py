@@ -3,12 +3,17 @@
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                      # cfg2 shape per rank (default at every N)
+    ... bench.py --gpus 8 --net 3x4                                  # BASELINE configs[2]: UNet(3,4), bs 32/GPU = 256 global
+    ... bench.py --gpus 8 --workload 3d --dtype bf16 --size 160      # BASELINE configs[4]: UNet3D(1,3), 2 volumes/GPU of 160^3
+    python bench.py --workload 3d --dtype f32                        # BASELINE configs[3]: UNet3D(1,3) bs=2 128^3 fp32 + on-device augment
 
 Workload = BASELINE.json configs[1]: unet2d 1-ch -> 2-class, bs=32 per GPU, 512x512, bf16 activations / fp32 master
 (weak scaling: 32 images per rank, gradients all-reduced over RCCL, overlapped with backward).
 Prints ONE JSON line (rank 0) with the throughput, the roofline of the dominant kernel (HIP-event timed in the
-timed region) and, at N=1, the CPU oracle timed on the host cores on a bounded sample of the same workload.
+timed region), the state of the network during the timed steps (per-step loss, live-activation fractions: the run
+FAILS if the net has collapsed) and, at N=1, the CPU oracle timed on the host cores with the cfg1 protocol of
+SURVEY.md §8(d) plus driver-timed secondary legs (2-D fp32 parity mode, cfg4 3-D fp32).
 """
 import argparse
 import json
@@ -22,30 +27,75 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_IMAGE_512 = 1154.0e9      # conv/convT MACs x2, fwd + wgrad + dgrad, UNet(1,2)
+FLOP_PER_VOLUME_128 = 11359.7e9    # SURVEY.md §8(d)
 PEAK_BF16_TFLOPS = 2500.0          # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_F32_TFLOPS = 157.3
+MIN_LIVE_FRACTION = 0.20           # a timed step with fewer live (non-zero) activations than this is a collapsed network: invalid
 
 
-def cpu_baseline(batch, size, steps=2, warmup=1):
-    """The CPU oracle (a port of the reference's ATen graph) on a bounded sample of the same workload."""
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1 only): the oracle = stock-PyTorch restatement of the reference's ATen graph
+# ------------------------------------------------------------------------------------------------------------------
+def host_cores():
+    """(logical CPUs this process may run on, physical cores among them)"""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    cores, proc, phys = set(), None, 0
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                proc = int(line.split(":")[1])
+            elif line.startswith("physical id"):
+                phys = int(line.split(":")[1])
+            elif line.startswith("core id") and proc in allowed:
+                cores.add((phys, int(line.split(":")[1])))
+    except OSError:
+        pass
+    return len(allowed), (len(cores) if cores else len(allowed))
+
+
+def _cpu_steps(threads, steps, warmup=1):
     from oracle import unet2d_oracle as o2
+    torch.set_num_threads(threads)
     p = o2.init_params(1, 2, seed=0)
-    opt = o2.AdamW(p)
+    opt = o2.AdamW(p)                      # lr 5e-3, wd 1e-3 on the non-bias parameters (HF split), clip 1.0 inside train_step
     g = torch.Generator().manual_seed(0)
-    images = torch.randn(batch, 1, size, size, generator=g)
-    labels = torch.randint(0, 2, (batch, size, size), generator=g)
+    images = torch.randn(4, 1, 256, 256, generator=g)
+    labels = torch.randint(0, 2, (4, 256, 256), generator=g)
     for _ in range(warmup):
         o2.train_step(p, opt, images, labels)
     t0 = time.perf_counter()
     for _ in range(steps):
         o2.train_step(p, opt, images, labels)
-    dt = (time.perf_counter() - t0) / steps
-    return batch / dt, dt
+    return (time.perf_counter() - t0) / steps
+
+
+def cpu_baseline():
+    """cfg1 protocol of SURVEY.md §8(d) / BASELINE.md §4: UNet(1,2), 4 x 1 x 256 x 256 N(0,1) (seed 0), int64 labels, CE, AdamW + clip,
+    fp32; 1 warm-up + 5 timed steps on all physical cores of the host (count stated) and 1 + 3 on 8 threads (the survey's figure)."""
+    before = torch.get_num_threads()
+    logical, physical = host_cores()
+    s_all = _cpu_steps(physical, 5)
+    s_8 = _cpu_steps(min(8, logical), 3) if physical != 8 else s_all
+    torch.set_num_threads(before)
+    img256 = 4.0 / s_all
+    return {"value": round(img256 / 4.0, 4), "unit": "images/s", "cores": physical, "kind": "port",
+            "sample": f"cfg1 protocol: oracle (stock-PyTorch CPU restatement of the reference) UNet(1,2) fp32 fwd+CE+bwd+clip+AdamW on 4x1x256x256, "
+                      f"1 warm-up + 5 timed steps on {physical} threads = physical cores of the host ({logical} logical CPUs available): {s_all:.2f} s/step = "
+                      f"{img256:.3f} 256x256-images/s = value x 4 (value is in 512x512-equivalents: same per-pixel work); "
+                      f"8 threads: {s_8:.2f} s/step = {4.0 / s_8:.3f} 256x256-images/s (survey container: 3.17 s/step)",
+            "s_per_step": round(s_all, 3), "images256_per_s": round(img256, 4), "threads8_s_per_step": round(s_8, 3),
+            "threads8_images256_per_s": round(4.0 / s_8, 4), "logical_cpus": logical}
 
 
 def cpu_baseline3d(size, steps=1, warmup=1):
     """The CPU oracle of the 3-D path (UNet3D(1,3) + BCE-Dice forward/backward + clip + AdamW in stock PyTorch) on ONE volume of the benchmark size."""
     from oracle import unet3d_oracle as o3
+    logical, physical = host_cores()
+    before = torch.get_num_threads()
+    torch.set_num_threads(physical)
     p = o3.init_params(1, 3, seed=0)
     params = [v.requires_grad_(True) for v in p.values()]
     opt = torch.optim.AdamW(params, lr=5e-3, weight_decay=1e-3)
@@ -65,7 +115,54 @@ def cpu_baseline3d(size, steps=1, warmup=1):
     for _ in range(steps):
         step()
     dt = (time.perf_counter() - t0) / steps
-    return 1.0 / dt, dt
+    torch.set_num_threads(before)
+    return 1.0 / dt, dt, physical
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def live_fractions(tensors):
+    """fraction of non-zero elements of post-ReLU activation buffers (one small reduction each, outside the timed region)"""
+    return {k: round(float((t > 0).float().mean().item()), 4) for k, t in tensors.items()}
+
+
+def kernel_tables(prof, steps, peak):
+    agg, layers = {}, {}
+    for key, flops, e0, e1 in prof:
+        ms = e0.elapsed_time(e1) * 1e-3
+        for table, k in ((layers, key), (agg, key[:5])):
+            a = table.setdefault(k, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += ms
+            a[2] += 1
+    key, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
+    ach = fl / sec / 1e12
+    roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            "kernel": "/".join(k for k in key if k), "launches": cnt, "avg_launch_ms": round(sec / cnt * 1e3, 4),
+            "alg_gflop_per_launch": round(fl / cnt / 1e9, 2)}
+    kernels = {"/".join(k for k in key if k): {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / steps * 1e3, 3),
+                                              "launches_per_step": v[2] // steps}
+               for key, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+    total = round(sum(v[1] for v in agg.values()) / steps * 1e3, 3)
+    return roof, kernels, total, layers
+
+
+def attach_traffic(roof, batch, size):
+    """HBM bytes per launch of the dominant kernel come from the rocprofv3 PMC passes of THIS command (profiles/README.md), which cannot run
+    inside the process.  The figure is only reported when the committed summary was taken on the same kernel sources (hash match) and shape."""
+    from mdeical_image_segmentation_amd import _lib
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tr = json.load(open(path))
+    except (OSError, ValueError):
+        return
+    ent = tr.get("kernels", {}).get(roof["kernel"])
+    roof["traffic_source_hash"] = tr.get("source_hash")
+    if ent is None or tr.get("source_hash") != _lib.source_hash() or tr.get("batch") != batch or tr.get("size") != size:
+        roof["traffic_note"] = "profiles/traffic.json was collected on other kernel sources or another shape: not reported"
+        return
+    roof["traffic"] = ent["hbm_read_bytes_per_launch"] + ent["hbm_write_bytes_per_launch"]
+    roof["traffic_unit"] = "bytes/launch (PMC: FETCH_SIZE x2 on gfx950 + WRITE_SIZE; separate --pmc passes)"
+    roof["traffic_profile"] = tr.get("profile")
 
 
 def main():
@@ -73,11 +170,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
-    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=None, help="units per GPU (default 32 images / 2 volumes)")
+    ap.add_argument("--size", type=int, default=None, help="edge length (default 512 / 128)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--lr", type=float, default=1e-5,
+                    help="constant learning rate of the timed steps.  The reference's 5e-3 (train.py:98) makes THIS synthetic task (random labels) "
+                         "diverge and collapse to dead ReLUs within ~10 steps (loss = ln 2, activations 0-2 % live): AdamW does the same work at any "
+                         "lr, so the benchmark keeps the network in its initial, live state instead of timing MFMAs on zeros")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary driver-timed legs (2-D fp32, cfg4 3-D fp32) of the default N=1 run")
     ap.add_argument("--layers", action="store_true", help="print a per-layer table of the MFMA kernels to stderr")
     ap.add_argument("--net", default="1x2", choices=["1x2", "3x4"],
                     help="2-D net: 1-channel -> 2 classes (BASELINE configs[1], default at every N) or 3 -> 4 (configs[2])")
@@ -90,39 +192,61 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run "
+                  f"(python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...)",
+                  file=sys.stderr)
+        sys.exit(2)
+
+    # the CPU baseline runs FIRST (GPU idle), so that the GPU legs form one contiguous busy window at the end of the run
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline and args.workload == "2d":
+        cpu = cpu_baseline()
+
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    from mdeical_image_segmentation_amd import ops
-    from mdeical_image_segmentation_amd.ddp import GradReducer
-    from mdeical_image_segmentation_amd.engine2d import UNet2DEngine
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl", (dist.get_world_size(), dist.get_backend())
 
     if args.workload == "3d":
-        return bench3d(args, rank, world, dev, dist)
+        out = run3d(args, rank, world, dev, dist, dtype=args.dtype, batch=args.batch or 2, size=args.size or 128, steps=args.steps,
+                    warmup=args.warmup, timing=not args.no_kernel_timing, layers=args.layers)
+        if rank == 0:
+            if world == 1 and not args.no_cpu_baseline:
+                v, sdt, cores = cpu_baseline3d(args.size or 128)
+                out["cpu_baseline"] = {"value": round(v, 4), "unit": "volumes/s", "cores": cores, "kind": "port",
+                                       "sample": f"oracle (stock PyTorch CPU restatement of the reference) fp32 train step on one {args.size or 128}^3 volume, "
+                                                 f"1 warm-up + 1 timed step on {cores} threads, {sdt:.2f} s/step (no augmentation)"}
+            print(json.dumps(out), flush=True)
+    else:
+        out = run2d(args, rank, world, dev, dist, dtype=args.dtype, batch=args.batch or 32, size=args.size or 512, steps=args.steps,
+                    warmup=args.warmup, timing=not args.no_kernel_timing, layers=args.layers)
+        if rank == 0:
+            if cpu is not None:
+                out["cpu_baseline"] = cpu
+            default_shape = (args.batch or 32) == 32 and (args.size or 512) == 512 and args.net == "1x2" and args.dtype == "bf16"
+            if world == 1 and default_shape and not args.no_extra:
+                # secondary legs, so that the driver's clock covers them too: the fp32 parity mode of the same workload and cfg4 (3-D fp32 + augment)
+                ex = {}
+                torch.cuda.empty_cache()
+                o = run2d(args, rank, world, dev, dist, dtype="f32", batch=32, size=512, steps=3, warmup=1, timing=True, layers=False)
+                ex["unet2d_f32_parity_mode"] = {k: o[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "model_tflops", "roofline", "loss_per_step",
+                                                                   "act_nonzero_frac")}
+                torch.cuda.empty_cache()
+                o = run3d(args, rank, world, dev, dist, dtype="f32", batch=2, size=128, steps=3, warmup=1, timing=True, layers=False)
+                ex["unet3d_cfg4_f32_128"] = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "model_tflops", "roofline",
+                                                                "loss_per_step", "config")}
+                out["extra"] = ex
+            print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    cin, ncls = (1, 2) if args.net == "1x2" else (3, 4)
-    eng = UNet2DEngine(cin, ncls, dtype=dtype, device=dev, seed=0)  # identical init on every rank
-    reducer = GradReducer(eng.flat) if world > 1 else None
-    g = torch.Generator().manual_seed(1000 + rank)                    # per-rank data shard
-    images = torch.randn(args.batch, cin, args.size, args.size, generator=g).to(dev)
-    labels = torch.randint(0, ncls, (args.batch, args.size, args.size), generator=g).to(dev)
 
-    def step():
-        eng.forward(images, labels, train=True, grad_scale=1.0 / world)
-        if reducer is None:
-            eng.backward()
-        else:
-            eng.backward(stage_cb=reducer.stage_done)
-            reducer.finish()
-        eng.optimizer_step()
+# ------------------------------------------------------------------------------------------------------------------
+def _timed_loop(step, steps, warmup, world, dist, dev, timing):
+    from mdeical_image_segmentation_amd import ops
 
     def fence():
         torch.cuda.synchronize()
@@ -130,14 +254,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    if not args.no_kernel_timing:
+    for i in range(warmup):
+        step(-1)
+    if timing:
         ops.PROFILE = []
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(steps):
+        step(i)
     fence()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
@@ -145,107 +269,41 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    loss = eng.loss_buf[0].item()
-
-    if rank == 0:
-        ms = dt / args.steps * 1e3
-        value = world * args.batch * args.steps / dt
-        out = {
-            "metric": "images/sec (2D 512x512 U-Net train step)", "value": round(value, 2), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"unet2d {cin}-ch->{ncls}-class, bs={args.batch}/GPU {args.size}x{args.size}, "
-                                   "fwd+CE loss+bwd+clip_grad_norm(1.0)+AdamW, random-init weights",
-                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(loss, 5)},
-        }
-        flop_img = FLOP_PER_IMAGE_512 * (args.size / 512.0) ** 2
-        out["model_tflops"] = round(value * flop_img / 1e12, 1)
-        if prof:
-            agg, layers = {}, {}
-            for key, flops, e0, e1 in prof:
-                la = layers.setdefault(key, [0.0, 0.0, 0])
-                la[0] += flops
-                la[1] += e0.elapsed_time(e1) * 1e-3
-                la[2] += 1
-                key = key[:5]
-                a = agg.setdefault(key, [0.0, 0.0, 0])
-                a[0] += flops
-                a[1] += e0.elapsed_time(e1) * 1e-3
-                a[2] += 1
-            dom = max(agg.items(), key=lambda kv: kv[1][1])
-            key, (fl, sec, cnt) = dom
-            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-            ach = fl / sec / 1e12
-            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(ach / peak, 4), "traffic": None, "kernel": "/".join(k for k in key if k),
-                               "launches": cnt, "avg_launch_ms": round(sec / cnt * 1e3, 4),
-                               "alg_gflop_per_launch": round(fl / cnt / 1e9, 2)}
-            # HBM traffic of the dominant kernel cannot be counted from inside this process: it comes from the committed rocprofv3 PMC
-            # passes of this same command (profiles/README.md), per launch like `achieved`
-            try:
-                import json as _json
-                tr = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_h_traffic.json")))
-                t = tr.get(out["roofline"]["kernel"])
-                if t is not None and args.batch == 32 and args.size == 512:
-                    out["roofline"]["traffic"] = t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"]
-                    out["roofline"]["traffic_unit"] = "bytes/launch (PMC: FETCH_SIZE x2 + WRITE_SIZE)"
-            except (OSError, ValueError, KeyError):
-                pass
-            out["kernels"] = {"/".join(k for k in key if k): {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / args.steps * 1e3, 3),
-                                                             "launches_per_step": v[2] // args.steps}
-                              for key, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
-            out["mfma_kernel_ms_per_step"] = round(sum(v[1] for v in agg.values()) / args.steps * 1e3, 3)
-        if prof and args.layers:
-            for key, v in sorted(layers.items(), key=lambda kv: -kv[1][1]):
-                print(f"{v[1] / args.steps * 1e3:8.3f} ms/step {v[0] / v[1] / 1e12:7.1f} TF/s x{v[2] // args.steps}  {' '.join(k for k in key if k)}",
-                      file=sys.stderr)
-        if world == 1 and not args.no_cpu_baseline:
-            cb, cs = 2, 512
-            v, sdt = cpu_baseline(cb, cs)
-            out["cpu_baseline"] = {"value": round(v, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-                                   "sample": f"oracle (stock PyTorch CPU restatement of the reference) fp32 train step, bs={cb} {cs}x{cs}, "
-                                             f"1 warm-up + 2 timed steps, {sdt:.2f} s/step"}
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    return dt, prof
 
 
-FLOP_PER_VOLUME_128 = 11359.7e9     # SURVEY.md §8(d)
+def _comm_report(reducer, eng, steps, world, dist, dev):
+    """multi-GPU self-description: RCCL really carried the gradients, how long the buckets took, how much of that was exposed, and whether
+    every rank ends the run with bit-identical parameters (same init + same summed gradients + same optimizer => must be equal)"""
+    rep = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "allreduce_bytes_per_step": int(eng.flat.total * 4),
+           "buckets_per_step": reducer.buckets_per_step}
+    ar, exposed = reducer.timing_ms()
+    rep["allreduce_ms_per_step"] = round(ar / steps, 3)
+    rep["exposed_comm_ms_per_step"] = round(exposed / steps, 3)
+    h = torch.stack([eng.flat.p.double().sum(), eng.flat.p.double().abs().sum(), eng.flat.g.double().sum()])
+    hs = [torch.zeros_like(h) for _ in range(world)]
+    dist.all_gather(hs, h)
+    rep["params_identical_across_ranks"] = bool(all(torch.equal(hs[0][:2], x[:2]) for x in hs))
+    rep["grads_identical_across_ranks"] = bool(all(torch.equal(hs[0][2], x[2]) for x in hs))
+    return rep
 
 
-def bench3d(args, rank, world, dev, dist):
-    from mdeical_image_segmentation_amd import ops
+def run2d(args, rank, world, dev, dist, *, dtype, batch, size, steps, warmup, timing, layers):
     from mdeical_image_segmentation_amd.ddp import GradReducer
-    from mdeical_image_segmentation_amd.engine3d import UNet3DEngine
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    batch = args.batch if args.batch != 32 else 2
-    size = args.size if args.size != 512 else 128
-    eng = UNet3DEngine(1, 3, dtype=dtype, device=dev, seed=0)
-    reducer = GradReducer(eng.flat) if world > 1 else None
-    g = torch.Generator().manual_seed(1000 + rank)
-    x = torch.randn(batch, 1, size, size, size, generator=g).to(dev)
-    t = (torch.rand(batch, 3, size, size, size, generator=g) > 0.5).float().to(dev)
+    from mdeical_image_segmentation_amd.engine2d import UNet2DEngine
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    cin, ncls = (1, 2) if args.net == "1x2" else (3, 4)
+    eng = UNet2DEngine(cin, ncls, dtype=tdt, device=dev, seed=0, lr=args.lr)  # identical init on every rank (PyTorch default init, seed 0)
+    reducer = GradReducer(eng.flat, timing=True) if world > 1 else None
+    g = torch.Generator().manual_seed(1000 + rank)                    # per-rank data shard
+    images = torch.randn(batch, cin, size, size, generator=g).to(dev)
+    labels = torch.randint(0, ncls, (batch, size, size), generator=g).to(dev)
+    losses = torch.zeros(max(steps, 1), dtype=torch.float32, device=dev)
 
-    # on-device augmentation inside the timed step (SURVEY.md §8d cfg4): flip + rot90 + rotate (+-30 deg, reflect; cubic spline
-    # order 3 on raw, order 0 on targets) on raw and targets in lock-step, contrast (p=1) + Gaussian noise (p=1) on raw; parameters from the reference's streams
-    import numpy as np
-    from mdeical_image_segmentation_amd.augment.unet3d_augment import transforms as tr
-    tr.GLOBAL_RANDOM_STATE = np.random.RandomState(47 + rank)
-    def geo_(order):
-        return [{"name": "RandomFlip"}, {"name": "RandomRotate90"},
-                {"name": "RandomRotate", "axes": [[2, 1]], "angle_spectrum": 30, "mode": "reflect", "order": order}]
-    geo = geo_(0)
-    tf = tr.Transformer({"raw": geo_(3) + [{"name": "RandomContrast", "execution_probability": 1.0},
-                                       {"name": "AdditiveGaussianNoise", "execution_probability": 1.0, "scale": [0.0, 0.1]}],
-                         "label": geo}, {"mean": 0.0, "std": 1.0})
-    rt, lt = tf.raw_transform(), tf.label_transform()
-    xa, ta = torch.empty_like(x), torch.empty_like(t)
-
-    def step():
-        for b in range(batch):
-            xa[b, 0] = rt(x[b, 0])
-            ta[b] = lt(t[b])
-        eng.forward(xa, ta, train=True, grad_scale=1.0 / world)
+    def step(i):
+        eng.forward(images, labels, train=True, grad_scale=1.0 / world)
+        if i >= 0:
+            losses[i:i + 1].copy_(eng.loss_buf[:1], non_blocking=True)        # device-side, 4 bytes, no synchronisation
         if reducer is None:
             eng.backward()
         else:
@@ -253,59 +311,122 @@ def bench3d(args, rank, world, dev, dist):
             reducer.finish()
         eng.optimizer_step()
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+    def acts():
+        return live_fractions({"down_conv.0.second": eng.cat[0][..., 64:], "down_conv.2.second": eng.cat[2][..., 256:],
+                               "middle_conv.second": eng.m2, "up_conv.3.first": eng.u1[3]})
 
-    for _ in range(args.warmup):
-        step()
-    if not args.no_kernel_timing:
-        ops.PROFILE = []
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
+    warmup = max(warmup, 1)           # the live-activation probe needs one completed step
+    step(-1)
+    live0 = acts()
+    if reducer is not None:
+        reducer.reset_timing()
+    dt, prof = _timed_loop(step, steps, warmup - 1, world, dist, dev, timing)
+    live1 = acts()
+    loss_list = [round(float(v), 5) for v in losses[:steps].cpu().tolist()]
+    out = None
+    comm = _comm_report(reducer, eng, steps, world, dist, dev) if reducer is not None else None
     if rank == 0:
-        value = world * batch * args.steps / dt
+        ms = dt / steps * 1e3
+        value = world * batch * steps / dt
+        out = {
+            "metric": "images/sec (2D 512x512 U-Net train step)", "value": round(value, 2), "unit": "images/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"unet2d {cin}-ch->{ncls}-class, bs={batch}/GPU {size}x{size}, "
+                                   f"fwd+CE loss+bwd+clip_grad_norm(1.0)+AdamW(lr {args.lr:g} constant, wd 1e-3 on weights), PyTorch-default init (seed 0), N(0,1) images",
+                       "global_batch": world * batch, "parallelism": f"dp{world}", "final_loss": loss_list[-1] if loss_list else None},
+            "loss_per_step": loss_list,
+            "act_nonzero_frac": {"before_timed_steps": live0, "after_timed_steps": live1},
+        }
+        out["model_tflops"] = round(value * FLOP_PER_IMAGE_512 * (size / 512.0) ** 2 / 1e12, 1)
+        if prof:
+            peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+            roof, kernels, total, ltab = kernel_tables(prof, steps, peak)
+            if dtype == "bf16":
+                attach_traffic(roof, batch, size)
+            out["roofline"], out["kernels"], out["mfma_kernel_ms_per_step"] = roof, kernels, total
+            if layers:
+                for key, v in sorted(ltab.items(), key=lambda kv: -kv[1][1]):
+                    print(f"{v[1] / steps * 1e3:8.3f} ms/step {v[0] / v[1] / 1e12:7.1f} TF/s x{v[2] // steps}  {' '.join(k for k in key if k)}", file=sys.stderr)
+        if comm is not None:
+            out["comm"] = comm
+        dead = {k: v for k, v in {**live0, **{k + "@end": v for k, v in live1.items()}}.items() if v < MIN_LIVE_FRACTION}
+        bad_loss = [v for v in loss_list if not (v == v) or v > 50.0]
+        if dead or bad_loss:
+            print(json.dumps(out), file=sys.stderr)
+            raise SystemExit(f"bench.py: the network collapsed during the timed steps (live fractions {dead}, losses {bad_loss}): number invalid")
+    return out
+
+
+def run3d(args, rank, world, dev, dist, *, dtype, batch, size, steps, warmup, timing, layers):
+    import numpy as np
+
+    from mdeical_image_segmentation_amd.augment.unet3d_augment import transforms as tr
+    from mdeical_image_segmentation_amd.ddp import GradReducer
+    from mdeical_image_segmentation_amd.engine3d import UNet3DEngine
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    eng = UNet3DEngine(1, 3, dtype=tdt, device=dev, seed=0, lr=args.lr)
+    reducer = GradReducer(eng.flat, timing=True) if world > 1 else None
+    g = torch.Generator().manual_seed(1000 + rank)
+    x = torch.randn(batch, 1, size, size, size, generator=g).to(dev)
+    t = (torch.rand(batch, 3, size, size, size, generator=g) > 0.5).float().to(dev)
+
+    # on-device augmentation inside the timed step (SURVEY.md §8d cfg4): flip + rot90 + rotate (+-30 deg, reflect; cubic spline
+    # order 3 on raw, order 0 on targets) on raw and targets in lock-step, contrast (p=1) + Gaussian noise (p=1) on raw; parameters from the reference's streams
+    tr.GLOBAL_RANDOM_STATE = np.random.RandomState(47 + rank)
+
+    def geo_(order):
+        return [{"name": "RandomFlip"}, {"name": "RandomRotate90"},
+                {"name": "RandomRotate", "axes": [[2, 1]], "angle_spectrum": 30, "mode": "reflect", "order": order}]
+    tf = tr.Transformer({"raw": geo_(3) + [{"name": "RandomContrast", "execution_probability": 1.0},
+                                           {"name": "AdditiveGaussianNoise", "execution_probability": 1.0, "scale": [0.0, 0.1]}],
+                         "label": geo_(0)}, {"mean": 0.0, "std": 1.0})
+    rt, lt = tf.raw_transform(), tf.label_transform()
+    xa, ta = torch.empty_like(x), torch.empty_like(t)
+    losses = torch.zeros(max(steps, 1), dtype=torch.float32, device=dev)
+
+    def step(i):
+        for b in range(batch):
+            xa[b, 0] = rt(x[b, 0])
+            ta[b] = lt(t[b])
+        eng.forward(xa, ta, train=True, grad_scale=1.0 / world)
+        if i >= 0:
+            losses[i:i + 1].copy_(eng.loss_buf[:1], non_blocking=True)
+        if reducer is None:
+            eng.backward()
+        else:
+            eng.backward(stage_cb=reducer.stage_done)
+            reducer.finish()
+        eng.optimizer_step()
+
+    warmup = max(warmup, 1)
+    step(-1)
+    if reducer is not None:
+        reducer.reset_timing()
+    dt, prof = _timed_loop(step, steps, warmup - 1, world, dist, dev, timing)
+    loss_list = [round(float(v), 5) for v in losses[:steps].cpu().tolist()]
+    comm = _comm_report(reducer, eng, steps, world, dist, dev) if reducer is not None else None
+    out = None
+    if rank == 0:
+        value = world * batch * steps / dt
         out = {"metric": f"volumes/sec (3D {size}^3 U-Net train step)", "value": round(value, 3), "unit": "volumes/s", "n_gpus": world,
-               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": f"unet3d 1-ch->3-class bs={batch}/GPU {size}^3, on-device augment (flip+rot90+rotate[order 3 raw / 0 targets]+contrast+noise) + fwd+BCEDice+bwd+clip+AdamW, random-init weights",
-                          "global_batch": world * batch, "parallelism": f"dp{world}", "final_loss": round(eng.loss_buf[0].item(), 5)}}
+               "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+               "config": {"workload": f"unet3d 1-ch->3-class bs={batch}/GPU {size}^3, on-device augment (flip+rot90+rotate[order 3 raw / 0 targets]+contrast+noise) + "
+                                      f"fwd+BCEDice+bwd+clip+AdamW(lr {args.lr:g}), random-init weights",
+                          "global_batch": world * batch, "parallelism": f"dp{world}", "final_loss": loss_list[-1] if loss_list else None},
+               "loss_per_step": loss_list}
         out["model_tflops"] = round(value * FLOP_PER_VOLUME_128 * (size / 128.0) ** 3 / 1e12, 1)
         if prof:
-            agg, layers = {}, {}
-            for key, flops, e0, e1 in prof:
-                la = layers.setdefault(key, [0.0, 0.0, 0])
-                la[0] += flops; la[1] += e0.elapsed_time(e1) * 1e-3; la[2] += 1
-                a = agg.setdefault(key[:5], [0.0, 0.0, 0])
-                a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
-            key, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
-            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-            out["roofline"] = {"bound": "mfma", "achieved": round(fl / sec / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(fl / sec / 1e12 / peak, 4), "traffic": None, "kernel": "/".join(k for k in key if k),
-                               "launches": cnt, "avg_launch_ms": round(sec / cnt * 1e3, 3)}
-            out["mfma_kernel_ms_per_step"] = round(sum(v[1] for v in agg.values()) / args.steps * 1e3, 2)
-            if args.layers:
-                for k, v in sorted(layers.items(), key=lambda kv: -kv[1][1]):
-                    print(f"{v[1] / args.steps * 1e3:9.3f} ms/step {v[0] / v[1] / 1e12:7.1f} TF/s x{v[2] // args.steps}  {' '.join(x for x in k if x)}", file=sys.stderr)
-        if world == 1 and not args.no_cpu_baseline:
-            v, sdt = cpu_baseline3d(size)
-            out["cpu_baseline"] = {"value": round(v, 4), "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
-                                   "sample": f"oracle (stock PyTorch CPU restatement of the reference) fp32 train step on one {size}^3 volume, "
-                                             f"1 warm-up + 1 timed step, {sdt:.2f} s/step (no augmentation)"}
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+            peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+            roof, kernels, total, ltab = kernel_tables(prof, steps, peak)
+            out["roofline"], out["kernels"], out["mfma_kernel_ms_per_step"] = roof, kernels, total
+            if layers:
+                for k, v in sorted(ltab.items(), key=lambda kv: -kv[1][1]):
+                    print(f"{v[1] / steps * 1e3:9.3f} ms/step {v[0] / v[1] / 1e12:7.1f} TF/s x{v[2] // steps}  {' '.join(x for x in k if x)}", file=sys.stderr)
+        if comm is not None:
+            out["comm"] = comm
+    return out
 
 
 if __name__ == "__main__":

@@ -225,6 +225,20 @@ def load():
     return lib
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) of the kernel sources + the C header this tree was built from: ties a committed profile
+    (profiles/traffic.json) to the build it was measured on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.hpp")) +
+                   glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) + [os.path.join(_HERE, "..", "include", "misamd.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def check(rc, what=""):
     if rc != 0:
         msg = load().mis_last_error().decode("utf-8", "replace")

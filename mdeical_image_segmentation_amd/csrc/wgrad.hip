@@ -539,19 +539,29 @@ static int wg_launch(const MisWgradDesc* d, const WgPlan& p, hipStream_t stream)
     hipLaunchKernelGGL((wgrad_kernel<T, G, USE_TR, WIDE>), dim3((unsigned)grid), dim3(256), lds, stream, a);
     MIS_LAUNCH_CHECK("wgrad");
     if (d->reduce_stream != nullptr && d->reduce_stream != (void*)stream) {   // reductions go to the side stream, after the MFMA kernel
-        // events come from a small ring that lives as long as the process: an event destroyed right after hipStreamWaitEvent was observed
-        // to let the waiting stream run ahead of the recorded work now and then (nondeterministic gradients)
-        static hipEvent_t ring[64];
-        static bool ring_ok[64] = {false};
-        static unsigned ring_pos = 0;
-        const unsigned slot = ring_pos++ % 64u;
-        if (!ring_ok[slot]) {
-            MIS_REQUIRE(hipEventCreateWithFlags(&ring[slot], hipEventDisableTiming) == hipSuccess, MIS_EHIP, "wgrad: hipEventCreate failed");
-            ring_ok[slot] = true;
-        }
+        // Ordering side stream after the MFMA kernel.  Default: events from a small ring that lives as long as the process.  MIS_WGRAD_EVENT_PER_CALL=1
+        // = create / record / wait / destroy per call (legal HIP; kept as an experiment switch: round 1 saw nondeterministic gradients with it, in the same
+        // commit that fixed a no-op wgrad_join - DESIGN.md records which of the two it was).
+        static const bool per_call = getenv("MIS_WGRAD_EVENT_PER_CALL") != nullptr;
         const hipStream_t side = reinterpret_cast<hipStream_t>(d->reduce_stream);
-        const bool ok = hipEventRecord(ring[slot], stream) == hipSuccess && hipStreamWaitEvent(side, ring[slot], 0) == hipSuccess;
-        MIS_REQUIRE(ok, MIS_EHIP, "wgrad: could not order the reduction stream after the MFMA kernel");
+        if (per_call) {
+            hipEvent_t ev;
+            MIS_REQUIRE(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, MIS_EHIP, "wgrad: hipEventCreate failed");
+            const bool ok = hipEventRecord(ev, stream) == hipSuccess && hipStreamWaitEvent(side, ev, 0) == hipSuccess;
+            (void)hipEventDestroy(ev);
+            MIS_REQUIRE(ok, MIS_EHIP, "wgrad: could not order the reduction stream after the MFMA kernel");
+        } else {
+            static hipEvent_t ring[64];
+            static bool ring_ok[64] = {false};
+            static std::atomic<unsigned> ring_pos{0};
+            const unsigned slot = ring_pos.fetch_add(1) % 64u;
+            if (!ring_ok[slot]) {
+                MIS_REQUIRE(hipEventCreateWithFlags(&ring[slot], hipEventDisableTiming) == hipSuccess, MIS_EHIP, "wgrad: hipEventCreate failed");
+                ring_ok[slot] = true;
+            }
+            const bool ok = hipEventRecord(ring[slot], stream) == hipSuccess && hipStreamWaitEvent(side, ring[slot], 0) == hipSuccess;
+            MIS_REQUIRE(ok, MIS_EHIP, "wgrad: could not order the reduction stream after the MFMA kernel");
+        }
         stream = side;
     }
     int nslab = p.nsplit;

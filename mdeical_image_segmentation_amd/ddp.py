@@ -31,23 +31,43 @@ def module_ranges(flat, prefixes):
 
 
 class GradReducer:
-    def __init__(self, flat, group=None):
+    """Events are PERSISTENT members (one per bucket slot, created on first use and reused every step): nothing in the ordering of the two
+    streams depends on the lifetime of a temporary event object.  timing=True additionally brackets every bucket (on the communication
+    stream) and the final join (on the compute stream) with timing events, read back by timing_ms() after a synchronisation:
+    all-reduce time = sum of bucket durations, exposed time = how long the compute stream sat in finish() waiting for the last bucket."""
+
+    def __init__(self, flat, group=None, timing=False):
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.on_gpu = flat.g.device.type == "cuda"
         self.stream = torch.cuda.Stream(device=flat.g.device) if self.on_gpu else None
         self.works = []
+        self.timing = timing and self.on_gpu
+        self._ready = []          # compute -> comm ordering events, one per bucket slot
+        self._done = torch.cuda.Event() if self.on_gpu else None
+        self._slot = 0
+        self.buckets_per_step = 0
+        self._t_buckets, self._t_join = [], []
 
     def _reduce(self, t):
         if self.world == 1:
             return
         if self.on_gpu:
-            ev = torch.cuda.Event()
+            if self._slot == len(self._ready):
+                self._ready.append(torch.cuda.Event())
+            ev = self._ready[self._slot]
+            self._slot += 1
             ev.record(torch.cuda.current_stream())
             self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
+                if self.timing:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.stream)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                if self.timing:
+                    e1.record(self.stream)
+                    self._t_buckets.append((e0, e1))
         else:
             self.works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -61,10 +81,31 @@ class GradReducer:
             return
         self._reduce(self.flat.g[self.flat.n_decay:])
         if self.on_gpu:
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-            torch.cuda.current_stream().wait_event(ev)
+            self.buckets_per_step = self._slot
+            self._slot = 0
+            self._done.record(self.stream)
+            cur = torch.cuda.current_stream()
+            if self.timing:
+                j0, j1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                j0.record(cur)
+            cur.wait_event(self._done)
+            if self.timing:
+                j1.record(cur)
+                self._t_join.append((j0, j1))
         else:
+            self.buckets_per_step = len(self.works)
             for w in self.works:
                 w.wait()
             self.works = []
+
+    def reset_timing(self):
+        self._t_buckets, self._t_join = [], []
+
+    def timing_ms(self):
+        """(sum of bucket all-reduce durations, sum of compute-stream waits in finish()) in ms since reset_timing(); synchronises"""
+        if not self.timing:
+            return 0.0, 0.0
+        torch.cuda.synchronize()
+        ar = sum(a.elapsed_time(b) for a, b in self._t_buckets)
+        ex = sum(a.elapsed_time(b) for a, b in self._t_join)
+        return ar, ex
