@@ -1,0 +1,30 @@
+// Kernel-argument structs shared by the implicit-GEMM convolution kernels (conv_igemm.hip, conv_pp.hip).
+#pragma once
+#include "common.hpp"
+
+struct SrcView {
+    const void* p;
+    int ld, D, H, W;
+};
+
+struct ConvArgs {
+    int N, D, H, W, Cin, Cout, Cin0, Cout0;
+    SrcView x0, x1;
+    const float* in_scale;
+    const float* in_shift;
+    const void* w;
+    const float* bias;
+    int relu;
+    const void* mask;
+    int mask_ld;
+    void* y0;
+    int y0_ld, y0_mode;
+    void* y1;
+    int y1_ld, y1_mode;
+    int tilesD, tilesH, tilesW, nSp, nCt;
+};
+
+// conv_pp.hip: the ping-pong 3x3 kernel for the bf16 2-D layers (returns MIS_OK after the launch, or an error); `eligible` says whether a
+// descriptor can take that path at all (dispatch in conv_igemm.hip decides)
+bool conv_pp_eligible(const MisConvDesc* d);
+int launch_conv_pp(const MisConvDesc* d, hipStream_t stream, const char** tag);

@@ -18,28 +18,7 @@
 #include <type_traits>
 
 #include "common.hpp"
-
-struct SrcView {
-    const void* p;
-    int ld, D, H, W;
-};
-
-struct ConvArgs {
-    int N, D, H, W, Cin, Cout, Cin0, Cout0;
-    SrcView x0, x1;
-    const float* in_scale;
-    const float* in_shift;
-    const void* w;
-    const float* bias;
-    int relu;
-    const void* mask;
-    int mask_ld;
-    void* y0;
-    int y0_ld, y0_mode;
-    void* y1;
-    int y1_ld, y1_mode;
-    int tilesD, tilesH, tilesW, nSp, nCt;
-};
+#include "conv_args.hpp"
 
 #ifndef MIS_WDMA_EXPLICIT_DRAIN
 #define MIS_WDMA_EXPLICIT_DRAIN 1
@@ -739,6 +718,16 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
         if (!is3d) {
             static const int v2 = getenv("MIS_CONV_V1") == nullptr;
             static const int v3 = getenv("MIS_CONV_V3") != nullptr;
+            if constexpr (sizeof(T) == 2) {
+                // bf16, Cout % 128 == 0, single source: the ping-pong kernel (conv_pp.hip)
+                const bool pp = getenv("MIS_CONV_NOPP") == nullptr;      // read per call: the parity tests toggle it to reach the pre-ping-pong configurations
+                if (pp && conv_pp_eligible(d)) {
+                    const char* tag = "";
+                    const int rc = launch_conv_pp(d, s, &tag);
+                    g_conv_last = tag;
+                    return rc;
+                }
+            }
             if constexpr (sizeof(T) == 2) {
                 // deep layers: 256 output columns per block (wave tile 128 ch x 64 px, one tap per barrier): every staged halo pixel and every pixel
                 // fragment read from LDS feeds twice the MFMAs (+7...12 % per layer for Cin >= 256 despite 19 spilled VGPRs)

@@ -1,0 +1,390 @@
+// Ping-pong implicit-GEMM 3x3 convolution for the bf16 2-D layers (gfx950): forward and dgrad of nn.Conv2d(k3, p1) with Cout % 128 == 0
+// (reference model/unet2d/layers.py:122-126), same arithmetic / operand packing / epilogues as conv_igemm.hip.
+//
+// Why another kernel: conv_igemm's 8 waves run in lockstep - all of them read fragments after a barrier, then all of them want the matrix pipe
+// (PMC: MFMA pipe 36-50 % busy, 40 % of wave cycles parked at waitcnt / barrier).  Here the two waves that share a SIMD (wave w and w + 4) are
+// staggered by one barrier and alternate strictly:
+//
+//       slot      0      1      2      3      4   ...          (a slot ends with an s_barrier of all 8 waves)
+//       G0 (w<4)  R0     M0     R1     M1     R2               R = fragment ds_reads (+ LDS-DMA issue), M = 32 MFMAs
+//       G1 (w>=4) -      R0     M0     R1     M1
+//
+// so that one wave per SIMD is always inside an MFMA cluster while its partner fetches the next fragments (the structure of the guide's 8-phase
+// GEMM template, cdna_hip_programming.md §5 / T3+T4).  Nothing is staged through registers: the input HALO tile (18 x 18 pixels x 64 channels,
+// once per K chunk, double-buffered) and the per-tap WEIGHT tile ([BN x 64 ch], double-buffered) both arrive by LDS-DMA (global_load_lds_dwordx4)
+// with the XOR swizzle applied to the per-lane SOURCE address; zero padding comes from a zero page in global memory; prefetches stay in flight
+// across barriers and are retired with counted s_waitcnt vmcnt.  Blocks are persistent (grid <= 256): the next tile's halo and first weight
+// tile are fetched under the current tile's last taps, and a tile's epilogue runs in the R slot of the next tile's first step, i.e. under the
+// partner group's MFMAs.
+//
+// LDS-DMA ordering rules used below (MI355X_MICROARCH.md, "Two waves per SIMD" item 7; cdna_hip_programming.md "Read a staged buffer one phase
+// AFTER the wait that retires it"): a buffer is re-filled only after every wave's last ds_read of it has been waited for (lgkmcnt(0) before the
+// slot's barrier) and a barrier passed; it is read only after EVERY issuing wave's vmcnt wait and a following barrier.
+//   weights of step s+1 -> buffer (s+1)&1: last read (by G1) in the slot before step s starts; issued in the first R of step s; retired by each
+//                          issuer at the end of step s (G0: after its last M, G1: after its last R - both in the last slot of step s).
+//   halo of chunk c+1  -> buffer (c+1)&1: last read in chunk c-1; issued one instruction per wave in steps 0..5 of chunk c (the YOUNGEST
+//                          outstanding op of the wave, so the per-step weight wait is vmcnt(1) in those steps); retired by vmcnt(0) in steps 6..8.
+#include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "conv_args.hpp"
+
+typedef __attribute__((address_space(3))) void pp_lds_void_t;
+typedef __attribute__((address_space(1))) const void pp_glob_void_t;
+
+namespace {
+constexpr int PP_TH = 16, PP_TW = 16, PP_HH = 18, PP_HW = 18, PP_HP = PP_HH * PP_HW;
+constexpr int PP_HITEMS = PP_HP * 8;                 // 16-byte items of one halo chunk image (128 B per pixel)
+constexpr int PP_HINSTR = (PP_HITEMS + 63) / 64;     // 41 wave-instructions (the last one half full: the image is padded to 41 KiB)
+constexpr int PP_HBUF = PP_HINSTR * 1024;
+constexpr int PP_ROWB = PP_HW * 128;                 // bytes per halo row
+
+template <typename F, int... I> __device__ __forceinline__ void pp_static_for_impl(F& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void pp_static_for(F&& f) { pp_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// One LDS-DMA instruction: 64 lanes x 16 bytes from buffer `r` at per-lane byte offset `voff` to LDS [dst, dst + 1 KiB) (dst wave-uniform).
+// buffer_load ... lds: 32-bit offsets (no 64-bit address registers), and an offset at or past num_records reads as ZERO - that is the conv's zero
+// padding and the tail of the last halo instruction (PP_OOB is past every buffer this kernel accepts).
+constexpr int PP_OOB = (int)0x80000000u;
+__device__ __forceinline__ void pp_dma16(__amdgpu_buffer_rsrc_t r, int voff, char* lds_dst_wave_uniform) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (pp_lds_void_t*)lds_dst_wave_uniform, 16, voff, 0, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pp_make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);   // raw buffer, stride 0, 32-bit data format (gfx9 family)
+}
+}   // namespace
+
+// the bias is the accumulators' initial value (per tile: the column tile, and with it the bias slice, may change between tiles)
+template <int NF>
+__device__ __forceinline__ void pp_acc_init(const ConvArgs& a, f32x4 (&acc)[NF][4], int ncol0, int wn, int lg) {
+    constexpr int NV = 4 * NF, WAVE_N = NF * 16;
+    const int colw = ncol0 + wn * WAVE_N;
+    const int col = colw + lg * NV;
+    const bool to0 = colw < a.Cout0;
+    int bcol = col;
+    if ((to0 ? a.y0_mode : a.y1_mode) == MIS_OUT_SHUFFLE2) {     // bias per real output channel c = column % Cq
+        const int cq = (to0 ? a.Cout0 : a.Cout - a.Cout0) >> 2;
+        const int lcol = to0 ? col : col - a.Cout0;
+        bcol = (to0 ? 0 : a.Cout0) + (lcol - (lcol / cq) * cq);
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias != nullptr) b4 = *reinterpret_cast<const f32x4*>(a.bias + bcol + f * 4);
+#pragma unroll
+        for (int pf = 0; pf < 4; ++pf) acc[f][pf] = b4;
+    }
+}
+
+// ---- epilogue: lane (li, lg) holds, per pixel row pf of its wave, NV = 4*NF consecutive output channels of pixel (h0 + wm*4 + pf, w0 + li) ----
+template <int NF>
+__device__ __forceinline__ void pp_epilogue(const ConvArgs& a, f32x4 (&acc)[NF][4], int n, int h0, int w0, int ncol0, int wm, int wn, int li, int lg) {
+    using T = __bf16;
+    constexpr int NV = 4 * NF, WAVE_N = NF * 16, EPC = 8;
+    const int colw = ncol0 + wn * WAVE_N;          // wave-uniform first column
+    const int col = colw + lg * NV;                // this lane's first column
+    const bool to0 = colw < a.Cout0;
+    T* ybase = reinterpret_cast<T*>(to0 ? a.y0 : a.y1);
+    const int yld = to0 ? a.y0_ld : a.y1_ld;
+    const int ymode = to0 ? a.y0_mode : a.y1_mode;
+    const int cview = to0 ? a.Cout0 : a.Cout - a.Cout0;
+    const int lcol = to0 ? col : col - a.Cout0;
+    int ab = 0, cq = 0;
+    if (ymode == MIS_OUT_SHUFFLE2) {
+        cq = cview >> 2;
+        ab = lcol / cq;
+    }
+#pragma unroll
+    for (int pf = 0; pf < 4; ++pf) {
+        const int y = h0 + wm * 4 + pf, x = w0 + li;
+        float o[NV];
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                o[f * 4 + q] = acc[f][pf][q];
+            }
+        if (y < a.H && x < a.W) {
+            if (a.relu) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) o[i] = fmaxf(o[i], 0.f);
+            }
+            const size_t pix = ((size_t)n * a.H + y) * a.W + x;
+            if (a.mask != nullptr) {
+                const T* mp = reinterpret_cast<const T*>(a.mask) + pix * a.mask_ld + col;
+#pragma unroll
+                for (int i = 0; i < NV; i += EPC) {
+                    float mf[EPC];
+                    unpack_chunk<T>(*reinterpret_cast<const u32x4*>(mp + i), mf);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) o[i + e] = (mf[e] > 0.f) ? o[i + e] : 0.f;
+                }
+            }
+            T* dst;
+            if (ymode == MIS_OUT_PLAIN) {
+                dst = ybase + pix * yld + lcol;
+            } else if (ymode == MIS_OUT_SHUFFLE2) {
+                const int oy = 2 * y + (ab >> 1), ox = 2 * x + (ab & 1);
+                const size_t opix = ((size_t)n * (2 * a.H) + oy) * (size_t)(2 * a.W) + ox;
+                dst = ybase + opix * yld + (lcol - ab * cq);
+            } else {   // MIS_OUT_UNSHUFFLE2
+                const int oh = a.H >> 1, ow = a.W >> 1;
+                const size_t opix = ((size_t)n * oh + (y >> 1)) * ow + (x >> 1);
+                dst = ybase + opix * yld + ((y & 1) * 2 + (x & 1)) * cview + lcol;
+            }
+#pragma unroll
+            for (int i = 0; i < NV; i += EPC) *reinterpret_cast<u32x4*>(dst + i) = pack_chunk<T>(o + i);
+        }
+    }
+}
+
+// NF = 16-channel fragments per wave along the output channels: 8 -> 256-column blocks (wave tile 64 px x 128 ch, one segment = one 32-channel
+// k-group), 4 -> 128-column blocks (wave tile 64 px x 64 ch, one segment = a whole 64-channel tap).  32 MFMAs per segment either way.
+template <int NF>
+__global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
+    using T = __bf16;
+    constexpr int PF = 4, WAVE_N = NF * 16, BN = 2 * WAVE_N, NV = 4 * NF;
+    constexpr int WTILE = BN * 128;                  // bytes of one tap's weight tile (BN rows x 64 channels)
+    constexpr int SEGK = (NF == 8) ? 1 : 2;          // 32-channel k-groups per segment
+    constexpr int SPS = 2 / SEGK;                    // segments per step (step = one tap of one 64-channel chunk)
+    constexpr int WPW = 4;                           // weight DMA instructions per issuing wave and step
+    constexpr int NWI = (BN / 8) / WPW;              // issuing waves: 8 (NF = 8) or 4 (NF = 4: group 0 only)
+    static_assert(NWI == 8 || NWI == 4, "");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const hbase = smem;                        // 2 x PP_HBUF
+    char* const wbase = smem + 2 * PP_HBUF;          // 2 x WTILE
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, grp = wave >> 2;
+    const int li = lane & 15, lg = lane >> 4;
+    const bool w_issuer = wave < NWI;
+
+    const int total_tiles = a.nSp * a.nCt;
+    const int tstride = (int)gridDim.x;
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    if (tile >= total_tiles) return;                 // block-uniform (the launcher never over-sizes the grid)
+    const int nchunks = a.Cin >> 6;
+    const int tpi = a.tilesH * a.tilesW;
+    // cout-tile major, spatial minor: concurrently running blocks share the weight tile in L2, neighbours share halo rows
+    auto decode = [&](int t, int& tn, int& th0, int& tw0, int& tcol) {
+        const int ct = t / a.nSp;
+        const int sp = t - ct * a.nSp;
+        tn = sp / tpi;
+        const int r = sp - tn * tpi;
+        const int th = r / a.tilesW;
+        th0 = th * PP_TH;
+        tw0 = (r - th * a.tilesW) * PP_TW;
+        tcol = ct * BN;
+    };
+
+    // ---- per-lane fragment offsets (the 16-byte chunk position is XORed with (row & 7) for weights, (halo column & 7) for pixels) ----
+    // k-group 1 (channels 32..63) sits at chunk positions 4..7: chunk bit 2 is untouched by the XOR's low... it is XORed too, so the second k-group's
+    // offset is the first one's with byte-offset bit 6 flipped - one v_xor per use instead of a second set of live registers
+    int a_off0, b_off0[3];
+    a_off0 = (wn * WAVE_N + li) * 128 + ((lg ^ (li & 7)) << 4);
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int px = li + kw;
+        b_off0[kw] = (wm * 4 * PP_HW + px) * 128 + ((lg ^ (px & 7)) << 4);
+    }
+    // ---- per-lane DMA source offsets.  An instruction fills 1 KiB of LDS linearly (lane l -> 16-byte slot 64*q + l): which (row, chunk) must land
+    //      in a slot follows from inverting the read-side swizzle and, for weights, the row permutation that gives a lane NV consecutive channels.
+    //      Weight instruction q = q0 + k (q0 = 4 * issuer index) covers LDS rows 8q .. 8q+7: its source row is that of k = 0 plus a lane-independent
+    //      (2*(k&1)*NV + 4*(k>>1)) rows, which goes into the scalar part of the offset ----
+    int w_goff0;
+    {
+        const int q = (wave & (NWI - 1)) * WPW;
+        const int slot = q * 64 + lane;
+        const int lrow = slot >> 3, pos = slot & 7;
+        const int dc16 = pos ^ (lrow & 7);
+        const int dwv = lrow / WAVE_N, j = lrow % WAVE_N;
+        const int drow = dwv * WAVE_N + ((j & 15) >> 2) * NV + (j >> 4) * 4 + (j & 3);
+        w_goff0 = (drow * a.Cin + dc16 * 8) * 2;          // bytes from the first weight of (tap, column tile, K chunk)
+    }
+    const __amdgpu_buffer_rsrc_t rx = pp_make_rsrc(a.x0.p, (unsigned)((((long long)a.N * a.H * a.W - 1) * a.x0.ld + a.Cin) * 2));
+    const __amdgpu_buffer_rsrc_t rw = pp_make_rsrc(a.w, (unsigned)((long long)9 * a.Cout * a.Cin * 2));
+
+    // one halo DMA of this wave: instruction id = j*8 + wave of the chunk image (n, h0, w0, channels c0..c0+63) into `dst`; false if id is past the image
+    auto issue_halo = [&](auto jc, int n, int h0, int w0, int c0, char* dst) -> bool {
+        constexpr int j = decltype(jc)::value;
+        const int id = j * 8 + wave;
+        if (id >= PP_HINSTR) return false;            // wave-uniform
+        // byte offset of halo pixel (0, 0) = image pixel (h0 - 1, w0 - 1): negative for tiles on the top / left border (only valid items add to it)
+        int toff = (int)(((((long long)n * a.H + (h0 - 1)) * a.W + (w0 - 1)) * (long long)a.x0.ld + c0) * 2);
+        asm volatile("" : "+s"(toff));                // opaque: keeps hipcc from pre-computing (and spilling) the offsets of a whole chunk's steps
+        // lane -> 16-byte slot of the image -> (halo pixel, channel chunk): the chunk position in LDS is XORed with (halo column & 7)
+        int item = id * 64 + lane;
+        asm volatile("" : "+v"(item));                // recomputed at every issue (a dozen VALU ops) instead of living in registers across the tile loop
+        const int p = item >> 3, pos = item & 7;
+        const int py = p / PP_HW, px = p - py * PP_HW;
+        const int rel = ((py * a.W + px) * a.x0.ld + ((pos ^ (px & 7)) << 3)) * 2;
+        const bool ok = item < PP_HITEMS && (unsigned)(h0 - 1 + py) < (unsigned)a.H && (unsigned)(w0 - 1 + px) < (unsigned)a.W;
+        pp_dma16(rx, ok ? toff + rel : PP_OOB, dst + id * 1024);
+        return true;
+    };
+    auto issue_weights = [&](int tap, int col, int c0, char* dst) {
+        int soff = (int)((((long long)tap * a.Cout + col) * a.Cin + c0) * 2);
+        asm volatile("" : "+s"(soff));
+        const int q0 = (wave & (NWI - 1)) * WPW;
+#pragma unroll
+        for (int k = 0; k < WPW; ++k) pp_dma16(rw, (soff + (2 * (k & 1) * NV + 4 * (k >> 1)) * a.Cin * 2) + w_goff0, dst + (q0 + k) * 1024);
+    };
+
+    int n, h0, w0, ncol0;
+    decode(tile, n, h0, w0, ncol0);
+    f32x4 acc[NF][PF];
+    pp_acc_init<NF>(a, acc, ncol0, wn, lg);
+    // ---- prologue: first weight tile and first halo chunk ----
+    if (w_issuer) issue_weights(0, ncol0, 0, wbase);
+    pp_static_for<6>([&](auto jc) { (void)issue_halo(jc, n, h0, w0, 0, hbase); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int wsel = 0, hsel = 0;
+    if (grp == 1) __builtin_amdgcn_s_barrier();       // the stagger: group 1 runs one slot behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll 1
+    for (; tile < total_tiles; tile += tstride) {
+        const bool has_next = tile + tstride < total_tiles;
+        int nn = n, nh0 = h0, nw0 = w0, ncolN = ncol0;
+        if (has_next) decode(tile + tstride, nn, nh0, nw0, ncolN);
+#pragma unroll 1
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int c0 = chunk << 6;
+            const bool last_chunk = chunk + 1 == nchunks;
+            // what the halo prefetch of this chunk's steps fetches: the next chunk of this tile, else chunk 0 of the next tile, else nothing
+            const bool hnext = !last_chunk || has_next;
+            const int hn = last_chunk ? nn : n, hh0 = last_chunk ? nh0 : h0, hw0 = last_chunk ? nw0 : w0, hc0 = last_chunk ? 0 : c0 + 64;
+            const char* hb = hbase + hsel * PP_HBUF;
+            char* hbn = hbase + (hsel ^ 1) * PP_HBUF;
+            pp_static_for<9>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int kh = t / 3, kw = t % 3;
+                const char* wb = wbase + wsel * WTILE;
+                char* wbn = wbase + (wsel ^ 1) * WTILE;
+                // the step after this one: next tap; after the last tap the next chunk's (or the next tile's) first tap
+                const bool wnext = (t < 8) || hnext;
+                const int wtap = (t < 8) ? t + 1 : 0;
+                const int wcol = (t < 8 || !last_chunk) ? ncol0 : ncolN;
+                const int wc0 = (t < 8) ? c0 : hc0;
+                bool hi = false;
+                pp_static_for<SPS>([&](auto sc) {
+                    constexpr int sg = decltype(sc)::value;
+                    // ================= R segment =================
+                    if constexpr (sg == 0) {
+                        if (w_issuer && wnext) issue_weights(wtap, wcol, wc0, wbn);
+                    }
+                    if constexpr (sg == SPS - 1 && t < 6) {
+                        if (hnext) hi = issue_halo(std::integral_constant<int, t>{}, hn, hh0, hw0, hc0, hbn);
+                    }
+                    u32x4 A[SEGK][NF], B[SEGK][PF];
+#pragma unroll
+                    for (int s = 0; s < SEGK; ++s) {
+                        const int kg = sg * SEGK + s;
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) A[s][f] = lds_read_b128(wb, (a_off0 ^ (kg << 6)) + f * 2048);
+#pragma unroll
+                        for (int pf = 0; pf < PF; ++pf) B[s][pf] = lds_read_b128(hb, (b_off0[kw] ^ (kg << 6)) + (pf + kh) * PP_ROWB);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragments in registers; also: this wave's reads of both buffers are over
+                    if constexpr (sg == SPS - 1) {
+                        if (grp == 1) {                                      // group 1's last slot of the step
+                            if (hi) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ================= M segment =================
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int s = 0; s < SEGK; ++s)
+#pragma unroll
+                        for (int f = 0; f < NF; ++f)
+#pragma unroll
+                            for (int pf = 0; pf < PF; ++pf) mma_b128<T>(acc[f][pf], A[s][f], B[s][pf]);
+                    __builtin_amdgcn_s_setprio(0);
+                    if constexpr (sg == SPS - 1) {
+                        if (grp == 0) {                                      // group 0's last slot of the step
+                            if (hi) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                wsel ^= 1;
+            });
+            hsel ^= 1;
+        }
+        // this wave's tile is complete: store it and re-arm the accumulators.  In program order this sits at the head of the wave's next R slot, i.e. it runs
+        // under the partner group's MFMAs (group 1 is still in its last M slot of the tile when group 0 gets here, and vice versa one slot later).
+        pp_epilogue<NF>(a, acc, n, h0, w0, ncol0, wm, wn, li, lg);
+        n = nn; h0 = nh0; w0 = nw0; ncol0 = ncolN;
+        if (has_next) pp_acc_init<NF>(a, acc, ncol0, wn, lg);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's last barrier
+}
+
+// ---------------------------------------------------------------------------------------------------------
+bool conv_pp_eligible(const MisConvDesc* d) {
+    if (d->dtype != MIS_BF16 || d->is3d || d->ksize != 3) return false;
+    if (d->x1 != nullptr || d->in_scale != nullptr) return false;
+    if (d->x0_H != d->H || d->x0_W != d->W || d->D != 1) return false;
+    if (d->Cin % 64 != 0 || d->Cout % 128 != 0) return false;
+    if (d->Cout0 % 128 != 0) return false;             // a wave's 64 / 128 columns go to ONE destination
+    if (d->Cout % 256 == 0 && d->Cout0 % 128 != 0) return false;
+    // 32-bit buffer offsets: the input view and the packed weights must each span less than 2 GiB (0x80000000 is the out-of-range marker)
+    if ((((long long)d->N * d->H * d->W - 1) * d->x0_ld + d->Cin) * 2 >= (1ll << 31)) return false;
+    if ((long long)9 * d->Cout * d->Cin * 2 >= (1ll << 31)) return false;
+    return true;
+}
+
+template <int NF> static int pp_launch(const MisConvDesc* d, hipStream_t stream) {
+    constexpr int BN = 2 * NF * 16;
+    ConvArgs a;
+    a.N = d->N; a.D = 1; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cin0 = d->Cin; a.Cout0 = d->Cout0;
+    a.x0 = SrcView{d->x0, d->x0_ld, 1, d->x0_H, d->x0_W};
+    a.x1 = SrcView{nullptr, 0, 0, 0, 0};
+    a.in_scale = nullptr; a.in_shift = nullptr;
+    a.w = d->w; a.bias = d->bias; a.relu = d->relu; a.mask = d->mask; a.mask_ld = d->mask_ld;
+    a.y0 = d->y0; a.y0_ld = d->y0_ld; a.y0_mode = d->y0_mode;
+    a.y1 = d->y1; a.y1_ld = d->y1_ld; a.y1_mode = d->y1_mode;
+    a.tilesD = 1;
+    a.tilesH = (d->H + PP_TH - 1) / PP_TH;
+    a.tilesW = (d->W + PP_TW - 1) / PP_TW;
+    const long long nsp = (long long)d->N * a.tilesH * a.tilesW;
+    a.nCt = d->Cout / BN;
+    MIS_REQUIRE(nsp * a.nCt < (1ll << 31), MIS_EUNSUPPORTED, "conv_igemm(pp): grid too large");
+    a.nSp = (int)nsp;
+    const size_t lds = 2 * (size_t)PP_HBUF + 2 * (size_t)BN * 128;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv_pp_kernel<NF>), lds, "conv_igemm(pp)")) return rc;
+    const long long total = nsp * a.nCt;
+    hipLaunchKernelGGL((conv_pp_kernel<NF>), dim3((unsigned)(total > 256 ? 256 : total)), dim3(512), lds, stream, a);
+    MIS_LAUNCH_CHECK("conv_igemm(pp)");
+    return MIS_OK;
+}
+
+int launch_conv_pp(const MisConvDesc* d, hipStream_t stream, const char** tag) {
+    if (d->Cout % 256 == 0 && (d->Cout0 % 256 == 0 || d->Cout0 % 128 == 0)) {
+        static const int no256 = getenv("MIS_CONV_PP_NO256") != nullptr;
+        if (!no256) {
+            *tag = "k3.2d.pp256";
+            return pp_launch<8>(d, stream);
+        }
+    }
+    *tag = "k3.2d.pp128";
+    return pp_launch<4>(d, stream);
+}

@@ -17,18 +17,29 @@ BF, F32 = torch.bfloat16, torch.float32
 
 # (dtype, N, H, W, Cin, Cout, expected configuration)
 K3_CASES = [
-    (BF, 2, 20, 36, 256, 256, "k3.2d.bn256"),        # deep layers: 256-column blocks
-    (BF, 1, 9, 17, 512, 256, "k3.2d.bn256"),
-    (BF, 1, 9, 17, 1024, 1024, "k3.2d.bn256"),       # middle_conv.second: 16 K chunks x 4 column tiles
-    (BF, 2, 100, 150, 128, 256, "k3.2d.bn128.persist"),   # shallow Cin: persistent tiles, 280 tiles > 256 blocks (tile loop taken)
-    (BF, 1, 20, 36, 64, 128, "k3.2d.bn128.persist"),
-    (BF, 2, 20, 36, 256, 128, "k3.2d.bn128.dma"),        # deep Cin, 128 columns: one tile per block
-    (BF, 1, 70, 90, 128, 64, "k3.2d.bn64.persist"),  # 64 columns, 32x16-pixel persistent tiles
-    (BF, 2, 20, 36, 128, 64, "k3.2d.bn64.v1"),          # small grid: 64-column 4-wave config
-    (F32, 2, 20, 36, 64, 128, "k3.2d.bn128.persist"),
-    (F32, 1, 9, 17, 128, 256, "k3.2d.bn128.dma"),
-    (F32, 1, 70, 90, 64, 64, "k3.2d.bn64.persist"),
-    (F32, 2, 9, 17, 32, 64, "k3.2d.bn64.v1"),
+    # ping-pong kernel (conv_pp.hip): bf16, Cout % 128 == 0
+    (BF, 2, 20, 36, 256, 256, "k3.2d.pp256", ""),        # ragged tiles, 4 K chunks
+    (BF, 1, 9, 17, 512, 256, "k3.2d.pp256", ""),
+    (BF, 1, 9, 17, 1024, 1024, "k3.2d.pp256", ""),       # middle_conv.second: 16 K chunks x 4 column tiles
+    (BF, 2, 100, 150, 128, 256, "k3.2d.pp256", ""),      # 140 spatial tiles
+    (BF, 3, 150, 170, 64, 256, "k3.2d.pp256", ""),       # 330 tiles > 256 persistent blocks: several tiles per block, one K chunk per tile
+    (BF, 1, 20, 36, 64, 128, "k3.2d.pp128", ""),
+    (BF, 2, 20, 36, 256, 128, "k3.2d.pp128", ""),
+    (BF, 3, 150, 170, 128, 128, "k3.2d.pp128", ""),      # 330 tiles > 256 blocks, 2 K chunks
+    (BF, 1, 16, 16, 64, 128, "k3.2d.pp128", ""),         # a single tile
+    # the configurations behind it (MIS_CONV_NOPP=1): still reachable, still tested
+    (BF, 2, 20, 36, 256, 256, "k3.2d.bn256", "MIS_CONV_NOPP"),
+    (BF, 1, 9, 17, 1024, 1024, "k3.2d.bn256", "MIS_CONV_NOPP"),
+    (BF, 2, 100, 150, 128, 256, "k3.2d.bn128.persist", "MIS_CONV_NOPP"),   # persistent tiles, 280 tiles > 256 blocks
+    (BF, 1, 20, 36, 64, 128, "k3.2d.bn128.persist", "MIS_CONV_NOPP"),
+    (BF, 2, 20, 36, 256, 128, "k3.2d.bn128.dma", "MIS_CONV_NOPP"),
+    # 64-column layers (no ping-pong variant)
+    (BF, 1, 70, 90, 128, 64, "k3.2d.bn64.persist", ""),  # 32x16-pixel persistent tiles
+    (BF, 2, 20, 36, 128, 64, "k3.2d.bn64.v1", ""),       # small grid: 64-column 4-wave config
+    (F32, 2, 20, 36, 64, 128, "k3.2d.bn128.persist", ""),
+    (F32, 1, 9, 17, 128, 256, "k3.2d.bn128.dma", ""),
+    (F32, 1, 70, 90, 64, 64, "k3.2d.bn64.persist", ""),
+    (F32, 2, 9, 17, 32, 64, "k3.2d.bn64.v1", ""),
 ]
 
 
@@ -36,10 +47,12 @@ def _conv_ref(x, w, b, dtype):
     return F.conv2d(q(x, dtype), q(w, dtype), b, padding=w.shape[-1] // 2)
 
 
-@pytest.mark.parametrize("case", K3_CASES, ids=lambda c: f"{'bf16' if c[0] == BF else 'f32'}-{c[1]}x{c[2]}x{c[3]}-{c[4]}to{c[5]}")
-def test_conv3x3_every_branch(case):
+@pytest.mark.parametrize("case", K3_CASES, ids=lambda c: f"{'bf16' if c[0] == BF else 'f32'}-{c[1]}x{c[2]}x{c[3]}-{c[4]}to{c[5]}-{c[6]}")
+def test_conv3x3_every_branch(case, monkeypatch):
     ops = _ops()
-    dtype, N, H, W, Cin, Cout, want_cfg = case
+    dtype, N, H, W, Cin, Cout, want_cfg, env = case
+    if env:
+        monkeypatch.setenv(env, "1")
     x = rnd(N, Cin, H, W, seed=110)
     w = rnd(Cout, Cin, 3, 3, seed=111, scale=(9 * Cin) ** -0.5)
     b = rnd(Cout, seed=112)
@@ -62,7 +75,7 @@ def test_conv3x3_every_branch(case):
     assert ops.conv_last_dispatch() == cfg
     assert_close(from_nhwc(y2), ref * (q(m, dtype) > 0), f"mask {cfg}", **t)
     # (c) two destinations (dgrad of up_conv.*.first): first half pixel-unshuffled, second half plain
-    if Cout % 128 == 0 and (Cout // 2) % (128 if "bn256" in cfg else 64) == 0 and H % 2 == 0 and W % 2 == 0:
+    if Cout % 128 == 0 and (Cout // 2) % (128 if ("bn256" in cfg or ".pp" in cfg) else 64) == 0 and H % 2 == 0 and W % 2 == 0:
         h = Cout // 2
         d0 = torch.full((N, H // 2, W // 2, 4 * h), float("nan"), dtype=dtype, device=DEV)
         d1 = torch.full((N, H, W, h), float("nan"), dtype=dtype, device=DEV)
