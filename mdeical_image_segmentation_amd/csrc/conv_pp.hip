@@ -48,8 +48,8 @@ template <int N, typename F> __device__ __forceinline__ void pp_static_for(F&& f
 
 // One LDS-DMA instruction: 64 lanes x 16 bytes from buffer `r` at per-lane byte offset `voff` to LDS [dst, dst + 1 KiB) (dst wave-uniform).
 // buffer_load ... lds: 32-bit offsets (no 64-bit address registers), and an offset at or past num_records reads as ZERO - that is the conv's zero
-// padding and the tail of the last halo instruction (PP_OOB is past every buffer this kernel accepts).
-constexpr int PP_OOB = (int)0x80000000u;
+// padding and the tail of the last halo instruction (PP_OOB is past every buffer this kernel accepts: one image of the input, < 4 GiB - 64 KiB, or the packed weights).
+constexpr int PP_OOB = (int)0xFFFFFF00u;
 __device__ __forceinline__ void pp_dma16(__amdgpu_buffer_rsrc_t r, int voff, char* lds_dst_wave_uniform) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (pp_lds_void_t*)lds_dst_wave_uniform, 16, voff, 0, 0, 0);
 }
@@ -208,7 +208,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
         const int drow = dwv * WAVE_N + ((j & 15) >> 2) * NV + (j >> 4) * 4 + (j & 3);
         w_goff0 = (drow * a.Cin + dc16 * 8) * 2;          // bytes from the first weight of (tap, column tile, K chunk)
     }
-    const __amdgpu_buffer_rsrc_t rx = pp_make_rsrc(a.x0.p, (unsigned)((((long long)a.N * a.H * a.W - 1) * a.x0.ld + a.Cin) * 2));
+    // the input's buffer resource is rebuilt PER IMAGE (scalar ops only): 32-bit offsets then only have to span one image, whatever the batch size
+    const unsigned img_x = (unsigned)(((long long)a.H * a.W - 1) * a.x0.ld + a.Cin) * 2u;
+    const char* const xb = reinterpret_cast<const char*>(a.x0.p);
     const __amdgpu_buffer_rsrc_t rw = pp_make_rsrc(a.w, (unsigned)((long long)9 * a.Cout * a.Cin * 2));
 
     // one halo DMA of this wave: instruction id = j*8 + wave of the chunk image (n, h0, w0, channels c0..c0+63) into `dst`; false if id is past the image
@@ -216,17 +218,18 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
         constexpr int j = decltype(jc)::value;
         const int id = j * 8 + wave;
         if (id >= PP_HINSTR) return false;            // wave-uniform
-        // byte offset of halo pixel (0, 0) = image pixel (h0 - 1, w0 - 1): negative for tiles on the top / left border (only valid items add to it)
-        int toff = (int)(((((long long)n * a.H + (h0 - 1)) * a.W + (w0 - 1)) * (long long)a.x0.ld + c0) * 2);
+        const __amdgpu_buffer_rsrc_t rx = pp_make_rsrc(xb + (size_t)n * a.H * a.W * a.x0.ld * 2, img_x);
+        // byte offset of halo pixel (0, 0) = image pixel (h0 - 1, w0 - 1) within the image: "negative" (wraps) for tiles on the top / left border, where only valid items add to it
+        unsigned toff = (unsigned)((((h0 - 1) * a.W + (w0 - 1)) * a.x0.ld + c0) * 2);
         asm volatile("" : "+s"(toff));                // opaque: keeps hipcc from pre-computing (and spilling) the offsets of a whole chunk's steps
         // lane -> 16-byte slot of the image -> (halo pixel, channel chunk): the chunk position in LDS is XORed with (halo column & 7)
         int item = id * 64 + lane;
         asm volatile("" : "+v"(item));                // recomputed at every issue (a dozen VALU ops) instead of living in registers across the tile loop
         const int p = item >> 3, pos = item & 7;
         const int py = p / PP_HW, px = p - py * PP_HW;
-        const int rel = ((py * a.W + px) * a.x0.ld + ((pos ^ (px & 7)) << 3)) * 2;
+        const unsigned rel = (unsigned)(((py * a.W + px) * a.x0.ld + ((pos ^ (px & 7)) << 3)) * 2);
         const bool ok = item < PP_HITEMS && (unsigned)(h0 - 1 + py) < (unsigned)a.H && (unsigned)(w0 - 1 + px) < (unsigned)a.W;
-        pp_dma16(rx, ok ? toff + rel : PP_OOB, dst + id * 1024);
+        pp_dma16(rx, ok ? (int)(toff + rel) : PP_OOB, dst + id * 1024);
         return true;
     };
     auto issue_weights = [&](int tap, int col, int c0, char* dst) {
@@ -345,9 +348,9 @@ bool conv_pp_eligible(const MisConvDesc* d) {
     if (d->Cin % 64 != 0 || d->Cout % 128 != 0) return false;
     if (d->Cout0 % 128 != 0) return false;             // a wave's 64 / 128 columns go to ONE destination
     if (d->Cout % 256 == 0 && d->Cout0 % 128 != 0) return false;
-    // 32-bit buffer offsets: the input view and the packed weights must each span less than 2 GiB (0x80000000 is the out-of-range marker)
-    if ((((long long)d->N * d->H * d->W - 1) * d->x0_ld + d->Cin) * 2 >= (1ll << 31)) return false;
-    if ((long long)9 * d->Cout * d->Cin * 2 >= (1ll << 31)) return false;
+    // 32-bit buffer offsets: ONE image of the input view and the packed weights must each span less than 4 GiB - 64 KiB
+    if ((((long long)d->H * d->W - 1) * d->x0_ld + d->Cin) * 2 >= (1ll << 32) - 65536) return false;
+    if ((long long)9 * d->Cout * d->Cin * 2 >= (1ll << 32) - 65536) return false;
     return true;
 }
 

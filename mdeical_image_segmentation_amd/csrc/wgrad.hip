@@ -16,6 +16,7 @@
 #include <utility>
 
 #include "common.hpp"
+#include "wgrad_args.hpp"
 
 #ifndef MIS_WG_BF16_UNROLL
 #define MIS_WG_BF16_UNROLL 1
@@ -28,24 +29,6 @@ template <typename F, int... I> __device__ __forceinline__ void static_for_impl(
     (f(std::integral_constant<int, I>{}), ...);
 }
 template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-
-struct WSrc {
-    const void* p;
-    int ld, D, H, W;
-};
-
-struct WgArgs {
-    int N, D, H, W, Cin, Cout, Cin0;
-    WSrc x0, x1;
-    const float* in_scale;
-    const float* in_shift;
-    const void* dy;
-    int dy_ld;
-    float* partial;
-    float* bias_partial;   // [nsplit][Cout] column sums of dy (bias gradient), or nullptr
-    int tilesD, tilesH, tilesW, ntiles, nsplit, tps;
-    int nCi, nCo, KDn, TT;
-};
 
 template <int TD_, int TH_, int TW_, int KS_, bool IS3D_> struct WGeom {
     static constexpr int TD = TD_, TH = TH_, TW = TW_, KS = KS_;
@@ -469,7 +452,7 @@ __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __r
 // ---------------------------------------------------------------------------------------------------------
 struct WgPlan {
     int tilesD, tilesH, tilesW, ntiles, nsplit, tps, nCi, nCo, KDn, TT, CT;
-    bool is3d, wide;
+    bool is3d, wide, pp;
 };
 
 static int wg_plan(const MisWgradDesc* d, WgPlan* p) {
@@ -511,6 +494,10 @@ static int wg_plan(const MisWgradDesc* d, WgPlan* p) {
     while (want > 1 && want * slab > (256ll << 20)) --want;
     p->tps = (int)((nt + want - 1) / want);
     p->nsplit = (int)((nt + p->tps - 1) / p->tps);
+    // bf16 2-D 3x3 layers: the ping-pong kernel (wgrad_pp.hip) with its own split plan (2 slabs per persistent block); read per call so that the
+    // parity tests can reach both kernels in one process
+    p->pp = getenv("MIS_WGRAD_NOPP") == nullptr && wgrad_pp_eligible(d);
+    if (p->pp) p->nsplit = wgrad_pp_nsplit(d);
     return MIS_OK;
 }
 
@@ -520,24 +507,9 @@ extern "C" size_t mis_wgrad_workspace_bytes(const MisWgradDesc* d) {
     return ((size_t)p.nsplit * p.TT * d->Cin * d->Cout + (size_t)p.nsplit * d->Cout) * sizeof(float);
 }
 
-template <typename T, typename G, bool USE_TR, bool WIDE = false>
-static int wg_launch(const MisWgradDesc* d, const WgPlan& p, hipStream_t stream) {
-    WgArgs a;
-    a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cin0 = d->Cin0;
-    a.x0 = WSrc{d->x0, d->x0_ld, d->x0_D, d->x0_H, d->x0_W};
-    a.x1 = WSrc{d->x1, d->x1_ld, d->x1_D, d->x1_H, d->x1_W};
-    a.in_scale = d->in_scale; a.in_shift = d->in_shift;
-    a.dy = d->dy; a.dy_ld = d->dy_ld; a.partial = d->workspace;
-    a.bias_partial = d->dbias != nullptr ? d->workspace + (size_t)p.nsplit * p.TT * d->Cin * d->Cout : nullptr;
-    a.tilesD = p.tilesD; a.tilesH = p.tilesH; a.tilesW = p.tilesW; a.ntiles = p.ntiles; a.nsplit = p.nsplit; a.tps = p.tps;
-    a.nCi = p.nCi; a.nCo = p.nCo; a.KDn = p.KDn; a.TT = p.TT;
-    const size_t lds = WIDE ? (size_t)(G::PHP + G::M) * 288 : (size_t)G::PHP * PSTR + (size_t)G::M * (sizeof(T) == 2 ? PSTR : 288);
-    static std::atomic<unsigned long long> attr_done{0};
-    if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&wgrad_kernel<T, G, USE_TR, WIDE>), lds, "wgrad")) return rc;
-    const long long grid = (long long)p.nCi * p.nCo * p.KDn * p.nsplit;
-    MIS_REQUIRE(grid < (1ll << 31), MIS_EUNSUPPORTED, "wgrad: grid too large");
-    hipLaunchKernelGGL((wgrad_kernel<T, G, USE_TR, WIDE>), dim3((unsigned)grid), dim3(256), lds, stream, a);
-    MIS_LAUNCH_CHECK("wgrad");
+// Everything after the MFMA kernel: order the reduction stream behind it, sum the split-K slabs in a fixed order, convert to the reference layout,
+// reduce the bias column sums.  Shared by wgrad_kernel and wgrad_pp_kernel.
+static int wg_finish(const MisWgradDesc* d, const WgPlan& p, float* bias_partial, hipStream_t stream) {
     if (d->reduce_stream != nullptr && d->reduce_stream != (void*)stream) {   // reductions go to the side stream, after the MFMA kernel
         // Ordering side stream after the MFMA kernel.  Default: events from a small ring that lives as long as the process.  MIS_WGRAD_EVENT_PER_CALL=1
         // = create / record / wait / destroy per call (legal HIP; kept as an experiment switch: round 1 saw nondeterministic gradients with it, in the same
@@ -579,10 +551,31 @@ static int wg_launch(const MisWgradDesc* d, const WgPlan& p, hipStream_t stream)
     if (d->dbias != nullptr) {
         const int fold = d->dw_layout == 1 ? 4 : 1;
         hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((d->Cout / fold + 3) / 4), dim3(256), 0, stream,
-                           (const float*)a.bias_partial, p.nsplit, d->Cout, fold, d->alpha, d->dbias);
+                           (const float*)bias_partial, p.nsplit, d->Cout, fold, d->alpha, d->dbias);
         MIS_LAUNCH_CHECK("wgrad_bias_reduce");
     }
     return MIS_OK;
+}
+
+template <typename T, typename G, bool USE_TR, bool WIDE = false>
+static int wg_launch(const MisWgradDesc* d, const WgPlan& p, hipStream_t stream) {
+    WgArgs a;
+    a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cin0 = d->Cin0;
+    a.x0 = WSrc{d->x0, d->x0_ld, d->x0_D, d->x0_H, d->x0_W};
+    a.x1 = WSrc{d->x1, d->x1_ld, d->x1_D, d->x1_H, d->x1_W};
+    a.in_scale = d->in_scale; a.in_shift = d->in_shift;
+    a.dy = d->dy; a.dy_ld = d->dy_ld; a.partial = d->workspace;
+    a.bias_partial = d->dbias != nullptr ? d->workspace + (size_t)p.nsplit * p.TT * d->Cin * d->Cout : nullptr;
+    a.tilesD = p.tilesD; a.tilesH = p.tilesH; a.tilesW = p.tilesW; a.ntiles = p.ntiles; a.nsplit = p.nsplit; a.tps = p.tps;
+    a.nCi = p.nCi; a.nCo = p.nCo; a.KDn = p.KDn; a.TT = p.TT;
+    const size_t lds = WIDE ? (size_t)(G::PHP + G::M) * 288 : (size_t)G::PHP * PSTR + (size_t)G::M * (sizeof(T) == 2 ? PSTR : 288);
+    static std::atomic<unsigned long long> attr_done{0};
+    if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&wgrad_kernel<T, G, USE_TR, WIDE>), lds, "wgrad")) return rc;
+    const long long grid = (long long)p.nCi * p.nCo * p.KDn * p.nsplit;
+    MIS_REQUIRE(grid < (1ll << 31), MIS_EUNSUPPORTED, "wgrad: grid too large");
+    hipLaunchKernelGGL((wgrad_kernel<T, G, USE_TR, WIDE>), dim3((unsigned)grid), dim3(256), lds, stream, a);
+    MIS_LAUNCH_CHECK("wgrad");
+    return wg_finish(d, p, a.bias_partial, stream);
 }
 
 // kernel configuration / split count of this thread's last mis_wgrad call (tests assert that a parity case reaches the branch it is meant for)
@@ -635,6 +628,14 @@ extern "C" int mis_wgrad(const MisWgradDesc* d, void* stream) {
         MIS_REQUIRE(okD && okH && okW, MIS_EUNSUPPORTED, "wgrad: source grid must equal the pixel grid or be exactly half of it");
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (p.pp) {
+        g_wgrad_last = "k3.2d.pp";
+        g_wgrad_last_nsplit = p.nsplit;
+        float* bias_partial = d->dbias != nullptr ? d->workspace + (size_t)p.nsplit * p.TT * d->Cin * d->Cout : nullptr;
+        rc = launch_wgrad_pp(d, d->workspace, bias_partial, s);
+        if (rc != MIS_OK) return rc;
+        return wg_finish(d, p, bias_partial, s);
+    }
     const char* e = getenv("MIS_WGRAD_NO_TR");
     const bool use_tr = !(e != nullptr && e[0] == '1');
     if (d->dtype == MIS_BF16) return use_tr ? wg_dispatch<__bf16, true>(d, p, s) : wg_dispatch<__bf16, false>(d, p, s);

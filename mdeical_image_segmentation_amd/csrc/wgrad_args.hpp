@@ -1,0 +1,28 @@
+// Kernel-argument structs shared by the weight-gradient kernels (wgrad.hip, wgrad_pp.hip).
+#pragma once
+#include "common.hpp"
+
+struct WSrc {
+    const void* p;
+    int ld, D, H, W;
+};
+
+struct WgArgs {
+    int N, D, H, W, Cin, Cout, Cin0;
+    WSrc x0, x1;
+    const float* in_scale;
+    const float* in_shift;
+    const void* dy;
+    int dy_ld;
+    float* partial;
+    float* bias_partial;   // [nsplit][Cout] column sums of dy (bias gradient), or nullptr
+    int tilesD, tilesH, tilesW, ntiles, nsplit, tps;
+    int nCi, nCo, KDn, TT;
+};
+
+// wgrad_pp.hip: ping-pong weight-gradient kernel for the bf16 2-D 3x3 layers.  `wgrad_pp_eligible` = the descriptor can take that path;
+// `wgrad_pp_nsplit` = number of fp32 partial slabs it writes (one per persistent block); the launch fills a.partial / a.bias_partial
+// exactly like wgrad_kernel (slab [split][tap][ci][co], bias [split][co]) so the same reduction kernels finish the job.
+bool wgrad_pp_eligible(const MisWgradDesc* d);
+int wgrad_pp_nsplit(const MisWgradDesc* d);
+int launch_wgrad_pp(const MisWgradDesc* d, float* partial, float* bias_partial, hipStream_t stream);

@@ -1,0 +1,356 @@
+// Ping-pong weight-gradient kernel for the bf16 2-D 3x3 layers (gfx950):  dW[tap][ci][co] = sum_pixels X[pixel + tap][ci] * dY[pixel][co]
+// (the weight part of aten::convolution_backward for nn.Conv2d(k3, p1), reference model/unet2d/layers.py:122,125).
+//
+// Same arithmetic, fragment mapping and slab format as wgrad_kernel (wgrad.hip): a block owns one (64 ci x 64 co) tile for all 9 taps, the MFMA K
+// dimension is the pixel axis, both operands are read from [pixel][channel] LDS images with the transposing ds_read_b64_tr_b16, fp32 partial slabs
+// are reduced in fixed order by the kernels of wgrad.hip.  What changes is the schedule (the conv_pp.hip structure):
+//   * 8 waves per block; a step stages one 16 x 16-pixel tile: the input halo (18 x 18 px x 64 ci) and the dY tile (256 px x 64 co), both by
+//     buffer_load ... lds (no register staging; zero padding / ragged edges = out-of-range buffer offsets, which read as zero), double-buffered,
+//     the next tile's 73 DMA instructions spread over the current tile's R segments and retired by one vmcnt(0) in the last slot of the step;
+//   * every wave accumulates 16 ci x 32 co x 9 taps (72 accumulator registers, which leaves room for 36-MFMA segments); wave group 0 (waves 0-3) owns
+//     input channels 0-31 of the tile, group 1 (waves 4-7) channels 32-63, both walk all 256 pixels - the groups are staggered by one barrier so
+//     that one wave per SIMD is always inside an MFMA cluster while its partner reads fragments and issues DMAs;
+//   * blocks are persistent over a contiguous range of pixel tiles (split-K): <= 256 blocks, one slab per block.
+// LDS images: 128-byte pixel rows, the 16-byte chunk position XORed with (column & 7) (halo column for X, tile column for dY) - 8 consecutive pixels
+// of a row then cover all 64 banks once for the transposing reads, a filter-row shift stays an immediate offset and the DMA fill stays lane-linear
+// (the XOR goes into the per-lane SOURCE offset).
+#include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "wgrad_args.hpp"
+
+typedef __attribute__((address_space(3))) void wp_lds_void_t;
+typedef __attribute__((address_space(3))) s16x4 wp_lds_s16x4;
+typedef __attribute__((address_space(3))) char wp_lds_char_t;
+
+namespace {
+constexpr int WP_TH = 16, WP_TW = 16, WP_HW = 18, WP_HP = 18 * 18;
+constexpr int WP_PITEMS = WP_HP * 8;                  // 16-byte items of the halo image
+constexpr int WP_PINSTR = (WP_PITEMS + 63) / 64;      // 41 wave-instructions (the image is padded to 41 KiB)
+constexpr int WP_PBUF = WP_PINSTR * 1024;
+constexpr int WP_QINSTR = 32;                         // 256 px x 8 items / 64
+constexpr int WP_QBUF = WP_QINSTR * 1024;
+constexpr int WP_STAGE = WP_PBUF + WP_QBUF;
+constexpr int WP_NINSTR = WP_PINSTR + WP_QINSTR;      // 73 per tile
+constexpr int WP_PER_WAVE = (WP_NINSTR + 7) / 8;      // 10 (the last round only reaches wave 0)
+constexpr int WP_ROWB = WP_HW * 128;
+constexpr int WP_OOB = (int)0xFFFFFF00u;             // past every per-image buffer this kernel accepts (< 4 GiB - 256)
+
+template <typename F, int... I> __device__ __forceinline__ void wp_static_for_impl(F& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void wp_static_for(F&& f) { wp_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+__device__ __forceinline__ void wp_dma16(__amdgpu_buffer_rsrc_t r, int voff, char* lds_dst_wave_uniform) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (wp_lds_void_t*)lds_dst_wave_uniform, 16, voff, 0, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wp_make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+// Transposing LDS read as INLINE ASM: through the builtin, hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) in front of every such read while an LDS-DMA is in flight
+// (it cannot tell the read from the DMA's destination), which serialises the whole prefetch pipeline (measured: 350 instead of 800+ TFLOP/s).  The asm form is
+// invisible to that analysis; in exchange NOTHING waits for the result automatically: every use sits behind the explicit lgkmcnt(0) + sched_barrier of its R segment
+// (cdna_hip_programming.md §5.4 rule 18, §5.7).
+template <int OFF> __device__ __forceinline__ s16x4 wp_tr_read(uint32_t lds_addr) {
+    s16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF));
+    return r;
+}
+// fragment for lane (i = lane & 15, g = lane >> 4): 8 pixels (k = 8g + 4s + e) of channel i of a 16-channel block: two transposing reads (pixel quads s = 0, 1)
+template <int OFF> __device__ __forceinline__ bf16x8_t wp_frag(uint32_t addr_s0, uint32_t addr_s1) {
+    const s16x4 lo = wp_tr_read<OFF>(addr_s0);
+    const s16x4 hi = wp_tr_read<OFF>(addr_s1);
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, r);
+}
+__device__ __forceinline__ float wp_sum8(const bf16x8_t& v) {     // fixed-order sum of the 8 bf16 values
+    const u32x4 w = __builtin_bit_cast(u32x4, v);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t u = w[i];
+        s += __uint_as_float(u << 16);
+        s += __uint_as_float(u & 0xffff0000u);
+    }
+    return s;
+}
+}   // namespace
+
+// KSS = 32-pixel k-steps per segment: a segment = KSS k-steps x all 9 taps = 18 * KSS MFMAs per wave.
+// Wave w: input channels 16*(w>>1) .. +15 (one A fragment per tap), output channels 32*(w&1) .. +31 (two B fragments): 9 x 1 x 2 accumulator tiles = 72
+// registers.  Both wave groups (w < 4 / w >= 4) walk ALL 256 pixels of the staged tile (8 k-steps) for their half of the input channels, so a block
+// writes ONE slab.  Per segment a wave reads 18 * KSS A fragments and 2 * KSS B fragments (two transposing reads each).
+template <int KSS>
+__global__ __launch_bounds__(512, 2) void wgrad_pp_kernel(const WgArgs a) {
+    constexpr int NS = 8 / KSS;                   // segments per step (step = one 16 x 16 pixel tile = 8 k-steps)
+    constexpr int DPS = (WP_PER_WAVE + NS - 2) / (NS - 1);   // DMA instructions per wave and R segment (none in the last segment of a step)
+    static_assert(DPS * (NS - 1) >= WP_PER_WAVE, "");
+    constexpr int NPJ = (WP_PINSTR + 7) / 8;      // halo-image DMA instructions per wave (6; ids wave + 8j)
+    constexpr int NQJ = WP_QINSTR / 8;            // dY-tile DMA instructions per wave (4; tile rows 2*(wave + 8j)/2 ...)
+    static_assert(NPJ + NQJ == WP_PER_WAVE, "");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wi = wave >> 1, wj = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const int q = li >> 2, pp = li & 3;
+
+    const int npairs = a.nCi * a.nCo;
+    int v = xcd_remap(blockIdx.x, gridDim.x);
+    const int pair = v % npairs;
+    const int split = v / npairs;
+    const int ci_t = pair / a.nCo, co_t = pair - ci_t * a.nCo;
+    const int ci0 = ci_t * 64, co0 = co_t * 64;
+    const int t_begin = split * a.tps;
+    int t_end = t_begin + a.tps;
+    if (t_end > a.ntiles) t_end = a.ntiles;
+    const int tpi = a.tilesH * a.tilesW;
+    auto tile_coords = [&](int t, int& n, int& h0, int& w0) {
+        n = t / tpi;
+        const int r = t - n * tpi;
+        const int th = r / a.tilesW;
+        h0 = th * WP_TH;
+        w0 = (r - th * a.tilesW) * WP_TW;
+    };
+
+    // ---- per-lane fragment offsets: pixel quad s of lane group lg is quad u = (lg&1) + 2s + 4(lg>>1) of the k-step's 2 x 16 pixels ----
+    int qoff[2], poff[2][3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int u = (lg & 1) + 2 * s + 4 * (lg >> 1);
+        const int hy = u >> 2, wx = (u & 3) * 4 + q;      // this lane's pixel (row within the k-step, column) of the quad
+        qoff[s] = (hy * 16 + wx) * 128 + (((wj * 4 + (pp >> 1)) ^ (wx & 7)) << 4) + (pp & 1) * 8;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int px = wx + kw;
+            poff[s][kw] = (hy * WP_HW + px) * 128 + (((wi * 2 + (pp >> 1)) ^ (px & 7)) << 4) + (pp & 1) * 8;
+        }
+    }
+
+    // ---- per-lane DMA source offsets, computed once (a DMA issue in the loop is then 2-10 VALU ops) ----
+    // halo image of X, instruction id = wave + 8j: lane -> 16-byte slot -> (halo pixel, chunk position); the chunk is XORed with (halo column & 7)
+    unsigned prel[NPJ];           // byte offset relative to halo pixel (0, 0), chunk included
+    int pcoord[NPJ];              // halo row | halo column << 8; -1 = no item (tail of the last instruction / no such instruction)
+#pragma unroll
+    for (int j = 0; j < NPJ; ++j) {
+        const int id = wave + 8 * j;
+        const int item = id * 64 + lane;
+        const int p = item >> 3, pos = item & 7;
+        const int py = p / WP_HW, px = p - py * WP_HW;
+        const bool have = id < WP_PINSTR && item < WP_PITEMS;
+        prel[j] = (unsigned)(((py * a.W + px) * a.x0.ld + ((pos ^ (px & 7)) << 3)) * 2);
+        pcoord[j] = have ? (py | (px << 8)) : -1;
+    }
+    // dY tile, instruction i = wave + 8j covers tile row i >> 1, columns 8 * (i & 1) .. + 7: lane -> (column 8*(i&1) + (lane >> 3), chunk position lane & 7)
+    const unsigned qlane = (unsigned)((((lane >> 3)) * a.dy_ld + (((lane & 7) ^ (lane >> 3)) << 3)) * 2);
+
+    // buffer resources are rebuilt PER IMAGE (scalar ops only): 32-bit offsets then only have to span one image, whatever the batch size
+    const unsigned img_x = (unsigned)(((long long)a.H * a.W - 1) * a.x0.ld + a.Cin) * 2u, img_q = (unsigned)(((long long)a.H * a.W - 1) * a.dy_ld + a.Cout) * 2u;
+    const char* const xb = reinterpret_cast<const char*>(a.x0.p);
+    const char* const qb = reinterpret_cast<const char*>(a.dy);
+
+    // DMA instruction jj (0..9) of this wave for the tile (n, h0, w0): jj < NPJ -> halo image, else dY tile
+    auto issue = [&](auto jc, int n, int h0, int w0, char* stage) {
+        constexpr int jj = decltype(jc)::value;
+        if constexpr (jj < NPJ) {
+            const int id = wave + 8 * jj;
+            if (id >= WP_PINSTR) return;                      // wave-uniform
+            const __amdgpu_buffer_rsrc_t rx = wp_make_rsrc(xb + (size_t)n * a.H * a.W * a.x0.ld * 2, img_x);
+            // byte offset of halo pixel (0,0) = image pixel (h0-1, w0-1) within the image: "negative" (wraps) on the top / left border, where only valid items add to it
+            const unsigned toff = (unsigned)((((h0 - 1) * a.W + (w0 - 1)) * a.x0.ld + ci0) * 2);
+            const bool interior = h0 >= 1 && h0 + WP_TH + 1 <= a.H && w0 >= 1 && w0 + WP_TW + 1 <= a.W;        // block-uniform
+            bool ok = pcoord[jj] >= 0;
+            if (!interior) {
+                const int py = pcoord[jj] & 0xff, px = pcoord[jj] >> 8;
+                ok = ok && (unsigned)(h0 - 1 + py) < (unsigned)a.H && (unsigned)(w0 - 1 + px) < (unsigned)a.W;
+            }
+            wp_dma16(rx, ok ? (int)(toff + prel[jj]) : WP_OOB, stage + id * 1024);
+        } else {
+            const int i = wave + 8 * (jj - NPJ);
+            const __amdgpu_buffer_rsrc_t rq = wp_make_rsrc(qb + (size_t)n * a.H * a.W * a.dy_ld * 2, img_q);
+            const int hy = i >> 1, wx0 = (i & 1) * 8;
+            const unsigned toff = (unsigned)((((h0 + hy) * a.W + (w0 + wx0)) * a.dy_ld + co0) * 2);
+            const bool ok = (h0 + hy) < a.H && (w0 + wx0 + (lane >> 3)) < a.W;
+            wp_dma16(rq, ok ? (int)(toff + qlane) : WP_OOB, stage + WP_PBUF + i * 1024);
+        }
+    };
+
+    f32x4 acc[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int fj = 0; fj < 2; ++fj) acc[t][fj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = (a.bias_partial != nullptr) && (ci_t == 0) && (wi == 0);     // wave-uniform: waves 0 and 1
+    float bsum[2] = {0.f, 0.f};
+
+    int n, h0, w0;
+    tile_coords(t_begin, n, h0, w0);
+    wp_static_for<WP_PER_WAVE>([&](auto jc) { issue(jc, n, h0, w0, smem); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int sel = 0;
+    if (grp == 1) __builtin_amdgcn_s_barrier();       // the stagger: group 1 runs one slot behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll 1
+    for (int t = t_begin; t < t_end; ++t) {
+        const bool has_next = t + 1 < t_end;
+        int nn = n, nh0 = h0, nw0 = w0;
+        if (has_next) tile_coords(t + 1, nn, nh0, nw0);
+        const uint32_t lds0 = (uint32_t)(uintptr_t)smem;                  // LDS byte address of the dynamic segment
+        const uint32_t lds_p = lds0 + sel * WP_STAGE;
+        const uint32_t lds_q = lds0 + sel * WP_STAGE + WP_PBUF;
+        char* nstage = smem + (sel ^ 1) * WP_STAGE;
+        wp_static_for<NS>([&](auto sgc) {
+            constexpr int sg = decltype(sgc)::value;
+            // ================= R segment =================
+            if constexpr (sg < NS - 1) {
+                if (has_next) {
+                    wp_static_for<DPS>([&](auto dc) {
+                        constexpr int jj = sg * DPS + decltype(dc)::value;
+                        if constexpr (jj < WP_PER_WAVE) issue(std::integral_constant<int, jj>{}, nn, nh0, nw0, nstage);
+                    });
+                }
+            }
+            bf16x8_t B[KSS][2], A[KSS][9];
+            wp_static_for<KSS>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                constexpr int ks = sg * KSS + s;
+                wp_static_for<2>([&](auto fjc) {
+                    constexpr int fj = decltype(fjc)::value;
+                    B[s][fj] = wp_frag<ks * (2 * 16 * 128)>(lds_q + (qoff[0] ^ (fj << 5)), lds_q + (qoff[1] ^ (fj << 5)));
+                });
+                wp_static_for<9>([&](auto tc) {
+                    constexpr int tap = decltype(tc)::value;
+                    constexpr int kh = tap / 3, kw = tap % 3;
+                    A[s][tap] = wp_frag<(ks * 2 + kh) * WP_ROWB>(lds_p + poff[0][kw], lds_p + poff[1][kw]);
+                });
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);               // nothing that consumes a fragment may move above the wait (the asm reads are opaque to hipcc)
+            if (do_bias) {
+#pragma unroll
+                for (int s = 0; s < KSS; ++s) {
+                    bsum[0] += wp_sum8(B[s][0]);
+                    bsum[1] += wp_sum8(B[s][1]);
+                }
+            }
+            if constexpr (sg == NS - 1) {
+                if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // group 1's last slot of the step: its DMAs for the next tile have landed
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ================= M segment =================
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < KSS; ++s)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                    for (int fj = 0; fj < 2; ++fj)
+                        acc[tap][fj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][tap], B[s][fj], acc[tap][fj], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            if constexpr (sg == NS - 1) {
+                if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // group 0's last slot of the step
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        sel ^= 1;
+        n = nn; h0 = nh0; w0 = nw0;
+    }
+
+    // ---- the block's partial slab: partial[split][tap][ci][co]; bias column sums likewise ----
+    float* out = a.partial + (size_t)split * a.TT * a.Cin * a.Cout;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int fj = 0; fj < 2; ++fj) {
+            const int co = co0 + (wj * 2 + fj) * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = ci0 + wi * 16 + lg * 4 + r;
+                out[((size_t)tap * a.Cin + ci) * a.Cout + co] = acc[tap][fj][r];
+            }
+        }
+    if (do_bias) {
+#pragma unroll
+        for (int fj = 0; fj < 2; ++fj) {
+            float s = bsum[fj];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (lg == 0) a.bias_partial[(size_t)split * a.Cout + co0 + (wj * 2 + fj) * 16 + li] = s;
+        }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's last barrier
+}
+
+// ---------------------------------------------------------------------------------------------------------
+bool wgrad_pp_eligible(const MisWgradDesc* d) {
+    if (d->dtype != MIS_BF16 || d->is3d || d->ksize != 3 || d->D != 1) return false;
+    if (d->x1 != nullptr || d->in_scale != nullptr) return false;
+    if (d->x0_H != d->H || d->x0_W != d->W) return false;
+    if (d->Cin % 64 != 0 || d->Cout % 64 != 0) return false;
+    if ((((long long)d->H * d->W - 1) * d->x0_ld + d->Cin) * 2 >= (1ll << 32) - 65536) return false;      // 32-bit buffer offsets within ONE image
+    if ((((long long)d->H * d->W - 1) * d->dy_ld + d->Cout) * 2 >= (1ll << 32) - 65536) return false;
+    const char* e = getenv("MIS_WGRAD_NO_TR");
+    if (e != nullptr && e[0] == '1') return false;
+    return true;
+}
+
+static void wp_plan(const MisWgradDesc* d, int* ntiles, int* tps, int* nsb, int* tilesH, int* tilesW) {
+    *tilesH = (d->H + WP_TH - 1) / WP_TH;
+    *tilesW = (d->W + WP_TW - 1) / WP_TW;
+    const long long nt = (long long)d->N * *tilesH * *tilesW;
+    const long long npairs = (long long)(d->Cin / 64) * (d->Cout / 64);
+    long long want = 256 / npairs;                // one persistent block per CU
+    if (want < 1) want = 1;
+    if (want > nt) want = nt;
+    *tps = (int)((nt + want - 1) / want);
+    *nsb = (int)((nt + *tps - 1) / *tps);
+    *ntiles = (int)nt;
+}
+
+int wgrad_pp_nsplit(const MisWgradDesc* d) {
+    int ntiles, tps, nsb, th, tw;
+    wp_plan(d, &ntiles, &tps, &nsb, &th, &tw);
+    return nsb;
+}
+
+int launch_wgrad_pp(const MisWgradDesc* d, float* partial, float* bias_partial, hipStream_t stream) {
+    WgArgs a;
+    a.N = d->N; a.D = 1; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cin0 = d->Cin;
+    a.x0 = WSrc{d->x0, d->x0_ld, 1, d->x0_H, d->x0_W};
+    a.x1 = WSrc{nullptr, 0, 0, 0, 0};
+    a.in_scale = nullptr; a.in_shift = nullptr;
+    a.dy = d->dy; a.dy_ld = d->dy_ld; a.partial = partial; a.bias_partial = bias_partial;
+    int nsb;
+    wp_plan(d, &a.ntiles, &a.tps, &nsb, &a.tilesH, &a.tilesW);
+    MIS_REQUIRE((long long)d->N * a.tilesH * a.tilesW < (1ll << 30), MIS_EUNSUPPORTED, "wgrad(pp): too many pixel tiles");
+    a.tilesD = 1; a.nsplit = nsb;
+    a.nCi = d->Cin / 64; a.nCo = d->Cout / 64; a.KDn = 1; a.TT = 9;
+    const size_t lds = 2 * (size_t)WP_STAGE;
+    const bool kss1 = getenv("MIS_WGRAD_PP_KSS1") != nullptr;     // default: two k-steps per segment (36 MFMAs per wave between barriers)
+    const long long grid = (long long)a.nCi * a.nCo * nsb;
+    MIS_REQUIRE(grid < (1ll << 31), MIS_EUNSUPPORTED, "wgrad(pp): grid too large");
+    if (kss1) {
+        static std::atomic<unsigned long long> attr_done{0};
+        if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&wgrad_pp_kernel<1>), lds, "wgrad(pp)")) return rc;
+        hipLaunchKernelGGL((wgrad_pp_kernel<1>), dim3((unsigned)grid), dim3(512), lds, stream, a);
+    } else {
+        static std::atomic<unsigned long long> attr_done{0};
+        if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&wgrad_pp_kernel<2>), lds, "wgrad(pp)")) return rc;
+        hipLaunchKernelGGL((wgrad_pp_kernel<2>), dim3((unsigned)grid), dim3(512), lds, stream, a);
+    }
+    MIS_LAUNCH_CHECK("wgrad(pp)");
+    return MIS_OK;
+}

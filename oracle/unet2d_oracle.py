@@ -125,6 +125,62 @@ def loss_and_grads(p, images, labels):
     return loss.detach(), logits.detach(), grads
 
 
+# ---- bf16-STORAGE emulation (test infrastructure for the engine's bf16 mode) -----------------------------------------------
+# The engine's bf16 mode stores activations, activation gradients and the packed conv weights in bf16 and accumulates in fp32; fp32 stay the
+# image, the first layer's and the head's weights, every weight gradient and the master weights.  The functions below restate exactly that on top
+# of the fp32 oracle (round-to-nearest-even at the same tensor boundaries), so the bf16 engine can be held to a tight bar: on this net the
+# bf16-storage gradients differ from the fp32 reference by 3-12 % (relative L2) by construction - measured with this emulation, no device
+# code involved - which a comparison against the fp32 oracle alone cannot tell from a wrong kernel.
+class _RoundAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+class _RoundWeight(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w):
+        return w.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def unet_forward_bf16_storage(p, images):
+    ra, rw = _RoundAct.apply, _RoundWeight.apply
+
+    def dc(x, prefix, first_fp32=False):
+        w1 = p[f"{prefix}.first.weight"] if first_fp32 else rw(p[f"{prefix}.first.weight"])
+        x = ra(F.relu(F.conv2d(x, w1, p[f"{prefix}.first.bias"], padding=1)))
+        return ra(F.relu(F.conv2d(x, rw(p[f"{prefix}.second.weight"]), p[f"{prefix}.second.bias"], padding=1)))
+
+    x = images
+    skips = []
+    for i in range(4):
+        x = dc(x, f"down_conv.{i}", first_fp32=(i == 0))
+        skips.append(x)
+        x = F.max_pool2d(x, 2)
+    x = dc(x, "middle_conv")
+    for i in range(4):
+        x = ra(F.conv_transpose2d(x, rw(p[f"up_sample.{i}.up.weight"]), p[f"up_sample.{i}.up.bias"], stride=2))
+        s = center_crop(skips.pop(), x.shape[2], x.shape[3])
+        x = dc(torch.cat([x, s], dim=1), f"up_conv.{i}")
+    return F.conv2d(x, p["final_conv.weight"], p["final_conv.bias"])
+
+
+def loss_and_grads_bf16_storage(p, images, labels):
+    ps = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    logits = unet_forward_bf16_storage(ps, images)
+    loss = criterion(logits, labels)
+    loss.backward()
+    return loss.detach(), logits.detach(), {k: v.grad.detach() for k, v in ps.items()}
+
+
 def clip_grad_norm(grads, max_norm=1.0):
     """torch.nn.utils.clip_grad_norm_: total = ||(||g_i||_2)_i||_2 ; coef = clamp(max/(total+1e-6), max=1)."""
     norms = torch.stack([g.norm(2) for g in grads.values()])

@@ -129,24 +129,31 @@ def test_gemm1x1_every_branch(case):
 
 
 WG_CASES = [
-    # (dtype, ksize, N, H, W, Cin, Cout, expected configuration)
-    (BF, 3, 2, 20, 36, 64, 64, "k3.2d"),          # many splits
-    (BF, 3, 1, 9, 17, 256, 256, "k3.2d"),
-    (BF, 3, 1, 9, 17, 1024, 1024, "k3.2d"),       # 256 channel-tile pairs, few splits
-    (BF, 3, 2, 40, 40, 512, 256, "k3.2d"),
-    (BF, 1, 2, 10, 18, 256, 512, "k1.2d.wide"),   # 128 x 128 channel tiles
-    (BF, 1, 1, 9, 17, 2048, 1024, "k1.2d.wide"),
-    (BF, 1, 2, 10, 18, 64, 256, "k1.2d.tr"),         # Cin not a multiple of 128: 64 x 64 tiles
-    (F32, 3, 2, 20, 36, 32, 64, "k3.2d"),
-    (F32, 3, 1, 9, 17, 256, 128, "k3.2d"),
-    (F32, 1, 2, 10, 18, 128, 256, "k1.2d"),
+    # (dtype, ksize, N, H, W, Cin, Cout, expected configuration, environment switch)
+    (BF, 3, 2, 20, 36, 64, 64, "k3.2d.pp", ""),         # ping-pong kernel: ragged tiles, many splits
+    (BF, 3, 1, 9, 17, 256, 256, "k3.2d.pp", ""),        # a single (ragged) pixel tile per block
+    (BF, 3, 1, 9, 17, 1024, 1024, "k3.2d.pp", ""),      # 256 channel-tile pairs
+    (BF, 3, 2, 40, 40, 512, 256, "k3.2d.pp", ""),
+    (BF, 3, 3, 50, 70, 64, 128, "k3.2d.pp", ""),        # 60 pixel tiles over 128 blocks... several tiles per block for 2 pairs
+    (BF, 3, 2, 150, 170, 64, 64, "k3.2d.pp", ""),       # 220 tiles, 1 pair: persistent blocks with the tile loop taken
+    (BF, 3, 2, 20, 36, 64, 64, "k3.2d.tr", "MIS_WGRAD_NOPP"),     # the kernel behind it
+    (BF, 3, 1, 9, 17, 1024, 1024, "k3.2d.tr", "MIS_WGRAD_NOPP"),
+    (BF, 3, 2, 40, 40, 512, 256, "k3.2d.tr", "MIS_WGRAD_NOPP"),
+    (BF, 1, 2, 10, 18, 256, 512, "k1.2d.wide", ""),   # 128 x 128 channel tiles
+    (BF, 1, 1, 9, 17, 2048, 1024, "k1.2d.wide", ""),
+    (BF, 1, 2, 10, 18, 64, 256, "k1.2d.tr", ""),      # Cin not a multiple of 128: 64 x 64 tiles
+    (F32, 3, 2, 20, 36, 32, 64, "k3.2d", ""),
+    (F32, 3, 1, 9, 17, 256, 128, "k3.2d", ""),
+    (F32, 1, 2, 10, 18, 128, 256, "k1.2d", ""),
 ]
 
 
-@pytest.mark.parametrize("case", WG_CASES, ids=lambda c: f"{'bf16' if c[0] == BF else 'f32'}-k{c[1]}-{c[2]}x{c[3]}x{c[4]}-{c[5]}to{c[6]}")
-def test_wgrad_every_branch(case):
+@pytest.mark.parametrize("case", WG_CASES, ids=lambda c: f"{'bf16' if c[0] == BF else 'f32'}-k{c[1]}-{c[2]}x{c[3]}x{c[4]}-{c[5]}to{c[6]}-{c[8]}")
+def test_wgrad_every_branch(case, monkeypatch):
     ops = _ops()
-    dtype, ks, N, H, W, Cin, Cout, want_cfg = case
+    dtype, ks, N, H, W, Cin, Cout, want_cfg, env = case
+    if env:
+        monkeypatch.setenv(env, "1")
     x = rnd(N, Cin, H, W, seed=130)
     dy = rnd(N, Cout, H, W, seed=131)
     wq = torch.zeros(Cout, Cin, ks, ks, requires_grad=True)

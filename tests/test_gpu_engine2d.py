@@ -86,7 +86,9 @@ def test_fp32_engine_matches_reference_goldens(tag, cin, cout):
 
 
 def test_bf16_engine_close_to_oracle():
-    """bf16 storage / fp32 accumulate: reported tolerance (not the bit-exact bar)."""
+    """bf16 storage / fp32 accumulate.  Two bars: (a) TIGHT, per gradient tensor, against the oracle with bf16 storage emulated at the same tensor
+    boundaries (oracle.unet2d_oracle.loss_and_grads_bf16_storage) - this is the parity statement for the bf16 kernels end to end; (b) against the fp32
+    reference, where bf16 storage itself costs 3-12 % relative L2 on this net (the emulation shows it without any device code)."""
     from oracle import unet2d_oracle as o2
     g = load_golden("g2_unet_1_2.npz")
     eng = _engine(1, 2, torch.bfloat16)
@@ -96,19 +98,26 @@ def test_bf16_engine_close_to_oracle():
     d = (logits.cpu() - ref_logits).abs().max().item()
     rel = d / ref_logits.abs().max().item()
     print(f"bf16: logits max|diff| {d:.3g} (rel {rel:.3g}), loss {loss.item():.5f} vs {float(g['loss']):.5f}")
-    assert rel < 0.05
-    assert abs(loss.item() - float(g["loss"])) < 2e-2
+    assert rel < 0.01
+    assert abs(loss.item() - float(g["loss"])) < 1e-3
     eng.backward()
     p = o2.init_params(1, 2, seed=0)
-    _, _, grads = o2.loss_and_grads(p, T(g["images"]), T(g["labels"]))
-    worst = ("", 0.0)
-    for n, gref in grads.items():          # all 46 tensors: relative L2 error of the bf16 gradient against the fp32 oracle
-        a, b = eng.G[n].cpu().flatten().double(), gref.flatten().double()
-        rel = ((a - b).norm() / (b.norm() + 1e-30)).item()
-        if rel > worst[1]:
-            worst = (n, rel)
-        assert rel <= 2e-2, (n, rel)
-    print(f"bf16: worst gradient rel-L2 {worst[1]:.3g} ({worst[0]})")
+    _, _, g32 = o2.loss_and_grads(p, T(g["images"]), T(g["labels"]))
+    el, elogits, g16 = o2.loss_and_grads_bf16_storage(p, T(g["images"]), T(g["labels"]))
+    assert (logits.cpu() - elogits).abs().max().item() < 2e-5 + 2e-3 * elogits.abs().max().item()
+    assert abs(loss.item() - el.item()) < 1e-4
+    worst_emu, worst_f32, storage = ("", 0.0), ("", 0.0), 0.0
+    for n in g32:          # all 46 tensors
+        a, b, c = eng.G[n].cpu().flatten().double(), g16[n].flatten().double(), g32[n].flatten().double()
+        r_emu = ((a - b).norm() / (b.norm() + 1e-30)).item()
+        r_f32 = ((a - c).norm() / (c.norm() + 1e-30)).item()
+        storage = max(storage, ((b - c).norm() / (c.norm() + 1e-30)).item())
+        worst_emu = max(worst_emu, (n, r_emu), key=lambda t: t[1])
+        worst_f32 = max(worst_f32, (n, r_f32), key=lambda t: t[1])
+        assert r_emu <= 2e-2, (n, "vs bf16-storage oracle", r_emu)
+        assert r_f32 <= 0.16, (n, "vs fp32 oracle", r_f32)
+    print(f"bf16: worst gradient rel-L2 vs the bf16-storage oracle {worst_emu[1]:.3g} ({worst_emu[0]}), vs the fp32 oracle {worst_f32[1]:.3g} "
+          f"({worst_f32[0]}); bf16-storage oracle vs fp32 oracle (no device code) up to {storage:.3g}")
 
 
 def test_larger_batch_vs_oracle_fp32():

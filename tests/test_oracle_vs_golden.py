@@ -265,3 +265,23 @@ def test_unet3plus_oracle():
     with torch.no_grad():
         ye = o3p.forward({k: v.detach() for k, v in sd.items()}, T(g["xe"]), training=False)
     assert torch.allclose(ye, T(g["ye"]), atol=2e-5)
+
+
+def test_bf16_storage_emulation_is_a_small_perturbation_of_the_pinned_oracle():
+    """oracle.unet2d_oracle.loss_and_grads_bf16_storage (the checker of the engine's bf16 mode) = the pinned fp32 oracle + round-to-bf16 at the
+    engine's tensor boundaries: same loss to 1e-3, logits to 1e-2 relative, and gradients within the 3-15 % band that bf16 STORAGE costs on this
+    randomly initialised net (recorded here so that the bf16 GPU test's loose fp32 bar has a CPU-side justification)."""
+    import numpy as np
+    import torch
+
+    from oracle import unet2d_oracle as o2
+    g = load_golden("g2_unet_1_2.npz")
+    images, labels = torch.from_numpy(g["images"]), torch.from_numpy(g["labels"])
+    p = o2.init_params(1, 2, seed=0)
+    l32, lg32, g32 = o2.loss_and_grads(p, images, labels)
+    l16, lg16, g16 = o2.loss_and_grads_bf16_storage(p, images, labels)
+    assert abs(l16.item() - float(g["loss"])) < 1e-3
+    assert (lg16 - lg32).abs().max().item() < 1e-2 * lg32.abs().max().item()
+    rels = {n: ((g16[n] - g32[n]).norm() / g32[n].norm()).item() for n in g32}
+    assert max(rels.values()) < 0.16 and rels["final_conv.weight"] < 1e-2, rels
+    assert max(rels.values()) > 0.02          # it is NOT negligible: a bf16 kernel test against the fp32 oracle alone would have to be this loose
