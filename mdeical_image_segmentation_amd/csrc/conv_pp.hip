@@ -53,36 +53,26 @@ constexpr int PP_OOB = (int)0xFFFFFF00u;
 __device__ __forceinline__ void pp_dma16(__amdgpu_buffer_rsrc_t r, int voff, char* lds_dst_wave_uniform) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (pp_lds_void_t*)lds_dst_wave_uniform, 16, voff, 0, 0, 0);
 }
+// LDS reads as INLINE ASM: hipcc (ROCm 7.2) may put an s_waitcnt vmcnt(N) in front of an LDS read it cannot tell apart from the destination of an LDS-DMA
+// in flight - which then waits for the prefetch that was just issued and serialises the pipeline (seen here as soon as a second kind of LDS-DMA, the 4-byte
+// bias fetch, joined the kernel; in wgrad_pp.hip with the transposing-read builtin).  The asm form is invisible to that analysis; in exchange NOTHING waits for the
+// result automatically: every use sits behind an explicit s_waitcnt lgkmcnt(0) + sched_barrier (cdna_hip_programming.md §5.4 rule 18, §5.7).
+template <int OFF> __device__ __forceinline__ u32x4 pp_lds_read128(uint32_t lds_addr) {
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF));
+    return r;
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t pp_make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);   // raw buffer, stride 0, 32-bit data format (gfx9 family)
 }
 }   // namespace
 
-// the bias is the accumulators' initial value (per tile: the column tile, and with it the bias slice, may change between tiles)
-template <int NF>
-__device__ __forceinline__ void pp_acc_init(const ConvArgs& a, f32x4 (&acc)[NF][4], int ncol0, int wn, int lg) {
-    constexpr int NV = 4 * NF, WAVE_N = NF * 16;
-    const int colw = ncol0 + wn * WAVE_N;
-    const int col = colw + lg * NV;
-    const bool to0 = colw < a.Cout0;
-    int bcol = col;
-    if ((to0 ? a.y0_mode : a.y1_mode) == MIS_OUT_SHUFFLE2) {     // bias per real output channel c = column % Cq
-        const int cq = (to0 ? a.Cout0 : a.Cout - a.Cout0) >> 2;
-        const int lcol = to0 ? col : col - a.Cout0;
-        bcol = (to0 ? 0 : a.Cout0) + (lcol - (lcol / cq) * cq);
-    }
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.bias != nullptr) b4 = *reinterpret_cast<const f32x4*>(a.bias + bcol + f * 4);
-#pragma unroll
-        for (int pf = 0; pf < 4; ++pf) acc[f][pf] = b4;
-    }
-}
-
 // ---- epilogue: lane (li, lg) holds, per pixel row pf of its wave, NV = 4*NF consecutive output channels of pixel (h0 + wm*4 + pf, w0 + li) ----
+// `bias_lds`: the block's BN bias values of this tile's column tile (zeros without a bias), staged in LDS by DMA: a global bias load here would sit behind the
+// previous stores in the in-order vmcnt queue and expose their latency once per tile.  The accumulators are re-armed with zeros.
 template <int NF>
-__device__ __forceinline__ void pp_epilogue(const ConvArgs& a, f32x4 (&acc)[NF][4], int n, int h0, int w0, int ncol0, int wm, int wn, int li, int lg) {
+__device__ __forceinline__ void pp_epilogue(const ConvArgs& a, f32x4 (&acc)[NF][4], uint32_t bias_lds, int n, int h0, int w0, int ncol0, int wm, int wn, int li,
+                                            int lg) {
     using T = __bf16;
     constexpr int NV = 4 * NF, WAVE_N = NF * 16, EPC = 8;
     const int colw = ncol0 + wn * WAVE_N;          // wave-uniform first column
@@ -98,16 +88,30 @@ __device__ __forceinline__ void pp_epilogue(const ConvArgs& a, f32x4 (&acc)[NF][
         cq = cview >> 2;
         ab = lcol / cq;
     }
+    // (fetching the ReLU-mask rows two pixel rows ahead of their use - to expose one global round trip per tile instead of four - made hipcc's register
+    //  scoreboard insert vmcnt waits in front of the first fragment reads of every chunk, which serialises the weight prefetch; kept simple instead)
+    constexpr int MC = NV / EPC;
 #pragma unroll
     for (int pf = 0; pf < 4; ++pf) {
         const int y = h0 + wm * 4 + pf, x = w0 + li;
         float o[NV];
+        {
+            u32x4 braw[NF];
+            pp_static_for<NF>([&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                braw[f] = pp_lds_read128<f * 16>(bias_lds + (wn * WAVE_N + lg * NV) * 4);
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int f = 0; f < NF; ++f)
+            for (int f = 0; f < NF; ++f)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                o[f * 4 + q] = acc[f][pf][q];
-            }
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t u = braw[f][q];
+                    o[f * 4 + q] = acc[f][pf][q] + __uint_as_float(u);
+                    acc[f][pf][q] = 0.f;
+                }
+        }
         if (y < a.H && x < a.W) {
             if (a.relu) {
 #pragma unroll
@@ -117,11 +121,11 @@ __device__ __forceinline__ void pp_epilogue(const ConvArgs& a, f32x4 (&acc)[NF][
             if (a.mask != nullptr) {
                 const T* mp = reinterpret_cast<const T*>(a.mask) + pix * a.mask_ld + col;
 #pragma unroll
-                for (int i = 0; i < NV; i += EPC) {
+                for (int i = 0; i < MC; ++i) {
                     float mf[EPC];
-                    unpack_chunk<T>(*reinterpret_cast<const u32x4*>(mp + i), mf);
+                    unpack_chunk<T>(*reinterpret_cast<const u32x4*>(mp + i * EPC), mf);
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) o[i + e] = (mf[e] > 0.f) ? o[i + e] : 0.f;
+                    for (int e = 0; e < EPC; ++e) o[i * EPC + e] = (mf[e] > 0.f) ? o[i * EPC + e] : 0.f;
                 }
             }
             T* dst;
@@ -142,6 +146,23 @@ __device__ __forceinline__ void pp_epilogue(const ConvArgs& a, f32x4 (&acc)[NF][
     }
 }
 
+// Diagnostic build (-DMIS_PP_STAMPS, never shipped): per wave, shader cycles spent (0) working in R segments, (1) parked at the barrier that ends an R segment,
+// (2) working in M segments, (3) parked at the barrier that ends an M segment, (4) in the tile-end epilogue; read back with mis_debug_pp_stamps().
+#ifdef MIS_PP_STAMPS
+__device__ unsigned long long g_pp_stamps[256 * 8 * 8];
+extern "C" int mis_debug_pp_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pp_stamps), sizeof(unsigned long long) * 256 * 8 * 8) == hipSuccess ? 0 : -1;
+}
+#define PP_STAMP(i)                                                  \
+    {                                                                \
+        const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); \
+        st_[i] += tn_ - tp_;                                         \
+        tp_ = tn_;                                                   \
+    }
+#else
+#define PP_STAMP(i)
+#endif
+
 // NF = 16-channel fragments per wave along the output channels: 8 -> 256-column blocks (wave tile 64 px x 128 ch, one segment = one 32-channel
 // k-group), 4 -> 128-column blocks (wave tile 64 px x 64 ch, one segment = a whole 64-channel tap).  32 MFMAs per segment either way.
 template <int NF>
@@ -151,20 +172,24 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
     constexpr int WTILE = BN * 128;                  // bytes of one tap's weight tile (BN rows x 64 channels)
     constexpr int SEGK = (NF == 8) ? 1 : 2;          // 32-channel k-groups per segment
     constexpr int SPS = 2 / SEGK;                    // segments per step (step = one tap of one 64-channel chunk)
-    constexpr int WPW = 4;                           // weight DMA instructions per issuing wave and step
-    constexpr int NWI = (BN / 8) / WPW;              // issuing waves: 8 (NF = 8) or 4 (NF = 4: group 0 only)
-    static_assert(NWI == 8 || NWI == 4, "");
+    // Weight DMA: BN/8 instructions per step, WPW per wave (all 8 waves issue).  Issuing is the expensive part of an R segment (~100-185 cycles per
+    // instruction next to ds_reads, ~60 inside an MFMA cluster), so the instructions are spread over the slots in which their buffer is free:
+    //   NF = 8 (4 per wave, 4 slots per step): 2 in R0, 2 inside the following M0 - both groups, for the NEXT step;
+    //   NF = 4 (2 per wave, 2 slots per step): group 0 in its R (next step), group 1 inside its M - for the step AFTER the next one: group 1's M of step s
+    //          runs in the first slot of group 0's step s+1, which is when the buffer of step s (= that of step s+2) falls free.
+    constexpr int WPW = (BN / 8) / 8;
+    static_assert(WPW == 4 || WPW == 2, "");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const hbase = smem;                        // 2 x PP_HBUF
     char* const wbase = smem + 2 * PP_HBUF;          // 2 x WTILE
+    char* const bbase = wbase + 2 * WTILE;           // 2 x BN floats: the bias slice of the current / next tile's column tile (by tile parity)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, grp = wave >> 2;
     const int li = lane & 15, lg = lane >> 4;
-    const bool w_issuer = wave < NWI;
 
     const int total_tiles = a.nSp * a.nCt;
     const int tstride = (int)gridDim.x;
@@ -200,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
     //      (2*(k&1)*NV + 4*(k>>1)) rows, which goes into the scalar part of the offset ----
     int w_goff0;
     {
-        const int q = (wave & (NWI - 1)) * WPW;
+        const int q = wave * WPW;
         const int slot = q * 64 + lane;
         const int lrow = slot >> 3, pos = slot & 7;
         const int dc16 = pos ^ (lrow & 7);
@@ -232,25 +257,46 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
         pp_dma16(rx, ok ? (int)(toff + rel) : PP_OOB, dst + id * 1024);
         return true;
     };
-    auto issue_weights = [&](int tap, int col, int c0, char* dst) {
+    // bias slice of a column tile -> LDS, 4 bytes per lane (waves 0 .. BN/64-1; without a bias the zero-sized buffer reads as zeros)
+    const __amdgpu_buffer_rsrc_t rb = pp_make_rsrc(a.bias != nullptr ? (const void*)a.bias : a.w, a.bias != nullptr ? (unsigned)a.Cout * 4u : 0u);
+    auto issue_bias = [&](int col, char* dst) {
+        if (wave < BN / 64)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (pp_lds_void_t*)(dst + wave * 256), 4, (col + wave * 64 + lane) * 4, 0, 0, 0);
+    };
+    // instructions [k0, k1) of this wave's WPW for the weight tile (tap, column tile col, K chunk c0)
+    auto issue_weights = [&](auto k0c, auto k1c, int tap, int col, int c0, char* dst) {
+        constexpr int k0 = decltype(k0c)::value, k1 = decltype(k1c)::value;
         int soff = (int)((((long long)tap * a.Cout + col) * a.Cin + c0) * 2);
         asm volatile("" : "+s"(soff));
-        const int q0 = (wave & (NWI - 1)) * WPW;
+        const int q0 = wave * WPW;
 #pragma unroll
-        for (int k = 0; k < WPW; ++k) pp_dma16(rw, (soff + (2 * (k & 1) * NV + 4 * (k >> 1)) * a.Cin * 2) + w_goff0, dst + (q0 + k) * 1024);
+        for (int k = k0; k < k1; ++k) pp_dma16(rw, (soff + (2 * (k & 1) * NV + 4 * (k >> 1)) * a.Cin * 2) + w_goff0, dst + (q0 + k) * 1024);
     };
+    using I0 = std::integral_constant<int, 0>;
+    using IH = std::integral_constant<int, WPW / 2>;
+    using IW = std::integral_constant<int, WPW>;
 
     int n, h0, w0, ncol0;
     decode(tile, n, h0, w0, ncol0);
     f32x4 acc[NF][PF];
-    pp_acc_init<NF>(a, acc, ncol0, wn, lg);
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int pf = 0; pf < PF; ++pf) acc[f][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    issue_bias(ncol0, bbase);
     // ---- prologue: first weight tile and first halo chunk ----
-    if (w_issuer) issue_weights(0, ncol0, 0, wbase);
+    issue_weights(I0{}, IW{}, 0, ncol0, 0, wbase);
+    if constexpr (NF == 4) {
+        if (grp == 1) issue_weights(I0{}, IW{}, 1, ncol0, 0, wbase + WTILE);      // group 1's share of step 1 (in the loop it issues two steps ahead)
+    }
     pp_static_for<6>([&](auto jc) { (void)issue_halo(jc, n, h0, w0, 0, hbase); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    int wsel = 0, hsel = 0;
+    int wsel = 0, hsel = 0, bsel = 0;
+#ifdef MIS_PP_STAMPS
+    unsigned long long st_[5] = {0, 0, 0, 0, 0}, tp_ = __builtin_amdgcn_s_memtime();
+#endif
     if (grp == 1) __builtin_amdgcn_s_barrier();       // the stagger: group 1 runs one slot behind group 0
     __builtin_amdgcn_sched_barrier(0);
 
@@ -266,55 +312,83 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
             // what the halo prefetch of this chunk's steps fetches: the next chunk of this tile, else chunk 0 of the next tile, else nothing
             const bool hnext = !last_chunk || has_next;
             const int hn = last_chunk ? nn : n, hh0 = last_chunk ? nh0 : h0, hw0 = last_chunk ? nw0 : w0, hc0 = last_chunk ? 0 : c0 + 64;
-            const char* hb = hbase + hsel * PP_HBUF;
+            const uint32_t hb = (uint32_t)(uintptr_t)hbase + hsel * PP_HBUF;      // LDS byte addresses (asm reads)
             char* hbn = hbase + (hsel ^ 1) * PP_HBUF;
             pp_static_for<9>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 constexpr int kh = t / 3, kw = t % 3;
-                const char* wb = wbase + wsel * WTILE;
+                const uint32_t wb = (uint32_t)(uintptr_t)wbase + wsel * WTILE;
                 char* wbn = wbase + (wsel ^ 1) * WTILE;
                 // the step after this one: next tap; after the last tap the next chunk's (or the next tile's) first tap
                 const bool wnext = (t < 8) || hnext;
                 const int wtap = (t < 8) ? t + 1 : 0;
                 const int wcol = (t < 8 || !last_chunk) ? ncol0 : ncolN;
                 const int wc0 = (t < 8) ? c0 : hc0;
+                // ... and the one after that (NF = 4, group 1)
+                const bool w2next = (t < 7) || hnext;
+                const int w2tap = (t < 7) ? t + 2 : t - 7;
+                const int w2col = (t < 7 || !last_chunk) ? ncol0 : ncolN;
+                const int w2c0 = (t < 7) ? c0 : hc0;
+                char* wb_self = wbase + wsel * WTILE;     // the buffer this step reads = the buffer of the step after the next one
                 bool hi = false;
                 pp_static_for<SPS>([&](auto sc) {
                     constexpr int sg = decltype(sc)::value;
                     // ================= R segment =================
                     if constexpr (sg == 0) {
-                        if (w_issuer && wnext) issue_weights(wtap, wcol, wc0, wbn);
+                        if constexpr (NF == 8) {
+                            if (wnext) issue_weights(I0{}, IH{}, wtap, wcol, wc0, wbn);
+                        } else {
+                            if (grp == 0 && wnext) issue_weights(I0{}, IW{}, wtap, wcol, wc0, wbn);
+                        }
                     }
                     if constexpr (sg == SPS - 1 && t < 6) {
                         if (hnext) hi = issue_halo(std::integral_constant<int, t>{}, hn, hh0, hw0, hc0, hbn);
                     }
                     u32x4 A[SEGK][NF], B[SEGK][PF];
-#pragma unroll
-                    for (int s = 0; s < SEGK; ++s) {
-                        const int kg = sg * SEGK + s;
-#pragma unroll
-                        for (int f = 0; f < NF; ++f) A[s][f] = lds_read_b128(wb, (a_off0 ^ (kg << 6)) + f * 2048);
-#pragma unroll
-                        for (int pf = 0; pf < PF; ++pf) B[s][pf] = lds_read_b128(hb, (b_off0[kw] ^ (kg << 6)) + (pf + kh) * PP_ROWB);
-                    }
+                    pp_static_for<SEGK>([&](auto sc) {
+                        constexpr int s = decltype(sc)::value;
+                        constexpr int kg = sg * SEGK + s;
+                        pp_static_for<NF>([&](auto fc) {
+                            constexpr int f = decltype(fc)::value;
+                            A[s][f] = pp_lds_read128<f * 2048>(wb + (a_off0 ^ (kg << 6)));
+                        });
+                        pp_static_for<PF>([&](auto pc) {
+                            constexpr int pf = decltype(pc)::value;
+                            B[s][pf] = pp_lds_read128<(pf + kh) * PP_ROWB>(hb + (b_off0[kw] ^ (kg << 6)));
+                        });
+                    });
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragments in registers; also: this wave's reads of both buffers are over
+                    __builtin_amdgcn_sched_barrier(0);                      // no consumer may move above the wait (the asm reads are opaque to hipcc)
                     if constexpr (sg == SPS - 1) {
-                        if (grp == 1) {                                      // group 1's last slot of the step
+                        // group 1's last slot of the step: its weight DMAs for the next step (issued one slot-pair ago) must have landed; a halo DMA issued in this
+                        // segment is the youngest op and stays in flight
+                        if (grp == 1) {
                             if (hi) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    PP_STAMP(0)
                     __builtin_amdgcn_s_barrier();
+                    PP_STAMP(1)
                     __builtin_amdgcn_sched_barrier(0);
                     // ================= M segment =================
                     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int s = 0; s < SEGK; ++s)
 #pragma unroll
-                        for (int f = 0; f < NF; ++f)
+                        for (int f = 0; f < NF; ++f) {
 #pragma unroll
                             for (int pf = 0; pf < PF; ++pf) mma_b128<T>(acc[f][pf], A[s][f], B[s][pf]);
+                            if (s == 0 && f == 1) {      // the second half of the weight DMAs goes out from inside the MFMA cluster
+                                if constexpr (NF == 8 && sg == 0) {
+                                    if (wnext) issue_weights(IH{}, IW{}, wtap, wcol, wc0, wbn);
+                                }
+                                if constexpr (NF == 4) {
+                                    if (grp == 1 && w2next) issue_weights(I0{}, IW{}, w2tap, w2col, w2c0, wb_self);
+                                }
+                            }
+                        }
                     __builtin_amdgcn_s_setprio(0);
                     if constexpr (sg == SPS - 1) {
                         if (grp == 0) {                                      // group 0's last slot of the step
@@ -323,7 +397,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    PP_STAMP(2)
                     __builtin_amdgcn_s_barrier();
+                    PP_STAMP(3)
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 wsel ^= 1;
@@ -332,12 +408,20 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
         }
         // this wave's tile is complete: store it and re-arm the accumulators.  In program order this sits at the head of the wave's next R slot, i.e. it runs
         // under the partner group's MFMAs (group 1 is still in its last M slot of the tile when group 0 gets here, and vice versa one slot later).
-        pp_epilogue<NF>(a, acc, n, h0, w0, ncol0, wm, wn, li, lg);
+        // The next tile's bias slice goes to the OTHER half of the bias region (last read one tile ago); it is retired by the step drains long before its epilogue.
+        pp_epilogue<NF>(a, acc, (uint32_t)(uintptr_t)bbase + bsel * (BN * 4), n, h0, w0, ncol0, wm, wn, li, lg);
         n = nn; h0 = nh0; w0 = nw0; ncol0 = ncolN;
-        if (has_next) pp_acc_init<NF>(a, acc, ncol0, wn, lg);
+        bsel ^= 1;
+        if (has_next) issue_bias(ncol0, bbase + bsel * (BN * 4));
         __builtin_amdgcn_sched_barrier(0);
+        PP_STAMP(4)
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's last barrier
+#ifdef MIS_PP_STAMPS
+    if (lane == 0 && blockIdx.x < 256) {
+        for (int i = 0; i < 5; ++i) g_pp_stamps[(blockIdx.x * 8 + wave) * 8 + i] = st_[i];
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -348,6 +432,7 @@ bool conv_pp_eligible(const MisConvDesc* d) {
     if (d->Cin % 64 != 0 || d->Cout % 128 != 0) return false;
     if (d->Cout0 % 128 != 0) return false;             // a wave's 64 / 128 columns go to ONE destination
     if (d->Cout % 256 == 0 && d->Cout0 % 128 != 0) return false;
+    if (d->bias != nullptr && (d->y0_mode == MIS_OUT_SHUFFLE2 || (d->y1 != nullptr && d->y1_mode == MIS_OUT_SHUFFLE2))) return false;   // bias is indexed by GEMM column here
     // 32-bit buffer offsets: ONE image of the input view and the packed weights must each span less than 4 GiB - 64 KiB
     if ((((long long)d->H * d->W - 1) * d->x0_ld + d->Cin) * 2 >= (1ll << 32) - 65536) return false;
     if ((long long)9 * d->Cout * d->Cin * 2 >= (1ll << 32) - 65536) return false;
@@ -371,7 +456,7 @@ template <int NF> static int pp_launch(const MisConvDesc* d, hipStream_t stream)
     a.nCt = d->Cout / BN;
     MIS_REQUIRE(nsp * a.nCt < (1ll << 31), MIS_EUNSUPPORTED, "conv_igemm(pp): grid too large");
     a.nSp = (int)nsp;
-    const size_t lds = 2 * (size_t)PP_HBUF + 2 * (size_t)BN * 128;
+    const size_t lds = 2 * (size_t)PP_HBUF + 2 * (size_t)BN * 128 + 2 * (size_t)BN * 4;
     static std::atomic<unsigned long long> attr_done{0};
     if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv_pp_kernel<NF>), lds, "conv_igemm(pp)")) return rc;
     const long long total = nsp * a.nCt;
