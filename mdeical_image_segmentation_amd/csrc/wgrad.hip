@@ -629,10 +629,9 @@ extern "C" int mis_wgrad(const MisWgradDesc* d, void* stream) {
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (p.pp) {
-        g_wgrad_last = "k3.2d.pp";
         g_wgrad_last_nsplit = p.nsplit;
         float* bias_partial = d->dbias != nullptr ? d->workspace + (size_t)p.nsplit * p.TT * d->Cin * d->Cout : nullptr;
-        rc = launch_wgrad_pp(d, d->workspace, bias_partial, s);
+        rc = launch_wgrad_pp(d, d->workspace, bias_partial, s, &g_wgrad_last);
         if (rc != MIS_OK) return rc;
         return wg_finish(d, p, bias_partial, s);
     }

@@ -25,4 +25,4 @@ struct WgArgs {
 // exactly like wgrad_kernel (slab [split][tap][ci][co], bias [split][co]) so the same reduction kernels finish the job.
 bool wgrad_pp_eligible(const MisWgradDesc* d);
 int wgrad_pp_nsplit(const MisWgradDesc* d);
-int launch_wgrad_pp(const MisWgradDesc* d, float* partial, float* bias_partial, hipStream_t stream);
+int launch_wgrad_pp(const MisWgradDesc* d, float* partial, float* bias_partial, hipStream_t stream, const char** tag);
