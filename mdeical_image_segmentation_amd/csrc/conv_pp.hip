@@ -430,8 +430,7 @@ bool conv_pp_eligible(const MisConvDesc* d) {
     if (d->x1 != nullptr || d->in_scale != nullptr) return false;
     if (d->x0_H != d->H || d->x0_W != d->W || d->D != 1) return false;
     if (d->Cin % 64 != 0 || d->Cout % 128 != 0) return false;
-    if (d->Cout0 % 128 != 0) return false;             // a wave's 64 / 128 columns go to ONE destination
-    if (d->Cout % 256 == 0 && d->Cout0 % 128 != 0) return false;
+    if (d->Cout0 % 64 != 0) return false;              // a wave's 64 (128-column blocks) / 128 (256-column blocks) columns go to ONE destination
     if (d->bias != nullptr && (d->y0_mode == MIS_OUT_SHUFFLE2 || (d->y1 != nullptr && d->y1_mode == MIS_OUT_SHUFFLE2))) return false;   // bias is indexed by GEMM column here
     // 32-bit buffer offsets: ONE image of the input view and the packed weights must each span less than 4 GiB - 64 KiB
     if ((((long long)d->H * d->W - 1) * d->x0_ld + d->Cin) * 2 >= (1ll << 32) - 65536) return false;
@@ -466,7 +465,7 @@ template <int NF> static int pp_launch(const MisConvDesc* d, hipStream_t stream)
 }
 
 int launch_conv_pp(const MisConvDesc* d, hipStream_t stream, const char** tag) {
-    if (d->Cout % 256 == 0 && (d->Cout0 % 256 == 0 || d->Cout0 % 128 == 0)) {
+    if (d->Cout % 256 == 0 && d->Cout0 % 128 == 0) {
         static const int no256 = getenv("MIS_CONV_PP_NO256") != nullptr;
         if (!no256) {
             *tag = "k3.2d.pp256";

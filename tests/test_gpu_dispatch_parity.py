@@ -75,7 +75,7 @@ def test_conv3x3_every_branch(case, monkeypatch):
     assert ops.conv_last_dispatch() == cfg
     assert_close(from_nhwc(y2), ref * (q(m, dtype) > 0), f"mask {cfg}", **t)
     # (c) two destinations (dgrad of up_conv.*.first): first half pixel-unshuffled, second half plain
-    if Cout % 128 == 0 and (Cout // 2) % (128 if ("bn256" in cfg or ".pp" in cfg) else 64) == 0 and H % 2 == 0 and W % 2 == 0:
+    if Cout % 128 == 0 and (Cout // 2) % (128 if ("bn256" in cfg or "pp256" in cfg) else 64) == 0 and H % 2 == 0 and W % 2 == 0:
         h = Cout // 2
         d0 = torch.full((N, H // 2, W // 2, 4 * h), float("nan"), dtype=dtype, device=DEV)
         d1 = torch.full((N, H, W, h), float("nan"), dtype=dtype, device=DEV)
