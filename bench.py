@@ -178,6 +178,9 @@ def main():
                     help="constant learning rate of the timed steps.  The reference's 5e-3 (train.py:98) makes THIS synthetic task (random labels) "
                          "diverge and collapse to dead ReLUs within ~10 steps (loss = ln 2, activations 0-2 % live): AdamW does the same work at any "
                          "lr, so the benchmark keeps the network in its initial, live state instead of timing MFMAs on zeros")
+    ap.add_argument("--comm", default="torch", choices=["torch", "native"],
+                    help="gradient exchange at N > 1: torch.distributed all_reduce (ProcessGroupNCCL = RCCL) or the RCCL communicator behind the C ABI "
+                         "(mis_comm_init / mis_allreduce_bucket, csrc/comm.cpp); same bucket schedule either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary driver-timed legs (2-D fp32, cfg4 3-D fp32) of the default N=1 run")
@@ -210,6 +213,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl", (dist.get_world_size(), dist.get_backend())
+        if args.comm == "native":
+            from mdeical_image_segmentation_amd.ddp import native_comm_init
+            assert native_comm_init() == args.gpus
 
     if args.workload == "3d":
         out = run3d(args, rank, world, dev, dist, dtype=args.dtype, batch=args.batch or 2, size=args.size or 128, steps=args.steps,
@@ -281,7 +287,8 @@ def _timed_loop(step, steps, warmup, world, dist, dev, timing):
 def _comm_report(reducer, eng, steps, world, dist, dev):
     """multi-GPU self-description: RCCL really carried the gradients, how long the buckets took, how much of that was exposed, and whether
     every rank ends the run with bit-identical parameters (same init + same summed gradients + same optimizer => must be equal)"""
-    rep = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "allreduce_bytes_per_step": int(eng.flat.total * 4),
+    rep = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend() + (" + C-ABI communicator (mis_allreduce_bucket)" if reducer.backend == "native" else ""),
+           "allreduce_bytes_per_step": int(eng.flat.total * 4),
            "buckets_per_step": reducer.buckets_per_step}
     ar, exposed = reducer.timing_ms()
     rep["allreduce_ms_per_step"] = round(ar / steps, 3)
@@ -300,7 +307,7 @@ def run2d(args, rank, world, dev, dist, *, dtype, batch, size, steps, warmup, ti
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
     cin, ncls = (1, 2) if args.net == "1x2" else (3, 4)
     eng = UNet2DEngine(cin, ncls, dtype=tdt, device=dev, seed=0, lr=args.lr)  # identical init on every rank (PyTorch default init, seed 0)
-    reducer = GradReducer(eng.flat, timing=True) if world > 1 else None
+    reducer = GradReducer(eng.flat, timing=True, backend=args.comm) if world > 1 else None
     g = torch.Generator().manual_seed(1000 + rank)                    # per-rank data shard
     images = torch.randn(batch, cin, size, size, generator=g).to(dev)
     labels = torch.randint(0, ncls, (batch, size, size), generator=g).to(dev)
@@ -373,7 +380,7 @@ def run3d(args, rank, world, dev, dist, *, dtype, batch, size, steps, warmup, ti
     from mdeical_image_segmentation_amd.engine3d import UNet3DEngine
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
     eng = UNet3DEngine(1, 3, dtype=tdt, device=dev, seed=0, lr=args.lr)
-    reducer = GradReducer(eng.flat, timing=True) if world > 1 else None
+    reducer = GradReducer(eng.flat, timing=True, backend=args.comm) if world > 1 else None
     g = torch.Generator().manual_seed(1000 + rank)
     x = torch.randn(batch, 1, size, size, size, generator=g).to(dev)
     t = (torch.rand(batch, 3, size, size, size, generator=g) > 0.5).float().to(dev)

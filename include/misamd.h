@@ -365,6 +365,16 @@ int mis_nhwc_to_nchw(int dtype_in, const void* x, int x_ld, float* y, int N, int
 /* test hooks: raw MFMA / LDS-transpose fragment probes (tests/test_gpu_fragments.py) */
 int mis_probe_mfma(int which, const float* a, const float* b, float* c, void* stream);
 
+/* ---- data-parallel gradient exchange: one RCCL communicator per process (csrc/comm.cpp) ----------------------------------------------
+ * Replaces nn.DataParallel in the reference's 3-D trainer (model/unet3d/trainer.py:23-24) / the DDP wrapper HF Trainer adds under torchrun (train.py).
+ * librccl is bound at run time; mis_comm_unique_id (rank 0) -> carry the 128 bytes to every rank -> mis_comm_init on the rank's HIP device ->
+ * mis_allreduce_bucket(buf, n, stream): in-place fp32 SUM over all ranks, enqueued on `stream`, never synchronises -> mis_comm_finalize. */
+int mis_comm_unique_id(void* out128);
+int mis_comm_init(const void* unique_id128, int rank, int world);
+int mis_comm_world(void);      /* ranks of the live communicator, 0 if none */
+int mis_allreduce_bucket(float* buf, long long n, void* stream);
+int mis_comm_finalize(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@ OUT_PLAIN, OUT_SHUFFLE2, OUT_UNSHUFFLE2 = 0, 1, 2
 EXPORTS = [
     "mis_last_error", "mis_version", "mis_conv_igemm", "mis_wgrad_workspace_bytes", "mis_wgrad",
     "mis_conv_last_dispatch", "mis_wgrad_last_dispatch", "mis_wgrad_last_nsplit",
+    "mis_comm_unique_id", "mis_comm_init", "mis_comm_world", "mis_allreduce_bucket", "mis_comm_finalize",
     "mis_conv3x3_first_fwd", "mis_conv3x3_first_wgrad_workspace_bytes", "mis_conv3x3_first_wgrad",
     "mis_colsum_workspace_bytes", "mis_colsum", "mis_maxpool2_fwd", "mis_maxpool2_bwd",
     "mis_pack_conv_weight", "mis_pack_convt_weight", "mis_head_workspace_bytes", "mis_head_loss",
@@ -107,6 +108,13 @@ def load():
         getattr(lib, name).argtypes = []
     lib.mis_wgrad_last_nsplit.restype = C.c_int
     lib.mis_wgrad_last_nsplit.argtypes = []
+    lib.mis_comm_unique_id.argtypes = [C.c_void_p]
+    lib.mis_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.mis_comm_world.argtypes = []
+    lib.mis_allreduce_bucket.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p]
+    lib.mis_comm_finalize.argtypes = []
+    for name in ("mis_comm_unique_id", "mis_comm_init", "mis_comm_world", "mis_allreduce_bucket", "mis_comm_finalize"):
+        getattr(lib, name).restype = C.c_int
     for name in ("mis_wgrad_workspace_bytes", "mis_head_workspace_bytes"):
         getattr(lib, name).restype = C.c_size_t
         getattr(lib, name).argtypes = [C.c_void_p]

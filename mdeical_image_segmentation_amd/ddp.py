@@ -7,8 +7,32 @@ have been enqueued, so the exchange (124 MB fp32 for the 2-D net, ~0.2-1.4 ms ov
 backward kernels.  The 1/world_size factor is folded into the loss gradient (grad_scale), so SUM gives the mean.
 Buckets are the contiguous ranges of the flat fp32 gradient buffer that belong to one module.
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
+
+
+def native_comm_init(group=None):
+    """Create this process's RCCL communicator behind the C ABI (mis_comm_init).  The 128-byte unique id is made by rank 0 and carried to the
+    other ranks over the existing torch.distributed group (any backend: it is host data).  Call on the rank's own HIP device."""
+    from . import _lib
+    lib = _lib.load()
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+    uid = (C.c_char * 128)()
+    if rank == 0:
+        _lib.check(lib.mis_comm_unique_id(uid), "mis_comm_unique_id")
+    if world > 1:
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=0, group=group)
+        uid = (C.c_char * 128).from_buffer_copy(box[0])
+    _lib.check(lib.mis_comm_init(uid, rank, world), "mis_comm_init")
+    return world
+
+
+def native_comm_finalize():
+    from . import _lib
+    _lib.check(_lib.load().mis_comm_finalize(), "mis_comm_finalize")
 
 
 def module_ranges(flat, prefixes):
@@ -36,10 +60,19 @@ class GradReducer:
     stream) and the final join (on the compute stream) with timing events, read back by timing_ms() after a synchronisation:
     all-reduce time = sum of bucket durations, exposed time = how long the compute stream sat in finish() waiting for the last bucket."""
 
-    def __init__(self, flat, group=None, timing=False):
+    def __init__(self, flat, group=None, timing=False, backend="torch"):
+        """backend "torch": torch.distributed all_reduce (ProcessGroupNCCL = RCCL on ROCm; gloo on CPU); "native": mis_allreduce_bucket on the
+        communicator made by native_comm_init() - same collective, no torch in the data path."""
         self.flat = flat
         self.group = group
+        self.backend = backend
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if backend == "native":
+            from . import _lib
+            self._lib = _lib.load()
+            self.world = self._lib.mis_comm_world()
+            if self.world < 1:
+                raise _lib.MisError("GradReducer(backend='native') needs native_comm_init() first")
         self.on_gpu = flat.g.device.type == "cuda"
         self.stream = torch.cuda.Stream(device=flat.g.device) if self.on_gpu else None
         self.works = []
@@ -51,7 +84,7 @@ class GradReducer:
         self._t_buckets, self._t_join = [], []
 
     def _reduce(self, t):
-        if self.world == 1:
+        if self.world == 1 and self.backend != "native":      # (a 1-rank native communicator still runs the collective: the single-GPU test of the ABI)
             return
         if self.on_gpu:
             if self._slot == len(self._ready):
@@ -64,7 +97,11 @@ class GradReducer:
                 if self.timing:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(self.stream)
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                if self.backend == "native":
+                    from . import _lib
+                    _lib.check(self._lib.mis_allreduce_bucket(t.data_ptr(), t.numel(), self.stream.cuda_stream), "mis_allreduce_bucket")
+                else:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
                 if self.timing:
                     e1.record(self.stream)
                     self._t_buckets.append((e0, e1))
@@ -77,7 +114,7 @@ class GradReducer:
 
     def finish(self):
         """Reduce the bias region and make the compute stream wait for every bucket."""
-        if self.world == 1:
+        if self.world == 1 and self.backend != "native":
             return
         self._reduce(self.flat.g[self.flat.n_decay:])
         if self.on_gpu:

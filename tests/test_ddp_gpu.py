@@ -69,3 +69,43 @@ def test_grad_reducer_two_ranks_one_gpu(kind):
     for r, (err, all_stages) in res.items():
         assert err < 1e-5, (r, err)
         assert all_stages, "a module never reported its gradients to the reducer"
+
+
+@pytest.mark.gpu
+def test_native_rccl_communicator_single_rank():
+    """The RCCL communicator behind the C ABI (mis_comm_unique_id / mis_comm_init / mis_allreduce_bucket / mis_comm_finalize) on the one GPU of this box:
+    a 1-rank communicator really goes through librccl (ncclCommInitRank + ncclAllReduce on a side stream); the sum over one rank is the identity, the
+    bucket schedule of GradReducer(backend="native") must leave the engine's gradients bit-identical, and the explicit init / finalize protocol holds."""
+    import torch
+
+    from mdeical_image_segmentation_amd import MisError, _lib
+    from mdeical_image_segmentation_amd.ddp import GradReducer, native_comm_finalize, native_comm_init
+    from mdeical_image_segmentation_amd.engine2d import UNet2DEngine
+    lib = _lib.load()
+    assert lib.mis_comm_world() == 0
+    eng = UNet2DEngine(1, 2, dtype=torch.float32, device="cuda", seed=0)
+    with pytest.raises(MisError):
+        GradReducer(eng.flat, backend="native")                # no communicator yet
+    assert native_comm_init() == 1 and lib.mis_comm_world() == 1
+    with pytest.raises(MisError):
+        native_comm_init()                                      # one communicator per process
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 1, 32, 32, generator=g).cuda()
+    y = torch.randint(0, 2, (2, 32, 32), generator=g).cuda()
+    eng.forward(x, y, train=True)
+    eng.backward()
+    torch.cuda.synchronize()
+    ref = eng.flat.g.clone()
+    red = GradReducer(eng.flat, backend="native", timing=True)
+    eng.forward(x, y, train=True)
+    eng.backward(stage_cb=red.stage_done)
+    red.finish()
+    torch.cuda.synchronize()
+    assert red.buckets_per_step >= 8
+    assert torch.equal(eng.flat.g, ref)
+    ar, exposed = red.timing_ms()
+    assert ar > 0.0
+    native_comm_finalize()
+    assert lib.mis_comm_world() == 0
+    buf = torch.ones(8, device="cuda")
+    assert lib.mis_allreduce_bucket(buf.data_ptr(), 8, None) != 0      # finalized: loud error, no crash
