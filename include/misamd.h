@@ -365,6 +365,15 @@ int mis_nhwc_to_nchw(int dtype_in, const void* x, int x_ld, float* y, int N, int
 /* test hooks: raw MFMA / LDS-transpose fragment probes (tests/test_gpu_fragments.py) */
 int mis_probe_mfma(int which, const float* a, const float* b, float* c, void* stream);
 
+/* numpy legacy RandomState.normal() on the device (csrc/mt19937.hip): the Gaussian-noise FIELD of AdditiveGaussianNoise, bit-comparable with the
+ * reference's `m + random_state.normal(0, std, size=m.shape)` (augment/unet3d_augment/transforms.py:608-619).
+ * mis_mt19937_words: the next n 32-bit outputs of MT19937 from (key[624], pos), both updated in place (device memory).
+ * mis_legacy_normal: out[i] = (float)((double)in[i] + scale * g_i), g = numpy's legacy_gauss over `words` (4 words per polar attempt; has_gauss / gauss0 = the
+ * generator's cache on entry); result5 (device) = {attempts consumed, cache filled?, cached value (double bits), -, 1 = success / 0 = words ran out}. */
+int mis_mt19937_words(unsigned int* key_io, int* pos_io, unsigned int* out, long long n, void* stream);
+int mis_legacy_normal(const unsigned int* words, long long nattempts, const float* in, float* out, long long count, double scale, int has_gauss, double gauss0,
+                      unsigned long long* result5, void* stream);
+
 /* ---- data-parallel gradient exchange: one RCCL communicator per process (csrc/comm.cpp) ----------------------------------------------
  * Replaces nn.DataParallel in the reference's 3-D trainer (model/unet3d/trainer.py:23-24) / the DDP wrapper HF Trainer adds under torchrun (train.py).
  * librccl is bound at run time; mis_comm_unique_id (rank 0) -> carry the 128 bytes to every rank -> mis_comm_init on the rank's HIP device ->

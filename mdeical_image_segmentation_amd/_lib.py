@@ -15,6 +15,7 @@ OUT_PLAIN, OUT_SHUFFLE2, OUT_UNSHUFFLE2 = 0, 1, 2
 EXPORTS = [
     "mis_last_error", "mis_version", "mis_conv_igemm", "mis_wgrad_workspace_bytes", "mis_wgrad",
     "mis_conv_last_dispatch", "mis_wgrad_last_dispatch", "mis_wgrad_last_nsplit",
+    "mis_mt19937_words", "mis_legacy_normal",
     "mis_comm_unique_id", "mis_comm_init", "mis_comm_world", "mis_allreduce_bucket", "mis_comm_finalize",
     "mis_conv3x3_first_fwd", "mis_conv3x3_first_wgrad_workspace_bytes", "mis_conv3x3_first_wgrad",
     "mis_colsum_workspace_bytes", "mis_colsum", "mis_maxpool2_fwd", "mis_maxpool2_bwd",
@@ -224,6 +225,8 @@ def load():
         "mis_aug_map_coordinates": [vp, vp, vp, ll, i, i, i, vp, vp, vp, dbl, i, i, vp],
         "mis_aug_pointwise": [vp, vp, ll, f, f, i, f, f, f, C.c_ulonglong, vp],
         "mis_aug_contrast": [vp, vp, ll, f, f, vp],
+        "mis_mt19937_words": [vp, vp, vp, ll, vp],
+        "mis_legacy_normal": [vp, ll, vp, vp, ll, dbl, i, dbl, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

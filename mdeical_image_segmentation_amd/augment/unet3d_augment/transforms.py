@@ -20,6 +20,8 @@ outputs are CUDA tensors.  Differences, all loud or documented:
 import ctypes as C
 import importlib
 
+import math
+
 import numpy as np
 import torch
 from scipy import special
@@ -278,8 +280,42 @@ class Normalize:
         return out
 
 
+def _legacy_normal_on_device(random_state, m, std):
+    """m + random_state.normal(0, std, size=m.shape) with the field drawn ON THE DEVICE from numpy's own stream (csrc/mt19937.hip): the generator's key / position /
+    gauss cache go to the device, MT19937 words and the polar rejection loop run there, and the host RandomState is advanced by exactly the words consumed (plus the
+    new cache content) so that every later draw of the pipeline matches the reference."""
+    lib = load()
+    name, key, pos, has_gauss, cached = random_state.get_state()
+    count = m.numel()
+    flat = m.reshape(-1)
+    out = torch.empty_like(flat)
+    pairs = (count - int(has_gauss) + 1) // 2
+    attempts = int(pairs * 1.2733 + 6.0 * math.sqrt(max(pairs, 1) * 0.274) + 64)     # acceptance pi/4 per attempt, six sigma of slack
+    while True:
+        key_d = torch.from_numpy(np.ascontiguousarray(key, dtype=np.uint32).view(np.int32)).to(m.device)
+        pos_d = torch.tensor([int(pos)], dtype=torch.int32, device=m.device)
+        words = torch.empty(4 * attempts, dtype=torch.int32, device=m.device)
+        res = torch.zeros(5, dtype=torch.int64, device=m.device)
+        check(lib.mis_mt19937_words(key_d.data_ptr(), pos_d.data_ptr(), words.data_ptr(), 4 * attempts, stream_ptr()), "mis_mt19937_words")
+        check(lib.mis_legacy_normal(words.data_ptr(), attempts, flat.data_ptr(), out.data_ptr(), count, float(std), int(has_gauss), float(cached), res.data_ptr(),
+                                    stream_ptr()), "mis_legacy_normal")
+        r = res.cpu().numpy()
+        if int(r[4]) == 1:
+            break
+        attempts *= 2                                     # (practically unreachable) the word stream ran out: start again from the same state with more
+    used = int(r[0])
+    if used:
+        random_state.randint(0, 4294967296, size=4 * used, dtype=np.uint32)      # one 32-bit word each: the same 4 * used words the device consumed
+    st = random_state.get_state()
+    random_state.set_state((st[0], st[1], st[2], int(r[1]), float(np.int64(r[2]).view(np.float64)) if int(r[1]) else 0.0))
+    return out.view(m.shape)
+
+
 class AdditiveGaussianNoise:
-    """transforms.py:608-619: if uniform() < p: std = uniform(scale); m + N(0, std)."""
+    """transforms.py:608-619: if uniform() < p: std = uniform(scale); m + N(0, std).
+    exact=False (default): the field comes from the counter-based generator of augment.hip (same distribution, one fused pass);
+    exact=True / "device": the reference's OWN field - numpy's MT19937 + legacy polar Box-Muller reproduced on the device, bit-comparable with the reference
+    (golden g16_gauss_noise.npz); exact="host": numpy on the host + upload (the round-1 parity mode)."""
 
     def __init__(self, random_state, scale=(0.0, 1.0), execution_probability=0.1, exact=False, **kwargs):
         self.execution_probability = execution_probability
@@ -291,9 +327,11 @@ class AdditiveGaussianNoise:
         if self.random_state.uniform() < self.execution_probability:
             std = self.random_state.uniform(self.scale[0], self.scale[1])
             m = _dev(m)
-            if self.exact:
+            if self.exact == "host":
                 noise = self.random_state.normal(0, std, size=tuple(m.shape))
-                return m + torch.from_numpy(noise).to(m.device, torch.float32)   # upload of a host-generated field (parity mode)
+                return (m.double() + torch.from_numpy(noise).to(m.device)).float()   # upload of a host-generated field
+            if self.exact:
+                return _legacy_normal_on_device(self.random_state, m.contiguous().float(), std)
             seed = int(self.random_state.randint(0, 2 ** 31 - 1))
             out = torch.empty_like(m)
             check(load().mis_aug_pointwise(m.data_ptr(), out.data_ptr(), m.numel(), 1.0, 0.0, 0, 0.0, 0.0, float(std), seed, stream_ptr()),

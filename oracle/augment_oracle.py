@@ -4,6 +4,8 @@
 ((0 + i*m[d][0]) + j*m[d][1]) + offset[d], reflect the coordinate about the half-sample edges, round half up, reflect
 the index), RandomContrast :115-133, Standardize :495-523.  Pinned against tests/golden/g5_augment.npz, generated from
 the real reference classes (which call scipy itself)."""
+import math
+
 import numpy as np
 from scipy import special
 
@@ -230,3 +232,79 @@ def poisson_noise(m, rs, lam_range):
     """AdditivePoissonNoise (transforms.py:622-633) after the execution draw: lam = uniform(range); m + poisson(lam) (float64 like numpy's promotion)."""
     lam = rs.uniform(lam_range[0], lam_range[1])
     return m + rs.poisson(lam, size=m.shape)
+
+
+# ---- AdditiveGaussianNoise on the reference's stream (transforms.py:608-619) ------------------------------------------------------------------
+# The field comes from numpy's LEGACY RandomState (third-party: numpy, reference pin numpy==1.26.4, requirements.txt; algorithm unchanged since 1.17):
+# numpy/random/src/mt19937/mt19937.c (mt19937_gen / tempering), numpy/random/src/legacy/legacy-distributions.c (legacy_double, legacy_gauss, legacy_normal).
+# Restated here word by word - it is the checker of csrc/mt19937.hip and is itself pinned against a golden drawn by the real reference class.
+def mt19937_words(key, pos, n):
+    """the next n 32-bit outputs of MT19937 from (key[624] uint32, pos); returns (words, key', pos')"""
+    mt = np.array(key, dtype=np.uint64).copy()
+    out = np.empty(n, dtype=np.uint32)
+    done = 0
+    U, L, A = np.uint64(0x80000000), np.uint64(0x7fffffff), np.uint64(0x9908b0df)
+    while done < n:
+        if pos >= 624:
+            for kk in range(624):                       # mt19937_gen: in place, in index order
+                y = (mt[kk] & U) | (mt[(kk + 1) % 624] & L)
+                mt[kk] = mt[(kk + 397) % 624] ^ (y >> np.uint64(1)) ^ (A if (y & np.uint64(1)) else np.uint64(0))
+            pos = 0
+        take = min(n - done, 624 - pos)
+        y = mt[pos:pos + take].copy()
+        y ^= (y >> np.uint64(11))
+        y ^= (y << np.uint64(7)) & np.uint64(0x9d2c5680)
+        y ^= (y << np.uint64(15)) & np.uint64(0xefc60000)
+        y ^= (y >> np.uint64(18))
+        out[done:done + take] = (y & np.uint64(0xffffffff)).astype(np.uint32)
+        done += take
+        pos += take
+    return out, (mt & np.uint64(0xffffffff)).astype(np.uint32), pos
+
+
+def legacy_normal_field(words, count, scale, has_gauss=0, cached=0.0):
+    """count samples of loc=0, scale*legacy_gauss drawn from the 32-bit word stream; returns (samples float64, words consumed, has_gauss', cached')"""
+    out = np.empty(count, dtype=np.float64)
+    w = 0
+    i = 0
+
+    def dbl():
+        nonlocal w
+        a, b = int(words[w]) >> 5, int(words[w + 1]) >> 6
+        w += 2
+        return (a * 67108864.0 + b) / 9007199254740992.0
+
+    while i < count:
+        if has_gauss:
+            g, has_gauss, cached = cached, 0, 0.0
+        else:
+            while True:
+                x1 = 2.0 * dbl() - 1.0
+                x2 = 2.0 * dbl() - 1.0
+                r2 = x1 * x1 + x2 * x2
+                if r2 < 1.0 and r2 != 0.0:
+                    break
+            f = math.sqrt(-2.0 * math.log(r2) / r2)
+            cached, has_gauss = f * x1, 1
+            g = f * x2
+        out[i] = 0.0 + scale * g
+        i += 1
+    return out, w, has_gauss, cached
+
+
+def additive_gaussian_noise(m, rs, scale_range, execution_probability):
+    """the whole transform on a numpy RandomState `rs` WITHOUT calling rs.normal: decision and std from the stream as the reference draws them, the field from the
+    restatement above; the generator is left where the reference leaves it."""
+    if not (rs.uniform() < execution_probability):
+        return m
+    std = rs.uniform(scale_range[0], scale_range[1])
+    name, key, pos, has_gauss, cached = rs.get_state()
+    n = m.size
+    need = int((n * 1.3 + 200)) * 2 * 2
+    words, _, _ = mt19937_words(key, pos, need)
+    field, used, hg, cv = legacy_normal_field(words, n, std, has_gauss, cached)
+    if used:
+        rs.randint(0, 4294967296, size=used, dtype=np.uint32)
+    st = rs.get_state()
+    rs.set_state((st[0], st[1], st[2], hg, cv))
+    return m.astype(np.float64) + field.reshape(m.shape)

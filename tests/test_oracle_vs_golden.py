@@ -285,3 +285,21 @@ def test_bf16_storage_emulation_is_a_small_perturbation_of_the_pinned_oracle():
     rels = {n: ((g16[n] - g32[n]).norm() / g32[n].norm()).item() for n in g32}
     assert max(rels.values()) < 0.16 and rels["final_conv.weight"] < 1e-2, rels
     assert max(rels.values()) > 0.02          # it is NOT negligible: a bf16 kernel test against the fp32 oracle alone would have to be this loose
+
+
+def test_gaussian_noise_stream_restatement_matches_the_reference_field():
+    """oracle.augment_oracle.additive_gaussian_noise (MT19937 + numpy's legacy polar Box-Muller, restated without calling RandomState.normal) against the
+    field the REAL reference class drew (g16_gauss_noise.npz): bit-identical float64 outputs over three consecutive calls - the cached second value crosses
+    the call boundaries - and the generator ends in the reference's state."""
+    import numpy as np
+
+    from oracle import augment_oracle as ao
+    g = load_golden("g16_gauss_noise.npz")
+    rs = np.random.RandomState(777)
+    for i in range(3):
+        out = ao.additive_gaussian_noise(g[f"in_{i}"], rs, (0.05, 0.3), 1.0)
+        assert np.array_equal(out, g[f"out_{i}"]), i
+    assert np.array_equal(np.array([rs.uniform(), rs.uniform()]), g["next_uniform"])
+    rs2 = np.random.RandomState(778)
+    out = ao.additive_gaussian_noise(g["in_0"], rs2, (0.0, 1.0), 0.0)
+    assert np.array_equal(np.asarray(out, dtype=np.float64), g["skip_out"]) and rs2.uniform() == g["skip_next"][0]
