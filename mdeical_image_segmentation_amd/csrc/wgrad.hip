@@ -511,29 +511,16 @@ extern "C" size_t mis_wgrad_workspace_bytes(const MisWgradDesc* d) {
 // reduce the bias column sums.  Shared by wgrad_kernel and wgrad_pp_kernel.
 static int wg_finish(const MisWgradDesc* d, const WgPlan& p, float* bias_partial, hipStream_t stream) {
     if (d->reduce_stream != nullptr && d->reduce_stream != (void*)stream) {   // reductions go to the side stream, after the MFMA kernel
-        // Ordering side stream after the MFMA kernel.  Default: events from a small ring that lives as long as the process.  MIS_WGRAD_EVENT_PER_CALL=1
-        // = create / record / wait / destroy per call (legal HIP; kept as an experiment switch: round 1 saw nondeterministic gradients with it, in the same
-        // commit that fixed a no-op wgrad_join - DESIGN.md records which of the two it was).
-        static const bool per_call = getenv("MIS_WGRAD_EVENT_PER_CALL") != nullptr;
+        // Order the reduction stream behind the MFMA kernel: one event per call, destroyed right after the wait has been enqueued (legal HIP: the runtime keeps what the
+        // wait needs).  Round 1 kept a process-lifetime ring of events here on the suspicion that the early destroy let the side stream run ahead; the round-2 experiment
+        // (scripts/exp_event_lifetime.py: 4 x 8 unsynchronised train steps, bit-identical parameters with either scheme) showed the nondeterminism of that time came from
+        // the no-op wgrad_join ("cuda" vs "cuda:0" key) fixed in the same commit, not from event lifetime.
         const hipStream_t side = reinterpret_cast<hipStream_t>(d->reduce_stream);
-        if (per_call) {
-            hipEvent_t ev;
-            MIS_REQUIRE(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, MIS_EHIP, "wgrad: hipEventCreate failed");
-            const bool ok = hipEventRecord(ev, stream) == hipSuccess && hipStreamWaitEvent(side, ev, 0) == hipSuccess;
-            (void)hipEventDestroy(ev);
-            MIS_REQUIRE(ok, MIS_EHIP, "wgrad: could not order the reduction stream after the MFMA kernel");
-        } else {
-            static hipEvent_t ring[64];
-            static bool ring_ok[64] = {false};
-            static std::atomic<unsigned> ring_pos{0};
-            const unsigned slot = ring_pos.fetch_add(1) % 64u;
-            if (!ring_ok[slot]) {
-                MIS_REQUIRE(hipEventCreateWithFlags(&ring[slot], hipEventDisableTiming) == hipSuccess, MIS_EHIP, "wgrad: hipEventCreate failed");
-                ring_ok[slot] = true;
-            }
-            const bool ok = hipEventRecord(ring[slot], stream) == hipSuccess && hipStreamWaitEvent(side, ring[slot], 0) == hipSuccess;
-            MIS_REQUIRE(ok, MIS_EHIP, "wgrad: could not order the reduction stream after the MFMA kernel");
-        }
+        hipEvent_t ev;
+        MIS_REQUIRE(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, MIS_EHIP, "wgrad: hipEventCreate failed");
+        const bool ok = hipEventRecord(ev, stream) == hipSuccess && hipStreamWaitEvent(side, ev, 0) == hipSuccess;
+        (void)hipEventDestroy(ev);
+        MIS_REQUIRE(ok, MIS_EHIP, "wgrad: could not order the reduction stream after the MFMA kernel");
         stream = side;
     }
     int nslab = p.nsplit;

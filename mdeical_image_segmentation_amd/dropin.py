@@ -98,6 +98,8 @@ def _make_training_arguments():
     import dataclasses
 
     import transformers
+    if "TrainingArguments" in globals():
+        return globals()["TrainingArguments"]
     base = transformers.TrainingArguments
     if getattr(base, "_misamd_compat", False):
         return base
@@ -111,8 +113,10 @@ def _make_training_arguments():
         def __init__(self, *args, **kw):
             super().__init__(*args, **_compat_kwargs(kw, fields))
 
+    # importable (hence picklable: HF Trainer torch.save()s its args into every checkpoint) as <this module>.TrainingArguments
     TrainingArguments.__qualname__ = TrainingArguments.__name__ = "TrainingArguments"
-    TrainingArguments.__module__ = base.__module__
+    TrainingArguments.__module__ = __name__
+    globals()["TrainingArguments"] = TrainingArguments
     return TrainingArguments
 
 

@@ -107,8 +107,9 @@ class UNet2DEngine:
             raise MisError("out_channels must be 1..4")
         ops.load()
         self.cin, self.cout = in_channels, out_channels
-        # wgrad's slab reductions (HBM-bound) run on a second stream under the following dgrad kernel
-        self.side_reduce = os.environ.get("MISAMD_NO_SIDE_REDUCE") is None
+        # wgrad's slab reductions can run on a second stream under the following dgrad kernel (MISAMD_SIDE_REDUCE=1).  Off by default since round 2: with
+        # one slab per persistent block the reductions are small, and the measured step is the same either way (817.2 vs 817.4 img/s) - one stream less to order.
+        self.side_reduce = os.environ.get("MISAMD_SIDE_REDUCE") is not None
         self.dtype = dtype
         self.device = torch.device(device)
         self.specs = unet2d_param_specs(in_channels, out_channels)

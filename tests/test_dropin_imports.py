@@ -101,3 +101,16 @@ def test_training_arguments_accepts_the_reference_keywords(installed, tmp_path):
     # the modern spelling still works through the same class
     a2 = TrainingArguments(output_dir=out / "r2", eval_strategy="no", warmup_steps=3, report_to=[])
     assert a2.warmup_steps == 3
+
+
+def test_compat_training_arguments_pickles(installed, tmp_path):
+    """HF Trainer torch.save()s its TrainingArguments into every checkpoint: the compatibility class must be importable by name"""
+    import io
+    import pickle
+
+    import torch
+    from transformers import TrainingArguments
+    a = TrainingArguments(output_dir=tmp_path / "o", evaluation_strategy="no", warmup_ratio=0.25, report_to=[])
+    b = pickle.loads(pickle.dumps(a))
+    assert type(b) is type(a) and float(b.warmup_steps) == 0.25
+    torch.save(a, io.BytesIO())
