@@ -164,7 +164,8 @@ extern "C" int mis_debug_pp_stamps(unsigned long long* host_out) {
 #endif
 
 // NF = 16-channel fragments per wave along the output channels: 8 -> 256-column blocks (wave tile 64 px x 128 ch, one segment = one 32-channel
-// k-group), 4 -> 128-column blocks (wave tile 64 px x 64 ch, one segment = a whole 64-channel tap).  32 MFMAs per segment either way.
+// k-group), 4 -> 128-column blocks (wave tile 64 px x 64 ch, one segment = a whole 64-channel tap): 32 MFMAs per segment either way;
+// 2 -> 64-column blocks (wave tile 64 px x 32 ch, one segment = a tap = 16 MFMAs) for the layers with 64 output channels.
 template <int NF>
 __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
     using T = __bf16;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
     //   NF = 4 (2 per wave, 2 slots per step): group 0 in its R (next step), group 1 inside its M - for the step AFTER the next one: group 1's M of step s
     //          runs in the first slot of group 0's step s+1, which is when the buffer of step s (= that of step s+2) falls free.
     constexpr int WPW = (BN / 8) / 8;
-    static_assert(WPW == 4 || WPW == 2, "");
+    static_assert(WPW == 4 || WPW == 2 || WPW == 1, "");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const hbase = smem;                        // 2 x PP_HBUF
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
     issue_bias(ncol0, bbase);
     // ---- prologue: first weight tile and first halo chunk ----
     issue_weights(I0{}, IW{}, 0, ncol0, 0, wbase);
-    if constexpr (NF == 4) {
+    if constexpr (NF != 8) {
         if (grp == 1) issue_weights(I0{}, IW{}, 1, ncol0, 0, wbase + WTILE);      // group 1's share of step 1 (in the loop it issues two steps ahead)
     }
     pp_static_for<6>([&](auto jc) { (void)issue_halo(jc, n, h0, w0, 0, hbase); });
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
                                 if constexpr (NF == 8 && sg == 0) {
                                     if (wnext) issue_weights(IH{}, IW{}, wtap, wcol, wc0, wbn);
                                 }
-                                if constexpr (NF == 4) {
+                                if constexpr (NF != 8) {
                                     if (grp == 1 && w2next) issue_weights(I0{}, IW{}, w2tap, w2col, w2c0, wb_self);
                                 }
                             }
@@ -429,7 +430,7 @@ bool conv_pp_eligible(const MisConvDesc* d) {
     if (d->dtype != MIS_BF16 || d->is3d || d->ksize != 3) return false;
     if (d->x1 != nullptr || d->in_scale != nullptr) return false;
     if (d->x0_H != d->H || d->x0_W != d->W || d->D != 1) return false;
-    if (d->Cin % 64 != 0 || d->Cout % 128 != 0) return false;
+    if (d->Cin % 64 != 0 || d->Cout % 64 != 0) return false;
     if (d->Cout0 % 64 != 0) return false;              // a wave's 64 (128-column blocks) / 128 (256-column blocks) columns go to ONE destination
     if (d->bias != nullptr && (d->y0_mode == MIS_OUT_SHUFFLE2 || (d->y1 != nullptr && d->y1_mode == MIS_OUT_SHUFFLE2))) return false;   // bias is indexed by GEMM column here
     // 32-bit buffer offsets: ONE image of the input view and the packed weights must each span less than 4 GiB - 64 KiB
@@ -472,6 +473,10 @@ int launch_conv_pp(const MisConvDesc* d, hipStream_t stream, const char** tag) {
             return pp_launch<8>(d, stream);
         }
     }
-    *tag = "k3.2d.pp128";
-    return pp_launch<4>(d, stream);
+    if (d->Cout % 128 == 0) {
+        *tag = "k3.2d.pp128";
+        return pp_launch<4>(d, stream);
+    }
+    *tag = "k3.2d.pp64";
+    return pp_launch<2>(d, stream);
 }

@@ -15,6 +15,7 @@ LAYERS = [  # (H, Cin, Cout, launches per step with this shape incl. dgrads)
     (512, 64, 128, 1), (256, 128, 128, 4), (256, 128, 256, 1), (256, 256, 128, 1), (128, 256, 256, 4), (128, 256, 512, 1), (128, 512, 256, 1),
     (64, 512, 512, 4), (64, 512, 1024, 1), (64, 1024, 512, 1), (32, 1024, 1024, 2), (32, 512, 1024, 1), (32, 1024, 512, 1),
     (256, 64, 128, 1), (128, 128, 256, 1), (128, 256, 128, 1), (64, 256, 512, 1), (64, 512, 256, 1),
+    (512, 64, 64, 4), (512, 128, 64, 1), (256, 128, 64, 1),
 ]
 arms = [("pp", {}), ("nopp", {"MIS_CONV_NOPP": "1"})]
 for a in sys.argv[1:]:

@@ -33,9 +33,13 @@ K3_CASES = [
     (BF, 2, 100, 150, 128, 256, "k3.2d.bn128.persist", "MIS_CONV_NOPP"),   # persistent tiles, 280 tiles > 256 blocks
     (BF, 1, 20, 36, 64, 128, "k3.2d.bn128.persist", "MIS_CONV_NOPP"),
     (BF, 2, 20, 36, 256, 128, "k3.2d.bn128.dma", "MIS_CONV_NOPP"),
-    # 64-column layers (no ping-pong variant)
+    # 64-column layers: the weight-stationary / bn64 configurations; the ping-pong kernel with 64-column blocks is selectable (MIS_CONV_PP64=1; slower)
     (BF, 1, 70, 90, 128, 64, "k3.2d.bn64.persist", ""),  # 32x16-pixel persistent tiles
     (BF, 2, 20, 36, 128, 64, "k3.2d.bn64.v1", ""),       # small grid: 64-column 4-wave config
+    (BF, 2, 256, 256, 64, 64, "k3.2d.ws64", ""),         # weight-stationary kernel
+    (BF, 1, 70, 90, 128, 64, "k3.2d.pp64", "MIS_CONV_PP64"),
+    (BF, 2, 20, 36, 64, 64, "k3.2d.pp64", "MIS_CONV_PP64"),
+    (BF, 3, 150, 170, 64, 64, "k3.2d.pp64", "MIS_CONV_PP64"),          # 330 tiles > 256 blocks: one K chunk per tile, tile loop taken
     (F32, 2, 20, 36, 64, 128, "k3.2d.bn128.persist", ""),
     (F32, 1, 9, 17, 128, 256, "k3.2d.bn128.dma", ""),
     (F32, 1, 70, 90, 64, 64, "k3.2d.bn64.persist", ""),
