@@ -1,0 +1,40 @@
+"""profiles/traffic.json from a PMC summary (scripts/pmc_summary.py) of `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-kernel-timing`:
+HBM bytes per launch of the bench's dominant kernel KEYS, launch-weighted over the kernel symbols that make up a key, stamped with the hash of the
+kernel sources (so bench.py only reports the figure for the build it was measured on).
+
+    python scripts/make_traffic.py profiles/r02_pmc_summary.json > profiles/traffic.json"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mdeical_image_segmentation_amd import _lib  # noqa: E402
+
+KEYS = {   # bench key -> kernel symbols (prefix match on the rocprof name) whose launches carry that key at the benchmark shapes
+    "conv_igemm/bf16/k3/2d/bn128": ["void conv_pp_kernel<8>", "void conv_pp_kernel<4>"],
+    "wgrad/bf16/k3/2d": ["wgrad_pp_wide_kernel", "void wgrad_pp_kernel<2>"],
+    "conv_igemm/bf16/k3/2d/bn64": ["conv64_ws_kernel"],
+}
+
+
+def main(path):
+    summ = json.load(open(path))
+    out = {"source_hash": _lib.source_hash(), "batch": 32, "size": 512, "profile": os.path.basename(path), "kernels": {}}
+    for key, syms in KEYS.items():
+        rd = wr = n = 0.0
+        used = []
+        for e in summ:
+            if any(e["kernel"].startswith(s) for s in syms) and "hbm_read_bytes_per_launch_x2_corrected" in e and "hbm_write_bytes_per_launch" in e:
+                k = e["launches"]
+                rd += e["hbm_read_bytes_per_launch_x2_corrected"] * k
+                wr += e["hbm_write_bytes_per_launch"] * k
+                n += k
+                used.append(f"{e['kernel'][:40]} x{k}")
+        if n:
+            out["kernels"][key] = {"hbm_read_bytes_per_launch": int(rd / n), "hbm_write_bytes_per_launch": int(wr / n), "launches_profiled": int(n),
+                                   "symbols": used, "note": "FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, separate --pmc passes"}
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
