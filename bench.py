@@ -207,12 +207,19 @@ def main():
         cpu = cpu_baseline()
 
     import torch.distributed as dist
+    if os.environ.get("MISAMD_BENCH_REHEARSAL"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl", (dist.get_world_size(), dist.get_backend())
+        # MISAMD_BENCH_REHEARSAL=gloo: several ranks SHARING one GPU over gloo - exercises the N > 1 code path (buckets, comm report) on a one-GPU box; never a number
+        backend = os.environ.get("MISAMD_BENCH_REHEARSAL", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == backend, (dist.get_world_size(), dist.get_backend())
         if args.comm == "native":
             from mdeical_image_segmentation_amd.ddp import native_comm_init
             assert native_comm_init() == args.gpus
