@@ -239,6 +239,23 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
     const char* const xb = reinterpret_cast<const char*>(a.x0.p);
     const __amdgpu_buffer_rsrc_t rw = pp_make_rsrc(a.w, (unsigned)((long long)9 * a.Cout * a.Cin * 2));
 
+    // Every instruction of an R segment costs the wave ~10 cycles (it shares the SIMD's issue port with its partner's MFMA cluster), so a halo DMA should be a handful of
+    // instructions: where registers allow (128- / 64-column variants) the per-lane source offset and halo coordinates of the wave's six halo instructions are computed
+    // ONCE; the 256-column variant (252 VGPRs) recomputes them at every issue instead.
+    constexpr bool HPRE = (NF != 8);
+    unsigned h_rel[HPRE ? 6 : 1];
+    int h_coord[HPRE ? 6 : 1];                    // halo row | halo column << 8; -1: no item (tail of the last instruction / no such instruction)
+    if constexpr (HPRE) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int id = j * 8 + wave;
+            const int item = id * 64 + lane;
+            const int p = item >> 3, pos = item & 7;
+            const int py = p / PP_HW, px = p - py * PP_HW;
+            h_rel[j] = (unsigned)(((py * a.W + px) * a.x0.ld + ((pos ^ (px & 7)) << 3)) * 2);
+            h_coord[j] = (id < PP_HINSTR && item < PP_HITEMS) ? (py | (px << 8)) : -1;
+        }
+    }
     // one halo DMA of this wave: instruction id = j*8 + wave of the chunk image (n, h0, w0, channels c0..c0+63) into `dst`; false if id is past the image
     auto issue_halo = [&](auto jc, int n, int h0, int w0, int c0, char* dst) -> bool {
         constexpr int j = decltype(jc)::value;
@@ -247,15 +264,25 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
         const __amdgpu_buffer_rsrc_t rx = pp_make_rsrc(xb + (size_t)n * a.H * a.W * a.x0.ld * 2, img_x);
         // byte offset of halo pixel (0, 0) = image pixel (h0 - 1, w0 - 1) within the image: "negative" (wraps) for tiles on the top / left border, where only valid items add to it
         unsigned toff = (unsigned)((((h0 - 1) * a.W + (w0 - 1)) * a.x0.ld + c0) * 2);
-        asm volatile("" : "+s"(toff));                // opaque: keeps hipcc from pre-computing (and spilling) the offsets of a whole chunk's steps
-        // lane -> 16-byte slot of the image -> (halo pixel, channel chunk): the chunk position in LDS is XORed with (halo column & 7)
-        int item = id * 64 + lane;
-        asm volatile("" : "+v"(item));                // recomputed at every issue (a dozen VALU ops) instead of living in registers across the tile loop
-        const int p = item >> 3, pos = item & 7;
-        const int py = p / PP_HW, px = p - py * PP_HW;
-        const unsigned rel = (unsigned)(((py * a.W + px) * a.x0.ld + ((pos ^ (px & 7)) << 3)) * 2);
-        const bool ok = item < PP_HITEMS && (unsigned)(h0 - 1 + py) < (unsigned)a.H && (unsigned)(w0 - 1 + px) < (unsigned)a.W;
-        pp_dma16(rx, ok ? (int)(toff + rel) : PP_OOB, dst + id * 1024);
+        if constexpr (HPRE) {
+            const bool interior = h0 >= 1 && h0 + PP_TH + 1 <= a.H && w0 >= 1 && w0 + PP_TW + 1 <= a.W;        // block-uniform
+            bool ok = h_coord[j] >= 0;
+            if (!interior) {
+                const int py = h_coord[j] & 0xff, px = h_coord[j] >> 8;
+                ok = ok && (unsigned)(h0 - 1 + py) < (unsigned)a.H && (unsigned)(w0 - 1 + px) < (unsigned)a.W;
+            }
+            pp_dma16(rx, ok ? (int)(toff + h_rel[j]) : PP_OOB, dst + id * 1024);
+        } else {
+            asm volatile("" : "+s"(toff));                // opaque: keeps hipcc from pre-computing (and spilling) the offsets of a whole chunk's steps
+            // lane -> 16-byte slot of the image -> (halo pixel, channel chunk): the chunk position in LDS is XORed with (halo column & 7)
+            int item = id * 64 + lane;
+            asm volatile("" : "+v"(item));                // recomputed at every issue instead of living in registers across the tile loop
+            const int p = item >> 3, pos = item & 7;
+            const int py = p / PP_HW, px = p - py * PP_HW;
+            const unsigned rel = (unsigned)(((py * a.W + px) * a.x0.ld + ((pos ^ (px & 7)) << 3)) * 2);
+            const bool ok = item < PP_HITEMS && (unsigned)(h0 - 1 + py) < (unsigned)a.H && (unsigned)(w0 - 1 + px) < (unsigned)a.W;
+            pp_dma16(rx, ok ? (int)(toff + rel) : PP_OOB, dst + id * 1024);
+        }
         return true;
     };
     // bias slice of a column tile -> LDS, 4 bytes per lane (waves 0 .. BN/64-1; without a bias the zero-sized buffer reads as zeros)
@@ -288,7 +315,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
     // ---- prologue: first weight tile and first halo chunk ----
     issue_weights(I0{}, IW{}, 0, ncol0, 0, wbase);
     if constexpr (NF != 8) {
-        if (grp == 1) issue_weights(I0{}, IW{}, 1, ncol0, 0, wbase + WTILE);      // group 1's share of step 1 (in the loop it issues two steps ahead)
+        if (grp == 1) issue_weights(I0{}, IW{}, 3, ncol0, 0, wbase + WTILE);      // group 1's share of step 1 = tap (kh 1, kw 0) (in the loop it issues two steps ahead)
     }
     pp_static_for<6>([&](auto jc) { (void)issue_halo(jc, n, h0, w0, 0, hbase); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -315,19 +342,25 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
             const int hn = last_chunk ? nn : n, hh0 = last_chunk ? nh0 : h0, hw0 = last_chunk ? nw0 : w0, hc0 = last_chunk ? 0 : c0 + 64;
             const uint32_t hb = (uint32_t)(uintptr_t)hbase + hsel * PP_HBUF;      // LDS byte addresses (asm reads)
             char* hbn = hbase + (hsel ^ 1) * PP_HBUF;
+            // Taps are walked COLUMN-major (kw outer, kh inner): the pixel fragment of tile row r for tap (kh, kw) is the fragment of row r + 1 for tap (kh - 1, kw), so
+            // in the 128- / 64-column variants the three taps of a filter column share six row fragments held in registers (4 + 1 + 1 reads instead of 3 x 4 per
+            // k-group: a quarter fewer ds_reads in the variant that is bound by its R segments).  The 256-column variant has no registers to spare and re-reads.
+            constexpr bool BREUSE = (NF != 8);
+            u32x4 Brow[BREUSE ? SEGK : 1][BREUSE ? 6 : 1];
             pp_static_for<9>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
-                constexpr int kh = t / 3, kw = t % 3;
+                constexpr int kw = t / 3, kh = t % 3;
+                auto tapidx = [](int tt) { return (tt % 3) * 3 + tt / 3; };       // loop position -> tap index (kh * 3 + kw) of the packed weights
                 const uint32_t wb = (uint32_t)(uintptr_t)wbase + wsel * WTILE;
                 char* wbn = wbase + (wsel ^ 1) * WTILE;
                 // the step after this one: next tap; after the last tap the next chunk's (or the next tile's) first tap
                 const bool wnext = (t < 8) || hnext;
-                const int wtap = (t < 8) ? t + 1 : 0;
+                const int wtap = (t < 8) ? tapidx(t + 1) : 0;
                 const int wcol = (t < 8 || !last_chunk) ? ncol0 : ncolN;
                 const int wc0 = (t < 8) ? c0 : hc0;
                 // ... and the one after that (NF = 4, group 1)
                 const bool w2next = (t < 7) || hnext;
-                const int w2tap = (t < 7) ? t + 2 : t - 7;
+                const int w2tap = tapidx((t + 2) % 9);
                 const int w2col = (t < 7 || !last_chunk) ? ncol0 : ncolN;
                 const int w2c0 = (t < 7) ? c0 : hc0;
                 char* wb_self = wbase + wsel * WTILE;     // the buffer this step reads = the buffer of the step after the next one
@@ -353,10 +386,19 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
                             constexpr int f = decltype(fc)::value;
                             A[s][f] = pp_lds_read128<f * 2048>(wb + (a_off0 ^ (kg << 6)));
                         });
-                        pp_static_for<PF>([&](auto pc) {
-                            constexpr int pf = decltype(pc)::value;
-                            B[s][pf] = pp_lds_read128<(pf + kh) * PP_ROWB>(hb + (b_off0[kw] ^ (kg << 6)));
-                        });
+                        if constexpr (BREUSE) {
+                            // rows needed by this tap: kh .. kh + 3; rows 0..3 are read at kh == 0, row 4 at kh == 1, row 5 at kh == 2
+                            pp_static_for<6>([&](auto rc) {
+                                constexpr int r = decltype(rc)::value;
+                                if constexpr ((kh == 0 && r < 4) || (kh == 1 && r == 4) || (kh == 2 && r == 5))
+                                    Brow[s][r] = pp_lds_read128<r * PP_ROWB>(hb + (b_off0[kw] ^ (kg << 6)));
+                            });
+                        } else {
+                            pp_static_for<PF>([&](auto pc) {
+                                constexpr int pf = decltype(pc)::value;
+                                B[s][pf] = pp_lds_read128<(pf + kh) * PP_ROWB>(hb + (b_off0[kw] ^ (kg << 6)));
+                            });
+                        }
                     });
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragments in registers; also: this wave's reads of both buffers are over
                     __builtin_amdgcn_sched_barrier(0);                      // no consumer may move above the wait (the asm reads are opaque to hipcc)
@@ -380,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
 #pragma unroll
                         for (int f = 0; f < NF; ++f) {
 #pragma unroll
-                            for (int pf = 0; pf < PF; ++pf) mma_b128<T>(acc[f][pf], A[s][f], B[s][pf]);
+                            for (int pf = 0; pf < PF; ++pf) mma_b128<T>(acc[f][pf], A[s][f], BREUSE ? Brow[s][pf + kh] : B[s][pf]);
                             if (s == 0 && f == 1) {      // the second half of the weight DMAs goes out from inside the MFMA cluster
                                 if constexpr (NF == 8 && sg == 0) {
                                     if (wnext) issue_weights(IH{}, IW{}, wtap, wcol, wc0, wbn);
