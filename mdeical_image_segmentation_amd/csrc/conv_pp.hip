@@ -147,7 +147,8 @@ __device__ __forceinline__ void pp_epilogue(const ConvArgs& a, f32x4 (&acc)[NF][
 }
 
 // Diagnostic build (-DMIS_PP_STAMPS, never shipped): per wave, shader cycles spent (0) working in R segments, (1) parked at the barrier that ends an R segment,
-// (2) working in M segments, (3) parked at the barrier that ends an M segment, (4) in the tile-end epilogue; read back with mis_debug_pp_stamps().
+// (2) working in M segments, (3) parked at the barrier that ends an M segment, (4) in the tile-end epilogue; R work is split further: (5) DMA issue incl. its scalar
+// bookkeeping, (6) issuing the fragment reads, (7) waiting for them (lgkmcnt), (0) the rest (vmcnt drain); read back with mis_debug_pp_stamps().
 #ifdef MIS_PP_STAMPS
 __device__ unsigned long long g_pp_stamps[256 * 8 * 8];
 extern "C" int mis_debug_pp_stamps(unsigned long long* host_out) {
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
 
     int wsel = 0, hsel = 0, bsel = 0;
 #ifdef MIS_PP_STAMPS
-    unsigned long long st_[5] = {0, 0, 0, 0, 0}, tp_ = __builtin_amdgcn_s_memtime();
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp_ = __builtin_amdgcn_s_memtime();
 #endif
     if (grp == 1) __builtin_amdgcn_s_barrier();       // the stagger: group 1 runs one slot behind group 0
     __builtin_amdgcn_sched_barrier(0);
@@ -378,6 +379,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
                     if constexpr (sg == SPS - 1 && t < 6) {
                         if (hnext) hi = issue_halo(std::integral_constant<int, t>{}, hn, hh0, hw0, hc0, hbn);
                     }
+                    PP_STAMP(5)
                     u32x4 A[SEGK][NF], B[SEGK][PF];
                     pp_static_for<SEGK>([&](auto sc) {
                         constexpr int s = decltype(sc)::value;
@@ -400,8 +402,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
                             });
                         }
                     });
+                    PP_STAMP(6)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragments in registers; also: this wave's reads of both buffers are over
                     __builtin_amdgcn_sched_barrier(0);                      // no consumer may move above the wait (the asm reads are opaque to hipcc)
+                    PP_STAMP(7)
                     if constexpr (sg == SPS - 1) {
                         // group 1's last slot of the step: its weight DMAs for the next step (issued one slot-pair ago) must have landed; a halo DMA issued in this
                         // segment is the youngest op and stays in flight
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
     if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's last barrier
 #ifdef MIS_PP_STAMPS
     if (lane == 0 && blockIdx.x < 256) {
-        for (int i = 0; i < 5; ++i) g_pp_stamps[(blockIdx.x * 8 + wave) * 8 + i] = st_[i];
+        for (int i = 0; i < 8; ++i) g_pp_stamps[(blockIdx.x * 8 + wave) * 8 + i] = st_[i];
     }
 #endif
 }

@@ -23,8 +23,8 @@ torch.cuda.synchronize()
 lib = ops.load()
 buf = np.zeros(256 * 8 * 8, dtype=np.uint64)
 assert lib.mis_debug_pp_stamps(buf.ctypes.data_as(C.c_void_p)) == 0
-st = buf.reshape(256, 8, 8)[:, :, :5].astype(np.float64)
-names = ["R work", "R barrier", "M work", "M barrier", "epilogue"]
+st = buf.reshape(256, 8, 8).astype(np.float64)
+names = ["R rest/drain", "R barrier", "M work", "M barrier", "epilogue", "R dma issue", "R read issue", "R lgkm wait"]
 print(ops.conv_last_dispatch(), f"{H}^2 {Cin}->{Cout}")
 for grp, sl in (("group 0 (waves 0-3)", slice(0, 4)), ("group 1 (waves 4-7)", slice(4, 8))):
     m = st[:, sl].mean((0, 1))

@@ -63,3 +63,34 @@ def test_3d_full_size_determinism_and_sample_independence():
     assert torch.isfinite(g1).all()
     _, lg0, am0, _ = run(x[:1].contiguous(), t[:1].contiguous())
     assert torch.equal(lg0, lg1[:1]) and torch.equal(am0, am1[:1]), "GroupNorm statistics leak across samples"
+
+
+def test_ping_pong_kernels_beyond_4gib_tensors():
+    """The ping-pong kernels address their operands through PER-IMAGE buffer resources with 32-bit offsets: tensors far beyond 4 GiB in total (here 40 images of
+    512 x 512 x 128 bf16 = 5.4 GB in, 10.7 GB dY) must behave exactly like small batches.  Checked by batch independence (the last and the first two images of the big
+    batch against a 2-image run: bit-equal conv outputs) and linearity of the weight gradient (40-image dW == sum of per-slice dWs to fp32 accumulation order)."""
+    from mdeical_image_segmentation_amd import ops
+    N, H, W, Cin, Cout = 40, 512, 512, 128, 256
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(N, H, W, Cin, device=DEV, generator=gen).to(torch.bfloat16)
+    assert x.numel() * 2 > (1 << 32)
+    w = (torch.randn(9, Cout, Cin, device=DEV, generator=gen) * (9 * Cin) ** -0.5).to(torch.bfloat16)
+    b = torch.randn(Cout, device=DEV, generator=gen)
+    y = torch.empty(N, H, W, Cout, device=DEV, dtype=torch.bfloat16)
+    ops.conv_igemm(x, w, y, ksize=3, Cin=Cin, Cout=Cout, bias=b, relu=True)
+    assert ops.conv_last_dispatch() == "k3.2d.pp256"
+    for sl in (slice(0, 2), slice(N - 2, N)):
+        ys = torch.empty(2, H, W, Cout, device=DEV, dtype=torch.bfloat16)
+        ops.conv_igemm(x[sl].contiguous(), w, ys, ksize=3, Cin=Cin, Cout=Cout, bias=b, relu=True)
+        assert torch.equal(ys, y[sl]), "an image's output depends on its position in a > 4 GiB batch"
+    # weight gradient over the whole batch vs the sum over 8-image slices (y doubles as dY)
+    dw = torch.empty(Cout, Cin, 3, 3, device=DEV)
+    ops.wgrad(x, y, dw, ksize=3, Cin=Cin, Cout=Cout)
+    assert ops.wgrad_last_dispatch()[0] == "k3.2d.ppw"
+    acc = torch.zeros_like(dw)
+    part = torch.empty_like(dw)
+    for i in range(0, N, 8):
+        ops.wgrad(x[i:i + 8].contiguous(), y[i:i + 8].contiguous(), part, ksize=3, Cin=Cin, Cout=Cout)
+        acc += part
+    rel = ((dw - acc).norm() / acc.norm()).item()
+    assert rel < 1e-5, rel
