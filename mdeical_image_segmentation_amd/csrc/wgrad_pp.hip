@@ -299,37 +299,44 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_kernel(const WgArgs a) {
 // 32-pixel k-step from 26 transposing reads instead of 44 - the 64 x 64 kernel above is bound by its R segments, i.e. by LDS reads per MFMA).  A step stages a
 // 16 x 8-pixel tile: halo (18 x 10 px x 64 ci, 128-byte rows) + dY (128 px x 128 co, 256-byte rows with the chunk position XORed with (column & 7) << 1, which keeps
 // a pixel's two 16-byte halves of a fragment apart from its neighbours' over all 64 banks).  Group 0 = output channels 0-63, group 1 = 64-127; a segment = one k-step.
-namespace {
-constexpr int W3_TH = 8, W3_PH = W3_TH + 2;
-constexpr int W3_PITEMS = W3_PH * WP_HW * 8;           // 1440
-constexpr int W3_PINSTR = (W3_PITEMS + 63) / 64;      // 23
-constexpr int W3_PBUF = W3_PINSTR * 1024;
-constexpr int W3_QINSTR = 128 * 16 / 64;              // 32: 4 pixels x 16 chunks per instruction
-constexpr int W3_QBUF = W3_QINSTR * 1024;
-constexpr int W3_STAGE = W3_PBUF + W3_QBUF;           // 56,320
-constexpr int W3_NPJ = (W3_PINSTR + 7) / 8;           // 3 halo instructions per wave
-constexpr int W3_NQJ = W3_QINSTR / 8;                 // 4 dY instructions per wave
-constexpr int W3_PER_WAVE = W3_NPJ + W3_NQJ;          // 7
-}
+// Template W3<SPLIT>: SPLIT = false is the layout described above (Cout % 128 == 0).  SPLIT = true serves the layers with 64 output channels per tile with the SAME
+// wave tile (16 ci x 64 co): a block owns 64 ci x 64 co, stages 16 x 16-pixel tiles (dY with 128-byte rows), group 0 accumulates tile rows 0-7 and group 1 rows 8-15 into
+// their own accumulators, and each group writes its own slab (2 slabs per block).
+template <bool SPLIT> struct W3 {
+    static constexpr int TH = SPLIT ? 16 : 8, PH = TH + 2;
+    static constexpr int CO = SPLIT ? 64 : 128;                       // output channels per block
+    static constexpr int QROW = CO * 2;                               // bytes per dY pixel row
+    static constexpr int PITEMS = PH * WP_HW * 8;
+    static constexpr int PINSTR = (PITEMS + 63) / 64;                 // 41 / 23
+    static constexpr int PBUF = PINSTR * 1024;
+    static constexpr int QINSTR = TH * 16 * (QROW / 16) / 64;         // 32 either way
+    static constexpr int QBUF = QINSTR * 1024;
+    static constexpr int STAGE = PBUF + QBUF;
+    static constexpr int NPJ = (PINSTR + 7) / 8;                      // halo instructions per wave: 6 / 3
+    static constexpr int NQJ = QINSTR / 8;                            // 4
+    static constexpr int PER_WAVE = NPJ + NQJ;
+};
 
+template <bool SPLIT>
 __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
-    constexpr int NS = 4;                              // segments per step = k-steps of the 128-pixel tile
-    constexpr int DPS = (W3_PER_WAVE + NS - 2) / (NS - 1);   // 3 DMA instructions per wave and R segment (none in the last one)
+    using G = W3<SPLIT>;
+    constexpr int NS = 4;                              // segments per step = the k-steps of a group's 128 pixels
+    constexpr int DPS = (G::PER_WAVE + NS - 2) / (NS - 1);   // DMA instructions per wave and R segment (none in the last one)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, wi = wave & 3, wj = wave >> 2;
+    const int grp = wave >> 2, wi = wave & 3, wj = SPLIT ? 0 : (wave >> 2);
     const int li = lane & 15, lg = lane >> 4;
     const int q = li >> 2, pp = li & 3;
 
-    const int npairs = a.nCi * a.nCo;                  // nCo counts 128-column tiles here
+    const int npairs = a.nCi * a.nCo;                  // nCo counts G::CO-column tiles
     int v = xcd_remap(blockIdx.x, gridDim.x);
     const int pair = v % npairs;
     const int split = v / npairs;
     const int ci_t = pair / a.nCo, co_t = pair - ci_t * a.nCo;
-    const int ci0 = ci_t * 64, co0 = co_t * 128;
+    const int ci0 = ci_t * 64, co0 = co_t * G::CO;
     const int t_begin = split * a.tps;
     int t_end = t_begin + a.tps;
     if (t_end > a.ntiles) t_end = a.ntiles;
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
         n = t / tpi;
         const int r = t - n * tpi;
         const int th = r / a.tilesW;
-        h0 = th * W3_TH;
+        h0 = th * G::TH;
         w0 = (r - th * a.tilesW) * WP_TW;
     };
 
@@ -347,40 +354,43 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
     for (int s = 0; s < 2; ++s) {
         const int u = (lg & 1) + 2 * s + 4 * (lg >> 1);
         const int hy = u >> 2, wx = (u & 3) * 4 + q;
-        qoff[s] = (hy * 16 + wx) * 256 + (((wj * 8 + (pp >> 1)) ^ ((wx & 7) << 1)) << 4) + (pp & 1) * 8;      // fragment fj: ^ (fj << 5)
+        if (SPLIT) qoff[s] = (hy * 16 + wx) * 128 + (((pp >> 1) ^ (wx & 7)) << 4) + (pp & 1) * 8;                       // fragment fj: ^ (fj << 5)
+        else qoff[s] = (hy * 16 + wx) * 256 + (((wj * 8 + (pp >> 1)) ^ ((wx & 7) << 1)) << 4) + (pp & 1) * 8;
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
             const int px = wx + kw;
             poff[s][kw] = (hy * WP_HW + px) * 128 + (((wi * 2 + (pp >> 1)) ^ (px & 7)) << 4) + (pp & 1) * 8;
         }
     }
-    unsigned prel[W3_NPJ];
-    int pcoord[W3_NPJ];
+    unsigned prel[G::NPJ];
+    int pcoord[G::NPJ];
 #pragma unroll
-    for (int j = 0; j < W3_NPJ; ++j) {
+    for (int j = 0; j < G::NPJ; ++j) {
         const int id = wave + 8 * j;
         const int item = id * 64 + lane;
         const int p = item >> 3, pos = item & 7;
         const int py = p / WP_HW, px = p - py * WP_HW;
-        const bool have = id < W3_PINSTR && item < W3_PITEMS;
+        const bool have = id < G::PINSTR && item < G::PITEMS;
         prel[j] = (unsigned)(((py * a.W + px) * a.x0.ld + ((pos ^ (px & 7)) << 3)) * 2);
         pcoord[j] = have ? (py | (px << 8)) : -1;
     }
-    // dY instruction i = wave + 8j: tile row i >> 2, columns 4 * (i & 3) .. + 3 (i & 3 == wave & 3 for every j); lane -> (column + (lane >> 4), chunk position lane & 15)
-    const int qcol = 4 * (wave & 3) + (lane >> 4);
-    const unsigned qlane = (unsigned)((qcol * a.dy_ld + (((lane & 15) ^ ((qcol & 7) << 1)) << 3)) * 2);
+    // dY instruction i = wave + 8j.  SPLIT: tile row i >> 1, columns 8 * (i & 1) + (lane >> 3), chunk position lane & 7 (XOR column & 7); (i & 1) == (wave & 1) for every j.
+    //                              else: tile row i >> 2, columns 4 * (i & 3) + (lane >> 4), chunk position lane & 15 (XOR (column & 7) << 1); (i & 3) == (wave & 3).
+    const int qcol = SPLIT ? 8 * (wave & 1) + (lane >> 3) : 4 * (wave & 3) + (lane >> 4);
+    const unsigned qlane = SPLIT ? (unsigned)((qcol * a.dy_ld + (((lane & 7) ^ (qcol & 7)) << 3)) * 2)
+                                 : (unsigned)((qcol * a.dy_ld + (((lane & 15) ^ ((qcol & 7) << 1)) << 3)) * 2);
 
     const unsigned img_x = (unsigned)(((long long)a.H * a.W - 1) * a.x0.ld + a.Cin) * 2u, img_q = (unsigned)(((long long)a.H * a.W - 1) * a.dy_ld + a.Cout) * 2u;
     const char* const xb = reinterpret_cast<const char*>(a.x0.p);
     const char* const qb = reinterpret_cast<const char*>(a.dy);
     auto issue = [&](auto jc, int n, int h0, int w0, char* stage) {
         constexpr int jj = decltype(jc)::value;
-        if constexpr (jj < W3_NPJ) {
+        if constexpr (jj < G::NPJ) {
             const int id = wave + 8 * jj;
-            if (id >= W3_PINSTR) return;
+            if (id >= G::PINSTR) return;
             const __amdgpu_buffer_rsrc_t rx = wp_make_rsrc(xb + (size_t)n * a.H * a.W * a.x0.ld * 2, img_x);
             const unsigned toff = (unsigned)((((h0 - 1) * a.W + (w0 - 1)) * a.x0.ld + ci0) * 2);
-            const bool interior = h0 >= 1 && h0 + W3_TH + 1 <= a.H && w0 >= 1 && w0 + WP_TW + 1 <= a.W;
+            const bool interior = h0 >= 1 && h0 + G::TH + 1 <= a.H && w0 >= 1 && w0 + WP_TW + 1 <= a.W;
             bool ok = pcoord[jj] >= 0;
             if (!interior) {
                 const int py = pcoord[jj] & 0xff, px = pcoord[jj] >> 8;
@@ -388,12 +398,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
             }
             wp_dma16(rx, ok ? (int)(toff + prel[jj]) : WP_OOB, stage + id * 1024);
         } else {
-            const int i = wave + 8 * (jj - W3_NPJ);
+            const int i = wave + 8 * (jj - G::NPJ);
             const __amdgpu_buffer_rsrc_t rq = wp_make_rsrc(qb + (size_t)n * a.H * a.W * a.dy_ld * 2, img_q);
-            const int hy = i >> 2;
+            const int hy = SPLIT ? (i >> 1) : (i >> 2);
             const unsigned toff = (unsigned)((((h0 + hy) * a.W + w0) * a.dy_ld + co0) * 2);
             const bool ok = (h0 + hy) < a.H && (w0 + qcol) < a.W;
-            wp_dma16(rq, ok ? (int)(toff + qlane) : WP_OOB, stage + W3_PBUF + i * 1024);
+            wp_dma16(rq, ok ? (int)(toff + qlane) : WP_OOB, stage + G::PBUF + i * 1024);
         }
     };
 
@@ -402,12 +412,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int fj = 0; fj < 4; ++fj) acc[t][fj] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = (a.bias_partial != nullptr) && (ci_t == 0) && (wi == 0);     // waves 0 and 4
+    const bool do_bias = (a.bias_partial != nullptr) && (ci_t == 0) && (wi == 0);     // one wave per group
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
     int n, h0, w0;
     tile_coords(t_begin, n, h0, w0);
-    wp_static_for<W3_PER_WAVE>([&](auto jc) { issue(jc, n, h0, w0, smem); });
+    wp_static_for<G::PER_WAVE>([&](auto jc) { issue(jc, n, h0, w0, smem); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -421,9 +431,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
         int nn = n, nh0 = h0, nw0 = w0;
         if (has_next) tile_coords(t + 1, nn, nh0, nw0);
         const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-        const uint32_t lds_p = lds0 + sel * W3_STAGE;
-        const uint32_t lds_q = lds0 + sel * W3_STAGE + W3_PBUF;
-        char* nstage = smem + (sel ^ 1) * W3_STAGE;
+        const uint32_t lds_p = lds0 + sel * G::STAGE + (SPLIT ? grp * (8 * WP_ROWB) : 0);              // SPLIT: this group's 8 tile rows (+ 2 halo rows)
+        const uint32_t lds_q = lds0 + sel * G::STAGE + G::PBUF + (SPLIT ? grp * (8 * 16 * 128) : 0);
+        char* nstage = smem + (sel ^ 1) * G::STAGE;
         wp_static_for<NS>([&](auto sgc) {
             constexpr int ks = decltype(sgc)::value;
             // ================= R segment =================
@@ -431,14 +441,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
                 if (has_next) {
                     wp_static_for<DPS>([&](auto dc) {
                         constexpr int jj = ks * DPS + decltype(dc)::value;
-                        if constexpr (jj < W3_PER_WAVE) issue(std::integral_constant<int, jj>{}, nn, nh0, nw0, nstage);
+                        if constexpr (jj < G::PER_WAVE) issue(std::integral_constant<int, jj>{}, nn, nh0, nw0, nstage);
                     });
                 }
             }
             bf16x8_t B[4], A[9];
             wp_static_for<4>([&](auto fjc) {
                 constexpr int fj = decltype(fjc)::value;
-                B[fj] = wp_frag<ks * (2 * 16 * 256)>(lds_q + (qoff[0] ^ (fj << 5)), lds_q + (qoff[1] ^ (fj << 5)));
+                B[fj] = wp_frag<ks * (2 * 16 * G::QROW)>(lds_q + (qoff[0] ^ (fj << 5)), lds_q + (qoff[1] ^ (fj << 5)));
             });
             wp_static_for<9>([&](auto tc) {
                 constexpr int tap = decltype(tc)::value;
@@ -475,7 +485,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
         n = nn; h0 = nh0; w0 = nw0;
     }
 
-    float* out = a.partial + (size_t)split * a.TT * a.Cin * a.Cout;
+    const int se = SPLIT ? 2 * split + grp : split;            // SPLIT: one slab per wave group
+    float* out = a.partial + (size_t)se * a.TT * a.Cin * a.Cout;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -493,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
             float s = bsum[fj];
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
-            if (lg == 0) a.bias_partial[(size_t)split * a.Cout + co0 + (wj * 4 + fj) * 16 + li] = s;
+            if (lg == 0) a.bias_partial[(size_t)se * a.Cout + co0 + (wj * 4 + fj) * 16 + li] = s;
         }
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
@@ -512,14 +523,19 @@ bool wgrad_pp_eligible(const MisWgradDesc* d) {
     return true;
 }
 
-static bool wp_wide(const MisWgradDesc* d) { return d->Cout % 128 == 0 && getenv("MIS_WGRAD_PP_NOWIDE") == nullptr; }
+// kernel choice: 0 = wide (Cout % 128 == 0), 1 = pixel-split wide tile (64-column tiles), 2 = the 64 x 64 kernel with 16 x 32 wave tiles (MIS_WGRAD_PP_NOWIDE=1)
+static int wp_kind(const MisWgradDesc* d) {
+    if (getenv("MIS_WGRAD_PP_NOWIDE") != nullptr) return 2;
+    return d->Cout % 128 == 0 ? 0 : 1;
+}
 
 static void wp_plan(const MisWgradDesc* d, int* ntiles, int* tps, int* nsb, int* tilesH, int* tilesW) {
-    const bool wide = wp_wide(d);
-    *tilesH = (d->H + (wide ? W3_TH : WP_TH) - 1) / (wide ? W3_TH : WP_TH);
+    const int kind = wp_kind(d);
+    const int th = kind == 0 ? 8 : 16;
+    *tilesH = (d->H + th - 1) / th;
     *tilesW = (d->W + WP_TW - 1) / WP_TW;
     const long long nt = (long long)d->N * *tilesH * *tilesW;
-    const long long npairs = (long long)(d->Cin / 64) * (d->Cout / (wide ? 128 : 64));
+    const long long npairs = (long long)(d->Cin / 64) * (d->Cout / (kind == 0 ? 128 : 64));
     long long want = 256 / npairs;                // one persistent block per CU
     if (want < 1) want = 1;
     if (want > nt) want = nt;
@@ -531,7 +547,7 @@ static void wp_plan(const MisWgradDesc* d, int* ntiles, int* tps, int* nsb, int*
 int wgrad_pp_nsplit(const MisWgradDesc* d) {
     int ntiles, tps, nsb, th, tw;
     wp_plan(d, &ntiles, &tps, &nsb, &th, &tw);
-    return nsb;
+    return wp_kind(d) == 1 ? 2 * nsb : nsb;
 }
 
 int launch_wgrad_pp(const MisWgradDesc* d, float* partial, float* bias_partial, hipStream_t stream, const char** tag) {
@@ -542,19 +558,25 @@ int launch_wgrad_pp(const MisWgradDesc* d, float* partial, float* bias_partial, 
     a.in_scale = nullptr; a.in_shift = nullptr;
     a.dy = d->dy; a.dy_ld = d->dy_ld; a.partial = partial; a.bias_partial = bias_partial;
     int nsb;
-    const bool wide = wp_wide(d);
+    const int kind = wp_kind(d);
     wp_plan(d, &a.ntiles, &a.tps, &nsb, &a.tilesH, &a.tilesW);
     MIS_REQUIRE((long long)d->N * a.tilesH * a.tilesW < (1ll << 30), MIS_EUNSUPPORTED, "wgrad(pp): too many pixel tiles");
-    a.tilesD = 1; a.nsplit = nsb;
-    a.nCi = d->Cin / 64; a.nCo = d->Cout / (wide ? 128 : 64); a.KDn = 1; a.TT = 9;
+    a.tilesD = 1; a.nsplit = kind == 1 ? 2 * nsb : nsb;
+    a.nCi = d->Cin / 64; a.nCo = d->Cout / (kind == 0 ? 128 : 64); a.KDn = 1; a.TT = 9;
     const long long grid = (long long)a.nCi * a.nCo * nsb;
     MIS_REQUIRE(grid < (1ll << 31), MIS_EUNSUPPORTED, "wgrad(pp): grid too large");
-    if (wide) {
+    if (kind == 0) {
         *tag = "k3.2d.ppw";
-        const size_t lds = 2 * (size_t)W3_STAGE;
+        const size_t lds = 2 * (size_t)W3<false>::STAGE;
         static std::atomic<unsigned long long> attr_done{0};
-        if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&wgrad_pp_wide_kernel), lds, "wgrad(ppw)")) return rc;
-        hipLaunchKernelGGL(wgrad_pp_wide_kernel, dim3((unsigned)grid), dim3(512), lds, stream, a);
+        if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&wgrad_pp_wide_kernel<false>), lds, "wgrad(ppw)")) return rc;
+        hipLaunchKernelGGL(wgrad_pp_wide_kernel<false>, dim3((unsigned)grid), dim3(512), lds, stream, a);
+    } else if (kind == 1) {
+        *tag = "k3.2d.pps";
+        const size_t lds = 2 * (size_t)W3<true>::STAGE;
+        static std::atomic<unsigned long long> attr_done{0};
+        if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&wgrad_pp_wide_kernel<true>), lds, "wgrad(pps)")) return rc;
+        hipLaunchKernelGGL(wgrad_pp_wide_kernel<true>, dim3((unsigned)grid), dim3(512), lds, stream, a);
     } else {
         *tag = "k3.2d.pp";
         const size_t lds = 2 * (size_t)WP_STAGE;

@@ -134,14 +134,16 @@ def test_gemm1x1_every_branch(case):
 
 WG_CASES = [
     # (dtype, ksize, N, H, W, Cin, Cout, expected configuration, environment switch)
-    (BF, 3, 2, 20, 36, 64, 64, "k3.2d.pp", ""),         # ping-pong kernel: ragged tiles, many splits
+    (BF, 3, 2, 20, 36, 64, 64, "k3.2d.pps", ""),        # 64-column tiles: pixel-split wide wave tiles, ragged tiles, two slabs per block
+    (BF, 3, 2, 20, 36, 64, 64, "k3.2d.pp", "MIS_WGRAD_PP_NOWIDE"),
     (BF, 3, 1, 9, 17, 256, 256, "k3.2d.ppw", ""),        # a single (ragged) pixel tile per block
     (BF, 3, 1, 9, 17, 1024, 1024, "k3.2d.ppw", ""),      # 256 channel-tile pairs
     (BF, 3, 2, 40, 40, 512, 256, "k3.2d.ppw", ""),
     (BF, 3, 2, 40, 40, 512, 256, "k3.2d.pp", "MIS_WGRAD_PP_NOWIDE"),   # the 64 x 64 ping-pong kernel on a multi-pair shape
     (BF, 3, 3, 50, 70, 64, 128, "k3.2d.ppw", ""),        # 60 pixel tiles over 128 blocks... several tiles per block for 2 pairs
-    (BF, 3, 2, 150, 170, 64, 64, "k3.2d.pp", ""),
-    (BF, 3, 2, 150, 170, 64, 128, "k3.2d.ppw", ""),      # wide kernel, persistent blocks with the tile loop taken, ragged 8-row tiles       # 220 tiles, 1 pair: persistent blocks with the tile loop taken
+    (BF, 3, 2, 150, 170, 64, 64, "k3.2d.pps", ""),       # 220 tiles, 1 pair: persistent blocks with the tile loop taken
+    (BF, 3, 1, 40, 40, 128, 64, "k3.2d.pps", ""),        # two input-channel tiles: only ci tile 0 writes the bias column sums
+    (BF, 3, 2, 150, 170, 64, 128, "k3.2d.ppw", ""),      # wide kernel, persistent blocks with the tile loop taken, ragged 8-row tiles
     (BF, 3, 2, 20, 36, 64, 64, "k3.2d.tr", "MIS_WGRAD_NOPP"),     # the kernel behind it
     (BF, 3, 1, 9, 17, 1024, 1024, "k3.2d.tr", "MIS_WGRAD_NOPP"),
     (BF, 3, 2, 40, 40, 512, 256, "k3.2d.tr", "MIS_WGRAD_NOPP"),
