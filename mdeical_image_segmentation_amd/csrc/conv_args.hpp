@@ -27,4 +27,5 @@ struct ConvArgs {
 // conv_pp.hip: the ping-pong 3x3 kernel for the bf16 2-D layers (returns MIS_OK after the launch, or an error); `eligible` says whether a
 // descriptor can take that path at all (dispatch in conv_igemm.hip decides)
 bool conv_pp_eligible(const MisConvDesc* d);
+bool conv_pp_rs64_eligible(const MisConvDesc* d);      // 64 -> 64 channels: the register-stationary ping-pong kernel
 int launch_conv_pp(const MisConvDesc* d, hipStream_t stream, const char** tag);

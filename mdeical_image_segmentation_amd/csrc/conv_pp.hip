@@ -472,6 +472,174 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// 64 -> 64 channels (down_conv.0.second, up_conv.3.second and their dgrads: the layers with the lowest FLOP per byte): ping-pong with the filter in REGISTERS.
+// A wave owns 64 px x 32 ch; its share of the whole 3x3 filter - 9 taps x 2 k-groups x 2 fragments = 144 VGPRs - is loaded once per kernel, so a segment only reads
+// pixel fragments: one filter COLUMN (kw) and one k-group per segment = six row fragments (rows r .. r+3 serve tap kh = r) for 24 MFMAs, no weight traffic at all,
+// one LDS-DMA stream (the halo tile of the next 16 x 16 tile, double-buffered).  Meant to replace conv64_ws_kernel (whole filter in LDS, 8 waves in lockstep: 38 % MFMA
+// busy) - but it measures 0.700 vs 0.654 ms on 64->64 at 512^2 (884 vs 946 TFLOP/s): with 6 fragment reads per 24 MFMAs this layer is evidently not bound by the R/M
+// structure but by its memory traffic (2.1-2.8 GB per launch, 16-byte store pieces here against 32-byte ones there).  Kept selectable (MIS_CONV_RS64=1) and tested.
+__global__ __launch_bounds__(512, 2) void conv_pp_rs64_kernel(const ConvArgs a) {
+    using T = __bf16;
+    constexpr int NF = 2, PF = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const hbase = smem;                        // 2 x PP_HBUF
+    char* const bbase = smem + 2 * PP_HBUF;          // 64 bias floats (zeros without a bias)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, grp = wave >> 2;
+    const int li = lane & 15, lg = lane >> 4;
+
+    const int total_tiles = a.nSp;
+    const int tstride = (int)gridDim.x;
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    if (tile >= total_tiles) return;
+    const int tpi = a.tilesH * a.tilesW;
+    auto decode = [&](int t, int& tn, int& th0, int& tw0) {
+        tn = t / tpi;
+        const int r = t - tn * tpi;
+        const int th = r / a.tilesW;
+        th0 = th * PP_TH;
+        tw0 = (r - th * a.tilesW) * PP_TW;
+    };
+
+    // ---- the filter: fragment (tap, kg, f) of this wave.  MFMA row i of fragment f must be output channel wn*32 + (i>>2)*8 + f*4 + (i&3), so that a lane ends up with
+    //      8 consecutive channels (rows lg*4 .. lg*4+3 of both fragments); lane (li, lg) supplies row li, input channels (kg*4 + lg)*8 .. +7 ----
+    u32x4 Wr[9][2][2];
+    {
+        const T* wp = reinterpret_cast<const T*>(a.w);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const int row = wn * 32 + (li >> 2) * 8 + f * 4 + (li & 3);
+                    Wr[tap][kg][f] = *reinterpret_cast<const u32x4*>(wp + ((size_t)tap * 64 + row) * 64 + (kg * 4 + lg) * 8);
+                }
+    }
+    if (tid < 64) reinterpret_cast<float*>(bbase)[tid] = a.bias != nullptr ? a.bias[tid] : 0.f;
+
+    int b_off0[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int px = li + kw;
+        b_off0[kw] = (wm * 4 * PP_HW + px) * 128 + ((lg ^ (px & 7)) << 4);
+    }
+    const unsigned img_x = (unsigned)(((long long)a.H * a.W - 1) * a.x0.ld + a.Cin) * 2u;
+    const char* const xb = reinterpret_cast<const char*>(a.x0.p);
+    // halo DMA j (0..5) of this wave: instruction id = j*8 + wave of the image of tile (n, h0, w0)
+    auto issue_halo = [&](auto jc, int n, int h0, int w0, char* dst) {
+        constexpr int j = decltype(jc)::value;
+        const int id = j * 8 + wave;
+        if (id >= PP_HINSTR) return;                  // wave-uniform
+        const __amdgpu_buffer_rsrc_t rx = pp_make_rsrc(xb + (size_t)n * a.H * a.W * a.x0.ld * 2, img_x);
+        unsigned toff = (unsigned)((((h0 - 1) * a.W + (w0 - 1)) * a.x0.ld) * 2);
+        asm volatile("" : "+s"(toff));
+        int item = id * 64 + lane;
+        asm volatile("" : "+v"(item));                // recomputed per issue: the filter leaves no registers for per-lane tables
+        const int p = item >> 3, pos = item & 7;
+        const int py = p / PP_HW, px = p - py * PP_HW;
+        const unsigned rel = (unsigned)(((py * a.W + px) * a.x0.ld + ((pos ^ (px & 7)) << 3)) * 2);
+        const bool ok = item < PP_HITEMS && (unsigned)(h0 - 1 + py) < (unsigned)a.H && (unsigned)(w0 - 1 + px) < (unsigned)a.W;
+        pp_dma16(rx, ok ? (int)(toff + rel) : PP_OOB, dst + id * 1024);
+    };
+
+    int n, h0, w0;
+    decode(tile, n, h0, w0);
+    f32x4 acc[NF][PF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int pf = 0; pf < PF; ++pf) acc[f][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    pp_static_for<6>([&](auto jc) { issue_halo(jc, n, h0, w0, hbase); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int hsel = 0;
+    if (grp == 1) __builtin_amdgcn_s_barrier();       // the stagger
+    __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll 1
+    for (; tile < total_tiles; tile += tstride) {
+        const bool has_next = tile + tstride < total_tiles;
+        int nn = n, nh0 = h0, nw0 = w0;
+        if (has_next) decode(tile + tstride, nn, nh0, nw0);
+        const uint32_t hb = (uint32_t)(uintptr_t)hbase + hsel * PP_HBUF;
+        char* hbn = hbase + (hsel ^ 1) * PP_HBUF;
+        pp_static_for<6>([&](auto sc) {                // segment = (filter column kw, k-group kg)
+            constexpr int sg = decltype(sc)::value;
+            constexpr int kw = sg >> 1, kg = sg & 1;
+            // ================= R segment =================
+            if constexpr (sg < 3) {                    // the next tile's halo: two instructions per wave in each of the first three segments
+                if (has_next) {
+                    issue_halo(std::integral_constant<int, 2 * sg>{}, nn, nh0, nw0, hbn);
+                    issue_halo(std::integral_constant<int, 2 * sg + 1>{}, nn, nh0, nw0, hbn);
+                }
+            }
+            u32x4 Brow[6];
+            pp_static_for<6>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                Brow[r] = pp_lds_read128<r * PP_ROWB>(hb + (b_off0[kw] ^ (kg << 6)));
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (sg == 5) {
+                if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // group 1's last slot of the tile: the next halo has landed
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ================= M segment: 3 taps x 2 fragments x 4 pixel rows =================
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+#pragma unroll
+                    for (int pf = 0; pf < PF; ++pf) mma_b128<T>(acc[f][pf], Wr[kh * 3 + kw][kg][f], Brow[pf + kh]);
+            __builtin_amdgcn_s_setprio(0);
+            if constexpr (sg == 5) {
+                if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // group 0's last slot of the tile
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        pp_epilogue<NF>(a, acc, (uint32_t)(uintptr_t)bbase, n, h0, w0, 0, wm, wn, li, lg);
+        hsel ^= 1;
+        n = nn; h0 = nh0; w0 = nw0;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+}
+
+static int pp_launch_rs64(const MisConvDesc* d, hipStream_t stream) {
+    ConvArgs a;
+    a.N = d->N; a.D = 1; a.H = d->H; a.W = d->W; a.Cin = 64; a.Cout = 64; a.Cin0 = 64; a.Cout0 = 64;
+    a.x0 = SrcView{d->x0, d->x0_ld, 1, d->x0_H, d->x0_W};
+    a.x1 = SrcView{nullptr, 0, 0, 0, 0};
+    a.in_scale = nullptr; a.in_shift = nullptr;
+    a.w = d->w; a.bias = d->bias; a.relu = d->relu; a.mask = d->mask; a.mask_ld = d->mask_ld;
+    a.y0 = d->y0; a.y0_ld = d->y0_ld; a.y0_mode = d->y0_mode;
+    a.y1 = nullptr; a.y1_ld = 0; a.y1_mode = 0;
+    a.tilesD = 1;
+    a.tilesH = (d->H + PP_TH - 1) / PP_TH;
+    a.tilesW = (d->W + PP_TW - 1) / PP_TW;
+    const long long nsp = (long long)d->N * a.tilesH * a.tilesW;
+    MIS_REQUIRE(nsp < (1ll << 31), MIS_EUNSUPPORTED, "conv_igemm(rs64): grid too large");
+    a.nSp = (int)nsp;
+    a.nCt = 1;
+    const size_t lds = 2 * (size_t)PP_HBUF + 256;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv_pp_rs64_kernel), lds, "conv_igemm(rs64)")) return rc;
+    hipLaunchKernelGGL(conv_pp_rs64_kernel, dim3((unsigned)(nsp > 256 ? 256 : nsp)), dim3(512), lds, stream, a);
+    MIS_LAUNCH_CHECK("conv_igemm(rs64)");
+    return MIS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 bool conv_pp_eligible(const MisConvDesc* d) {
     if (d->dtype != MIS_BF16 || d->is3d || d->ksize != 3) return false;
     if (d->x1 != nullptr || d->in_scale != nullptr) return false;
@@ -511,7 +679,15 @@ template <int NF> static int pp_launch(const MisConvDesc* d, hipStream_t stream)
     return MIS_OK;
 }
 
+bool conv_pp_rs64_eligible(const MisConvDesc* d) {
+    return conv_pp_eligible(d) && d->Cin == 64 && d->Cout == 64 && d->Cout0 == 64 && d->y0_mode == MIS_OUT_PLAIN && getenv("MIS_CONV_RS64") != nullptr;      // opt-in: measured 0.700 vs 0.654 ms against conv64_ws_kernel
+}
+
 int launch_conv_pp(const MisConvDesc* d, hipStream_t stream, const char** tag) {
+    if (conv_pp_rs64_eligible(d)) {
+        *tag = "k3.2d.rs64";
+        return pp_launch_rs64(d, stream);
+    }
     if (d->Cout % 256 == 0 && d->Cout0 % 128 == 0) {
         static const int no256 = getenv("MIS_CONV_PP_NO256") != nullptr;
         if (!no256) {

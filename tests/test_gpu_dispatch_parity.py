@@ -36,7 +36,10 @@ K3_CASES = [
     # 64-column layers: the weight-stationary / bn64 configurations; the ping-pong kernel with 64-column blocks is selectable (MIS_CONV_PP64=1; slower)
     (BF, 1, 70, 90, 128, 64, "k3.2d.bn64.persist", ""),  # 32x16-pixel persistent tiles
     (BF, 2, 20, 36, 128, 64, "k3.2d.bn64.v1", ""),       # small grid: 64-column 4-wave config
-    (BF, 2, 256, 256, 64, 64, "k3.2d.ws64", ""),         # weight-stationary kernel
+    (BF, 2, 256, 256, 64, 64, "k3.2d.ws64", ""),         # weight-stationary (LDS) kernel
+    (BF, 2, 256, 256, 64, 64, "k3.2d.rs64", "MIS_CONV_RS64"),          # 64 -> 64: register-stationary ping-pong kernel (filter in VGPRs; opt-in, slower)
+    (BF, 3, 150, 170, 64, 64, "k3.2d.rs64", "MIS_CONV_RS64"),          # ragged, 330 tiles > 256 blocks
+    (BF, 1, 20, 36, 64, 64, "k3.2d.rs64", "MIS_CONV_RS64"),
     (BF, 1, 70, 90, 128, 64, "k3.2d.pp64", "MIS_CONV_PP64"),
     (BF, 2, 20, 36, 64, 64, "k3.2d.pp64", "MIS_CONV_PP64"),
     (BF, 3, 150, 170, 64, 64, "k3.2d.pp64", "MIS_CONV_PP64"),          # 330 tiles > 256 blocks: one K chunk per tile, tile loop taken
