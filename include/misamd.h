@@ -358,6 +358,34 @@ int mis_patch_accumulate(const float* pred, int C, int PD, int PH, int PW, int h
                          int ox, float* map, unsigned char* norm, int D, int H, int W, void* stream);
 int mis_pred_finalize(const float* map, const unsigned char* norm, int C, long long nvox, float* prob, unsigned short* seg, void* stream);
 
+/* Stand-alone / general-shape 3-D building blocks (csrc/blocks3d.hip): what the fused engines refuse.  Replaces, per call, the torch modules that
+ * model/unet3d/buildingblocks.py:14-113 `create_conv` strings together for an arbitrary order ('gcr', 'cge', 'cl', 'crg', ...), the Encoder's
+ * MaxPool3d / AvgPool3d (:409-418) and `F.interpolate(x, size=encoder_features.size()[2:], mode='nearest')` (:671-673).
+ * Channels-last (N, D, H, W, ld) tensors; C = the channels touched (a multiple of 16 bytes except for the gathers, which are scalar).
+ *   act: 0 none, 1 ReLU, 2 LeakyReLU(slope), 3 ELU(alpha = slope);  scale / shift: [N][C] fp32 or both NULL (activation only).
+ *   mis_norm_act_fwd: y = act(scale*x + shift);  mis_norm_act_bwd: dz = dy * act'(scale*x + shift)  (gradient w.r.t. the affine's output)
+ *   mis_gn_*_finalize_ld: GroupNorm finalisation as mis_gn_fwd_finalize / mis_gn_bwd_finalize, for per-channel arrays with row stride ld >= C whose
+ *     padding entries [C, ld) are written as 0 (sum / sq / S1 / S2 / scale / shift / p / q / r all [N][ld]).
+ *   mis_pool3d_*: mode 0 = max, 1 = average; window = stride = (kd, kh, kw), floor mode (output D/kd x H/kh x W/kw); the max gradient goes to the
+ *     first maximum in (d, h, w) order, as torch's max_pool3d does.
+ *   mis_gather3d_fwd: y[n,d,h,w,c] = x[n,mD[d],mH[h],mW[w],c], c < C (x, y point at the first channel of the slices); mD/mH/mW = DEVICE int arrays.
+ *   mis_gather3d_bwd: dx[n,s..] = sum of dy over the destination indices [rX[2s], rX[2s+1]) per axis (DEVICE int pairs), fixed order. */
+int mis_norm_act_fwd(int dtype, const void* x, int x_ld, void* y, int y_ld, int N, long long npix, int C, const float* scale, const float* shift, int act,
+                     float slope, void* stream);
+int mis_norm_act_bwd(int dtype, const void* dy, int dy_ld, const void* x, int x_ld, void* dz, int dz_ld, int N, long long npix, int C, const float* scale,
+                     const float* shift, int act, float slope, void* stream);
+int mis_gn_fwd_finalize_ld(const float* sum, const float* sq, int N, int C, int ld, int G, double count, const float* gamma, const float* beta, float eps,
+                           float* scale, float* shift, float* mean, float* rstd, void* stream);
+int mis_gn_bwd_finalize_ld(const float* S1, const float* S2, const float* mean, const float* rstd, const float* gamma, int N, int C, int ld, int G,
+                           double count, float* p, float* q, float* r, float* dgamma, float* dbeta, void* stream);
+int mis_pool3d_fwd(int dtype, int mode, int kd, int kh, int kw, const void* x, int x_ld, void* y, int y_ld, int N, int D, int H, int W, int C, void* stream);
+int mis_pool3d_bwd(int dtype, int mode, int kd, int kh, int kw, const void* x, int x_ld, const void* dy, int dy_ld, void* dx, int dx_ld, int N, int D, int H,
+                   int W, int C, void* stream);
+int mis_gather3d_fwd(int dtype, const void* x, int x_ld, void* y, int y_ld, int N, int sD, int sH, int sW, int dD, int dH, int dW, int C, const int* mD,
+                     const int* mH, const int* mW, void* stream);
+int mis_gather3d_bwd(int dtype, const void* dy, int dy_ld, void* dx, int dx_ld, int N, int sD, int sH, int sW, int dD, int dH, int dW, int C, const int* rD,
+                     const int* rH, const int* rW, void* stream);
+
 /* layout helpers */
 int mis_nchw_to_nhwc(int dtype_out, const float* x, void* y, int y_ld, int N, int C, long long spatial, void* stream);
 int mis_nhwc_to_nchw(int dtype_in, const void* x, int x_ld, float* y, int N, int C, long long spatial, void* stream);

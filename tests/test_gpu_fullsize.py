@@ -66,11 +66,11 @@ def test_3d_full_size_determinism_and_sample_independence():
 
 
 def test_ping_pong_kernels_beyond_4gib_tensors():
-    """The ping-pong kernels address their operands through PER-IMAGE buffer resources with 32-bit offsets: tensors far beyond 4 GiB in total (here 40 images of
-    512 x 512 x 128 bf16 = 5.4 GB in, 10.7 GB dY) must behave exactly like small batches.  Checked by batch independence (the last and the first two images of the big
-    batch against a 2-image run: bit-equal conv outputs) and linearity of the weight gradient (40-image dW == sum of per-slice dWs to fp32 accumulation order)."""
+    """The ping-pong kernels address their operands through PER-IMAGE buffer resources with 32-bit offsets: tensors far beyond 4 GiB in total (here 72 images of
+    512 x 512 x 128 bf16 = 4.8 GB in, 9.7 GB out / dY) must behave exactly like small batches.  Checked by batch independence (the last and the first two images of the big
+    batch against a 2-image run: bit-equal conv outputs) and linearity of the weight gradient (72-image dW == sum of per-slice dWs to fp32 accumulation order)."""
     from mdeical_image_segmentation_amd import ops
-    N, H, W, Cin, Cout = 40, 512, 512, 128, 256
+    N, H, W, Cin, Cout = 72, 512, 512, 128, 256
     gen = torch.Generator(device=DEV).manual_seed(3)
     x = torch.randn(N, H, W, Cin, device=DEV, generator=gen).to(torch.bfloat16)
     assert x.numel() * 2 > (1 << 32)
