@@ -1,0 +1,452 @@
+"""Stand-alone 3-D building blocks on MI355X: the arithmetic behind `model.unet3d.buildingblocks.{SingleConv, DoubleConv, ResNetBlock, Encoder, Decoder}`
+when a block is called ON ITS OWN, and behind the 3-D U-Nets whenever the fused engines (engine3d*.py) do not cover the configuration (channel counts that
+are not multiples of 64, in_channels > 1, AvgPool3d / other pooling windows, grids that are not divisible by 2^(levels-1), layer orders other than 'gcr').
+
+Reference behaviour: model/unet3d/buildingblocks.py:14-113 (`create_conv` order strings), :116-159 SingleConv, :162-252 DoubleConv, :255-325 ResNetBlock,
+:365-439 Encoder, :442-550 Decoder, :553-673 upsampling (`F.interpolate(size=encoder_features.size()[2:])`).
+
+Layout: every activation lives channels-last, (N, D, H, W, Cp) with Cp = C rounded up to 64 and the padding kept exactly 0 (zero weights, zero scale/shift),
+so every convolution runs on the MFMA implicit-GEMM kernels (ops.conv_igemm / ops.wgrad) whatever C is.  Each function below is a torch.autograd.Function
+whose forward AND backward are HIP kernels of libmisamd; torch is the allocator and the tape, nothing else.  There is no CPU path.
+"""
+import os
+
+import torch
+
+from . import ops
+from ._lib import MisError
+from .ops import View
+
+ACT_CODES = {"r": (ops.ACT_RELU, 0.0), "l": (ops.ACT_LEAKY, 0.01), "e": (ops.ACT_ELU, 1.0)}
+
+
+def compute_dtype(name=None):
+    name = (name or os.environ.get("MISAMD_DTYPE", "f32")).lower()
+    if name in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    if name in ("f32", "fp32", "float32"):
+        return torch.float32
+    raise MisError(f"compute dtype must be 'f32' or 'bf16', got {name!r}")
+
+
+def pad64(c):
+    return (c + 63) // 64 * 64
+
+
+class CL:
+    """a channels-last activation: t = (N, D, H, W, pad64(C)) tensor on the tape, C = its logical channel count"""
+
+    def __init__(self, t, C):
+        self.t, self.C = t, C
+
+    @property
+    def grid(self):
+        return tuple(self.t.shape[:4])
+
+
+def _need_cuda(x):
+    if x.device.type != "cuda":
+        raise MisError(f"the 3-D building blocks run on MI355X only: got a tensor on {x.device} (no CPU fallback)")
+    if x.dim() != 5:
+        raise MisError(f"expected a (N, C, D, H, W) tensor, got {tuple(x.shape)}")
+
+
+# ---- layout ------------------------------------------------------------------------------------------------------------------------------
+class _ToCL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        x = x.contiguous().float()
+        N, C = x.shape[:2]
+        y = torch.zeros(N, *x.shape[2:], pad64(C), dtype=dtype, device=x.device)
+        ops.nchw_to_nhwc(x, View(y, 0, C))
+        ctx.C = C
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        N, D, H, W, _ = g.shape
+        dx = torch.empty(N, ctx.C, D, H, W, dtype=torch.float32, device=g.device)
+        ops.nhwc_to_nchw(View(g, 0, ctx.C), dx)
+        return dx, None
+
+
+class _FromCL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, C):
+        t = t.contiguous()
+        N, D, H, W, _ = t.shape
+        y = torch.empty(N, C, D, H, W, dtype=torch.float32, device=t.device)
+        ops.nhwc_to_nchw(View(t, 0, C), y)
+        ctx.C, ctx.dtype, ctx.Cp = C, t.dtype, t.shape[-1]
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().float()
+        N, _, D, H, W = g.shape
+        dt = torch.zeros(N, D, H, W, ctx.Cp, dtype=ctx.dtype, device=g.device)
+        ops.nchw_to_nhwc(g, View(dt, 0, ctx.C))
+        return dt, None
+
+
+def to_cl(x, dtype=None):
+    _need_cuda(x)
+    return CL(_ToCL.apply(x, compute_dtype() if dtype is None else dtype), x.shape[1])
+
+
+def from_cl(a):
+    return _FromCL.apply(a.t, a.C)
+
+
+# ---- GroupNorm statistics shared by the two normalising functions ----------------------------------------------------------------------------
+def _gn_forward(t, C, G, gamma, beta):
+    N, Cp = t.shape[0], t.shape[-1]
+    dev = t.device
+    s, sq = torch.empty(N, Cp, device=dev), torch.empty(N, Cp, device=dev)
+    ops.chanstats(t, s, sq)
+    scale, shift = torch.empty(N, Cp, device=dev), torch.empty(N, Cp, device=dev)
+    mean, rstd = torch.empty(N, G, device=dev), torch.empty(N, G, device=dev)
+    ops.gn_fwd_finalize_ld(s, sq, N, C, Cp, G, t[0, ..., 0].numel(), gamma, beta, scale, shift, mean, rstd)
+    return scale, shift, mean, rstd
+
+
+def _gn_backward(dz, x, C, G, gamma, mean, rstd):
+    """dz = dL/d(GroupNorm output), x = its input -> (dx, dgamma, dbeta)"""
+    N, Cp = x.shape[0], x.shape[-1]
+    dev = x.device
+    grid = tuple(x.shape[:4])
+    S1, S2 = torch.empty(N, Cp, device=dev), torch.empty(N, Cp, device=dev)
+    ops.gn_bwd_stats(dz, x, Cp, False, grid, S1, S2, Cp, 0)
+    p, q, r = (torch.empty(N, Cp, device=dev) for _ in range(3))
+    dgamma, dbeta = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    ops.gn_bwd_finalize_ld(S1, S2, mean, rstd, gamma, N, C, Cp, G, x[0, ..., 0].numel(), p, q, r, dgamma, dbeta)
+    dx = torch.empty_like(x)
+    ops.gn_bwd_apply(dz, x, Cp, False, grid, p, q, r, Cp, 0, dx)
+    return dx, dgamma, dbeta
+
+
+# ---- [GroupNorm ->] Conv3d [+ bias] [-> ReLU] -----------------------------------------------------------------------------------------------------
+class _Conv(torch.autograd.Function):
+    """x (N, D, H, W, Cinp) -> y (N, D, H, W, Coutp).  weight: the reference's (Cout, Cin, k, k, k) fp32 parameter, k = 3 (padding 1) or 1.  A GroupNorm in
+    front of the convolution is folded into the operand staging of the forward and of the weight-gradient kernel (the normalised tensor is never written);
+    a ReLU behind it is the forward's epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, cin, cout, groups, relu):
+        x = x.contiguous()
+        dev, dt = x.device, x.dtype
+        ks = weight.shape[-1]
+        cinp, coutp = x.shape[-1], pad64(cout)
+        if tuple(weight.shape) != (cout, cin) + (ks,) * 3 or ks not in (1, 3) or cinp != pad64(cin):
+            raise MisError(f"conv block: weight {tuple(weight.shape)} does not fit {cin} -> {cout} channels (kernel 1 or 3)")
+        wpad = torch.zeros(coutp, cinp, ks, ks, ks, device=dev)
+        wpad[:cout, :cin] = weight.detach()
+        taps = ks ** 3
+        wf = torch.empty(taps, coutp, cinp, dtype=dt, device=dev)
+        wd = torch.empty(taps, cinp, coutp, dtype=dt, device=dev)
+        ops.pack_conv_weight(wpad, wf, wd)
+        scale = shift = mean = rstd = None
+        if gamma is not None:
+            scale, shift, mean, rstd = _gn_forward(x, cin, groups, gamma.detach().float(), beta.detach().float())
+        bpad = None
+        if bias is not None:
+            bpad = torch.zeros(coutp, device=dev)
+            bpad[:cout] = bias.detach()
+        y = torch.empty(*x.shape[:4], coutp, dtype=dt, device=dev)
+        ops.conv_igemm(x, wf, y, ksize=ks, Cin=cinp, Cout=coutp, bias=bpad, relu=relu, in_scale=scale, in_shift=shift)
+        ctx.save_for_backward(x, y if relu else None, wd, scale, shift, mean, rstd, None if gamma is None else gamma.detach().float())
+        ctx.cfg = (cin, cout, groups, relu, ks, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, wd, scale, shift, mean, rstd, gamma = ctx.saved_tensors
+        cin, cout, groups, relu, ks, has_bias = ctx.cfg
+        dev = x.device
+        cinp, coutp = x.shape[-1], g.shape[-1]
+        g = g.contiguous()
+        if relu:
+            gm = torch.empty_like(g)
+            ops.relu_mask(g, y, gm)
+            g = gm
+        dwp = torch.empty(coutp, cinp, ks, ks, ks, device=dev)
+        dbp = torch.empty(coutp, device=dev) if has_bias else None
+        ops.wgrad(x, g, dwp, ksize=ks, Cin=cinp, Cout=coutp, in_scale=scale, in_shift=shift, dbias=dbp)
+        dw = dwp[:cout, :cin].contiguous()
+        db = dbp[:cout].contiguous() if has_bias else None
+        dx = dgamma = dbeta = None
+        if ctx.needs_input_grad[0] or gamma is not None:
+            dn = torch.empty_like(x)
+            ops.conv_igemm(g, wd, dn, ksize=ks, Cin=coutp, Cout=cinp)
+            if gamma is not None:
+                dx, dgamma, dbeta = _gn_backward(dn, x, cin, groups, gamma, mean, rstd)
+            else:
+                dx = dn
+        return dx, dw, db, dgamma, dbeta, None, None, None, None
+
+
+def conv(a, weight, bias=None, gn=None, relu=False):
+    """gn = (nn.GroupNorm in front of the convolution) or None"""
+    cout, cin = weight.shape[:2]
+    if cin != a.C:
+        raise MisError(f"conv block: input has {a.C} channels, the weight expects {cin}")
+    gamma = beta = None
+    groups = 1
+    if gn is not None:
+        gamma, beta, groups = gn.weight, gn.bias, gn.num_groups
+        if gn.num_channels != cin or abs(gn.eps - 1e-5) > 0:
+            raise MisError("conv block: GroupNorm(num_channels = conv in_channels, eps = 1e-5) expected")
+    return CL(_Conv.apply(a.t, weight, bias, gamma, beta, cin, cout, groups, relu), cout)
+
+
+# ---- [GroupNorm ->] activation behind a convolution ('cge', 'cl', 'crg', ...) ------------------------------------------------------------------------
+class _NormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, C, groups, act, slope):
+        x = x.contiguous()
+        scale = shift = mean = rstd = None
+        if gamma is not None:
+            scale, shift, mean, rstd = _gn_forward(x, C, groups, gamma.detach().float(), beta.detach().float())
+        y = torch.empty_like(x)
+        ops.norm_act_fwd(x, y, scale, shift, act, slope)
+        ctx.save_for_backward(x, scale, shift, mean, rstd, None if gamma is None else gamma.detach().float())
+        ctx.cfg = (C, groups, act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, scale, shift, mean, rstd, gamma = ctx.saved_tensors
+        C, groups, act, slope = ctx.cfg
+        g = g.contiguous()
+        if act != ops.ACT_NONE:
+            dz = torch.empty_like(g)
+            ops.norm_act_bwd(g, x, dz, scale, shift, act, slope)
+        else:
+            dz = g
+        if gamma is None:
+            return dz, None, None, None, None, None, None
+        dx, dgamma, dbeta = _gn_backward(dz, x, C, groups, gamma, mean, rstd)
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+def norm_act(a, gn=None, act=None, slope=None):
+    """act: None | 'r' | 'l' | 'e' (create_conv's letters)"""
+    code, sl = (ops.ACT_NONE, 0.0) if act is None else ACT_CODES[act]
+    if slope is not None:
+        sl = slope
+    gamma = beta = None
+    groups = 1
+    if gn is not None:
+        gamma, beta, groups = gn.weight, gn.bias, gn.num_groups
+        if gn.num_channels != a.C:
+            raise MisError(f"GroupNorm over {gn.num_channels} channels applied to {a.C}")
+    if gn is None and act is None:
+        return a
+    return CL(_NormAct.apply(a.t, gamma, beta, a.C, groups, code, sl), a.C)
+
+
+# ---- pooling -------------------------------------------------------------------------------------------------------------------------------------
+def _triple(k):
+    return (k, k, k) if isinstance(k, int) else tuple(k)
+
+
+class _Pool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, avg):
+        x = x.contiguous()
+        N, D, H, W, Cp = x.shape
+        kd, kh, kw = k
+        if D < kd or H < kh or W < kw:
+            raise MisError(f"pooling window {k} is larger than the {D}x{H}x{W} grid")
+        y = torch.empty(N, D // kd, H // kh, W // kw, Cp, dtype=x.dtype, device=x.device)
+        ops.pool3d_fwd(x, y, k, avg)
+        ctx.save_for_backward(x)
+        ctx.cfg = (k, avg)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        k, avg = ctx.cfg
+        dx = torch.empty_like(x)
+        ops.pool3d_bwd(x, g.contiguous(), dx, k, avg)
+        return dx, None, None
+
+
+def pool(a, kernel_size=2, avg=False):
+    return CL(_Pool.apply(a.t, _triple(kernel_size), avg), a.C)
+
+
+# ---- nearest resize + concatenation (Decoder joining) -------------------------------------------------------------------------------------------------
+class _ResizeCat(torch.autograd.Function):
+    """out[..., :c0] = skip[..., :c0]; out[..., c0:c0+c1] = nearest-resize(low)[..., :c1] on skip's grid (skip may be None: plain resize to `size`)"""
+
+    @staticmethod
+    def forward(ctx, skip, low, c0, c1, size):
+        low = low.contiguous()
+        N = low.shape[0]
+        src = tuple(low.shape[1:4])
+        dev = low.device
+        out = torch.zeros(N, *size, pad64(c0 + c1), dtype=low.dtype, device=dev)
+        fwd, inv = ops.nearest_maps(src, size, dev)
+        ops.gather3d_fwd(View(low, 0, c1), View(out, c0, c1), fwd)
+        if skip is not None:
+            skip = skip.contiguous()
+            ident, _ = ops.nearest_maps(size, size, dev)
+            ops.gather3d_fwd(View(skip, 0, c0), View(out, 0, c0), ident)
+        ctx.cfg = (c0, c1, size, src, low.shape[-1], None if skip is None else skip.shape[-1])
+        ctx.inv = inv
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        c0, c1, size, src, lowp, skipp = ctx.cfg
+        g = g.contiguous()
+        N, dev = g.shape[0], g.device
+        dlow = torch.zeros(N, *src, lowp, dtype=g.dtype, device=dev)
+        ops.gather3d_bwd(View(g, c0, c1), View(dlow, 0, c1), ctx.inv)
+        dskip = None
+        if skipp is not None:
+            dskip = torch.zeros(N, *size, skipp, dtype=g.dtype, device=dev)
+            ident, _ = ops.nearest_maps(size, size, dev)
+            ops.gather3d_fwd(View(g, 0, c0), View(dskip, 0, c0), ident)
+        return dskip, dlow, None, None, None
+
+
+def resize_nearest(a, size):
+    size = tuple(int(s) for s in size)
+    if a.grid[1:] == size:
+        return a
+    return CL(_ResizeCat.apply(None, a.t, 0, a.C, size), a.C)
+
+
+def concat_resized(skip, low):
+    """torch.cat((encoder_features, F.interpolate(x, size=encoder_features.size()[2:], mode='nearest')), dim=1)   (buildingblocks.py:548, :671-673)"""
+    return CL(_ResizeCat.apply(skip.t, low.t, skip.C, low.C, skip.grid[1:]), skip.C + low.C)
+
+
+# ---- sum joining / residual add ------------------------------------------------------------------------------------------------------------------------
+class _AddAct(torch.autograd.Function):
+    """y = act(a + b): `out += residual; out = non_linearity(out)` (buildingblocks.py:318-323) and the ResNet decoders' summation joining (:546)"""
+
+    @staticmethod
+    def forward(ctx, a, b, act, slope):
+        a, b = a.contiguous(), b.contiguous()
+        s = torch.empty_like(a)
+        ops.add_act(a, b, s, relu=False)
+        if act == ops.ACT_NONE:
+            ctx.act = act
+            return s
+        y = torch.empty_like(a)
+        ops.norm_act_fwd(s, y, None, None, act, slope)
+        ctx.save_for_backward(s)
+        ctx.act, ctx.slope = act, slope
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        if ctx.act == ops.ACT_NONE:
+            return g, g, None, None
+        (s,) = ctx.saved_tensors
+        dz = torch.empty_like(g)
+        ops.norm_act_bwd(g, s, dz, None, None, ctx.act, ctx.slope)
+        return dz, dz, None, None
+
+
+def add_act(a, b, act=None, slope=None):
+    if a.C != b.C or a.grid != b.grid:
+        raise MisError(f"sum joining of {a.grid + (a.C,)} and {b.grid + (b.C,)}")
+    code, sl = (ops.ACT_NONE, 0.0) if act is None else ACT_CODES[act]
+    if slope is not None:
+        sl = slope
+    return CL(_AddAct.apply(a.t, b.t, code, sl), a.C)
+
+
+# ---- ConvTranspose3d(k3, s2, p1, bias=False) + nearest resize to the encoder grid (TransposeConvUpsampling, buildingblocks.py:676-728) -------------------
+class _ConvT2x(torch.autograd.Function):
+    """low (N, d, h, w, Cinp) -> (N, 2d, 2h, 2w, Coutp): the (2d-1)^3 transposed-conv output resized (nearest) to exactly twice the input grid - the case
+    the fused engine's column kernels (csrc/convt3d.hip) implement: one Cin -> 27*Cout GEMM, then a gather"""
+
+    @staticmethod
+    def forward(ctx, low, weight, cin, cout):
+        low = low.contiguous()
+        dev, dt = low.device, low.dtype
+        N, d, h, w, cinp = low.shape
+        coutp = pad64(cout)
+        if tuple(weight.shape) != (cin, cout, 3, 3, 3):
+            raise MisError(f"transposed conv: weight {tuple(weight.shape)} != ({cin}, {cout}, 3, 3, 3)")
+        w2d = torch.zeros(27 * coutp, cinp, 1, device=dev)                       # row k*Coutp + co
+        w2d.view(27, coutp, cinp)[:, :cout, :cin] = weight.detach().reshape(cin, cout, 27).permute(2, 1, 0)
+        wf = torch.empty(1, 27 * coutp, cinp, dtype=dt, device=dev)
+        wd = torch.empty(1, cinp, 27 * coutp, dtype=dt, device=dev)
+        ops.pack_conv_weight(w2d, wf, wd)
+        cols = torch.empty(N, d, h, w, 27 * coutp, dtype=dt, device=dev)
+        ops.conv_igemm(low, wf, cols, ksize=1, Cin=cinp, Cout=27 * coutp)
+        up = torch.empty(N, 2 * d, 2 * h, 2 * w, coutp, dtype=dt, device=dev)
+        ops.convt3_col2im(cols, up)
+        ctx.save_for_backward(low, wd)
+        ctx.cfg = (cin, cout)
+        return up
+
+    @staticmethod
+    def backward(ctx, g):
+        low, wd = ctx.saved_tensors
+        cin, cout = ctx.cfg
+        g = g.contiguous()
+        N, d, h, w, cinp = low.shape
+        coutp = g.shape[-1]
+        dev = low.device
+        gcols = torch.empty(N, d, h, w, 27 * coutp, dtype=g.dtype, device=dev)
+        ops.convt3_im2col(g, gcols)
+        dw2d = torch.empty(27 * coutp, cinp, device=dev)
+        ops.wgrad(low, gcols, dw2d, ksize=1, Cin=cinp, Cout=27 * coutp)
+        dw = dw2d.view(27, coutp, cinp)[:, :cout, :cin].permute(2, 1, 0).reshape(cin, cout, 3, 3, 3).contiguous()
+        dlow = None
+        if ctx.needs_input_grad[0]:
+            dlow = torch.empty_like(low)
+            ops.conv_igemm(gcols, wd, dlow, ksize=1, Cin=27 * coutp, Cout=cinp)
+        return dlow, dw, None, None
+
+
+def conv_transpose_2x(a, weight, size):
+    cin, cout = weight.shape[:2]
+    if cin != a.C:
+        raise MisError(f"transposed conv: input has {a.C} channels, the weight expects {cin}")
+    if tuple(size) != tuple(2 * s for s in a.grid[1:]):
+        raise MisError(f"transposed-conv upsampling is built for an encoder grid of exactly twice the input grid: {a.grid[1:]} -> {tuple(size)}")
+    return CL(_ConvT2x.apply(a.t, weight, cin, cout), cout)
+
+
+# ---- create_conv order strings -------------------------------------------------------------------------------------------------------------------------
+def run_single_conv(mod, a):
+    """mod: a SingleConv container (children named as create_conv names them, `mod.order` = the order string).  Fusions: 'g' directly in front of 'c'
+    is folded into the convolution, 'r' directly behind 'c' is its epilogue, 'g' + non-linearity behind the convolution is one pass."""
+    order = mod.order
+    i = 0
+    while i < len(order):
+        ch = order[i]
+        nxt = order[i + 1] if i + 1 < len(order) else ""
+        if ch == "g" and nxt == "c":
+            relu = order[i + 2:i + 3] == "r"
+            a = conv(a, mod.conv.weight, mod.conv.bias, gn=mod.groupnorm, relu=relu)
+            i += 3 if relu else 2
+        elif ch == "c":
+            relu = nxt == "r"
+            a = conv(a, mod.conv.weight, mod.conv.bias, relu=relu)
+            i += 2 if relu else 1
+        elif ch == "g":
+            act = nxt if nxt in ACT_CODES else None
+            a = norm_act(a, gn=mod.groupnorm, act=act)
+            i += 2 if act else 1
+        elif ch in ACT_CODES:
+            a = norm_act(a, act=ch)
+            i += 1
+        elif ch in "dD":
+            if mod.training and getattr(mod, "dropout_prob", 0.0) > 0:
+                raise NotImplementedError("dropout inside a conv layer ('d' / 'D') is not built on MI355X for training; eval mode is the identity")
+            i += 1
+        else:
+            raise NotImplementedError(f"layer order character '{ch}' is not built on MI355X (built: g, c, r, l, e)")
+    return a

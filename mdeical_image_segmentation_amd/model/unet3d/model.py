@@ -1,13 +1,19 @@
-"""Mirror of model/unet3d/model.py: `AbstractUNet` / `UNet3D` (:13-194) executed by engine3d.UNet3DEngine.
+"""Mirror of model/unet3d/model.py: `AbstractUNet` / `UNet3D` / `ResidualUNet3D` / `ResidualUNetSE3D` (:13-280).
 
-`forward(x)` returns LOGITS (the reference disabled the final activation, model.py:145-149) and is differentiable: one
-autograd.Function runs the fused forward; its backward feeds the external dL/dlogits to the head kernel and then the
-fused backward.  Parameters are stock containers aliased onto the engine's flat fp32 master buffer."""
+`forward(x)` returns LOGITS (the reference disabled the final activation, model.py:145-149) and is differentiable.  Two routes:
+  * FUSED (engine3d*.py) for the configurations the whole-network engines cover - 1 input channel, f_maps = multiples of 64 starting at 64, layer order 'gcr',
+    MaxPool3d(2), grids divisible by 2^(levels-1): one autograd.Function runs the fused forward; its backward feeds the external dL/dlogits to the head
+    kernel and then the fused backward.  Parameters are stock containers aliased onto the engine's flat fp32 master buffer.
+  * BLOCKS (blocks3d.py through buildingblocks.*._cl) for everything else the reference's constructor accepts: any channel counts, in_channels > 1, other
+    pooling windows, odd grids (`F.interpolate(size=...)`), 'cge' / 'cl' / 'crg' ... layer orders; the reference's forward loop (model.py:121-150) over
+    per-layer HIP autograd functions, channels-last from the first encoder to the final 1x1x1 convolution.
+`MISAMD_3D_ROUTE=blocks` forces the second route (tests compare the two on the same weights); `=fused` makes an uncovered configuration an error."""
 import os
 
 import torch
 from torch import nn
 
+from ... import blocks3d as B
 from ..._lib import MisError
 from ...engine3d import UNet3DEngine
 from ...engine3d_res import ResidualUNet3DEngine, ResidualUNetSE3DEngine
@@ -70,8 +76,43 @@ class AbstractUNet(nn.Module):
         else:
             self.final_activation = None
         self._cfg = (in_channels, out_channels, list(f_maps), num_groups, "deconv" if upsample == "deconv" else "default")
+        ups_ok = upsample in ("default", "deconv") if self._residual else upsample in ("default", "nearest", "deconv")
+        # what the whole-network engines cover (engine3d.UNet3DEngine.__init__ / engine3d_res): everything else takes the per-block route
+        self._fused_cfg_ok = (in_channels == 1 and 1 <= out_channels <= 4 and f_maps[0] == 64 and all(f % 64 == 0 for f in f_maps) and
+                              layer_order == "gcr" and conv_kernel_size == 3 and conv_padding == 1 and conv_upscale == 2 and
+                              pool_kernel_size in (2, (2, 2, 2)) and ups_ok)
         self._compute_dtype = compute_dtype
         self._engine = None
+
+    def _route(self, x):
+        want = os.environ.get("MISAMD_3D_ROUTE", "auto").lower()
+        if want not in ("auto", "fused", "blocks"):
+            raise MisError(f"MISAMD_3D_ROUTE must be auto, fused or blocks, got {want!r}")
+        div = 1 << (len(self.encoders) - 1)
+        fused_ok = self._fused_cfg_ok and x.dim() == 5 and all(int(d) % div == 0 for d in x.shape[2:])
+        if want == "fused" and not fused_ok:
+            raise MisError("MISAMD_3D_ROUTE=fused, but this configuration / input grid is outside the fused 3-D engines (see model/unet3d/model.py)")
+        if want == "blocks" or not fused_ok:
+            if self._se:
+                raise NotImplementedError("ResidualUNetSE3D runs on the fused engine only: 1 input channel, f_maps multiples of 64 from 64, order 'gcr', "
+                                          f"grid divisible by {div}")
+            return "blocks"
+        return "fused"
+
+    def _forward_blocks(self, x):
+        """the reference's forward loop (model.py:121-150) over the channels-last HIP blocks; logits out"""
+        if x.device.type != "cuda":
+            raise MisError(f"UNet3D runs on MI355X only: got input on {x.device} (no CPU fallback)")
+        if any(p.device != x.device for p in self.parameters()):
+            self.to(x.device)
+        a = B.to_cl(x, _dtype_from(self._compute_dtype))
+        feats = []
+        for enc in self.encoders:
+            a = enc._cl(a)
+            feats.insert(0, a)
+        for dec, skip in zip(self.decoders, feats[1:]):
+            a = dec._cl(skip, a)
+        return B.from_cl(B.conv(a, self.final_conv.weight, self.final_conv.bias))
 
     def _engine_for(self, x):
         if x.device.type != "cuda":
@@ -98,6 +139,8 @@ class AbstractUNet(nn.Module):
         eng.repack()                                        # every call: see model/unet2d/unet.py
 
     def forward(self, x):
+        if self._route(x) == "blocks":
+            return self._forward_blocks(x)
         return _FusedUNet3D.apply(x, self, *self.parameters())
 
 

@@ -570,3 +570,96 @@ def expand1_bwd(x, dy, dw, db):
     ws = workspace(lib.mis_expand1_bwd_workspace_bytes(dy.C), x.device, "expand1")
     check(lib.mis_expand1_bwd(dtype_code(dy.dtype), x.data_ptr(), dy.ptr, dy.ld, dy.npix, dy.C, ws.data_ptr(), dw.data_ptr(), db.data_ptr(), stream_ptr()),
           "mis_expand1_bwd")
+
+
+# ---- stand-alone / general-shape 3-D blocks (csrc/blocks3d.hip) --------------------------------------------
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU = 0, 1, 2, 3
+
+
+def norm_act_fwd(x, y, scale, shift, act, slope=0.0):
+    """y = act(scale[n, c] * x + shift[n, c]); scale = shift = None: activation only"""
+    lib = load()
+    x, y = _v(x), _v(y)
+    check(lib.mis_norm_act_fwd(dtype_code(x.dtype), x.ptr, x.ld, y.ptr, y.ld, x.N, x.D * x.H * x.W, x.C, None if scale is None else scale.data_ptr(),
+                               None if shift is None else shift.data_ptr(), act, slope, stream_ptr()), "mis_norm_act_fwd")
+
+
+def norm_act_bwd(dy, x, dz, scale, shift, act, slope=0.0):
+    lib = load()
+    dy, x, dz = _v(dy), _v(x), _v(dz)
+    check(lib.mis_norm_act_bwd(dtype_code(x.dtype), dy.ptr, dy.ld, x.ptr, x.ld, dz.ptr, dz.ld, x.N, x.D * x.H * x.W, x.C,
+                               None if scale is None else scale.data_ptr(), None if shift is None else shift.data_ptr(), act, slope, stream_ptr()),
+          "mis_norm_act_bwd")
+
+
+def gn_fwd_finalize_ld(s, sq, N, Cc, ld, G, count, gamma, beta, scale, shift, mean, rstd, eps=1e-5):
+    lib = load()
+    check(lib.mis_gn_fwd_finalize_ld(s.data_ptr(), sq.data_ptr(), N, Cc, ld, G, float(count), gamma.data_ptr(), beta.data_ptr(), eps, scale.data_ptr(),
+                                     shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), stream_ptr()), "mis_gn_fwd_finalize_ld")
+
+
+def gn_bwd_finalize_ld(S1, S2, mean, rstd, gamma, N, Cc, ld, G, count, p, q, r, dgamma, dbeta):
+    lib = load()
+    check(lib.mis_gn_bwd_finalize_ld(S1.data_ptr(), S2.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), N, Cc, ld, G, float(count),
+                                     p.data_ptr(), q.data_ptr(), r.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), stream_ptr()), "mis_gn_bwd_finalize_ld")
+
+
+def pool3d_fwd(x, y, k, avg=False):
+    """x (N, D, H, W, C) -> y (N, D//kd, H//kh, W//kw, C): MaxPool3d / AvgPool3d(kernel = stride = k), floor mode"""
+    lib = load()
+    x, y = _v(x), _v(y)
+    kd, kh, kw = k
+    if (y.N, y.D, y.H, y.W) != (x.N, x.D // kd, x.H // kh, x.W // kw) or y.C != x.C:
+        raise MisError(f"pool3d_fwd: output grid {(y.N, y.D, y.H, y.W, y.C)} does not match input {(x.N, x.D, x.H, x.W, x.C)} / window {k}")
+    check(lib.mis_pool3d_fwd(dtype_code(x.dtype), 1 if avg else 0, kd, kh, kw, x.ptr, x.ld, y.ptr, y.ld, x.N, x.D, x.H, x.W, x.C, stream_ptr()),
+          "mis_pool3d_fwd")
+
+
+def pool3d_bwd(x, dy, dx, k, avg=False):
+    lib = load()
+    x, dy, dx = _v(x), _v(dy), _v(dx)
+    kd, kh, kw = k
+    if (dy.N, dy.D, dy.H, dy.W) != (x.N, x.D // kd, x.H // kh, x.W // kw) or (dx.N, dx.D, dx.H, dx.W) != (x.N, x.D, x.H, x.W) or dy.C != x.C or dx.C != x.C:
+        raise MisError("pool3d_bwd: grids do not match")
+    check(lib.mis_pool3d_bwd(dtype_code(x.dtype), 1 if avg else 0, kd, kh, kw, x.ptr, x.ld, dy.ptr, dy.ld, dx.ptr, dx.ld, x.N, x.D, x.H, x.W, x.C,
+                             stream_ptr()), "mis_pool3d_bwd")
+
+
+def nearest_maps(src, dst, device):
+    """torch's `F.interpolate(mode='nearest', size=dst)` index rule (aten UpSample.h nearest_idx: floor(dst_index * (float)src / dst), clamped), per axis:
+    (forward maps dst -> src, inverse [lo, hi) ranges src -> dst), int32 device tensors"""
+    import numpy as np
+    fwd, inv = [], []
+    for s, d in zip(src, dst):
+        scale = np.float32(s) / np.float32(d)
+        m = np.minimum(np.floor(np.arange(d, dtype=np.float32) * scale).astype(np.int64), s - 1)
+        if d == s:
+            m = np.arange(d)
+        r = np.zeros((s, 2), dtype=np.int32)
+        for j in range(s):
+            hit = np.nonzero(m == j)[0]
+            if hit.size:
+                r[j] = (hit[0], hit[-1] + 1)
+                assert hit[-1] - hit[0] + 1 == hit.size       # monotone map: the readers of a source index are contiguous
+        fwd.append(torch.from_numpy(m.astype(np.int32)).to(device))
+        inv.append(torch.from_numpy(r.reshape(-1)).to(device))
+    return fwd, inv
+
+
+def gather3d_fwd(x, y, maps):
+    """y[n, d, h, w, :] = x[n, mD[d], mH[h], mW[w], :] over the Views' channel slices (equal channel counts)"""
+    lib = load()
+    x, y = _v(x), _v(y)
+    if x.C != y.C or x.N != y.N or [m.numel() for m in maps] != [y.D, y.H, y.W]:
+        raise MisError("gather3d_fwd: slices / maps do not match")
+    check(lib.mis_gather3d_fwd(dtype_code(x.dtype), x.ptr, x.ld, y.ptr, y.ld, x.N, x.D, x.H, x.W, y.D, y.H, y.W, x.C, maps[0].data_ptr(), maps[1].data_ptr(),
+                               maps[2].data_ptr(), stream_ptr()), "mis_gather3d_fwd")
+
+
+def gather3d_bwd(dy, dx, ranges):
+    lib = load()
+    dy, dx = _v(dy), _v(dx)
+    if dx.C != dy.C or dx.N != dy.N or [r.numel() for r in ranges] != [2 * dx.D, 2 * dx.H, 2 * dx.W]:
+        raise MisError("gather3d_bwd: slices / ranges do not match")
+    check(lib.mis_gather3d_bwd(dtype_code(dy.dtype), dy.ptr, dy.ld, dx.ptr, dx.ld, dx.N, dx.D, dx.H, dx.W, dy.D, dy.H, dy.W, dx.C, ranges[0].data_ptr(),
+                               ranges[1].data_ptr(), ranges[2].data_ptr(), stream_ptr()), "mis_gather3d_bwd")
