@@ -1,8 +1,8 @@
 """Mirror of the patch side of the reference's 3-D datasets: `SliceBuilder` / `FilterSliceBuilder` (dataset/unet3d_dataset/utils.py:47-157),
 `calculate_stats` (:290-311), `get_slice_builder` (:168-172), and `VolumeDataset`, the HBM-resident counterpart of `AbstractHDF5Dataset`
 (dataset/unet3d_dataset/hdf5.py:44-200): the raw / label volumes live in device memory, a sample is a patch cut from them and pushed through the
-on-device `Transformer` (augment mirror) - nothing is read from disk or moved over PCIe per sample.  HDF5 input itself (h5py) is out of scope: pass
-arrays.  The slice bookkeeping is one-time host logic, identical to the reference's (golden `tests/golden/g14_slices.npz`)."""
+on-device `Transformer` (augment mirror) - nothing is read from disk or moved over PCIe per sample.  File-backed datasets (`hdf5.py`) read the
+volumes once and hand them to `VolumeDataset`; `get_train_loaders` (:182-227) builds the loaders `create_trainer` needs.  The slice bookkeeping is one-time host logic, identical to the reference's (golden `tests/golden/g14_slices.npz`)."""
 import numpy as np
 import torch
 
@@ -156,3 +156,28 @@ class VolumeDataset(torch.utils.data.Dataset):
 
     def __len__(self):
         return self.patch_count
+
+
+def _loader_classes(class_name):
+    """utils.py:166-172"""
+    from . import hdf5
+    if not hasattr(hdf5, class_name):
+        raise RuntimeError(f"Unsupported dataset class: {class_name}")
+    return getattr(hdf5, class_name)
+
+
+def get_train_loaders(config):
+    """utils.py:182-227: {'train': DataLoader, 'val': DataLoader} over ConcatDataset(create_datasets(...)).  The samples are device tensors (the volumes live in
+    HBM), so the loaders run in the training process (num_workers and pin_memory of the config do not apply); batch_size is the config's, per process - data
+    parallelism is one process per GPU here, not nn.DataParallel's batch_size * device_count."""
+    from torch.utils.data import ConcatDataset, DataLoader
+    assert "loaders" in config, "Could not find data loaders configuration"
+    loaders_config = config["loaders"]
+    dataset_class = _loader_classes(loaders_config.get("dataset", None) or "StandardHDF5Dataset")
+    assert set(loaders_config["train"]["file_paths"]).isdisjoint(loaders_config["val"]["file_paths"]), \
+        "Train and validation 'file_paths' overlap. One cannot use validation data for training!"
+    train_datasets = dataset_class.create_datasets(loaders_config, phase="train")
+    val_datasets = dataset_class.create_datasets(loaders_config, phase="val")
+    batch_size = loaders_config.get("batch_size", 1)
+    return {"train": DataLoader(ConcatDataset(train_datasets), batch_size=batch_size, shuffle=True, num_workers=0),
+            "val": DataLoader(ConcatDataset(val_datasets), batch_size=batch_size, shuffle=False, num_workers=0)}

@@ -3,8 +3,8 @@ validation / LR-scheduler / best-score / checkpoint semantics (`last_checkpoint.
 num_iterations, model_state_dict, best_eval_score, optimizer_state_dict) around the MI355X model, loss and metric mirrors.  Control code only:
 every tensor op it triggers runs in the HIP engine (model forward/backward), the loss kernels and the metric kernels.  TensorBoard is optional
 here (the package is absent in this image): scalars are always kept in `self.scalars` and forwarded to a SummaryWriter when one can be built.
-`create_trainer` (config file -> HDF5 loaders) is out of scope: build the parts with get_model / get_loss_criterion / get_evaluation_metric /
-create_optimizer / create_lr_scheduler and pass the loaders."""
+`create_trainer(config)` (trainer.py:19-55) assembles model, loss, metric, loaders, optimizer and scheduler from one configuration dictionary; where the reference
+wraps the model in nn.DataParallel (:23-24) the MI355X design is one process per GPU with the gradient all-reduce of ddp.py."""
 import os
 from datetime import datetime
 
@@ -16,6 +16,30 @@ from . import utils
 from .utils import get_logger
 
 logger = get_logger("UNetTrainer")
+
+
+def create_trainer(config):
+    """trainer.py:19-55"""
+    from ...dataset.unet3d_dataset.utils import get_train_loaders
+    from .losses import get_loss_criterion
+    from .metrics import get_evaluation_metric
+    from .model import get_model
+    model = get_model(config["model"])
+    if str(config.get("device", "cuda")) == "cpu":
+        raise NotImplementedError("create_trainer: device 'cpu' - the MI355X mirror has no CPU path")
+    model = model.cuda()
+    logger.info(f"Number of learnable params {utils.get_number_of_learnable_parameters(model)}")
+    loss_criterion = get_loss_criterion(config)
+    eval_criterion = get_evaluation_metric(config)
+    loaders = get_train_loaders(config)
+    optimizer = utils.create_optimizer(config["optimizer"], model)
+    lr_scheduler = utils.create_lr_scheduler(config.get("lr_scheduler", None), optimizer)
+    trainer_config = config["trainer"]
+    tensorboard_formatter = utils.get_tensorboard_formatter(trainer_config.pop("tensorboard_formatter", None))
+    resume = trainer_config.pop("resume", None)
+    pre_trained = trainer_config.pop("pre_trained", None)
+    return UNetTrainer(model=model, optimizer=optimizer, lr_scheduler=lr_scheduler, loss_criterion=loss_criterion, eval_criterion=eval_criterion,
+                       loaders=loaders, tensorboard_formatter=tensorboard_formatter, resume=resume, pre_trained=pre_trained, **trainer_config)
 
 
 class _ScalarLog:

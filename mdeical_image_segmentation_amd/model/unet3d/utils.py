@@ -99,3 +99,59 @@ def create_lr_scheduler(lr_config, optimizer):
     clazz = getattr(importlib.import_module("torch.optim.lr_scheduler"), lr_config.pop("name"))
     lr_config["optimizer"] = optimizer
     return clazz(**lr_config)
+
+
+class _TensorboardFormatter:
+    """utils.py:113-151: batch -> [(tag, CHW image)]"""
+
+    def __init__(self, **kwargs):
+        pass
+
+    def __call__(self, name, batch):
+        import numpy as np
+        out = []
+        for tag, img in self.process_batch(name, batch):
+            assert img.ndim == 2 or img.ndim == 3, "Only 2D (HW) and 3D (CHW) images are accepted for display"
+            if img.ndim == 2:
+                img = np.expand_dims(img, axis=0)
+            else:
+                assert img.shape[0] in (1, 3), "Only (1, H, W) or (3, H, W) images are supported"
+            out.append((tag, img))
+        return out
+
+    def process_batch(self, name, batch):
+        raise NotImplementedError
+
+
+class DefaultTensorboardFormatter(_TensorboardFormatter):
+    """utils.py:154-187: the middle z-slice of every (sample, channel), min-max normalised"""
+
+    def __init__(self, skip_last_target=False, **kwargs):
+        super().__init__(**kwargs)
+        self.skip_last_target = skip_last_target
+
+    def process_batch(self, name, batch):
+        import numpy as np
+        if name == "targets" and self.skip_last_target:
+            batch = batch[:, :-1, ...]
+        norm = lambda img: np.nan_to_num((img - np.min(img)) / np.ptp(img))
+        out = []
+        if batch.ndim == 5:
+            z = batch.shape[2] // 2
+            for b in range(batch.shape[0]):
+                for c in range(batch.shape[1]):
+                    out.append((f"{name}/batch_{b}/channel_{c}/slice_{z}", norm(batch[b, c, z, ...])))
+        else:
+            z = batch.shape[1] // 2
+            for b in range(batch.shape[0]):
+                out.append((f"{name}/batch_{b}/channel_0/slice_{z}", norm(batch[b, z, ...])))
+        return out
+
+
+def get_tensorboard_formatter(formatter_config):
+    """utils.py:212-219"""
+    if formatter_config is None:
+        return DefaultTensorboardFormatter()
+    cfg = dict(formatter_config)
+    clazz = globals()[cfg["name"]]
+    return clazz(**cfg)

@@ -67,3 +67,49 @@ def test_unet_trainer_matches_reference_run(tmp_path):
     assert t2.checkpoint_dir == str(tmp_path)
     for (k, a), b in zip(net2.state_dict().items(), last["model_state_dict"].values()):
         assert torch.equal(a.cpu(), b), k
+
+
+def test_create_trainer_from_config(tmp_path):
+    """`create_trainer(config)` (reference model/unet3d/trainer.py:19-55): model, loss, metric, file-backed loaders (dataset/unet3d_dataset/hdf5.py
+    `create_datasets`, utils.py:182-227 `get_train_loaders`), optimizer and scheduler from one dictionary; then two epochs of the loop on the HIP path."""
+    from mdeical_image_segmentation_amd.model.unet3d.trainer import UNetTrainer, create_trainer
+    rng = np.random.RandomState(0)
+    paths = {}
+    for name in ("train", "val"):
+        raw = rng.randn(16, 32, 64).astype(np.float32)
+        label = (raw + 0.3 * rng.randn(16, 32, 64) > 0.2).astype(np.float32)
+        paths[name] = str(tmp_path / f"{name}.npz")
+        np.savez(paths[name], raw=raw, label=label)
+
+    def phase(p, aug):
+        raw_t = [{"name": "Standardize"}] + ([{"name": "RandomFlip"}] if aug else []) + [{"name": "ToTensor", "expand_dims": True}]
+        lab_t = ([{"name": "RandomFlip"}] if aug else []) + [{"name": "ToTensor", "expand_dims": True}]
+        return {"file_paths": [p], "slice_builder": {"name": "SliceBuilder", "patch_shape": [16, 32, 32], "stride_shape": [16, 32, 32], "skip_shape_check": True},
+                "transformer": {"raw": raw_t, "label": lab_t}}
+
+    config = {
+        "device": "cuda",
+        "model": {"name": "UNet3D", "in_channels": 1, "out_channels": 1, "f_maps": [64, 128], "num_levels": 2, "layer_order": "gcr", "final_sigmoid": True},
+        "loss": {"name": "BCEDiceLoss"},
+        "eval_metric": {"name": "DiceCoefficient"},
+        "optimizer": {"learning_rate": 2e-3, "weight_decay": 1e-5},
+        "lr_scheduler": {"name": "StepLR", "step_size": 2, "gamma": 0.5},
+        "loaders": {"dataset": "StandardHDF5Dataset", "batch_size": 1, "num_workers": 2, "raw_internal_path": "raw", "label_internal_path": "label",
+                    "global_normalization": True, "train": phase(paths["train"], True), "val": phase(paths["val"], False)},
+        "trainer": {"checkpoint_dir": str(tmp_path / "ckpt"), "max_num_epochs": 2, "max_num_iterations": 100, "validate_after_iters": 2, "log_after_iters": 1,
+                    "eval_score_higher_is_better": True},
+    }
+    t = create_trainer(config)
+    assert isinstance(t, UNetTrainer) and len(t.loaders["train"]) == 2 and len(t.loaders["val"]) == 2
+    x, y = next(iter(t.loaders["val"]))
+    assert x.is_cuda and tuple(x.shape) == (1, 1, 16, 32, 32) and tuple(y.shape) == (1, 1, 16, 32, 32)
+    t.fit()
+    assert t.num_epochs == 2 and t.num_iterations == 5          # the counter starts at 1 (trainer.py:108) and advances once per batch
+    losses = [v for tag, v, _ in t.scalars if tag == "train_loss_avg"]
+    assert len(losses) == 4 and all(np.isfinite(losses)) and len(set(losses)) == 4      # (the loop's numerics are pinned by the golden run above)
+    assert any(tag == "val_eval_score_avg" for tag, _, _ in t.scalars)
+    assert os.path.exists(tmp_path / "ckpt" / "last_checkpoint.pytorch") and os.path.exists(tmp_path / "ckpt" / "best_checkpoint.pytorch")
+    with pytest.raises(ImportError, match="h5py"):
+        from mdeical_image_segmentation_amd.dataset.unet3d_dataset.hdf5 import read_volumes
+        (tmp_path / "x.h5").write_bytes(b"")
+        read_volumes(str(tmp_path / "x.h5"), ["raw"])
