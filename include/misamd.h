@@ -238,6 +238,9 @@ int mis_aug_rotate3(const float* src, float* dst, double* workspace, long long n
  * normalised kernel of radius int(4*sigma+0.5), on the device), and scipy.ndimage.map_coordinates(order 0 | 3, mode='reflect') at the voxel
  * grid displaced by alpha * (fz, fy, fx) (fz may be NULL). */
 int mis_aug_gauss1d(const double* src, double* dst, long long nvol, int D, int H, int W, int axis, const double* weights, int radius, void* stream);
+/* GaussianBlur3D (transforms.py:708-718: skimage.filters.gaussian(x, sigma) = scipy.ndimage.gaussian_filter(fp32 volume, sigma, mode='nearest', truncate=4)):
+ * the same separable pass on fp32 volumes, rounded to fp32 after every axis as scipy does; mode 0 = 'reflect', 1 = 'nearest'. */
+int mis_aug_gauss1d_f32(const float* src, float* dst, long long nvol, int D, int H, int W, int axis, const double* weights, int radius, int mode, void* stream);
 int mis_aug_map_coordinates(const void* src, void* dst, double* workspace, long long nvol, int D, int H, int W, const double* fz, const double* fy,
                             const double* fx, double alpha, int order, int elem_size, void* stream);
 int mis_aug_pointwise(const float* src, float* dst, long long n, float a, float b, int do_clip, float lo, float hi, float noise_std,

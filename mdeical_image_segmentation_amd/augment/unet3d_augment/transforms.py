@@ -15,7 +15,7 @@ outputs are CUDA tensors.  Differences, all loud or documented:
   * AdditivePoissonNoise: the integer field comes from the reference's stream on the host (uploaded, added on the device: bit-exact);
   * CropToFixed: window / mirror padding as one gather kernel, start positions from the reference's stream;
   * PercentileNormalizer: the order statistics are selected with torch.kthvalue on the device, numpy's interpolation rule;
-  * GaussianBlur3D (needs skimage), label->boundary transforms: out of scope.
+  * label->boundary transforms (skimage find_boundaries / measure.label): out of scope.
 """
 import ctypes as C
 import importlib
@@ -468,7 +468,45 @@ class Identity:
         return m
 
 
-GaussianBlur3D = _unbuilt("GaussianBlur3D")
+class GaussianBlur3D:
+    """transforms.py:708-718: with probability p (Python's global `random`, like the reference), skimage.filters.gaussian(x, sigma ~ U(sigma[0], sigma[1])).
+    For a float volume that is scipy.ndimage.gaussian_filter(x, sigma, mode='nearest', truncate=4.0) in the volume's dtype: three separable passes on the
+    device (csrc/augment.hip aug_gauss1d_kernel<float, NEAREST>), each rounded to fp32 like scipy's per-axis output array.  A 4-D input (C, D, H, W) is
+    what skimage would treat as one 4-D image (it would also blur ACROSS channels); the reference only applies it to 3-D raw patches and so does this."""
+
+    def __init__(self, sigma=[.1, 2.], execution_probability=0.5, **kwargs):
+        self.sigma = sigma
+        self.execution_probability = execution_probability
+
+    def __call__(self, x):
+        import random
+        if random.random() < self.execution_probability:
+            sigma = random.uniform(self.sigma[0], self.sigma[1])
+            return self.blur(x, sigma)
+        return x
+
+    @staticmethod
+    def blur(x, sigma):
+        x = _dev(x)
+        if x.dim() != 3:
+            raise MisError(f"GaussianBlur3D: a (D, H, W) volume is expected, got {tuple(x.shape)}")
+        a = x.to(torch.float32).contiguous()
+        sd = float(sigma)
+        radius = int(4.0 * sd + 0.5)
+        xs = np.arange(-radius, radius + 1)
+        phi = np.exp(-0.5 / (sd * sd) * xs ** 2)
+        phi = (phi / phi.sum())[::-1].copy()
+        wdev = torch.from_numpy(phi).to(a.device)
+        D, H, W = a.shape
+        b = torch.empty_like(a)
+        src = a
+        for ax in range(3):
+            dst = b if src is not b else torch.empty_like(a)
+            check(load().mis_aug_gauss1d_f32(src.data_ptr(), dst.data_ptr(), 1, D, H, W, ax, wdev.data_ptr(), radius, 1, stream_ptr()), "mis_aug_gauss1d_f32")
+            src = dst
+        return src
+
+
 # label -> boundary / affinity targets and connected-component relabelling need skimage (find_boundaries, measure.label): names kept, construction raises
 for _n in ("AbstractLabelToBoundary", "StandardLabelToBoundary", "BlobsToMask", "RandomLabelToAffinities", "LabelToAffinities", "LabelToZAffinities",
            "LabelToBoundaryAndAffinities", "LabelToMaskAndAffinities", "Relabel", "RgbToLabel"):

@@ -305,7 +305,10 @@ extern "C" int mis_aug_rotate3(const float* src, float* dst, double* workspace, 
 //   aug_mapcoord*_kernel: coordinate reflect, order 0 = round-half-up gather, order 3 = 4x4x4 cubic B-spline taps on float64 coefficients
 //                        (the prefilter is the per-axis aug_spline3_filter_kernel above, run over all three axes)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void aug_gauss1d_kernel(const double* __restrict__ src, double* __restrict__ dst, long long nvol, int D, int H, int W, int ax,
+// E = double: ElasticDeformation's fields.  E = float: GaussianBlur3D (skimage.filters.gaussian = gaussian_filter on the fp32 volume): scipy runs every axis on a
+// double line buffer and rounds the result to the array's type after each axis, which is what the float instantiation does.  NEAREST: mode='nearest' extension.
+template <typename E, bool NEAREST>
+__global__ __launch_bounds__(256) void aug_gauss1d_kernel(const E* __restrict__ src, E* __restrict__ dst, long long nvol, int D, int H, int W, int ax,
                                                           const double* __restrict__ wgt /*[2r+1], already reversed (symmetric)*/, int radius) {
     const long long per = (long long)D * H * W, total = nvol * per;
     const int dims[3] = {D, H, W};
@@ -319,10 +322,14 @@ __global__ __launch_bounds__(256) void aug_gauss1d_kernel(const double* __restri
         c[1] = (int)((r / W) % H);
         c[0] = (int)(r / ((long long)H * W));
         const int l = c[ax];
-        const double* line = src + (i - (long long)l * st);
-        double t = line[(long long)l * st] * wgt[radius];
-        for (int k = -radius; k < 0; ++k) t += (line[(long long)refl_idx(l + k, n) * st] + line[(long long)refl_idx(l - k, n) * st]) * wgt[k + radius];
-        dst[i] = t;
+        const E* line = src + (i - (long long)l * st);
+        auto at = [&](int j) -> double {
+            const int jj = NEAREST ? (j < 0 ? 0 : (j >= n ? n - 1 : j)) : refl_idx(j, n);
+            return (double)line[(long long)jj * st];
+        };
+        double t = (double)line[(long long)l * st] * wgt[radius];
+        for (int k = -radius; k < 0; ++k) t += (at(l + k) + at(l - k)) * wgt[k + radius];
+        dst[i] = (E)t;
     }
 }
 
@@ -381,9 +388,24 @@ extern "C" int mis_aug_gauss1d(const double* src, double* dst, long long nvol, i
     (void)hipGetLastError();
     MIS_REQUIRE(src && dst && src != dst && weights && nvol > 0 && D > 0 && H > 0 && W > 0 && axis >= 0 && axis <= 2 && radius >= 0, MIS_EINVAL,
                 "aug_gauss1d: bad argument");
-    hipLaunchKernelGGL(aug_gauss1d_kernel, dim3(aug_grid(nvol * D * H * W)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, nvol, D, H, W, axis,
-                       weights, radius);
+    hipLaunchKernelGGL((aug_gauss1d_kernel<double, false>), dim3(aug_grid(nvol * D * H * W)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, nvol, D,
+                       H, W, axis, weights, radius);
     MIS_LAUNCH_CHECK("aug_gauss1d");
+    return MIS_OK;
+}
+
+// fp32 volumes, mode 0 = 'reflect', 1 = 'nearest' (GaussianBlur3D: skimage.filters.gaussian's default)
+extern "C" int mis_aug_gauss1d_f32(const float* src, float* dst, long long nvol, int D, int H, int W, int axis, const double* weights /*device, 2r+1*/, int radius,
+                                   int mode, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(src && dst && src != dst && weights && nvol > 0 && D > 0 && H > 0 && W > 0 && axis >= 0 && axis <= 2 && radius >= 0 && (mode == 0 || mode == 1),
+                MIS_EINVAL, "aug_gauss1d_f32: bad argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (mode == 1)
+        hipLaunchKernelGGL((aug_gauss1d_kernel<float, true>), dim3(aug_grid(nvol * D * H * W)), dim3(256), 0, s, src, dst, nvol, D, H, W, axis, weights, radius);
+    else
+        hipLaunchKernelGGL((aug_gauss1d_kernel<float, false>), dim3(aug_grid(nvol * D * H * W)), dim3(256), 0, s, src, dst, nvol, D, H, W, axis, weights, radius);
+    MIS_LAUNCH_CHECK("aug_gauss1d_f32");
     return MIS_OK;
 }
 

@@ -159,6 +159,17 @@ def elastic(m, rs, spline_order, alpha=2000, sigma=50, apply_3d=True):
     return np.stack([map_coordinates(c, idx, order=spline_order, mode="reflect") for c in m], axis=0)
 
 
+def gaussian_blur3d(m, sigma):
+    """GaussianBlur3D.__call__ after its two `random` draws (transforms.py:713-718): `skimage.filters.gaussian(x, sigma=sigma)`.  scikit-image (pinned 0.23.2 in
+    the reference's requirements.txt:143) is absent from this image; its published algorithm for a float image without channel_axis
+    (skimage/filters/_gaussian.py: mode='nearest', cval=0, truncate=4.0, preserve_range=False leaves float data unscaled, float32 stays float32) is
+    exactly `scipy.ndimage.gaussian_filter(image, sigma, output=<same float dtype>, mode='nearest', cval=0, truncate=4.0)`, and scipy is present here."""
+    from scipy.ndimage import gaussian_filter
+    m = np.asarray(m)
+    ft = np.float32 if m.dtype in (np.float16, np.float32) else np.float64
+    return gaussian_filter(m.astype(ft), sigma, mode="nearest", cval=0, truncate=4.0)
+
+
 def contrast(m, mean, alpha):
     return np.clip(mean + alpha * (m - mean), -1, 1)
 

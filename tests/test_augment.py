@@ -181,3 +181,25 @@ def test_gaussian_noise_field_on_the_reference_stream():
     a = tr.AdditiveGaussianNoise(rs3, scale=(0.1, 0.2), execution_probability=1.0, exact=True)(torch.from_numpy(v).cuda()).cpu().numpy()
     b = ao.additive_gaussian_noise(v, rs4, (0.1, 0.2), 1.0).astype(np.float32)
     assert int((a != b).sum()) <= 1 and rs3.uniform() == rs4.uniform()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sigma", [0.1, 0.45, 1.3, 2.0])
+def test_gaussian_blur3d_matches_scipy(sigma):
+    """GaussianBlur3D (reference transforms.py:708-718) against the oracle's scipy call: the kernel walks a symmetric kernel the way scipy's correlate1d does
+    (centre tap, then pairs from the far end inwards, double accumulation, fp32 rounding after every axis), so the result is bit-equal"""
+    import random
+
+    from mdeical_image_segmentation_amd.augment.unet3d_augment.transforms import GaussianBlur3D
+    v = np.random.RandomState(5).randn(12, 20, 17).astype(np.float32)
+    want = ao.gaussian_blur3d(v, sigma)
+    got = GaussianBlur3D.blur(torch.from_numpy(v).cuda(), sigma).cpu().numpy()
+    assert got.dtype == np.float32 and np.array_equal(got, want), np.abs(got - want).max()
+    # the two draws come from Python's global generator, like the reference's
+    random.seed(11)
+    t = GaussianBlur3D(sigma=[0.5, 1.5], execution_probability=1.0)
+    out = t(torch.from_numpy(v).cuda()).cpu().numpy()
+    random.seed(11)
+    random.random()
+    assert np.array_equal(out, ao.gaussian_blur3d(v, random.uniform(0.5, 1.5)))
+    assert GaussianBlur3D(execution_probability=0.0)(v) is v
