@@ -158,7 +158,7 @@ def attach_traffic(roof, batch, size):
         return
     ent = tr.get("kernels", {}).get(roof["kernel"])
     roof["traffic_source_hash"] = tr.get("source_hash")
-    if ent is None or tr.get("source_hash") != _lib.source_hash() or tr.get("batch") != batch or tr.get("size") != size:
+    if ent is None or tr.get("source_hash") != _lib.source_hash(_lib.TRAFFIC_SOURCES) or tr.get("batch") != batch or tr.get("size") != size:
         roof["traffic_note"] = "profiles/traffic.json was collected on other kernel sources or another shape: not reported"
         return
     roof["traffic"] = ent["hbm_read_bytes_per_launch"] + ent["hbm_write_bytes_per_launch"]

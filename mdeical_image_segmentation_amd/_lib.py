@@ -246,14 +246,21 @@ def load():
     return lib
 
 
-def source_hash():
-    """sha256 (first 16 hex digits) of the kernel sources + the C header this tree was built from: ties a committed profile
-    (profiles/traffic.json) to the build it was measured on"""
+# the sources that define the kernels whose HBM traffic profiles/traffic.json records (the 3x3 convolution / weight-gradient kernels of the benchmark)
+TRAFFIC_SOURCES = ("common.hpp", "conv_args.hpp", "conv_igemm.hip", "conv_pp.hip", "wgrad_args.hpp", "wgrad.hip", "wgrad_pp.hip")
+
+
+def source_hash(only=None):
+    """sha256 (first 16 hex digits) of the kernel sources + the C header this tree was built from.  `only`: restrict to these csrc file names
+    (source_hash(TRAFFIC_SOURCES) ties profiles/traffic.json to the sources of the kernels it was measured on, and to nothing else)"""
     import glob
     import hashlib
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.hpp")) +
-                   glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) + [os.path.join(_HERE, "..", "include", "misamd.h")])
+    if only is None:
+        files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.hpp")) +
+                       glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) + [os.path.join(_HERE, "..", "include", "misamd.h")])
+    else:
+        files = [os.path.join(_HERE, "csrc", f) for f in sorted(only)]
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())

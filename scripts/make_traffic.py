@@ -12,14 +12,14 @@ from mdeical_image_segmentation_amd import _lib  # noqa: E402
 
 KEYS = {   # bench key -> kernel symbols (prefix match on the rocprof name) whose launches carry that key at the benchmark shapes
     "conv_igemm/bf16/k3/2d/bn128": ["void conv_pp_kernel<8>", "void conv_pp_kernel<4>"],
-    "wgrad/bf16/k3/2d": ["wgrad_pp_wide_kernel", "void wgrad_pp_kernel<2>"],
+    "wgrad/bf16/k3/2d": ["void wgrad_pp_wide_kernel<", "wgrad_pp_wide_kernel", "void wgrad_pp_kernel<2>"],
     "conv_igemm/bf16/k3/2d/bn64": ["conv64_ws_kernel"],
 }
 
 
 def main(path):
     summ = json.load(open(path))
-    out = {"source_hash": _lib.source_hash(), "batch": 32, "size": 512, "profile": os.path.basename(path), "kernels": {}}
+    out = {"source_hash": _lib.source_hash(_lib.TRAFFIC_SOURCES), "hashed_sources": list(_lib.TRAFFIC_SOURCES), "batch": 32, "size": 512, "profile": os.path.basename(path), "kernels": {}}
     for key, syms in KEYS.items():
         rd = wr = n = 0.0
         used = []
