@@ -166,6 +166,9 @@ def attach_traffic(roof, batch, size):
     roof["traffic_profile"] = tr.get("profile")
 
 
+DDP_ON = False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,10 +214,17 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # MISAMD_BENCH_REHEARSAL=nccl1 (with --gpus 1): the whole N > 1 code path - RCCL process group, bucketed all-reduces on the side stream under the backward,
+    # barriers, max-over-ranks, comm report - with a communicator of ONE rank, which is what a one-GPU box can run of it; never a number
+    global DDP_ON
+    DDP_ON = world > 1 or os.environ.get("MISAMD_BENCH_REHEARSAL") == "nccl1"
+    if DDP_ON:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         # MISAMD_BENCH_REHEARSAL=gloo: several ranks SHARING one GPU over gloo - exercises the N > 1 code path (buckets, comm report) on a one-GPU box; never a number
         backend = os.environ.get("MISAMD_BENCH_REHEARSAL", "nccl")
+        if backend == "nccl1":
+            backend = "nccl"
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -254,7 +264,7 @@ def main():
                                                                 "loss_per_step", "config")}
                 out["extra"] = ex
             print(json.dumps(out), flush=True)
-    if world > 1:
+    if DDP_ON:
         dist.destroy_process_group()
 
 
@@ -264,7 +274,7 @@ def _timed_loop(step, steps, warmup, world, dist, dev, timing):
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if DDP_ON:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -284,7 +294,7 @@ def _timed_loop(step, steps, warmup, world, dist, dev, timing):
     fence()
     dt = time.perf_counter() - t0
     prof = (prof, len(timed_steps)) if timing else None
-    if world > 1:
+    if DDP_ON:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -314,7 +324,7 @@ def run2d(args, rank, world, dev, dist, *, dtype, batch, size, steps, warmup, ti
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
     cin, ncls = (1, 2) if args.net == "1x2" else (3, 4)
     eng = UNet2DEngine(cin, ncls, dtype=tdt, device=dev, seed=0, lr=args.lr)  # identical init on every rank (PyTorch default init, seed 0)
-    reducer = GradReducer(eng.flat, timing=True, backend=args.comm) if world > 1 else None
+    reducer = GradReducer(eng.flat, timing=True, backend=args.comm) if DDP_ON else None
     g = torch.Generator().manual_seed(1000 + rank)                    # per-rank data shard
     images = torch.randn(batch, cin, size, size, generator=g).to(dev)
     labels = torch.randint(0, ncls, (batch, size, size), generator=g).to(dev)
@@ -387,7 +397,7 @@ def run3d(args, rank, world, dev, dist, *, dtype, batch, size, steps, warmup, ti
     from mdeical_image_segmentation_amd.engine3d import UNet3DEngine
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
     eng = UNet3DEngine(1, 3, dtype=tdt, device=dev, seed=0, lr=args.lr)
-    reducer = GradReducer(eng.flat, timing=True, backend=args.comm) if world > 1 else None
+    reducer = GradReducer(eng.flat, timing=True, backend=args.comm) if DDP_ON else None
     g = torch.Generator().manual_seed(1000 + rank)
     x = torch.randn(batch, 1, size, size, size, generator=g).to(dev)
     t = (torch.rand(batch, 3, size, size, size, generator=g) > 0.5).float().to(dev)

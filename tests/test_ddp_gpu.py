@@ -109,3 +109,46 @@ def test_native_rccl_communicator_single_rank():
     assert lib.mis_comm_world() == 0
     buf = torch.ones(8, device="cuda")
     assert lib.mis_allreduce_bucket(buf.data_ptr(), 8, None) != 0      # finalized: loud error, no crash
+
+
+def _nccl1_worker(rank, port, out):
+    import torch
+    import torch.distributed as dist
+
+    from mdeical_image_segmentation_amd.ddp import GradReducer
+    from mdeical_image_segmentation_amd.engine2d import UNet2DEngine
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        eng = UNet2DEngine(1, 2, dtype=torch.float32, device="cuda", seed=0)
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(2, 1, 32, 32, generator=g).cuda()
+        y = torch.randint(0, 2, (2, 32, 32), generator=g).cuda()
+        eng.forward(x, y, train=True)
+        eng.backward()
+        torch.cuda.synchronize()
+        ref = eng.flat.g.clone()
+        red = GradReducer(eng.flat, timing=True)                 # backend "torch" = ProcessGroupNCCL = RCCL
+        for _ in range(2):                                       # twice: the persistent events / bucket slots are reused
+            eng.forward(x, y, train=True)
+            eng.backward(stage_cb=red.stage_done)
+            red.finish()
+        dist.barrier()
+        torch.cuda.synchronize()
+        ar, _ = red.timing_ms()
+        out["res"] = (dist.get_backend(), red.buckets_per_step, bool(torch.equal(eng.flat.g, ref)), ar > 0.0)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_torch_rccl_process_group_single_rank():
+    """GradReducer's default backend on the real transport: torch.distributed 'nccl' (= RCCL) with a one-rank group on this box's GPU - the same calls an 8-GPU
+    launch makes (init with device_id, all_reduce per bucket under the side stream, barrier), in a child process so that the group's lifetime is its own"""
+    port = _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_nccl1_worker, args=(port, out), nprocs=1, join=True)
+        res = out["res"]
+    assert res[0] == "nccl" and res[1] >= 8 and res[2] and res[3], res
