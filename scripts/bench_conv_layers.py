@@ -1,7 +1,7 @@
 """A/B of mis_conv_igemm configurations on the 3x3 layer shapes of the 2-D benchmark net (bs 32, 512^2, bf16, random data), interleaved rounds in ONE
 process (cdna_hip_programming.md §5.4 rule 24).  Arms are environment switches read per call by the dispatcher.
 
-    python scripts/bench_conv_layers.py                       # ping-pong kernel vs MIS_CONV_NOPP=1
+    python scripts/bench_conv_layers.py                       # column-segment kernel vs conv_pp_kernel (MIS_CONV_NOPPC=1) vs the round-1 kernels (MIS_CONV_NOPP=1)
     python scripts/bench_conv_layers.py MIS_CONV_PP_NO256=1   # extra arm(s): NAME=VALUE"""
 import os
 import sys
@@ -17,7 +17,7 @@ LAYERS = [  # (H, Cin, Cout, launches per step with this shape incl. dgrads)
     (256, 64, 128, 1), (128, 128, 256, 1), (128, 256, 128, 1), (64, 256, 512, 1), (64, 512, 256, 1),
     (512, 64, 64, 4), (512, 128, 64, 1), (256, 128, 64, 1),
 ]
-arms = [("pp", {}), ("nopp", {"MIS_CONV_NOPP": "1"})]
+arms = [("ppc", {}), ("pp", {"MIS_CONV_NOPPC": "1"}), ("nopp", {"MIS_CONV_NOPP": "1"})]
 for a in sys.argv[1:]:
     k, v = a.split("=")
     arms.append((a, {k: v}))

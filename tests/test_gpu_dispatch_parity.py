@@ -17,7 +17,7 @@ BF, F32 = torch.bfloat16, torch.float32
 
 # (dtype, N, H, W, Cin, Cout, expected configuration)
 K3_CASES = [
-    # ping-pong kernel (conv_pp.hip): bf16, Cout % 128 == 0
+    # ping-pong kernel conv_pp_kernel<8 / 4> (16 x 16-pixel tiles): bf16, Cout % 128 == 0, grids the 32-row tiles of conv_ppc_kernel do not fit (or MIS_CONV_NOPPC=1)
     (BF, 2, 20, 36, 256, 256, "k3.2d.pp256", ""),        # ragged tiles, 4 K chunks
     (BF, 1, 9, 17, 512, 256, "k3.2d.pp256", ""),
     (BF, 1, 9, 17, 1024, 1024, "k3.2d.pp256", ""),       # middle_conv.second: 16 K chunks x 4 column tiles
@@ -25,8 +25,17 @@ K3_CASES = [
     (BF, 3, 150, 170, 64, 256, "k3.2d.pp256", ""),       # 330 tiles > 256 persistent blocks: several tiles per block, one K chunk per tile
     (BF, 1, 20, 36, 64, 128, "k3.2d.pp128", ""),
     (BF, 2, 20, 36, 256, 128, "k3.2d.pp128", ""),
-    (BF, 3, 150, 170, 128, 128, "k3.2d.pp128", ""),      # 330 tiles > 256 blocks, 2 K chunks
+    (BF, 3, 150, 170, 128, 128, "k3.2d.pp128", "MIS_CONV_NOPPC"),      # 330 tiles > 256 blocks, 2 K chunks
     (BF, 1, 16, 16, 64, 128, "k3.2d.pp128", ""),         # a single tile
+    # column-segment ping-pong kernel (conv_ppc_kernel<8>: 32 x 16-pixel tiles, 32-channel K chunks, a filter column = 96 MFMAs per segment): the default for
+    # the 128-column layers (Cout % 256 != 0) when its 32-row tiles fit the grid; MIS_CONV_PPC=1 gives it every Cout % 128 == 0 layer
+    (BF, 3, 150, 170, 64, 256, "k3.2d.ppc8", "MIS_CONV_PPC"),        # 3 x 5 x 11 tiles x 2 column tiles = 330 > 256 persistent blocks
+    (BF, 5, 150, 170, 128, 128, "k3.2d.ppc8", ""),                   # 275 tiles, 4 K chunks
+    (BF, 2, 64, 64, 128, 128, "k3.2d.ppc8", ""),                     # interior tiles
+    (BF, 1, 20, 36, 64, 128, "k3.2d.ppc8", "MIS_CONV_PPC"),          # ragged in both directions
+    (BF, 2, 20, 36, 256, 256, "k3.2d.ppc8", "MIS_CONV_PPC"),         # two column tiles, 8 K chunks
+    (BF, 1, 9, 17, 1024, 1024, "k3.2d.ppc8", "MIS_CONV_PPC"),        # 32 K chunks x 8 column tiles
+    (BF, 1, 32, 16, 64, 128, "k3.2d.ppc8", "MIS_CONV_PPC"),          # a single tile, exactly: the whole run is prologue + six segments
     # the configurations behind it (MIS_CONV_NOPP=1): still reachable, still tested
     (BF, 2, 20, 36, 256, 256, "k3.2d.bn256", "MIS_CONV_NOPP"),
     (BF, 1, 9, 17, 1024, 1024, "k3.2d.bn256", "MIS_CONV_NOPP"),
@@ -59,7 +68,7 @@ def test_conv3x3_every_branch(case, monkeypatch):
     ops = _ops()
     dtype, N, H, W, Cin, Cout, want_cfg, env = case
     if env:
-        monkeypatch.setenv(env, "1")
+        monkeypatch.setenv(*(env.split("=") if "=" in env else (env, "1")))
     x = rnd(N, Cin, H, W, seed=110)
     w = rnd(Cout, Cin, 3, 3, seed=111, scale=(9 * Cin) ** -0.5)
     b = rnd(Cout, seed=112)
