@@ -22,14 +22,14 @@ K3_CASES = [
     (BF, 1, 9, 17, 512, 256, "k3.2d.pp256", ""),
     (BF, 1, 9, 17, 1024, 1024, "k3.2d.pp256", ""),       # middle_conv.second: 16 K chunks x 4 column tiles
     (BF, 2, 100, 150, 128, 256, "k3.2d.pp256", ""),      # 140 spatial tiles
-    (BF, 3, 150, 170, 64, 256, "k3.2d.pp256", ""),       # 330 tiles > 256 persistent blocks: several tiles per block, one K chunk per tile
+    (BF, 3, 150, 170, 64, 256, "k3.2d.pp256", "MIS_CONV_NOPPC"),       # 330 tiles > 256 persistent blocks: several tiles per block, one K chunk per tile
     (BF, 1, 20, 36, 64, 128, "k3.2d.pp128", ""),
     (BF, 2, 20, 36, 256, 128, "k3.2d.pp128", ""),
     (BF, 3, 150, 170, 128, 128, "k3.2d.pp128", "MIS_CONV_NOPPC"),      # 330 tiles > 256 blocks, 2 K chunks
     (BF, 1, 16, 16, 64, 128, "k3.2d.pp128", ""),         # a single tile
     # column-segment ping-pong kernel (conv_ppc_kernel<8>: 32 x 16-pixel tiles, 32-channel K chunks, a filter column = 96 MFMAs per segment): the default for
-    # the 128-column layers (Cout % 256 != 0) when its 32-row tiles fit the grid; MIS_CONV_PPC=1 gives it every Cout % 128 == 0 layer
-    (BF, 3, 150, 170, 64, 256, "k3.2d.ppc8", "MIS_CONV_PPC"),        # 3 x 5 x 11 tiles x 2 column tiles = 330 > 256 persistent blocks
+    # Cout % 128 == 0 when its 32-row tiles fit the grid (MIS_CONV_PPC=1 takes it regardless)
+    (BF, 3, 150, 170, 64, 256, "k3.2d.ppc8", ""),                    # default dispatch: 3 x 5 x 11 tiles x 2 column tiles = 330 > 256 persistent blocks
     (BF, 5, 150, 170, 128, 128, "k3.2d.ppc8", ""),                   # 275 tiles, 4 K chunks
     (BF, 2, 64, 64, 128, 128, "k3.2d.ppc8", ""),                     # interior tiles
     (BF, 1, 20, 36, 64, 128, "k3.2d.ppc8", "MIS_CONV_PPC"),          # ragged in both directions

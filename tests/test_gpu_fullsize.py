@@ -78,7 +78,7 @@ def test_ping_pong_kernels_beyond_4gib_tensors():
     b = torch.randn(Cout, device=DEV, generator=gen)
     y = torch.empty(N, H, W, Cout, device=DEV, dtype=torch.bfloat16)
     ops.conv_igemm(x, w, y, ksize=3, Cin=Cin, Cout=Cout, bias=b, relu=True)
-    assert ops.conv_last_dispatch() == "k3.2d.pp256"
+    assert ops.conv_last_dispatch() == "k3.2d.ppc8"
     for sl in (slice(0, 2), slice(N - 2, N)):
         ys = torch.empty(2, H, W, Cout, device=DEV, dtype=torch.bfloat16)
         ops.conv_igemm(x[sl].contiguous(), w, ys, ksize=3, Cin=Cin, Cout=Cout, bias=b, relu=True)
