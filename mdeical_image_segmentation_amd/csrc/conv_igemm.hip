@@ -723,7 +723,7 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
                 const bool pp = getenv("MIS_CONV_NOPP") == nullptr;      // read per call: the parity tests toggle it to reach the pre-ping-pong configurations
                 // 64-column layers stay on the weight-stationary / bn64 configurations: the ping-pong kernel with 64-column blocks (wave tile 64 px x 32 ch: 12 fragment
                 // reads per 16 MFMAs) is bound by its R segments - measured 629 vs 959 TFLOP/s (64->64 at 512^2) and 784 vs 916 (128->64); MIS_CONV_PP64=1 selects it
-                const bool pp64 = getenv("MIS_CONV_PP64") != nullptr;
+                const bool pp64 = getenv("MIS_CONV_PP64") != nullptr || getenv("MIS_CONV_PPC64") != nullptr;
                 if (pp && conv_pp_eligible(d) && (d->Cout % 128 == 0 || pp64 || conv_pp_rs64_eligible(d))) {      // (rs64: opt-in, MIS_CONV_RS64=1)
                     const char* tag = "";
                     const int rc = launch_conv_pp(d, s, &tag);

@@ -494,10 +494,11 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
 // DMA schedule per wave: weights 3 instructions per segment (group 0 in its R for the next segment, group 1 in its M for the segment after the next one, as in conv_pp_kernel);
 // halo of the next chunk: instructions j = 0..2 in the R of column 0, j = 3.. in the R of column 1, none in column 2 (so that everything has had a slot pair to land before the
 // chunk's last barrier); every wait is a counted vmcnt that leaves exactly the halo instructions issued in the same segment in flight.
-template <int PF>
+template <int PF, int NF>
 __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
     using T = __bf16;
-    constexpr int NF = 4, WAVE_N = 64, BN = 128, NV = 16;
+    constexpr int WAVE_N = NF * 16, BN = 2 * WAVE_N, NV = 4 * NF;       // NF = 4: 128-column blocks; NF = 2: 64-column blocks (wave tile 128 px x 32 ch)
+    constexpr int WWAVES = BN / 16;                                      // waves that carry a weight DMA instruction per tap (16 rows of 64 B each)
     constexpr int TH = 4 * PF, TW = 16, HH = TH + 2, HW = 18, HP = HH * HW;
     constexpr int HITEMS = HP * 4, HINSTR = (HITEMS + 63) / 64, HBUF = HINSTR * 1024, ROWB = HW * 64;
     constexpr int HJ = (HINSTR + 7) / 8;             // halo instructions per wave per chunk (PF 8: 5, PF 6: 4)
@@ -579,6 +580,7 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
         int soff = (int)((((long long)kw * a.Cout + col) * a.Cin + c0) * 2);
         asm volatile("" : "+s"(soff));
         const int tapstride = 3 * a.Cout * a.Cin * 2;          // tap index = kh*3 + kw
+        if (wave >= WWAVES) return;                    // wave-uniform (NF = 2: the four waves of group 0 carry the whole tile)
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) pp_dma16(rw, soff + kh * tapstride + w_goff0, dst + kh * TAPB + wave * 1024);
     };
@@ -710,7 +712,8 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
     if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's last barrier
 }
 
-template <int PF> static int pp_launch_col(const MisConvDesc* d, hipStream_t stream) {
+template <int PF, int NF> static int pp_launch_col(const MisConvDesc* d, hipStream_t stream) {
+    constexpr int BN = 2 * NF * 16;
     constexpr int TH = 4 * PF, HINSTR = ((TH + 2) * 18 * 4 + 63) / 64;
     ConvArgs a;
     a.N = d->N; a.D = 1; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cin0 = d->Cin; a.Cout0 = d->Cout0;
@@ -724,14 +727,14 @@ template <int PF> static int pp_launch_col(const MisConvDesc* d, hipStream_t str
     a.tilesH = (d->H + TH - 1) / TH;
     a.tilesW = (d->W + 15) / 16;
     const long long nsp = (long long)d->N * a.tilesH * a.tilesW;
-    a.nCt = d->Cout / 128;
+    a.nCt = d->Cout / BN;
     MIS_REQUIRE(nsp * a.nCt < (1ll << 31), MIS_EUNSUPPORTED, "conv_igemm(ppc): grid too large");
     a.nSp = (int)nsp;
-    const size_t lds = 2 * (size_t)HINSTR * 1024 + 2 * (size_t)3 * 128 * 64 + 2 * (size_t)128 * 4;
+    const size_t lds = 2 * (size_t)HINSTR * 1024 + 2 * (size_t)3 * BN * 64 + 2 * (size_t)BN * 4;
     static std::atomic<unsigned long long> attr_done{0};
-    if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv_ppc_kernel<PF>), lds, "conv_igemm(ppc)")) return rc;
+    if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv_ppc_kernel<PF, NF>), lds, "conv_igemm(ppc)")) return rc;
     const long long total = nsp * a.nCt;
-    hipLaunchKernelGGL((conv_ppc_kernel<PF>), dim3((unsigned)(total > 256 ? 256 : total)), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((conv_ppc_kernel<PF, NF>), dim3((unsigned)(total > 256 ? 256 : total)), dim3(512), lds, stream, a);
     MIS_LAUNCH_CHECK("conv_igemm(ppc)");
     return MIS_OK;
 }
@@ -957,7 +960,11 @@ int launch_conv_pp(const MisConvDesc* d, hipStream_t stream, const char** tag) {
     // (both read per call: the parity tests reach every kernel on small grids that way)
     if (d->Cout % 128 == 0 && getenv("MIS_CONV_NOPPC") == nullptr && (((d->H + 31) / 32) * 32 * 100 <= d->H * 115 || getenv("MIS_CONV_PPC") != nullptr)) {
         *tag = "k3.2d.ppc8";
-        return pp_launch_col<8>(d, stream);
+        return pp_launch_col<8, 4>(d, stream);
+    }
+    if (d->Cout % 64 == 0 && getenv("MIS_CONV_PPC64") != nullptr) {      // 64-column blocks of the same kernel (opt-in A/B switch, read per call)
+        *tag = "k3.2d.ppc8n2";
+        return pp_launch_col<8, 2>(d, stream);
     }
     if (d->Cout % 256 == 0 && d->Cout0 % 128 == 0) {
         static const int no256 = getenv("MIS_CONV_PP_NO256") != nullptr;

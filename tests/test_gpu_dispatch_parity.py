@@ -52,6 +52,11 @@ K3_CASES = [
     (BF, 1, 70, 90, 128, 64, "k3.2d.pp64", "MIS_CONV_PP64"),
     (BF, 2, 20, 36, 64, 64, "k3.2d.pp64", "MIS_CONV_PP64"),
     (BF, 3, 150, 170, 64, 64, "k3.2d.pp64", "MIS_CONV_PP64"),          # 330 tiles > 256 blocks: one K chunk per tile, tile loop taken
+    (BF, 1, 70, 90, 128, 64, "k3.2d.ppc8n2", "MIS_CONV_PPC64"),        # 64-column blocks of the column-segment kernel (opt-in)
+    (BF, 2, 20, 36, 64, 64, "k3.2d.ppc8n2", "MIS_CONV_PPC64"),
+    (BF, 3, 150, 170, 64, 64, "k3.2d.ppc8n2", "MIS_CONV_PPC64"),       # 165 tiles
+    (BF, 9, 150, 170, 64, 64, "k3.2d.ppc8n2", "MIS_CONV_PPC64"),       # 495 tiles > 256 persistent blocks
+    (BF, 1, 40, 40, 64, 192, "k3.2d.ppc8n2", "MIS_CONV_PPC64"),        # three column tiles
     (F32, 2, 20, 36, 64, 128, "k3.2d.bn128.persist", ""),
     (F32, 1, 9, 17, 128, 256, "k3.2d.bn128.dma", ""),
     (F32, 1, 70, 90, 64, 64, "k3.2d.bn64.persist", ""),
