@@ -523,9 +523,18 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
     if (tile >= total_tiles) return;                 // block-uniform
     const int nchunks = a.Cin >> 5;
     const int tpi = a.tilesH * a.tilesW;
+    // tile order (a.tilesD, set by the launcher): 1 = column-tile major (all spatial tiles of one column tile, then the next: the weight tile is shared by every running block);
+    // 2 = spatial major (the nCt column tiles of a spatial tile are neighbours in the tile order, i.e. run at the same time on the same XCD: its halo is fetched from HBM
+    // once instead of once per column tile; a block still keeps its column tile from tile to tile because the persistent stride is a multiple of nCt)
     auto decode = [&](int t, int& tn, int& th0, int& tw0, int& tcol) {
-        const int ct = t / a.nSp;
-        const int sp = t - ct * a.nSp;
+        int ct, sp;
+        if (a.tilesD == 2) {
+            sp = t / a.nCt;
+            ct = t - sp * a.nCt;
+        } else {
+            ct = t / a.nSp;
+            sp = t - ct * a.nSp;
+        }
         tn = sp / tpi;
         const int r = sp - tn * tpi;
         const int th = r / a.tilesW;
@@ -723,11 +732,12 @@ template <int PF, int NF> static int pp_launch_col(const MisConvDesc* d, hipStre
     a.w = d->w; a.bias = d->bias; a.relu = d->relu; a.mask = d->mask; a.mask_ld = d->mask_ld;
     a.y0 = d->y0; a.y0_ld = d->y0_ld; a.y0_mode = d->y0_mode;
     a.y1 = d->y1; a.y1_ld = d->y1_ld; a.y1_mode = d->y1_mode;
-    a.tilesD = 1;
     a.tilesH = (d->H + TH - 1) / TH;
     a.tilesW = (d->W + 15) / 16;
     const long long nsp = (long long)d->N * a.tilesH * a.tilesW;
     a.nCt = d->Cout / BN;
+    // spatial-major tile order when the persistent stride keeps a block on its column tile (256 % nCt == 0); MIS_CONV_PPC_COLMAJOR=1: the other order (A/B switch, read per call)
+    a.tilesD = (256 % a.nCt == 0 && getenv("MIS_CONV_PPC_COLMAJOR") == nullptr) ? 2 : 1;
     MIS_REQUIRE(nsp * a.nCt < (1ll << 31), MIS_EUNSUPPORTED, "conv_igemm(ppc): grid too large");
     a.nSp = (int)nsp;
     const size_t lds = 2 * (size_t)HINSTR * 1024 + 2 * (size_t)3 * BN * 64 + 2 * (size_t)BN * 4;
