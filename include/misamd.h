@@ -124,6 +124,16 @@ int mis_maxpool2_bwd(int dtype, const void* x, int x_ld, const void* dy, int dy_
 
 /* Weight repack: fp32 master in the reference layout -> packed operand layouts of mis_conv_igemm. */
 /* conv: w [Cout][Cin][taps] -> fwd pack [tap][Cout][Cin] and (optional) dgrad pack [tap'][Cin][Cout] with tap' mirrored */
+/* All weight repacks of a network in ONE launch (the per-layer calls cost a launch each: 22 per 2-D train step).  `items_dev`: DEVICE array of n entries;
+ * kind 0 = mis_pack_conv_weight(w, rows = Cout, cols = Cin, taps), kind 1 = mis_pack_convt_weight(w, rows = Cin, cols = Cq); max_rows / max_cols = the largest
+ * rows / cols over the entries (grid extent; smaller entries' surplus blocks exit). */
+typedef struct MisPackItem {
+    const float* w;
+    void* w_fwd;
+    void* w_dgrad;     /* may be NULL for kind 0 */
+    int rows, cols, taps, kind;
+} MisPackItem;
+int mis_pack_batch(int dtype, const MisPackItem* items_dev, int n, int max_rows, int max_cols, void* stream);
 int mis_pack_conv_weight(int dtype, const float* w, int Cout, int Cin, int taps, void* w_fwd, void* w_dgrad, void* stream);
 /* convT k2s2: w [Cin][Cq][2][2] -> fwd pack [1][4*Cq][Cin] (row = ab*Cq + c) and dgrad pack [1][Cin][4*Cq] */
 int mis_pack_convt_weight(int dtype, const float* w, int Cin, int Cq, void* w_fwd, void* w_dgrad, void* stream);

@@ -19,7 +19,7 @@ EXPORTS = [
     "mis_comm_unique_id", "mis_comm_init", "mis_comm_world", "mis_allreduce_bucket", "mis_comm_finalize",
     "mis_conv3x3_first_fwd", "mis_conv3x3_first_wgrad_workspace_bytes", "mis_conv3x3_first_wgrad",
     "mis_colsum_workspace_bytes", "mis_colsum", "mis_maxpool2_fwd", "mis_maxpool2_bwd",
-    "mis_pack_conv_weight", "mis_pack_convt_weight", "mis_head_workspace_bytes", "mis_head_loss",
+    "mis_pack_conv_weight", "mis_pack_convt_weight", "mis_pack_batch", "mis_head_workspace_bytes", "mis_head_loss",
     "mis_adamw_workspace_bytes", "mis_sumsq", "mis_adamw_step", "mis_adamw_step_dev", "mis_sumsq_npartials",
     "mis_chanstats_workspace_bytes", "mis_chanstats", "mis_nchw_to_nhwc", "mis_nhwc_to_nchw", "mis_probe_mfma",
     "mis_gn_fwd_finalize", "mis_gn_bwd_stats_workspace_bytes", "mis_gn_bwd_stats", "mis_gn_bwd_finalize", "mis_gn_bwd_apply",
@@ -227,6 +227,7 @@ def load():
         "mis_aug_map_coordinates": [vp, vp, vp, ll, i, i, i, vp, vp, vp, dbl, i, i, vp],
         "mis_aug_pointwise": [vp, vp, ll, f, f, i, f, f, f, C.c_ulonglong, vp],
         "mis_aug_contrast": [vp, vp, ll, f, f, vp],
+        "mis_pack_batch": [i, vp, i, i, i, vp],
         "mis_norm_act_fwd": [i, vp, i, vp, i, i, ll, i, vp, vp, i, f, vp],
         "mis_norm_act_bwd": [i, vp, i, vp, i, vp, i, i, ll, i, vp, vp, i, f, vp],
         "mis_gn_fwd_finalize_ld": [vp, vp, i, i, i, i, dbl, vp, vp, f, vp, vp, vp, vp, vp],

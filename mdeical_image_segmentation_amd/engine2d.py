@@ -155,12 +155,20 @@ class UNet2DEngine:
         self.repack()
 
     def repack(self):
-        for base, wf in self.wf.items():
-            w = self.P[base + ".weight"]
-            if base.startswith("up_sample"):
-                ops.pack_convt_weight(w, wf, self.wd_[base])
-            else:
-                ops.pack_conv_weight(w, wf, self.wd_[base])
+        """fp32 master weights -> the packed MFMA operands of every layer, ONE launch (the flat parameter buffer and the operand buffers never move, so the table of
+        their addresses is built once; MISAMD_REPACK_PER_LAYER=1: one launch per layer, the pre-batching path)"""
+        if os.environ.get("MISAMD_REPACK_PER_LAYER"):
+            for base, wf in self.wf.items():
+                w = self.P[base + ".weight"]
+                if base.startswith("up_sample"):
+                    ops.pack_convt_weight(w, wf, self.wd_[base])
+                else:
+                    ops.pack_conv_weight(w, wf, self.wd_[base])
+            return
+        if getattr(self, "_pack_table", None) is None:
+            self._pack_table = ops.PackTable([(self.P[base + ".weight"], wf, self.wd_[base], 1 if base.startswith("up_sample") else 0)
+                                              for base, wf in self.wf.items()], self.device)
+        ops.pack_batch(self._pack_table)
 
     # ---- buffers ---------------------------------------------------------------------------------------
     def _alloc(self, N, H, W):

@@ -275,6 +275,38 @@ def pack_conv_weight(w, w_fwd, w_dgrad=None):
                                    None if w_dgrad is None else w_dgrad.data_ptr(), stream_ptr()), "mis_pack_conv_weight")
 
 
+class PackTable:
+    """device-resident table for `pack_batch`: entries (w fp32, w_fwd, w_dgrad | None, kind) with kind 0 = pack_conv_weight layout (w [Cout, Cin, *k]),
+    kind 1 = pack_convt_weight (w [Cin, Cq, 2, 2]).  The tensors' addresses are baked in: rebuild it if a buffer is re-allocated."""
+
+    def __init__(self, entries, device):
+        import numpy as np
+        dt = np.dtype([("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("taps", "<i4"), ("kind", "<i4")])
+        assert dt.itemsize == 40
+        tab = np.zeros(len(entries), dtype=dt)
+        self.keep = []
+        dts = set()
+        for i, (w, wf, wd, kind) in enumerate(entries):
+            assert w.dtype == torch.float32 and w.is_contiguous() and wf.is_contiguous() and (wd is None or wd.is_contiguous())
+            rows, cols = w.shape[0], w.shape[1]
+            taps = w[0, 0].numel() if kind == 0 else 4
+            tab[i] = (w.data_ptr(), wf.data_ptr(), 0 if wd is None else wd.data_ptr(), rows, cols, taps, kind)
+            dts.add(wf.dtype)
+            self.keep.append((w, wf, wd))
+        assert len(dts) == 1
+        self.dtype = dts.pop()
+        self.n = len(entries)
+        self.max_rows, self.max_cols = int(tab["rows"].max()), int(tab["cols"].max())
+        self.ptrs = tuple(int(v) for v in tab["w"]) + tuple(int(v) for v in tab["wf"])
+        self.dev = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(device)
+
+
+def pack_batch(table):
+    """every weight repack of a network in one launch (mis_pack_batch)"""
+    lib = load()
+    check(lib.mis_pack_batch(dtype_code(table.dtype), table.dev.data_ptr(), table.n, table.max_rows, table.max_cols, stream_ptr()), "mis_pack_batch")
+
+
 def pack_convt_weight(w, w_fwd, w_dgrad):
     lib = load()
     Cin, Cq = w.shape[0], w.shape[1]

@@ -379,3 +379,24 @@ def test_errors_are_loud():
     y = torch.zeros(1, 8, 8, 64, device=DEV)
     with pytest.raises(MisError):
         ops.conv_igemm(x, w, y, ksize=3, Cin=48, Cout=64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_batched_weight_repack_equals_per_layer(dtype, monkeypatch):
+    """mis_pack_batch (every layer's operand repack in one launch) against the per-layer mis_pack_conv_weight / mis_pack_convt_weight calls: bit-equal operands"""
+    from mdeical_image_segmentation_amd.engine2d import UNet2DEngine
+    eng = UNet2DEngine(3, 4, dtype=dtype, device=DEV, seed=1)
+    monkeypatch.setenv("MISAMD_REPACK_PER_LAYER", "1")
+    eng.repack()
+    torch.cuda.synchronize()
+    want = {k: (eng.wf[k].clone(), eng.wd_[k].clone()) for k in eng.wf}
+    for k in eng.wf:
+        eng.wf[k].zero_()
+        eng.wd_[k].zero_()
+    monkeypatch.delenv("MISAMD_REPACK_PER_LAYER")
+    eng.repack()
+    torch.cuda.synchronize()
+    assert eng._pack_table.n == len(eng.wf) >= 20
+    for k, (wf, wd) in want.items():
+        assert torch.equal(eng.wf[k], wf) and torch.equal(eng.wd_[k], wd), k
