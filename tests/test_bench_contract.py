@@ -1,0 +1,35 @@
+"""The committed bench line and traffic profile keep the measurement contract: one JSON object with the driver's keys, a `roofline` and a `cpu_baseline` object, and a
+`profiles/traffic.json` that was measured on THIS tree's conv / wgrad kernel sources (otherwise bench.py would print `traffic: null` on the driver's run: re-run the PMC
+passes of profiles/README.md after touching those files)."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_keys():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(d["value"] - d["config"]["global_batch"] / d["ms_per_step"] * 1e3) < 0.5
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+
+
+def test_traffic_profile_belongs_to_this_tree():
+    from mdeical_image_segmentation_amd import _lib
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert t["source_hash"] == _lib.source_hash(_lib.TRAFFIC_SOURCES), "profiles/traffic.json was measured on other conv / wgrad kernel sources: re-run the PMC passes"
+    ent = t["kernels"]["conv_igemm/bf16/k3/2d/bn128"]
+    assert ent["hbm_read_bytes_per_launch"] > 0 and ent["hbm_write_bytes_per_launch"] > 0
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
+    assert d["roofline"]["traffic"] == ent["hbm_read_bytes_per_launch"] + ent["hbm_write_bytes_per_launch"]
