@@ -72,6 +72,12 @@ int mis_conv_igemm(const MisConvDesc* d, void* stream);
 /* Name of the kernel configuration the calling thread's last mis_conv_igemm ran, e.g. "k3.2d.bn256.dma" (diagnostic: the parity tests assert
  * that each case reaches the dispatch branch it is written for). */
 const char* mis_conv_last_dispatch(void);
+/* Kernel-selection switches (A/B arms and fall-back configurations of mis_conv_igemm / mis_wgrad and a few others, e.g. "MIS_CONV_NOPP", "MIS_WGRAD_NOPP",
+ * "MIS_CONV3D_PF"): each is read from the environment variable of the same name ONCE per process; this entry point overrides one of them at run time
+ * (value >= 0), or returns it to the environment's value / its default (value < 0); name == NULL resets all.  mis_dispatch_switch returns the current value.
+ * Unknown names: MIS_EINVAL.  This is how the parity tests reach every kernel configuration in one process; the launch path itself never calls getenv. */
+int mis_dispatch_override(const char* name, int value);
+int mis_dispatch_switch(const char* name);
 
 /* Weight-gradient GEMM: dW[tap][ci][co] = sum_pixels x[pixel+tap][ci] * dy[pixel][co]   (split-K over pixel tiles,
  * fp32 partial slabs + deterministic reduction).  Replaces the weight part of convolution_backward for
@@ -186,6 +192,12 @@ int mis_chanstats(int dtype, const void* x, int ld, int N, long long npix, int C
 int mis_gn_fwd_finalize(const float* sum0, const float* sq0, int C0, float mult0, const float* sum1, const float* sq1, int C1, float mult1,
                         int N, int G, double count, const float* gamma, const float* beta, float eps, int Cpad, float* scale, float* shift,
                         float* mean, float* rstd, void* stream);
+/* fwd apply (bf16 engines): y[n][v][c_off + c] = round(fma(x[n][src(v)][c], scale[n*Ctot + c_off + c], shift[...])) for the Cs channels of ONE source of the
+ * (virtual concat) input - the GroupNorm output of model/unet3d/buildingblocks.py:87-92 written once per SingleConv, with the arithmetic and rounding mis_conv_igemm applies
+ * when it folds the affine into operand staging; up != 0: the source lives on the half grid (F.interpolate nearest 2x, buildingblocks.py:671-673).  y = channel 0 of the
+ * destination tensor (row stride y_ld >= Ctot).  It feeds the ping-pong kernels, whose operands arrive by LDS-DMA (no ALU on that path). */
+int mis_gn_apply(int dtype, const void* x, int x_ld, int Cs, int up, int N, int D, int H, int W, const float* scale, const float* shift, int Ctot, int c_off,
+                 void* y, int y_ld, void* stream);
 /* bwd: S1 = sum dy, S2 = sum dy*x for one source (up != 0: source on the half grid, dy summed over the 8 children) */
 size_t mis_gn_bwd_stats_workspace_bytes(int N, int Cs);
 int mis_gn_bwd_stats(int dtype, const void* dy, int dy_ld, const void* x, int x_ld, int Cs, int up, int N, int D, int H, int W,

@@ -14,7 +14,7 @@ OUT_PLAIN, OUT_SHUFFLE2, OUT_UNSHUFFLE2 = 0, 1, 2
 
 EXPORTS = [
     "mis_last_error", "mis_version", "mis_conv_igemm", "mis_wgrad_workspace_bytes", "mis_wgrad",
-    "mis_conv_last_dispatch", "mis_wgrad_last_dispatch", "mis_wgrad_last_nsplit",
+    "mis_conv_last_dispatch", "mis_wgrad_last_dispatch", "mis_wgrad_last_nsplit", "mis_dispatch_override", "mis_dispatch_switch", "mis_gn_apply",
     "mis_mt19937_words", "mis_legacy_normal",
     "mis_comm_unique_id", "mis_comm_init", "mis_comm_world", "mis_allreduce_bucket", "mis_comm_finalize",
     "mis_conv3x3_first_fwd", "mis_conv3x3_first_wgrad_workspace_bytes", "mis_conv3x3_first_wgrad",
@@ -110,6 +110,10 @@ def load():
         getattr(lib, name).argtypes = []
     lib.mis_wgrad_last_nsplit.restype = C.c_int
     lib.mis_wgrad_last_nsplit.argtypes = []
+    lib.mis_dispatch_override.restype = C.c_int
+    lib.mis_dispatch_override.argtypes = [C.c_char_p, C.c_int]
+    lib.mis_dispatch_switch.restype = C.c_int
+    lib.mis_dispatch_switch.argtypes = [C.c_char_p]
     lib.mis_comm_unique_id.argtypes = [C.c_void_p]
     lib.mis_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.mis_comm_world.argtypes = []
@@ -176,6 +180,7 @@ def load():
         "mis_probe_mfma": [i, vp, vp, vp, vp],
         "mis_gn_fwd_finalize": [vp, vp, i, f, vp, vp, i, f, i, i, dbl, vp, vp, f, i, vp, vp, vp, vp, vp],
         "mis_gn_bwd_stats": [i, vp, i, vp, i, i, i, i, i, i, i, vp, vp, vp, i, i, vp],
+        "mis_gn_apply": [i, vp, i, i, i, i, i, i, i, vp, vp, i, i, vp, i, vp],
         "mis_gn_bwd_finalize": [vp, vp, vp, vp, vp, i, i, i, dbl, vp, vp, vp, vp, vp, vp],
         "mis_gn_bwd_apply": [i, vp, i, vp, i, i, i, i, i, i, i, vp, vp, vp, i, i, i, vp, i, vp, i, vp],
         "mis_first3d_fwd": [i, vp, vp, vp, i, i, i, i, i, vp, i, vp, i, i, vp],
@@ -248,7 +253,7 @@ def load():
 
 
 # the sources that define the kernels whose HBM traffic profiles/traffic.json records (the 3x3 convolution / weight-gradient kernels of the benchmark)
-TRAFFIC_SOURCES = ("common.hpp", "conv_args.hpp", "conv_igemm.hip", "conv_pp.hip", "wgrad_args.hpp", "wgrad.hip", "wgrad_pp.hip")
+TRAFFIC_SOURCES = ("common.hpp", "conv_args.hpp", "conv_pp_common.hpp", "conv_igemm.hip", "conv_pp.hip", "wgrad_args.hpp", "wgrad.hip", "wgrad_pp.hip")
 
 
 def source_hash(only=None):

@@ -1,0 +1,330 @@
+// Column-segment ping-pong implicit GEMM for the bf16 3x3x3 layers (gfx950): forward and dgrad of nn.Conv3d(k3, p1, bias=False) of the 'gcr' SingleConv
+// (reference model/unet3d/buildingblocks.py:64-66,87-92), on the structure of conv_ppc_kernel (conv_pp.hip) - round 2 left these layers on the lock-step
+// conv_igemm_kernel (36-49 % MFMA pipe busy), because the GroupNorm affine was applied while the operand was staged through registers and an LDS-DMA has no ALU.
+// Here the operand is the NORMALISED tensor, written once per SingleConv by mis_gn_apply (groupnorm.hip; the same tensor feeds the weight gradient), so the
+// kernel sees a plain single-source bf16 convolution and nothing is staged through registers.
+//
+// A 3x3x3 filter = three 3x3 filters on the depth planes z-1, z, z+1: the output tile is a 2-D tile (4*PF rows x 16 columns) of ONE depth plane (n, z) x BN
+// channels, and the K loop walks (dz, 32-channel chunk) pairs - per pair one halo image of plane z + dz - 1 (out-of-range planes: every lane's DMA offset is
+// past the buffer, which reads as zero) and three column segments of three taps (tap index dz*9 + kh*3 + kw of the packed [27][Cout][Cin] weights).
+// NDHWC makes the planes of a batch one contiguous sequence of H x W images, so the epilogue of the 2-D kernel serves unchanged with the plane index as its image.
+//
+// Tiles: PF = 5 (20 rows) divides the grids of the 160^3 configuration at every level (160 / 80 / 40 / 20), PF = 8 (32 rows) those of 128^3; the launcher
+// takes whichever wastes fewer rows.  NF = 4: 128-column blocks (Cout % 128 == 0), NF = 2: 64-column blocks (wave tile 16*PF px x 32 ch).
+// Plane walk: the tiles of ZG consecutive depth planes are interleaved (plane fastest), so the ~32 tiles an XCD runs at a time cover ZG + 2 input planes for ZG
+// output planes out of its L2 instead of 3 for 1.
+#include <stdlib.h>
+
+#include "conv_pp_common.hpp"
+#include "dispatch_cfg.hpp"
+
+template <int PF, int NF>
+__global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
+    using T = __bf16;
+    constexpr int WAVE_N = NF * 16, BN = 2 * WAVE_N, NV = 4 * NF;
+    constexpr int WWAVES = BN / 16;                                      // waves that carry a weight DMA instruction per tap (16 rows of 64 B each)
+    constexpr int TH = 4 * PF, TW = 16, HH = TH + 2, HW = 18, HP = HH * HW;
+    constexpr int HITEMS = HP * 4, HINSTR = (HITEMS + 63) / 64, HBUF = HINSTR * 1024, ROWB = HW * 64;
+    constexpr int HJ = (HINSTR + 7) / 8;             // halo instructions per wave per chunk
+    constexpr int HJ0 = HJ < 3 ? HJ : 3, HJ1 = HJ - HJ0;
+    static_assert(HJ1 <= 3, "halo instructions of a chunk must fit the R segments of columns 0 and 1");
+    constexpr int TAPB = BN * 64;                    // one tap's weight tile
+    constexpr int WTILE = 3 * TAPB;                  // one column's weight tiles
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const hbase = smem;                        // 2 x HBUF
+    char* const wbase = smem + 2 * HBUF;             // 2 x WTILE
+    char* const bbase = wbase + 2 * WTILE;           // 2 x BN floats
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, grp = wave >> 2;
+    const int li = lane & 15, lg = lane >> 4;
+
+    const int total_tiles = a.nSp * a.nCt;
+    const int tstride = (int)gridDim.x;
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    if (tile >= total_tiles) return;                 // block-uniform
+    const int nchunks = a.Cin >> 5;
+    const int nvc = 3 * nchunks;                     // (dz, chunk) pairs per tile
+    const int tpi = a.tilesH * a.tilesW;
+    // tile -> (plane = n*D + z, z, h0, w0, first column).  Within a volume the planes are walked in groups of a.zg: (group, tile position, plane in group).
+    auto decode = [&](int t, int& tpl, int& tz, int& th0, int& tw0, int& tcol) {
+        int ct, sp;
+        if (a.order == 2) {
+            sp = t / a.nCt;
+            ct = t - sp * a.nCt;
+        } else {
+            ct = t / a.nSp;
+            sp = t - ct * a.nSp;
+        }
+        const int per_vol = a.D * tpi;
+        const int n = sp / per_vol;
+        const int r = sp - n * per_vol;
+        const int zgrp = r / (a.zg * tpi);
+        const int r2 = r - zgrp * (a.zg * tpi);
+        int gsz = a.D - zgrp * a.zg;
+        if (gsz > a.zg) gsz = a.zg;
+        const int pos = r2 / gsz;
+        tz = zgrp * a.zg + (r2 - pos * gsz);
+        tpl = n * a.D + tz;
+        const int th = pos / a.tilesW;
+        th0 = th * TH;
+        tw0 = (pos - th * a.tilesW) * TW;
+        tcol = ct * BN;
+    };
+
+    // LDS swizzle for 64-byte rows (conv_pp.hip): chunk position ^= (column >> 1) & 3 (pixels) / (row >> 1) & 3 (weights) - conflict-free for ds_read_b128
+    const int a_off0 = (wn * WAVE_N + li) * 64 + ((lg ^ ((li >> 1) & 3)) << 4);
+    int b_off0[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int px = li + kw;
+        b_off0[kw] = (wm * PF * HW + px) * 64 + ((lg ^ ((px >> 1) & 3)) << 4);
+    }
+    int w_goff0;       // this wave's instruction of a tap tile: LDS rows 16*wave .. +15
+    {
+        const int slot = wave * 64 + lane;
+        const int lrow = slot >> 2, pos = slot & 3;
+        const int dc16 = pos ^ ((lrow >> 1) & 3);
+        const int dwv = lrow / WAVE_N, j = lrow % WAVE_N;
+        const int drow = dwv * WAVE_N + ((j & 15) >> 2) * NV + (j >> 4) * 4 + (j & 3);
+        w_goff0 = (drow * a.Cin + dc16 * 8) * 2;
+    }
+    const unsigned img_x = (unsigned)(((long long)a.H * a.W - 1) * a.x0.ld + a.Cin) * 2u;      // bytes of ONE depth plane of the input view
+    const size_t plane_b = (size_t)a.H * a.W * a.x0.ld * 2;
+    const char* const xb = reinterpret_cast<const char*>(a.x0.p);
+    const __amdgpu_buffer_rsrc_t rw = pp_make_rsrc(a.w, (unsigned)((long long)27 * a.Cout * a.Cin * 2));
+
+    // halo DMA j of this wave (instruction id = j*8 + wave) from plane `spl` (valid = the plane exists; otherwise the image is zero-filled)
+    auto issue_halo = [&](auto jc, int spl, bool valid, int h0, int w0, int c0, char* dst) {
+        constexpr int j = decltype(jc)::value;
+        const int id = j * 8 + wave;
+        if (id >= HINSTR) return;                     // wave-uniform
+        const __amdgpu_buffer_rsrc_t rx = pp_make_rsrc(xb + (size_t)(valid ? spl : 0) * plane_b, img_x);
+        unsigned toff = (unsigned)((((h0 - 1) * a.W + (w0 - 1)) * a.x0.ld + c0) * 2);
+        asm volatile("" : "+s"(toff));
+        int item = id * 64 + lane;
+        asm volatile("" : "+v"(item));
+        const int p = item >> 2, pos = item & 3;
+        const int py = p / HW, px = p - py * HW;
+        const unsigned rel = (unsigned)(((py * a.W + px) * a.x0.ld + ((pos ^ ((px >> 1) & 3)) << 3)) * 2);
+        const bool ok = valid && item < HITEMS && (unsigned)(h0 - 1 + py) < (unsigned)a.H && (unsigned)(w0 - 1 + px) < (unsigned)a.W;
+        pp_dma16(rx, ok ? (int)(toff + rel) : PP_OOB, dst + id * 1024);
+    };
+    const __amdgpu_buffer_rsrc_t rb = pp_make_rsrc(a.bias != nullptr ? (const void*)a.bias : a.w, a.bias != nullptr ? (unsigned)a.Cout * 4u : 0u);
+    auto issue_bias = [&](int col, char* dst) {
+        if (wave < BN / 64)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (pp_lds_void_t*)(dst + wave * 256), 4, (col + wave * 64 + lane) * 4, 0, 0, 0);
+    };
+    // the three tap tiles (kh = 0..2) of depth slice dz, filter column kw, column tile col, channels c0..c0+31: one instruction per tap per wave
+    auto issue_weights = [&](int dz, int kw, int col, int c0, char* dst) {
+        int soff = (int)((((long long)(dz * 9 + kw) * a.Cout + col) * a.Cin + c0) * 2);
+        asm volatile("" : "+s"(soff));
+        const int tapstride = 3 * a.Cout * a.Cin * 2;          // tap index = dz*9 + kh*3 + kw
+        if (wave >= WWAVES) return;                    // wave-uniform (NF = 2: the four waves of group 0 carry the whole tile)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) pp_dma16(rw, soff + kh * tapstride + w_goff0, dst + kh * TAPB + wave * 1024);
+    };
+
+    int pl, z, h0, w0, ncol0;
+    decode(tile, pl, z, h0, w0, ncol0);
+    f32x4 acc[NF][PF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int pf = 0; pf < PF; ++pf) acc[f][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    issue_bias(ncol0, bbase);
+    issue_weights(0, 0, ncol0, 0, wbase);
+    if (grp == 1) issue_weights(0, 1, ncol0, 0, wbase + WTILE);       // segment 1 (in the loop group 1 issues two segments ahead)
+    pp_static_for<HJ>([&](auto jc) { issue_halo(jc, pl - 1, z >= 1, h0, w0, 0, hbase); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int wsel = 0, hsel = 0, bsel = 0;
+    if (grp == 1) __builtin_amdgcn_s_barrier();       // the stagger: group 1 runs one slot behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll 1
+    for (; tile < total_tiles; tile += tstride) {
+        const bool has_next = tile + tstride < total_tiles;
+        int npl = pl, nz = z, nh0 = h0, nw0 = w0, ncolN = ncol0;
+        if (has_next) decode(tile + tstride, npl, nz, nh0, nw0, ncolN);
+        int dz = 0, c0 = 0;
+#pragma unroll 1
+        for (int vc = 0; vc < nvc; ++vc) {
+            // the (dz, chunk) pair after this one within the tile
+            int ndz = dz, nc0 = c0 + 32;
+            if (nc0 == a.Cin) {
+                nc0 = 0;
+                ndz = dz + 1;
+            }
+            const bool last_chunk = vc + 1 == nvc;
+            const bool hnext = !last_chunk || has_next;
+            // what the halo prefetch of this pair's segments fetches: the next pair of this tile, else pair (dz 0, chunk 0) of the next tile
+            const int hdz = last_chunk ? 0 : ndz, hc0 = last_chunk ? 0 : nc0;
+            const int hpl = last_chunk ? npl - 1 : pl + ndz - 1;
+            const bool hval = last_chunk ? (nz >= 1) : ((unsigned)(z + ndz - 1) < (unsigned)a.D);
+            const int hh0 = last_chunk ? nh0 : h0, hw0 = last_chunk ? nw0 : w0;
+            const uint32_t hb = (uint32_t)(uintptr_t)hbase + hsel * HBUF;
+            char* hbn = hbase + (hsel ^ 1) * HBUF;
+            pp_static_for<3>([&](auto kc) {
+                constexpr int kw = decltype(kc)::value;
+                const uint32_t wb = (uint32_t)(uintptr_t)wbase + wsel * WTILE;
+                char* wbn = wbase + (wsel ^ 1) * WTILE;
+                char* wb_self = wbase + wsel * WTILE;
+                // the segment after this one / the one after that
+                const bool wnext = (kw < 2) || hnext;
+                const int wkw = (kw < 2) ? kw + 1 : 0;
+                const int wcol = (kw < 2 || !last_chunk) ? ncol0 : ncolN;
+                const int wc0 = (kw < 2) ? c0 : hc0;
+                const int wdz = (kw < 2) ? dz : hdz;
+                const bool w2next = (kw < 1) || hnext;
+                const int w2kw = (kw + 2) % 3;
+                const int w2col = (kw < 1 || !last_chunk) ? ncol0 : ncolN;
+                const int w2c0 = (kw < 1) ? c0 : hc0;
+                const int w2dz = (kw < 1) ? dz : hdz;
+                // ================= R segment =================
+                if (grp == 0 && wnext) issue_weights(wdz, wkw, wcol, wc0, wbn);
+                constexpr int NH = kw == 0 ? HJ0 : (kw == 1 ? HJ1 : 0);          // halo instructions issued in this segment (per wave; the last may be past the image)
+                if constexpr (NH > 0) {
+                    if (hnext)
+                        pp_static_for<NH>([&](auto jc) { issue_halo(std::integral_constant<int, (kw == 0 ? 0 : HJ0) + decltype(jc)::value>{}, hpl, hval, hh0, hw0, hc0, hbn); });
+                }
+                u32x4 A[3][NF], Brow[PF + 2];
+                pp_static_for<3>([&](auto hc) {
+                    constexpr int kh = decltype(hc)::value;
+                    pp_static_for<NF>([&](auto fc) {
+                        constexpr int f = decltype(fc)::value;
+                        A[kh][f] = pp_lds_read128<kh * TAPB + f * 1024>(wb + a_off0);
+                    });
+                });
+                pp_static_for<PF + 2>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    Brow[r] = pp_lds_read128<r * ROWB>(hb + b_off0[kw]);
+                });
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                // how many of this wave's youngest DMAs may stay in flight: the halo instructions of THIS segment
+                constexpr int KEEP = NH;
+                if (grp == 1) {                                  // group 1: its weight DMAs for the next segment (issued one slot pair ago, in its M) must have landed
+                    if (hnext && KEEP > 0) {
+                        const int last_id = ((kw == 0 ? 0 : HJ0) + KEEP - 1) * 8 + wave;      // wave-uniform: did this wave really issue KEEP halo instructions?
+                        if (last_id < HINSTR) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP > 0 ? KEEP - 1 : 0) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ================= M segment: 3 taps x NF x PF MFMAs =================
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+                        for (int pf = 0; pf < PF; ++pf) mma_b128<T>(acc[f][pf], A[kh][f], Brow[pf + kh]);
+                        if (kh == 0 && f == 0) {
+                            if (grp == 1 && w2next) issue_weights(w2dz, w2kw, w2col, w2c0, wb_self);
+                        }
+                    }
+                __builtin_amdgcn_s_setprio(0);
+                if (grp == 0) {                                  // group 0: the weight DMAs it issued in this segment's R
+                    if (hnext && KEEP > 0) {
+                        const int last_id = ((kw == 0 ? 0 : HJ0) + KEEP - 1) * 8 + wave;
+                        if (last_id < HINSTR) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP > 0 ? KEEP - 1 : 0) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                wsel ^= 1;
+            });
+            hsel ^= 1;
+            dz = ndz;
+            c0 = nc0;
+        }
+        pp_epilogue<NF, PF>(a, acc, (uint32_t)(uintptr_t)bbase + bsel * (BN * 4), pl, h0, w0, ncol0, wm, wn, li, lg);
+        pl = npl; z = nz; h0 = nh0; w0 = nw0; ncol0 = ncolN;
+        bsel ^= 1;
+        if (has_next) issue_bias(ncol0, bbase + bsel * (BN * 4));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's last barrier
+}
+
+// ---------------------------------------------------------------------------------------------------------
+bool conv3d_pp_eligible(const MisConvDesc* d) {
+    if (d->dtype != MIS_BF16 || !d->is3d || d->ksize != 3) return false;
+    if (d->x1 != nullptr || d->in_scale != nullptr) return false;
+    if (d->x0_D != d->D || d->x0_H != d->H || d->x0_W != d->W) return false;
+    if (d->Cin % 32 != 0 || d->Cout % 64 != 0 || d->Cout0 % 64 != 0) return false;
+    if (d->y0_mode != MIS_OUT_PLAIN || (d->y1 != nullptr && d->y1_mode != MIS_OUT_PLAIN)) return false;
+    // 32-bit buffer offsets, computed in (signed) int: ONE depth plane of the input view and the packed weights must each span less than 2 GiB
+    if ((((long long)d->H * d->W - 1) * d->x0_ld + d->Cin) * 2 >= (1ll << 31) - 65536) return false;
+    if ((long long)27 * d->Cout * d->Cin * 2 >= (1ll << 31) - 65536) return false;
+    return true;
+}
+
+template <int PF, int NF> static int pp3_launch(const MisConvDesc* d, hipStream_t stream) {
+    constexpr int BN = 2 * NF * 16;
+    constexpr int TH = 4 * PF, HINSTR = ((TH + 2) * 18 * 4 + 63) / 64;
+    ConvArgs a;
+    a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cin0 = d->Cin; a.Cout0 = d->Cout0;
+    a.x0 = SrcView{d->x0, d->x0_ld, d->x0_D, d->x0_H, d->x0_W};
+    a.x1 = SrcView{nullptr, 0, 0, 0, 0};
+    a.in_scale = nullptr; a.in_shift = nullptr;
+    a.w = d->w; a.bias = d->bias; a.relu = d->relu; a.mask = d->mask; a.mask_ld = d->mask_ld;
+    a.y0 = d->y0; a.y0_ld = d->y0_ld; a.y0_mode = d->y0_mode;
+    a.y1 = d->y1; a.y1_ld = d->y1_ld; a.y1_mode = d->y1_mode;
+    a.tilesD = d->D;
+    a.tilesH = (d->H + TH - 1) / TH;
+    a.tilesW = (d->W + 15) / 16;
+    const long long nsp = (long long)d->N * d->D * a.tilesH * a.tilesW;
+    a.nCt = d->Cout / BN;
+    // spatial-major tile order when the persistent stride keeps a block on its column tile (256 % nCt == 0)
+    a.order = (256 % a.nCt == 0 && !mis_sw(SW_CONV3D_COLMAJOR)) ? 2 : 1;
+    int zg = mis_sw(SW_CONV3D_ZG);
+    if (zg < 1) zg = 1;
+    if (zg > d->D) zg = d->D;
+    a.zg = zg;
+    MIS_REQUIRE(nsp * a.nCt < (1ll << 31), MIS_EUNSUPPORTED, "conv_igemm(3d pp): grid too large");
+    a.nSp = (int)nsp;
+    const size_t lds = 2 * (size_t)HINSTR * 1024 + 2 * (size_t)3 * BN * 64 + 2 * (size_t)BN * 4;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv3d_ppc_kernel<PF, NF>), lds, "conv_igemm(3d pp)")) return rc;
+    const long long total = nsp * a.nCt;
+    hipLaunchKernelGGL((conv3d_ppc_kernel<PF, NF>), dim3((unsigned)(total > 256 ? 256 : total)), dim3(512), lds, stream, a);
+    MIS_LAUNCH_CHECK("conv_igemm(3d pp)");
+    return MIS_OK;
+}
+
+int launch_conv3d_pp(const MisConvDesc* d, hipStream_t stream, const char** tag) {
+    // rows per tile: 20 (PF 5) or 32 (PF 8), whichever pads the H axis less (ties: the taller tile - fewer fragment reads per MFMA); MIS_CONV3D_PF forces one
+    int pf = mis_sw(SW_CONV3D_PF);
+    if (pf != 5 && pf != 8) {
+        const int pad5 = (d->H + 19) / 20 * 20, pad8 = (d->H + 31) / 32 * 32;
+        pf = pad5 < pad8 ? 5 : 8;
+    }
+    if (d->Cout % 128 == 0) {
+        if (pf == 5) {
+            *tag = "k3.3d.ppc5";
+            return pp3_launch<5, 4>(d, stream);
+        }
+        *tag = "k3.3d.ppc8";
+        return pp3_launch<8, 4>(d, stream);
+    }
+    if (pf == 5) {
+        *tag = "k3.3d.ppc5n2";
+        return pp3_launch<5, 2>(d, stream);
+    }
+    *tag = "k3.3d.ppc8n2";
+    return pp3_launch<8, 2>(d, stream);
+}

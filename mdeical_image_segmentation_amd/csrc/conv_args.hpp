@@ -22,6 +22,7 @@ struct ConvArgs {
     void* y1;
     int y1_ld, y1_mode;
     int tilesD, tilesH, tilesW, nSp, nCt;
+    int order, zg;     // conv3d_pp.hip: tile order (1 = column-tile major, 2 = spatial major) and depth-group size of the plane walk
 };
 
 // conv_pp.hip: the ping-pong 3x3 kernel for the bf16 2-D layers (returns MIS_OK after the launch, or an error); `eligible` says whether a
@@ -29,3 +30,6 @@ struct ConvArgs {
 bool conv_pp_eligible(const MisConvDesc* d);
 bool conv_pp_rs64_eligible(const MisConvDesc* d);      // 64 -> 64 channels: the register-stationary ping-pong kernel
 int launch_conv_pp(const MisConvDesc* d, hipStream_t stream, const char** tag);
+// conv3d_pp.hip: the same structure for the bf16 3x3x3 layers (single source, no operand affine)
+bool conv3d_pp_eligible(const MisConvDesc* d);
+int launch_conv3d_pp(const MisConvDesc* d, hipStream_t stream, const char** tag);

@@ -19,6 +19,7 @@
 
 #include "common.hpp"
 #include "conv_args.hpp"
+#include "dispatch_cfg.hpp"
 
 #ifndef MIS_WDMA_EXPLICIT_DRAIN
 #define MIS_WDMA_EXPLICIT_DRAIN 1
@@ -722,14 +723,14 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
     const bool wide = (d->Cout % 128) == 0;
     if (d->ksize == 3) {
         if (!is3d) {
-            static const int v2 = getenv("MIS_CONV_V1") == nullptr;
-            static const int v3 = getenv("MIS_CONV_V3") != nullptr;
+            const int v2 = !mis_sw(SW_CONV_V1);
+            const int v3 = mis_sw(SW_CONV_V3);
             if constexpr (sizeof(T) == 2) {
                 // bf16, Cout % 128 == 0, single source: the ping-pong kernel (conv_pp.hip)
-                const bool pp = getenv("MIS_CONV_NOPP") == nullptr;      // read per call: the parity tests toggle it to reach the pre-ping-pong configurations
+                const bool pp = !mis_sw(SW_CONV_NOPP);      // (the parity tests reach the pre-ping-pong configurations through mis_dispatch_override)
                 // 64-column layers stay on the weight-stationary / bn64 configurations: the ping-pong kernel with 64-column blocks (wave tile 64 px x 32 ch: 12 fragment
                 // reads per 16 MFMAs) is bound by its R segments - measured 629 vs 959 TFLOP/s (64->64 at 512^2) and 784 vs 916 (128->64); MIS_CONV_PP64=1 selects it
-                const bool pp64 = getenv("MIS_CONV_PP64") != nullptr || getenv("MIS_CONV_PPC64") != nullptr;
+                const bool pp64 = mis_sw(SW_CONV_PP64) || mis_sw(SW_CONV_PPC64);
                 if (pp && conv_pp_eligible(d) && (d->Cout % 128 == 0 || pp64 || conv_pp_rs64_eligible(d))) {      // (rs64: opt-in, MIS_CONV_RS64=1)
                     const char* tag = "";
                     const int rc = launch_conv_pp(d, s, &tag);
@@ -740,39 +741,48 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
             if constexpr (sizeof(T) == 2) {
                 // deep layers: 256 output columns per block (wave tile 128 ch x 64 px, one tap per barrier): every staged halo pixel and every pixel
                 // fragment read from LDS feeds twice the MFMAs (+7...12 % per layer for Cin >= 256 despite 19 spilled VGPRs)
-                static const int k3w = getenv("MIS_CONV_K3_NO256") == nullptr;
-                static const int k3min = getenv("MIS_CONV_K3_256_MINCIN") ? atoi(getenv("MIS_CONV_K3_256_MINCIN")) : 256;
+                const int k3w = !mis_sw(SW_CONV_K3_NO256);
+                const int k3min = mis_sw(SW_CONV_K3_256_MINCIN);
                 if (k3w && v2 && d->Cout % 256 == 0 && d->Cin >= k3min) RUN("k3.2d.bn256.dma", launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 8, 512, 1, 4, false, true>(d, s));
             }
             if (wide && v3 && sizeof(T) == 2) RUN("k3.2d.bn128.v3", launch_cfg<T, Geom<1, 32, 16, 3, false>, 2, 4, 512, 1, 8>(d, s));   // 8 waves, wave tile 128 px x 64 ch
             // persistent tiles pay off when a tile has few K steps (prologue latency dominates); deep layers run ~5 % faster without
             const bool shallow = d->Cin <= 2 * (int)Tr<T>::CK;
             if (wide && v2 && shallow) RUN("k3.2d.bn128.persist.dma", launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3, 4, true, true>(d, s));
-            static const int dma = getenv("MIS_CONV_NODMA") == nullptr;
+            const int dma = !mis_sw(SW_CONV_NODMA);
             if (wide && v2 && dma) RUN("k3.2d.bn128.dma", launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3, 4, false, true>(d, s));
             if (wide && v2) RUN("k3.2d.bn128.reg", launch_cfg<T, Geom<1, 16, 16, 3, false>, 2, 4, 512, 3, 4, false>(d, s));   // 8 waves, one filter row per barrier
             if (wide) RUN("k3.2d.bn128.v1", launch_cfg<T, Geom<1, 8, 16, 3, false>, 2, 4>(d, s));
             if constexpr (sizeof(T) == 2) {
-                static const int ws = getenv("MIS_CONV_NOWS64") == nullptr;
+                const int ws = !mis_sw(SW_CONV_NOWS64);
                 const bool plain = d->x1 == nullptr && d->in_scale == nullptr && d->y0_mode == MIS_OUT_PLAIN && d->x0_H == d->H && d->x0_W == d->W;
                 if (ws && plain && d->Cin == 64 && d->Cout == 64 && (long long)d->N * d->H * d->W >= 256ll * 512 && (d->mask == nullptr || d->mask_ld % 8 == 0)) RUN("k3.2d.ws64", launch_ws64(d, s));
             }
             if (v2 && (long long)d->H * d->W >= 64 * 64) RUN("k3.2d.bn64.persist.dma", launch_cfg<T, Geom<1, 32, 16, 3, false>, 1, 4, 512, 3, 4, true, true>(d, s));
             RUN("k3.2d.bn64.v1", launch_cfg<T, Geom<1, 16, 16, 3, false>, 1, 4>(d, s));
         }
+        if constexpr (sizeof(T) == 2) {
+            // bf16, single source, no operand affine (the engines hand over the normalised tensor): the column-segment ping-pong kernel (conv3d_pp.hip)
+            if (!mis_sw(SW_CONV3D_NOPP) && conv3d_pp_eligible(d)) {
+                const char* tag = "";
+                const int rc = launch_conv3d_pp(d, s, &tag);
+                g_conv_last = tag;
+                return rc;
+            }
+        }
         if (wide) RUN("k3.3d.bn128", launch_cfg<T, Geom<4, 4, 8, 3, true>, 2, 4>(d, s));
         // bf16, Cout not a multiple of 128 (the 64- and 192-column layers at full resolution): 8 waves on a 4x8x8 voxel tile, LDS-DMA weight
         // tiles, 3 taps per barrier (+6...11 % over the 4-wave 4x4x8 config; the same tile with 1 tap per barrier or 4 waves was slower)
-        static const int bn64v2 = getenv("MIS_CONV3D_BN64V1") == nullptr;
+        const int bn64v2 = !mis_sw(SW_CONV3D_BN64V1);
         if (bn64v2 && sizeof(T) == 2) RUN("k3.3d.bn64.dma", launch_cfg<T, Geom<4, 8, 8, 3, true>, 2, 2, 512, 3, 4, false, true>(d, s));
         RUN("k3.3d.bn64.v1", launch_cfg<T, Geom<4, 4, 8, 3, true>, 2, 2>(d, s));
     }
     if (!is3d) {
-        static const int k1v2 = getenv("MIS_CONV_K1V1") == nullptr;
-        static const int k1p = getenv("MIS_CONV_K1NOPERSIST") == nullptr;
+        const int k1v2 = !mis_sw(SW_CONV_K1V1);
+        const int k1p = !mis_sw(SW_CONV_K1NOPERSIST);
         if constexpr (sizeof(T) == 2) {
             // deep 1x1 GEMMs (transposed-conv forward / dgrad): 256 output columns per block = twice the MFMA work per staged pixel tile and barrier
-            static const int k1nf8 = getenv("MIS_CONV_K1_NO256") == nullptr;
+            const int k1nf8 = !mis_sw(SW_CONV_K1_NO256);
             if (k1nf8 && k1v2 && d->Cout % 256 == 0 && d->Cin >= 4 * (int)Tr<T>::CK)
                 RUN("k1.2d.bn256.dma", launch_cfg<T, Geom<1, 16, 16, 1, false>, 2, 8, 512, 1, 4, false, true>(d, s));
         }

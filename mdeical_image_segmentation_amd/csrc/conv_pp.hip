@@ -26,13 +26,8 @@
 //                          outstanding op of the wave, so the per-step weight wait is vmcnt(1) in those steps); retired by vmcnt(0) in steps 6..8.
 #include <stdlib.h>
 
-#include <type_traits>
-#include <utility>
-
-#include "conv_args.hpp"
-
-typedef __attribute__((address_space(3))) void pp_lds_void_t;
-typedef __attribute__((address_space(1))) const void pp_glob_void_t;
+#include "conv_pp_common.hpp"
+#include "dispatch_cfg.hpp"
 
 namespace {
 constexpr int PP_TH = 16, PP_TW = 16, PP_HH = 18, PP_HW = 18, PP_HP = PP_HH * PP_HW;
@@ -41,112 +36,7 @@ constexpr int PP_HINSTR = (PP_HITEMS + 63) / 64;     // 41 wave-instructions (th
 constexpr int PP_HBUF = PP_HINSTR * 1024;
 constexpr int PP_ROWB = PP_HW * 128;                 // bytes per halo row
 
-template <typename F, int... I> __device__ __forceinline__ void pp_static_for_impl(F& f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F> __device__ __forceinline__ void pp_static_for(F&& f) { pp_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-
-// One LDS-DMA instruction: 64 lanes x 16 bytes from buffer `r` at per-lane byte offset `voff` to LDS [dst, dst + 1 KiB) (dst wave-uniform).
-// buffer_load ... lds: 32-bit offsets (no 64-bit address registers), and an offset at or past num_records reads as ZERO - that is the conv's zero
-// padding and the tail of the last halo instruction (PP_OOB is past every buffer this kernel accepts: one image of the input, < 4 GiB - 64 KiB, or the packed weights).
-constexpr int PP_OOB = (int)0xFFFFFF00u;
-__device__ __forceinline__ void pp_dma16(__amdgpu_buffer_rsrc_t r, int voff, char* lds_dst_wave_uniform) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (pp_lds_void_t*)lds_dst_wave_uniform, 16, voff, 0, 0, 0);
-}
-// LDS reads as INLINE ASM: hipcc (ROCm 7.2) may put an s_waitcnt vmcnt(N) in front of an LDS read it cannot tell apart from the destination of an LDS-DMA
-// in flight - which then waits for the prefetch that was just issued and serialises the pipeline (seen here as soon as a second kind of LDS-DMA, the 4-byte
-// bias fetch, joined the kernel; in wgrad_pp.hip with the transposing-read builtin).  The asm form is invisible to that analysis; in exchange NOTHING waits for the
-// result automatically: every use sits behind an explicit s_waitcnt lgkmcnt(0) + sched_barrier (cdna_hip_programming.md §5.4 rule 18, §5.7).
-template <int OFF> __device__ __forceinline__ u32x4 pp_lds_read128(uint32_t lds_addr) {
-    u32x4 r;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF));
-    return r;
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t pp_make_rsrc(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);   // raw buffer, stride 0, 32-bit data format (gfx9 family)
-}
 }   // namespace
-
-// ---- epilogue: lane (li, lg) holds, per pixel row pf of its wave, NV = 4*NF consecutive output channels of pixel (h0 + wm*4 + pf, w0 + li) ----
-// `bias_lds`: the block's BN bias values of this tile's column tile (zeros without a bias), staged in LDS by DMA: a global bias load here would sit behind the
-// previous stores in the in-order vmcnt queue and expose their latency once per tile.  The accumulators are re-armed with zeros.
-template <int NF, int PF = 4>
-__device__ __forceinline__ void pp_epilogue(const ConvArgs& a, f32x4 (&acc)[NF][PF], uint32_t bias_lds, int n, int h0, int w0, int ncol0, int wm, int wn, int li,
-                                            int lg) {
-    using T = __bf16;
-    constexpr int NV = 4 * NF, WAVE_N = NF * 16, EPC = 8;
-    const int colw = ncol0 + wn * WAVE_N;          // wave-uniform first column
-    const int col = colw + lg * NV;                // this lane's first column
-    const bool to0 = colw < a.Cout0;
-    T* ybase = reinterpret_cast<T*>(to0 ? a.y0 : a.y1);
-    const int yld = to0 ? a.y0_ld : a.y1_ld;
-    const int ymode = to0 ? a.y0_mode : a.y1_mode;
-    const int cview = to0 ? a.Cout0 : a.Cout - a.Cout0;
-    const int lcol = to0 ? col : col - a.Cout0;
-    int ab = 0, cq = 0;
-    if (ymode == MIS_OUT_SHUFFLE2) {
-        cq = cview >> 2;
-        ab = lcol / cq;
-    }
-    // The ReLU-mask rows are loaded where they are used: one exposed global round trip per pixel row (the masked dgrad form of a layer runs 5-22 % slower than its
-    // forward form in isolation).  Two attempts to hide them lost: fetching two rows ahead made hipcc's register scoreboard insert vmcnt waits in front of the first
-    // fragment reads of every chunk (serialises the weight prefetch); fetching 4 or 8 rows of a tile ahead of the stores is 3-7 % faster in isolation and 1-3 % SLOWER in
-    // the live train step (conv_ppc_kernel, scripts/ab_step.py, one process: 37.76 / 39.01 / 38.31 ms per step for 0 / 4 / 8 rows ahead).
-    constexpr int MC = NV / EPC;
-#pragma unroll
-    for (int pf = 0; pf < PF; ++pf) {
-        const int y = h0 + wm * PF + pf, x = w0 + li;
-        float o[NV];
-        {
-            u32x4 braw[NF];
-            pp_static_for<NF>([&](auto fc) {
-                constexpr int f = decltype(fc)::value;
-                braw[f] = pp_lds_read128<f * 16>(bias_lds + (wn * WAVE_N + lg * NV) * 4);
-            });
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int f = 0; f < NF; ++f)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t u = braw[f][q];
-                    o[f * 4 + q] = acc[f][pf][q] + __uint_as_float(u);
-                    acc[f][pf][q] = 0.f;
-                }
-        }
-        if (y < a.H && x < a.W) {
-            if (a.relu) {
-#pragma unroll
-                for (int i = 0; i < NV; ++i) o[i] = fmaxf(o[i], 0.f);
-            }
-            const size_t pix = ((size_t)n * a.H + y) * a.W + x;
-            if (a.mask != nullptr) {
-                const T* mp = reinterpret_cast<const T*>(a.mask) + pix * a.mask_ld + col;
-#pragma unroll
-                for (int i = 0; i < MC; ++i) {
-                    float mf[EPC];
-                    unpack_chunk<T>(*reinterpret_cast<const u32x4*>(mp + i * EPC), mf);
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) o[i * EPC + e] = (mf[e] > 0.f) ? o[i * EPC + e] : 0.f;
-                }
-            }
-            T* dst;
-            if (ymode == MIS_OUT_PLAIN) {
-                dst = ybase + pix * yld + lcol;
-            } else if (ymode == MIS_OUT_SHUFFLE2) {
-                const int oy = 2 * y + (ab >> 1), ox = 2 * x + (ab & 1);
-                const size_t opix = ((size_t)n * (2 * a.H) + oy) * (size_t)(2 * a.W) + ox;
-                dst = ybase + opix * yld + (lcol - ab * cq);
-            } else {   // MIS_OUT_UNSHUFFLE2
-                const int oh = a.H >> 1, ow = a.W >> 1;
-                const size_t opix = ((size_t)n * oh + (y >> 1)) * ow + (x >> 1);
-                dst = ybase + opix * yld + ((y & 1) * 2 + (x & 1)) * cview + lcol;
-            }
-#pragma unroll
-            for (int i = 0; i < NV; i += EPC) *reinterpret_cast<u32x4*>(dst + i) = pack_chunk<T>(o + i);
-        }
-    }
-}
 
 // Diagnostic build (-DMIS_PP_STAMPS, never shipped): per wave, shader cycles spent (0) working in R segments, (1) parked at the barrier that ends an R segment,
 // (2) working in M segments, (3) parked at the barrier that ends an M segment, (4) in the tile-end epilogue; R work is split further: (5) DMA issue incl. its scalar
@@ -736,8 +626,8 @@ template <int PF, int NF> static int pp_launch_col(const MisConvDesc* d, hipStre
     a.tilesW = (d->W + 15) / 16;
     const long long nsp = (long long)d->N * a.tilesH * a.tilesW;
     a.nCt = d->Cout / BN;
-    // spatial-major tile order when the persistent stride keeps a block on its column tile (256 % nCt == 0); MIS_CONV_PPC_COLMAJOR=1: the other order (A/B switch, read per call)
-    a.tilesD = (256 % a.nCt == 0 && getenv("MIS_CONV_PPC_COLMAJOR") == nullptr) ? 2 : 1;
+    // spatial-major tile order when the persistent stride keeps a block on its column tile (256 % nCt == 0); MIS_CONV_PPC_COLMAJOR=1: the other order (A/B switch)
+    a.tilesD = (256 % a.nCt == 0 && !mis_sw(SW_CONV_PPC_COLMAJOR)) ? 2 : 1;
     MIS_REQUIRE(nsp * a.nCt < (1ll << 31), MIS_EUNSUPPORTED, "conv_igemm(ppc): grid too large");
     a.nSp = (int)nsp;
     const size_t lds = 2 * (size_t)HINSTR * 1024 + 2 * (size_t)3 * BN * 64 + 2 * (size_t)BN * 4;
@@ -925,9 +815,9 @@ bool conv_pp_eligible(const MisConvDesc* d) {
     if (d->Cin % 64 != 0 || d->Cout % 64 != 0) return false;
     if (d->Cout0 % 64 != 0) return false;              // a wave's 64 (128-column blocks) / 128 (256-column blocks) columns go to ONE destination
     if (d->bias != nullptr && (d->y0_mode == MIS_OUT_SHUFFLE2 || (d->y1 != nullptr && d->y1_mode == MIS_OUT_SHUFFLE2))) return false;   // bias is indexed by GEMM column here
-    // 32-bit buffer offsets: ONE image of the input view and the packed weights must each span less than 4 GiB - 64 KiB
-    if ((((long long)d->H * d->W - 1) * d->x0_ld + d->Cin) * 2 >= (1ll << 32) - 65536) return false;
-    if ((long long)9 * d->Cout * d->Cin * 2 >= (1ll << 32) - 65536) return false;
+    // 32-bit buffer offsets, computed in (signed) int by the kernels: ONE image of the input view and the packed weights must each span less than 2 GiB
+    if ((((long long)d->H * d->W - 1) * d->x0_ld + d->Cin) * 2 >= (1ll << 31) - 65536) return false;
+    if ((long long)9 * d->Cout * d->Cin * 2 >= (1ll << 31) - 65536) return false;
     return true;
 }
 
@@ -958,7 +848,7 @@ template <int NF> static int pp_launch(const MisConvDesc* d, hipStream_t stream)
 }
 
 bool conv_pp_rs64_eligible(const MisConvDesc* d) {
-    return conv_pp_eligible(d) && d->Cin == 64 && d->Cout == 64 && d->Cout0 == 64 && d->y0_mode == MIS_OUT_PLAIN && getenv("MIS_CONV_RS64") != nullptr;      // opt-in: measured 0.700 vs 0.654 ms against conv64_ws_kernel
+    return conv_pp_eligible(d) && d->Cin == 64 && d->Cout == 64 && d->Cout0 == 64 && d->y0_mode == MIS_OUT_PLAIN && mis_sw(SW_CONV_RS64);      // opt-in: measured 0.700 vs 0.654 ms against conv64_ws_kernel
 }
 
 int launch_conv_pp(const MisConvDesc* d, hipStream_t stream, const char** tag) {
@@ -967,17 +857,17 @@ int launch_conv_pp(const MisConvDesc* d, hipStream_t stream, const char** tag) {
         return pp_launch_rs64(d, stream);
     }
     // Cout % 128 == 0: the column-segment kernel, unless its 32-row tiles waste more than 15 % of the rows (MIS_CONV_PPC=1 takes it regardless) or MIS_CONV_NOPPC is set
-    // (both read per call: the parity tests reach every kernel on small grids that way)
-    if (d->Cout % 128 == 0 && getenv("MIS_CONV_NOPPC") == nullptr && (((d->H + 31) / 32) * 32 * 100 <= d->H * 115 || getenv("MIS_CONV_PPC") != nullptr)) {
+    // (the parity tests reach every kernel on small grids that way)
+    if (d->Cout % 128 == 0 && !mis_sw(SW_CONV_NOPPC) && (((d->H + 31) / 32) * 32 * 100 <= d->H * 115 || mis_sw(SW_CONV_PPC))) {
         *tag = "k3.2d.ppc8";
         return pp_launch_col<8, 4>(d, stream);
     }
-    if (d->Cout % 64 == 0 && getenv("MIS_CONV_PPC64") != nullptr) {      // 64-column blocks of the same kernel (opt-in A/B switch, read per call)
+    if (d->Cout % 64 == 0 && mis_sw(SW_CONV_PPC64)) {      // 64-column blocks of the same kernel (opt-in A/B switch)
         *tag = "k3.2d.ppc8n2";
         return pp_launch_col<8, 2>(d, stream);
     }
     if (d->Cout % 256 == 0 && d->Cout0 % 128 == 0) {
-        static const int no256 = getenv("MIS_CONV_PP_NO256") != nullptr;
+        const int no256 = mis_sw(SW_CONV_PP_NO256);
         if (!no256) {
             *tag = "k3.2d.pp256";
             return pp_launch<8>(d, stream);

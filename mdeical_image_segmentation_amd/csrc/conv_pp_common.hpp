@@ -1,0 +1,118 @@
+// Shared pieces of the ping-pong implicit-GEMM convolution kernels (conv_pp.hip: 2-D 3x3; conv3d_pp.hip: 3x3x3): compile-time loops, the LDS-DMA / LDS-read
+// primitives and the tile epilogue.  See conv_pp.hip for the structure they serve.
+#pragma once
+#include <type_traits>
+#include <utility>
+
+#include "conv_args.hpp"
+
+typedef __attribute__((address_space(3))) void pp_lds_void_t;
+typedef __attribute__((address_space(1))) const void pp_glob_void_t;
+
+namespace {
+template <typename F, int... I> __device__ __forceinline__ void pp_static_for_impl(F& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void pp_static_for(F&& f) { pp_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// One LDS-DMA instruction: 64 lanes x 16 bytes from buffer `r` at per-lane byte offset `voff` to LDS [dst, dst + 1 KiB) (dst wave-uniform).
+// buffer_load ... lds: 32-bit offsets (no 64-bit address registers), and an offset at or past num_records reads as ZERO - that is the conv's zero
+// padding and the tail of the last halo instruction (PP_OOB is past every buffer this kernel accepts: one image of the input, < 4 GiB - 64 KiB, or the packed weights).
+constexpr int PP_OOB = (int)0xFFFFFF00u;
+__device__ __forceinline__ void pp_dma16(__amdgpu_buffer_rsrc_t r, int voff, char* lds_dst_wave_uniform) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (pp_lds_void_t*)lds_dst_wave_uniform, 16, voff, 0, 0, 0);
+}
+// LDS reads as INLINE ASM: hipcc (ROCm 7.2) may put an s_waitcnt vmcnt(N) in front of an LDS read it cannot tell apart from the destination of an LDS-DMA
+// in flight - which then waits for the prefetch that was just issued and serialises the pipeline (seen here as soon as a second kind of LDS-DMA, the 4-byte
+// bias fetch, joined the kernel; in wgrad_pp.hip with the transposing-read builtin).  The asm form is invisible to that analysis; in exchange NOTHING waits for the
+// result automatically: every use sits behind an explicit s_waitcnt lgkmcnt(0) + sched_barrier (cdna_hip_programming.md §5.4 rule 18, §5.7).
+template <int OFF> __device__ __forceinline__ u32x4 pp_lds_read128(uint32_t lds_addr) {
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF));
+    return r;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pp_make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);   // raw buffer, stride 0, 32-bit data format (gfx9 family)
+}
+}   // namespace
+
+// ---- epilogue: lane (li, lg) holds, per pixel row pf of its wave, NV = 4*NF consecutive output channels of pixel (h0 + wm*4 + pf, w0 + li) ----
+// `bias_lds`: the block's BN bias values of this tile's column tile (zeros without a bias), staged in LDS by DMA: a global bias load here would sit behind the
+// previous stores in the in-order vmcnt queue and expose their latency once per tile.  The accumulators are re-armed with zeros.
+template <int NF, int PF = 4>
+__device__ __forceinline__ void pp_epilogue(const ConvArgs& a, f32x4 (&acc)[NF][PF], uint32_t bias_lds, int n, int h0, int w0, int ncol0, int wm, int wn, int li,
+                                            int lg) {
+    using T = __bf16;
+    constexpr int NV = 4 * NF, WAVE_N = NF * 16, EPC = 8;
+    const int colw = ncol0 + wn * WAVE_N;          // wave-uniform first column
+    const int col = colw + lg * NV;                // this lane's first column
+    const bool to0 = colw < a.Cout0;
+    T* ybase = reinterpret_cast<T*>(to0 ? a.y0 : a.y1);
+    const int yld = to0 ? a.y0_ld : a.y1_ld;
+    const int ymode = to0 ? a.y0_mode : a.y1_mode;
+    const int cview = to0 ? a.Cout0 : a.Cout - a.Cout0;
+    const int lcol = to0 ? col : col - a.Cout0;
+    int ab = 0, cq = 0;
+    if (ymode == MIS_OUT_SHUFFLE2) {
+        cq = cview >> 2;
+        ab = lcol / cq;
+    }
+    // The ReLU-mask rows are loaded where they are used: one exposed global round trip per pixel row (the masked dgrad form of a layer runs 5-22 % slower than its
+    // forward form in isolation).  Two attempts to hide them lost: fetching two rows ahead made hipcc's register scoreboard insert vmcnt waits in front of the first
+    // fragment reads of every chunk (serialises the weight prefetch); fetching 4 or 8 rows of a tile ahead of the stores is 3-7 % faster in isolation and 1-3 % SLOWER in
+    // the live train step (conv_ppc_kernel, scripts/ab_step.py, one process: 37.76 / 39.01 / 38.31 ms per step for 0 / 4 / 8 rows ahead).
+    constexpr int MC = NV / EPC;
+#pragma unroll
+    for (int pf = 0; pf < PF; ++pf) {
+        const int y = h0 + wm * PF + pf, x = w0 + li;
+        float o[NV];
+        {
+            u32x4 braw[NF];
+            pp_static_for<NF>([&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                braw[f] = pp_lds_read128<f * 16>(bias_lds + (wn * WAVE_N + lg * NV) * 4);
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t u = braw[f][q];
+                    o[f * 4 + q] = acc[f][pf][q] + __uint_as_float(u);
+                    acc[f][pf][q] = 0.f;
+                }
+        }
+        if (y < a.H && x < a.W) {
+            if (a.relu) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) o[i] = fmaxf(o[i], 0.f);
+            }
+            const size_t pix = ((size_t)n * a.H + y) * a.W + x;
+            if (a.mask != nullptr) {
+                const T* mp = reinterpret_cast<const T*>(a.mask) + pix * a.mask_ld + col;
+#pragma unroll
+                for (int i = 0; i < MC; ++i) {
+                    float mf[EPC];
+                    unpack_chunk<T>(*reinterpret_cast<const u32x4*>(mp + i * EPC), mf);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) o[i * EPC + e] = (mf[e] > 0.f) ? o[i * EPC + e] : 0.f;
+                }
+            }
+            T* dst;
+            if (ymode == MIS_OUT_PLAIN) {
+                dst = ybase + pix * yld + lcol;
+            } else if (ymode == MIS_OUT_SHUFFLE2) {
+                const int oy = 2 * y + (ab >> 1), ox = 2 * x + (ab & 1);
+                const size_t opix = ((size_t)n * (2 * a.H) + oy) * (size_t)(2 * a.W) + ox;
+                dst = ybase + opix * yld + (lcol - ab * cq);
+            } else {   // MIS_OUT_UNSHUFFLE2
+                const int oh = a.H >> 1, ow = a.W >> 1;
+                const size_t opix = ((size_t)n * oh + (y >> 1)) * ow + (x >> 1);
+                dst = ybase + opix * yld + ((y & 1) * 2 + (x & 1)) * cview + lcol;
+            }
+#pragma unroll
+            for (int i = 0; i < NV; i += EPC) *reinterpret_cast<u32x4*>(dst + i) = pack_chunk<T>(o + i);
+        }
+    }
+}

@@ -1,0 +1,73 @@
+// The dispatch-switch table behind dispatch_cfg.hpp (see there).  A switch that is present in the environment with a numeric value takes that value, present
+// with any other text counts as 1, absent = its default.
+#include "dispatch_cfg.hpp"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <mutex>
+
+#include "common.hpp"
+
+namespace {
+struct SwDef {
+    const char* name;
+    int dflt;
+};
+// order = enum MisSwitch
+const SwDef g_defs[SW_COUNT] = {
+    {"MIS_CONV_V1", 0}, {"MIS_CONV_V3", 0}, {"MIS_CONV_NOPP", 0}, {"MIS_CONV_PP64", 0}, {"MIS_CONV_PPC64", 0}, {"MIS_CONV_K3_NO256", 0},
+    {"MIS_CONV_K3_256_MINCIN", 256}, {"MIS_CONV_NODMA", 0}, {"MIS_CONV_NOWS64", 0},
+    {"MIS_CONV3D_BN64V1", 0}, {"MIS_CONV_K1V1", 0}, {"MIS_CONV_K1NOPERSIST", 0}, {"MIS_CONV_K1_NO256", 0},
+    {"MIS_CONV_PPC_COLMAJOR", 0}, {"MIS_CONV_RS64", 0}, {"MIS_CONV_NOPPC", 0}, {"MIS_CONV_PPC", 0}, {"MIS_CONV_PP_NO256", 0},
+    {"MIS_CONV3D_NOPP", 0}, {"MIS_CONV3D_PF", 0}, {"MIS_CONV3D_ZG", 4}, {"MIS_CONV3D_COLMAJOR", 0},
+    {"MIS_WGRAD_K1_NARROW", 0}, {"MIS_WGRAD_NO_TR", 0}, {"MIS_WGRAD_BLOCKS", 1024}, {"MIS_WGRAD_NOPP", 0}, {"MIS_WGRAD_PP_NOWIDE", 0},
+    {"MIS_WGRAD_PP_KSS1", 0}, {"MIS_WGRAD3D_NOPP", 0},
+    {"MIS_FIRST2D_UNTILED", 0}, {"MIS_FIRST3D_UNTILED", 0}, {"MIS_UPCONV_BWD_GENERIC", 0},
+};
+std::atomic<int> g_val[SW_COUNT];
+std::once_flag g_once;
+
+int from_env(int k) {
+    const char* e = getenv(g_defs[k].name);
+    if (e == nullptr) return g_defs[k].dflt;
+    char* end = nullptr;
+    const long v = strtol(e, &end, 10);
+    return (end != e && *end == '\0') ? (int)v : 1;
+}
+void parse_all() {
+    for (int k = 0; k < SW_COUNT; ++k) g_val[k].store(from_env(k), std::memory_order_relaxed);
+}
+}   // namespace
+
+int mis_sw(MisSwitch k) {
+    std::call_once(g_once, parse_all);
+    return g_val[k].load(std::memory_order_relaxed);
+}
+
+// value >= 0: the switch takes `value` for the rest of the process (or until the next override); value < 0: back to the environment's value / the default.
+// name == NULL: reset every switch.  Unknown name: MIS_EINVAL.
+extern "C" int mis_dispatch_override(const char* name, int value) {
+    std::call_once(g_once, parse_all);
+    if (name == nullptr) {
+        parse_all();
+        return MIS_OK;
+    }
+    for (int k = 0; k < SW_COUNT; ++k)
+        if (strcmp(name, g_defs[k].name) == 0) {
+            g_val[k].store(value >= 0 ? value : from_env(k), std::memory_order_relaxed);
+            return MIS_OK;
+        }
+    mis_set_error("mis_dispatch_override: unknown switch '%s'", name);
+    return MIS_EINVAL;
+}
+
+extern "C" int mis_dispatch_switch(const char* name) {
+    std::call_once(g_once, parse_all);
+    if (name != nullptr)
+        for (int k = 0; k < SW_COUNT; ++k)
+            if (strcmp(name, g_defs[k].name) == 0) return g_val[k].load(std::memory_order_relaxed);
+    mis_set_error("mis_dispatch_switch: unknown switch '%s'", name ? name : "(null)");
+    return MIS_EINVAL;
+}

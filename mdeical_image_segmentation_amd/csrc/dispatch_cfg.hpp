@@ -1,0 +1,17 @@
+// Every A/B switch of the kernel dispatchers in ONE table: parsed from the environment once per process (first use), read from then on as a relaxed
+// atomic load - no getenv on the launch path.  Tests and benchmarks that must reach a non-default configuration inside one process use the explicit
+// override entry point (mis_dispatch_override, include/misamd.h) instead of mutating the environment.
+#pragma once
+
+enum MisSwitch {
+    SW_CONV_V1, SW_CONV_V3, SW_CONV_NOPP, SW_CONV_PP64, SW_CONV_PPC64, SW_CONV_K3_NO256, SW_CONV_K3_256_MINCIN, SW_CONV_NODMA, SW_CONV_NOWS64,
+    SW_CONV3D_BN64V1, SW_CONV_K1V1, SW_CONV_K1NOPERSIST, SW_CONV_K1_NO256,
+    SW_CONV_PPC_COLMAJOR, SW_CONV_RS64, SW_CONV_NOPPC, SW_CONV_PPC, SW_CONV_PP_NO256,
+    SW_CONV3D_NOPP, SW_CONV3D_PF, SW_CONV3D_ZG, SW_CONV3D_COLMAJOR,
+    SW_WGRAD_K1_NARROW, SW_WGRAD_NO_TR, SW_WGRAD_BLOCKS, SW_WGRAD_NOPP, SW_WGRAD_PP_NOWIDE, SW_WGRAD_PP_KSS1, SW_WGRAD3D_NOPP,
+    SW_FIRST2D_UNTILED, SW_FIRST3D_UNTILED, SW_UPCONV_BWD_GENERIC,
+    SW_COUNT
+};
+
+// current value of a switch: the override if one is set, else the environment's value at first use, else the switch's default (0 for the on/off ones)
+int mis_sw(MisSwitch k);

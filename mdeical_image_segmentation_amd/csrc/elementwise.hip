@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "dispatch_cfg.hpp"
 
 // =========================================================================================================
 // First layer: x fp32 NCHW (Cin <= 4) -> y NHWC [pixel][64], 3x3 pad 1, bias, ReLU.   reference: layers.py:122-123
@@ -154,7 +155,7 @@ extern "C" int mis_conv3x3_first_fwd(int dtype, const float* x, int N, int Cin, 
     MIS_REQUIRE(y_ld % 8 == 0, MIS_EINVAL, "first_fwd: y_ld alignment");
     const long long npix = (long long)N * H * W;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    static const int tiled = getenv("MIS_FIRST2D_UNTILED") == nullptr;
+    const int tiled = !mis_sw(SW_FIRST2D_UNTILED);
     if (tiled) {
         long long tiles = (long long)N * ((H + 1) / 2) * ((W + 63) / 64);
         if (tiles > 4096) tiles = 4096;
@@ -364,7 +365,7 @@ extern "C" int mis_conv3x3_first_wgrad(int dtype, const float* x, int N, int Cin
     long long blocks = (npix + 31) / 32;
     if (blocks > FW_BLOCKS) blocks = FW_BLOCKS;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    static const int tiled = getenv("MIS_FIRST2D_UNTILED") == nullptr;
+    const int tiled = !mis_sw(SW_FIRST2D_UNTILED);
     if (tiled) {
         const long long tiles = (long long)N * ((H + 1) / 2) * ((W + 63) / 64);
         blocks = tiles < FW_BLOCKS ? tiles : FW_BLOCKS;

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "dispatch_cfg.hpp"
 
 // ---------------------------------------------------------------------------------------------------------
 // forward finalize: per (n, g) mean / rstd from per-channel sums of up to two sources; per (n, c) scale / shift
@@ -66,6 +67,67 @@ extern "C" int mis_gn_fwd_finalize(const float* sum0, const float* sq0, int C0, 
     hipLaunchKernelGGL(gn_fwd_finalize_kernel, dim3((N * G + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), sum0, sq0, C0, mult0,
                        sum1, sq1, C1, mult1, N, G, count, gamma, beta, eps, Cpad, scale, shift, mean, rstd);
     MIS_LAUNCH_CHECK("gn_fwd_finalize");
+    return MIS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward apply (round 3, bf16 engines): the normalised tensor of ONE source of the (virtual concat) input, written once per SingleConv -
+//   y[n][v][c_off + c] = round(fma(x[n][src(v)][c], scale[n][c_off + c], shift[n][c_off + c])),   src(v) = v, or (z>>1, y>>1, x>>1) for the nearest-upsampled source
+// - the SAME arithmetic and rounding conv_igemm / wgrad apply while staging (HaloStager::store), so the ping-pong kernels (conv3d_pp.hip, wgrad_pp.hip), whose
+// operands arrive by LDS-DMA, see a plain single-source tensor.  One 16-byte chunk per thread; the 8 readers of a coarse voxel hit L2.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int x_ld, int Cs, int up, int N, int D, int H, int W,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift, int Ctot, int c_off,
+                                                       T* __restrict__ y, int y_ld) {
+    constexpr int EPC = Tr<T>::EPC;
+    const int nch = Cs / EPC;
+    const long long np = (long long)D * H * W;
+    const long long total = (long long)N * np * nch;
+    const int sH = up ? H / 2 : H, sW = up ? W / 2 : W;
+    const long long snp = (long long)(up ? D / 2 : D) * sH * sW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        const long long pp = i / nch;
+        const int n = (int)(pp / np);
+        const long long v = pp - (long long)n * np;
+        long long sv = v;
+        if (up) {
+            const int xx = (int)(v % W);
+            const long long t = v / W;
+            const int yy = (int)(t % H), zz = (int)(t / H);
+            sv = ((long long)(zz >> 1) * sH + (yy >> 1)) * sW + (xx >> 1);
+        }
+        float f[EPC];
+        unpack_chunk<T>(*reinterpret_cast<const u32x4*>(x + ((size_t)n * snp + sv) * x_ld + (size_t)ch * EPC), f);
+        const float* sc = scale + (size_t)n * Ctot + c_off + ch * EPC;
+        const float* sh = shift + (size_t)n * Ctot + c_off + ch * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
+        *reinterpret_cast<u32x4*>(y + ((size_t)n * np + v) * y_ld + c_off + (size_t)ch * EPC) = pack_chunk<T>(f);
+    }
+}
+
+extern "C" int mis_gn_apply(int dtype, const void* x, int x_ld, int Cs, int up, int N, int D, int H, int W, const float* scale, const float* shift, int Ctot,
+                            int c_off, void* y, int y_ld, void* stream) {
+    (void)hipGetLastError();
+    const int EPC = dtype == MIS_BF16 ? 8 : 4;
+    MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, MIS_EINVAL, "gn_apply: bad dtype");
+    MIS_REQUIRE(x && scale && shift && y, MIS_EINVAL, "gn_apply: null pointer");
+    MIS_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cs > 0 && Cs % EPC == 0 && x_ld % EPC == 0 && y_ld % EPC == 0 && c_off % EPC == 0 && c_off >= 0 &&
+                    c_off + Cs <= Ctot && Ctot <= y_ld,
+                MIS_EINVAL, "gn_apply: sizes / alignment");
+    MIS_REQUIRE(!up || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0), MIS_EUNSUPPORTED, "gn_apply: upsampled source needs an even grid");
+    long long blocks = ((long long)N * D * H * W * (Cs / EPC) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIS_BF16)
+        hipLaunchKernelGGL(gn_apply_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, (const __bf16*)x, x_ld, Cs, up, N, D, H, W, scale, shift, Ctot, c_off,
+                           (__bf16*)y, y_ld);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x, x_ld, Cs, up, N, D, H, W, scale, shift, Ctot, c_off,
+                           (float*)y, y_ld);
+    MIS_LAUNCH_CHECK("gn_apply");
     return MIS_OK;
 }
 
@@ -475,7 +537,7 @@ extern "C" int mis_first3d_fwd(int dtype, const float* x, const float* scale, co
                 "first3d_fwd: Cout %d / Cpad %d", Cout, Cpad);
     const long long total = (long long)N * D * H * W;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    static const int tiled = getenv("MIS_FIRST3D_UNTILED") == nullptr;
+    const int tiled = !mis_sw(SW_FIRST3D_UNTILED);
     const long long tiles = (long long)N * D * ((H + 3) / 4) * ((W + 63) / 64);
     if (tiled && Cout == 32 && tiles < (1ll << 31)) {
         if (dtype == MIS_BF16)
@@ -781,7 +843,7 @@ extern "C" int mis_first3d_bwd(int dtype, const float* x, const float* mean, con
     if (blocks > F3_BLOCKS) blocks = F3_BLOCKS;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* gs = workspace + (size_t)F3_BLOCKS * 3 * 2 * 576;
-    static const int tiled = getenv("MIS_FIRST3D_UNTILED") == nullptr;
+    const int tiled = !mis_sw(SW_FIRST3D_UNTILED);
     if (tiled && Cout == 32) {
         const long long tiles = (long long)N * D * ((H + 3) / 4) * ((W + 63) / 64);
         blocks = tiles < F3_BLOCKS ? tiles : F3_BLOCKS;

@@ -11,6 +11,7 @@
 // Bilinear rule (align_corners=False): src = max(0, (dst + 0.5)/s - 0.5), i0 = floor(src), i1 = min(i0 + 1, n - 1), lambda = src - i0.
 // Both gathers are index work bound by cache/HBM bandwidth: one 16-byte channel chunk per thread, fp32 accumulation in a fixed order.
 #include "common.hpp"
+#include "dispatch_cfg.hpp"
 
 __device__ __forceinline__ void upc_src(int dst, float inv_scale, int n, int& i0, int& i1, float& lam) {
     float src = ((float)dst + 0.5f) * inv_scale - 0.5f;
@@ -369,7 +370,7 @@ extern "C" int mis_upconv_gather_bwd(int dtype, const void* dy, int dy_ld, void*
     if (int rc = upc_check("upconv_gather_bwd", dtype, dy, dz, dy_ld, N, h, w, scale, C)) return rc;
     const int EPC = dtype == MIS_BF16 ? 8 : 4;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (C == 64 && getenv("MIS_UPCONV_BWD_GENERIC") == nullptr) {
+    if (C == 64 && !mis_sw(SW_UPCONV_BWD_GENERIC)) {
         if (dtype == MIS_BF16)
             upc_dispatch_bwd64<__bf16>(dy, dy_ld, dz, N, h, w, scale, st);
         else

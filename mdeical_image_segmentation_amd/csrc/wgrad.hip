@@ -16,6 +16,7 @@
 #include <utility>
 
 #include "common.hpp"
+#include "dispatch_cfg.hpp"
 #include "wgrad_args.hpp"
 
 #ifndef MIS_WG_BF16_UNROLL
@@ -462,9 +463,8 @@ static int wg_plan(const MisWgradDesc* d, WgPlan* p) {
     MIS_REQUIRE(d->N > 0 && d->D > 0 && d->H > 0 && d->W > 0, MIS_EINVAL, "wgrad: empty grid");
     p->CT = d->dtype == MIS_BF16 ? 64 : 32;
     {   // bf16 1x1 layers (the GEMMs of the transposed convolutions): 128 x 128 channel tiles - twice the MFMA work per staged byte
-        static const bool no_wide = getenv("MIS_WGRAD_K1_NARROW") != nullptr;
-        const char* e = getenv("MIS_WGRAD_NO_TR");
-        const bool use_tr = !(e != nullptr && e[0] == '1');
+        const bool no_wide = mis_sw(SW_WGRAD_K1_NARROW) != 0;
+        const bool use_tr = !mis_sw(SW_WGRAD_NO_TR);
         p->wide = !no_wide && use_tr && d->dtype == MIS_BF16 && d->ksize == 1 && d->Cin % 128 == 0 && d->Cout % 128 == 0 && d->Cin0 % 128 == 0 &&
                   d->in_scale == nullptr;
         if (p->wide) p->CT = 128;
@@ -485,7 +485,7 @@ static int wg_plan(const MisWgradDesc* d, WgPlan* p) {
     p->KDn = (p->is3d && d->ksize == 3) ? 3 : 1;
     p->TT = d->ksize == 3 ? (p->is3d ? 27 : 9) : 1;
     const long long base = (long long)p->nCi * p->nCo * p->KDn;
-    static const int target_blocks = getenv("MIS_WGRAD_BLOCKS") ? atoi(getenv("MIS_WGRAD_BLOCKS")) : 1024;
+    const int target_blocks = mis_sw(SW_WGRAD_BLOCKS);
     long long want = (target_blocks + base - 1) / base;     // aim for >= ~1024 blocks (2 per CU x 2 rounds)
     if (want < 1) want = 1;
     if (want > nt) want = nt;
@@ -494,9 +494,8 @@ static int wg_plan(const MisWgradDesc* d, WgPlan* p) {
     while (want > 1 && want * slab > (256ll << 20)) --want;
     p->tps = (int)((nt + want - 1) / want);
     p->nsplit = (int)((nt + p->tps - 1) / p->tps);
-    // bf16 2-D 3x3 layers: the ping-pong kernel (wgrad_pp.hip) with its own split plan (2 slabs per persistent block); read per call so that the
-    // parity tests can reach both kernels in one process
-    p->pp = getenv("MIS_WGRAD_NOPP") == nullptr && wgrad_pp_eligible(d);
+    // bf16 3x3 / 3x3x3 layers with a plain single-source operand: the ping-pong kernels (wgrad_pp.hip) with their own split plan (one or two slabs per persistent block)
+    p->pp = !mis_sw(SW_WGRAD_NOPP) && wgrad_pp_eligible(d);
     if (p->pp) p->nsplit = wgrad_pp_nsplit(d);
     return MIS_OK;
 }
@@ -511,15 +510,21 @@ extern "C" size_t mis_wgrad_workspace_bytes(const MisWgradDesc* d) {
 // reduce the bias column sums.  Shared by wgrad_kernel and wgrad_pp_kernel.
 static int wg_finish(const MisWgradDesc* d, const WgPlan& p, float* bias_partial, hipStream_t stream) {
     if (d->reduce_stream != nullptr && d->reduce_stream != (void*)stream) {   // reductions go to the side stream, after the MFMA kernel
-        // Order the reduction stream behind the MFMA kernel: one event per call, destroyed right after the wait has been enqueued (legal HIP: the runtime keeps what the
-        // wait needs).  Round 1 kept a process-lifetime ring of events here on the suspicion that the early destroy let the side stream run ahead; the round-2 experiment
-        // (scripts/exp_event_lifetime.py: 4 x 8 unsynchronised train steps, bit-identical parameters with either scheme) showed the nondeterminism of that time came from
-        // the no-op wgrad_join ("cuda" vs "cuda:0" key) fixed in the same commit, not from event lifetime.
+        // Order the reduction stream behind the MFMA kernel with an event from a process-lifetime ring (per thread; never destroyed while work may reference it).
+        // Round 2 replaced the ring by create / record / wait / destroy per call on the strength of an experiment that did not exercise this path;
+        // the ring is back, and tests/test_gpu_fullsize.py holds the side-stream path of the 2-D and 3-D engines to bit-identical unsynchronised steps.
         const hipStream_t side = reinterpret_cast<hipStream_t>(d->reduce_stream);
-        hipEvent_t ev;
-        MIS_REQUIRE(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, MIS_EHIP, "wgrad: hipEventCreate failed");
-        const bool ok = hipEventRecord(ev, stream) == hipSuccess && hipStreamWaitEvent(side, ev, 0) == hipSuccess;
-        (void)hipEventDestroy(ev);
+        constexpr int RING = 64, MAXDEV = 16;              // events belong to a device: one ring per device ordinal
+        static thread_local hipEvent_t ring[MAXDEV][RING];
+        static thread_local unsigned made[MAXDEV] = {}, next[MAXDEV] = {};
+        int dev = 0;
+        MIS_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAXDEV, MIS_EHIP, "wgrad: hipGetDevice failed");
+        const unsigned slot = next[dev]++ % RING;
+        if (slot >= made[dev]) {
+            MIS_REQUIRE(hipEventCreateWithFlags(&ring[dev][slot], hipEventDisableTiming) == hipSuccess, MIS_EHIP, "wgrad: hipEventCreate failed");
+            made[dev] = slot + 1;
+        }
+        const bool ok = hipEventRecord(ring[dev][slot], stream) == hipSuccess && hipStreamWaitEvent(side, ring[dev][slot], 0) == hipSuccess;
         MIS_REQUIRE(ok, MIS_EHIP, "wgrad: could not order the reduction stream after the MFMA kernel");
         stream = side;
     }
@@ -622,8 +627,7 @@ extern "C" int mis_wgrad(const MisWgradDesc* d, void* stream) {
         if (rc != MIS_OK) return rc;
         return wg_finish(d, p, bias_partial, s);
     }
-    const char* e = getenv("MIS_WGRAD_NO_TR");
-    const bool use_tr = !(e != nullptr && e[0] == '1');
+    const bool use_tr = !mis_sw(SW_WGRAD_NO_TR);
     if (d->dtype == MIS_BF16) return use_tr ? wg_dispatch<__bf16, true>(d, p, s) : wg_dispatch<__bf16, false>(d, p, s);
     return wg_dispatch<float, false>(d, p, s);
 }

@@ -19,6 +19,7 @@
 #include <type_traits>
 #include <utility>
 
+#include "dispatch_cfg.hpp"
 #include "wgrad_args.hpp"
 
 typedef __attribute__((address_space(3))) void wp_lds_void_t;
@@ -317,7 +318,11 @@ template <bool SPLIT> struct W3 {
     static constexpr int PER_WAVE = NPJ + NQJ;
 };
 
-template <bool SPLIT>
+// IS3D (round 3): the weight gradient of a 3x3x3 layer = three 3x3 weight gradients, one per depth slice kd of the filter, each against the input plane z + kd - 1:
+// kd joins (ci tile, co tile) in the block's identity (the three blocks of a pair walk the same dY tiles and input planes one apart, and sit next to each other in the
+// launch order, i.e. on one XCD), a "pixel tile" is a 2-D tile of one depth plane (NDHWC: the planes of a batch are one contiguous sequence of H x W images), planes
+// outside the volume read as zero through out-of-range DMA offsets, and the slab row is kd*9 + tap of TT = 27.
+template <bool SPLIT, bool IS3D = false>
 __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
     using G = W3<SPLIT>;
     constexpr int NS = 4;                              // segments per step = the k-steps of a group's 128 pixels
@@ -331,11 +336,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
     const int li = lane & 15, lg = lane >> 4;
     const int q = li >> 2, pp = li & 3;
 
-    const int npairs = a.nCi * a.nCo;                  // nCo counts G::CO-column tiles
+    constexpr int KDN = IS3D ? 3 : 1;
+    const int npairs = a.nCi * a.nCo * KDN;            // nCo counts G::CO-column tiles
     int v = xcd_remap(blockIdx.x, gridDim.x);
     const int pair = v % npairs;
     const int split = v / npairs;
-    const int ci_t = pair / a.nCo, co_t = pair - ci_t * a.nCo;
+    const int kd = IS3D ? pair % 3 : 0;
+    const int pc = IS3D ? pair / 3 : pair;
+    const int ci_t = pc / a.nCo, co_t = pc - ci_t * a.nCo;
     const int ci0 = ci_t * 64, co0 = co_t * G::CO;
     const int t_begin = split * a.tps;
     int t_end = t_begin + a.tps;
@@ -347,6 +355,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
         const int th = r / a.tilesW;
         h0 = th * G::TH;
         w0 = (r - th * a.tilesW) * WP_TW;
+    };
+    auto src_plane = [&](int n, int& xn, bool& zok) {      // once per tile (the modulo is scalar work)
+        xn = n;
+        zok = true;
+        if constexpr (IS3D) {
+            const int z = n % a.D + kd - 1;
+            zok = (unsigned)z < (unsigned)a.D;
+            xn = zok ? n + kd - 1 : n;
+        }
     };
 
     int qoff[2], poff[2][3];
@@ -383,15 +400,16 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
     const unsigned img_x = (unsigned)(((long long)a.H * a.W - 1) * a.x0.ld + a.Cin) * 2u, img_q = (unsigned)(((long long)a.H * a.W - 1) * a.dy_ld + a.Cout) * 2u;
     const char* const xb = reinterpret_cast<const char*>(a.x0.p);
     const char* const qb = reinterpret_cast<const char*>(a.dy);
-    auto issue = [&](auto jc, int n, int h0, int w0, char* stage) {
+    // IS3D: n is the plane index (sample * D + z) of the dY tile; its input plane is xn = n + kd - 1 when that lies inside the volume (zok), else it reads as zeros
+    auto issue = [&](auto jc, int n, int h0, int w0, char* stage, int xn, bool zok) {
         constexpr int jj = decltype(jc)::value;
         if constexpr (jj < G::NPJ) {
             const int id = wave + 8 * jj;
             if (id >= G::PINSTR) return;
-            const __amdgpu_buffer_rsrc_t rx = wp_make_rsrc(xb + (size_t)n * a.H * a.W * a.x0.ld * 2, img_x);
+            const __amdgpu_buffer_rsrc_t rx = wp_make_rsrc(xb + (size_t)xn * a.H * a.W * a.x0.ld * 2, img_x);
             const unsigned toff = (unsigned)((((h0 - 1) * a.W + (w0 - 1)) * a.x0.ld + ci0) * 2);
             const bool interior = h0 >= 1 && h0 + G::TH + 1 <= a.H && w0 >= 1 && w0 + WP_TW + 1 <= a.W;
-            bool ok = pcoord[jj] >= 0;
+            bool ok = pcoord[jj] >= 0 && zok;
             if (!interior) {
                 const int py = pcoord[jj] & 0xff, px = pcoord[jj] >> 8;
                 ok = ok && (unsigned)(h0 - 1 + py) < (unsigned)a.H && (unsigned)(w0 - 1 + px) < (unsigned)a.W;
@@ -412,12 +430,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int fj = 0; fj < 4; ++fj) acc[t][fj] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = (a.bias_partial != nullptr) && (ci_t == 0) && (wi == 0);     // one wave per group
+    const bool do_bias = (a.bias_partial != nullptr) && (ci_t == 0) && (wi == 0) && (!IS3D || kd == 1);     // one wave per group (3-D: of the centre-slice block)
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
-    int n, h0, w0;
+    int n, h0, w0, xn;
+    bool zok;
     tile_coords(t_begin, n, h0, w0);
-    wp_static_for<G::PER_WAVE>([&](auto jc) { issue(jc, n, h0, w0, smem); });
+    src_plane(n, xn, zok);
+    wp_static_for<G::PER_WAVE>([&](auto jc) { issue(jc, n, h0, w0, smem, xn, zok); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -428,8 +448,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
 #pragma unroll 1
     for (int t = t_begin; t < t_end; ++t) {
         const bool has_next = t + 1 < t_end;
-        int nn = n, nh0 = h0, nw0 = w0;
-        if (has_next) tile_coords(t + 1, nn, nh0, nw0);
+        int nn = n, nh0 = h0, nw0 = w0, nxn = xn;
+        bool nzok = zok;
+        if (has_next) {
+            tile_coords(t + 1, nn, nh0, nw0);
+            src_plane(nn, nxn, nzok);
+        }
         const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
         const uint32_t lds_p = lds0 + sel * G::STAGE + (SPLIT ? grp * (8 * WP_ROWB) : 0);              // SPLIT: this group's 8 tile rows (+ 2 halo rows)
         const uint32_t lds_q = lds0 + sel * G::STAGE + G::PBUF + (SPLIT ? grp * (8 * 16 * 128) : 0);
@@ -441,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
                 if (has_next) {
                     wp_static_for<DPS>([&](auto dc) {
                         constexpr int jj = ks * DPS + decltype(dc)::value;
-                        if constexpr (jj < G::PER_WAVE) issue(std::integral_constant<int, jj>{}, nn, nh0, nw0, nstage);
+                        if constexpr (jj < G::PER_WAVE) issue(std::integral_constant<int, jj>{}, nn, nh0, nw0, nstage, nxn, nzok);
                     });
                 }
             }
@@ -482,7 +506,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         });
         sel ^= 1;
-        n = nn; h0 = nh0; w0 = nw0;
+        n = nn; h0 = nh0; w0 = nw0; xn = nxn; zok = nzok;
     }
 
     const int se = SPLIT ? 2 * split + grp : split;            // SPLIT: one slab per wave group
@@ -495,7 +519,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ci = ci0 + wi * 16 + lg * 4 + r;
-                out[((size_t)tap * a.Cin + ci) * a.Cout + co] = acc[tap][fj][r];
+                out[((size_t)(kd * 9 + tap) * a.Cin + ci) * a.Cout + co] = acc[tap][fj][r];
             }
         }
     if (do_bias) {
@@ -512,20 +536,25 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------
 bool wgrad_pp_eligible(const MisWgradDesc* d) {
-    if (d->dtype != MIS_BF16 || d->is3d || d->ksize != 3 || d->D != 1) return false;
+    if (d->dtype != MIS_BF16 || d->ksize != 3) return false;
+    if (d->is3d) {
+        if (mis_sw(SW_WGRAD3D_NOPP) || d->x0_D != d->D) return false;
+    } else if (d->D != 1) {
+        return false;
+    }
     if (d->x1 != nullptr || d->in_scale != nullptr) return false;
     if (d->x0_H != d->H || d->x0_W != d->W) return false;
     if (d->Cin % 64 != 0 || d->Cout % 64 != 0) return false;
-    if ((((long long)d->H * d->W - 1) * d->x0_ld + d->Cin) * 2 >= (1ll << 32) - 65536) return false;      // 32-bit buffer offsets within ONE image
-    if ((((long long)d->H * d->W - 1) * d->dy_ld + d->Cout) * 2 >= (1ll << 32) - 65536) return false;
-    const char* e = getenv("MIS_WGRAD_NO_TR");
-    if (e != nullptr && e[0] == '1') return false;
+    // 32-bit buffer offsets within ONE image / depth plane, computed in (signed) int: below 2 GiB
+    if ((((long long)d->H * d->W - 1) * d->x0_ld + d->Cin) * 2 >= (1ll << 31) - 65536) return false;
+    if ((((long long)d->H * d->W - 1) * d->dy_ld + d->Cout) * 2 >= (1ll << 31) - 65536) return false;
+    if (mis_sw(SW_WGRAD_NO_TR)) return false;
     return true;
 }
 
-// kernel choice: 0 = wide (Cout % 128 == 0), 1 = pixel-split wide tile (64-column tiles), 2 = the 64 x 64 kernel with 16 x 32 wave tiles (MIS_WGRAD_PP_NOWIDE=1)
+// kernel choice: 0 = wide (Cout % 128 == 0), 1 = pixel-split wide tile (64-column tiles), 2 = the 64 x 64 kernel with 16 x 32 wave tiles (MIS_WGRAD_PP_NOWIDE=1; 2-D only)
 static int wp_kind(const MisWgradDesc* d) {
-    if (getenv("MIS_WGRAD_PP_NOWIDE") != nullptr) return 2;
+    if (!d->is3d && mis_sw(SW_WGRAD_PP_NOWIDE)) return 2;
     return d->Cout % 128 == 0 ? 0 : 1;
 }
 
@@ -534,8 +563,8 @@ static void wp_plan(const MisWgradDesc* d, int* ntiles, int* tps, int* nsb, int*
     const int th = kind == 0 ? 8 : 16;
     *tilesH = (d->H + th - 1) / th;
     *tilesW = (d->W + WP_TW - 1) / WP_TW;
-    const long long nt = (long long)d->N * *tilesH * *tilesW;
-    const long long npairs = (long long)(d->Cin / 64) * (d->Cout / (kind == 0 ? 128 : 64));
+    const long long nt = (long long)d->N * (d->is3d ? d->D : 1) * *tilesH * *tilesW;      // 3-D: one 2-D tile grid per depth plane
+    const long long npairs = (long long)(d->Cin / 64) * (d->Cout / (kind == 0 ? 128 : 64)) * (d->is3d ? 3 : 1);
     long long want = 256 / npairs;                // one persistent block per CU
     if (want < 1) want = 1;
     if (want > nt) want = nt;
@@ -550,37 +579,40 @@ int wgrad_pp_nsplit(const MisWgradDesc* d) {
     return wp_kind(d) == 1 ? 2 * nsb : nsb;
 }
 
+template <bool SPLIT, bool IS3D> static int wp_launch_wide(const WgArgs& a, long long grid, hipStream_t stream, const char* what) {
+    const size_t lds = 2 * (size_t)W3<SPLIT>::STAGE;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&wgrad_pp_wide_kernel<SPLIT, IS3D>), lds, what)) return rc;
+    hipLaunchKernelGGL((wgrad_pp_wide_kernel<SPLIT, IS3D>), dim3((unsigned)grid), dim3(512), lds, stream, a);
+    return MIS_OK;
+}
+
 int launch_wgrad_pp(const MisWgradDesc* d, float* partial, float* bias_partial, hipStream_t stream, const char** tag) {
+    const bool is3d = d->is3d != 0;
     WgArgs a;
-    a.N = d->N; a.D = 1; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cin0 = d->Cin;
-    a.x0 = WSrc{d->x0, d->x0_ld, 1, d->x0_H, d->x0_W};
+    a.N = d->N; a.D = is3d ? d->D : 1; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cin0 = d->Cin;
+    a.x0 = WSrc{d->x0, d->x0_ld, a.D, d->x0_H, d->x0_W};
     a.x1 = WSrc{nullptr, 0, 0, 0, 0};
     a.in_scale = nullptr; a.in_shift = nullptr;
     a.dy = d->dy; a.dy_ld = d->dy_ld; a.partial = partial; a.bias_partial = bias_partial;
     int nsb;
     const int kind = wp_kind(d);
     wp_plan(d, &a.ntiles, &a.tps, &nsb, &a.tilesH, &a.tilesW);
-    MIS_REQUIRE((long long)d->N * a.tilesH * a.tilesW < (1ll << 30), MIS_EUNSUPPORTED, "wgrad(pp): too many pixel tiles");
-    a.tilesD = 1; a.nsplit = kind == 1 ? 2 * nsb : nsb;
-    a.nCi = d->Cin / 64; a.nCo = d->Cout / (kind == 0 ? 128 : 64); a.KDn = 1; a.TT = 9;
-    const long long grid = (long long)a.nCi * a.nCo * nsb;
+    MIS_REQUIRE((long long)d->N * a.D * a.tilesH * a.tilesW < (1ll << 30), MIS_EUNSUPPORTED, "wgrad(pp): too many pixel tiles");
+    a.tilesD = a.D; a.nsplit = kind == 1 ? 2 * nsb : nsb;
+    a.nCi = d->Cin / 64; a.nCo = d->Cout / (kind == 0 ? 128 : 64); a.KDn = is3d ? 3 : 1; a.TT = is3d ? 27 : 9;
+    const long long grid = (long long)a.nCi * a.nCo * a.KDn * nsb;
     MIS_REQUIRE(grid < (1ll << 31), MIS_EUNSUPPORTED, "wgrad(pp): grid too large");
     if (kind == 0) {
-        *tag = "k3.2d.ppw";
-        const size_t lds = 2 * (size_t)W3<false>::STAGE;
-        static std::atomic<unsigned long long> attr_done{0};
-        if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&wgrad_pp_wide_kernel<false>), lds, "wgrad(ppw)")) return rc;
-        hipLaunchKernelGGL(wgrad_pp_wide_kernel<false>, dim3((unsigned)grid), dim3(512), lds, stream, a);
+        *tag = is3d ? "k3.3d.ppw" : "k3.2d.ppw";
+        if (const int rc = is3d ? wp_launch_wide<false, true>(a, grid, stream, "wgrad(ppw3)") : wp_launch_wide<false, false>(a, grid, stream, "wgrad(ppw)")) return rc;
     } else if (kind == 1) {
-        *tag = "k3.2d.pps";
-        const size_t lds = 2 * (size_t)W3<true>::STAGE;
-        static std::atomic<unsigned long long> attr_done{0};
-        if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&wgrad_pp_wide_kernel<true>), lds, "wgrad(pps)")) return rc;
-        hipLaunchKernelGGL(wgrad_pp_wide_kernel<true>, dim3((unsigned)grid), dim3(512), lds, stream, a);
+        *tag = is3d ? "k3.3d.pps" : "k3.2d.pps";
+        if (const int rc = is3d ? wp_launch_wide<true, true>(a, grid, stream, "wgrad(pps3)") : wp_launch_wide<true, false>(a, grid, stream, "wgrad(pps)")) return rc;
     } else {
         *tag = "k3.2d.pp";
         const size_t lds = 2 * (size_t)WP_STAGE;
-        const bool kss1 = getenv("MIS_WGRAD_PP_KSS1") != nullptr;     // default: two k-steps per segment (36 MFMAs per wave between barriers)
+        const bool kss1 = mis_sw(SW_WGRAD_PP_KSS1) != 0;     // default: two k-steps per segment (36 MFMAs per wave between barriers)
         if (kss1) {
             static std::atomic<unsigned long long> attr_done{0};
             if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&wgrad_pp_kernel<1>), lds, "wgrad(pp)")) return rc;

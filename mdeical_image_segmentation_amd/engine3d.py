@@ -102,6 +102,10 @@ class UNet3DEngine:
         self.dtype, self.device = dtype, torch.device(device)
         # split-K slab reductions of the weight-gradient kernels run on a second stream under the next MFMA kernel (joined per DDP stage / at the end)
         self.side_reduce = os.environ.get("MISAMD_NO_SIDE_REDUCE") is None
+        # bf16: the GroupNorm output is WRITTEN once per SingleConv (mis_gn_apply: same arithmetic and rounding as the operand-staging fold) and feeds both the forward
+        # convolution and the weight gradient as a plain single-source tensor - which is what lets them run on the all-DMA ping-pong kernels (conv3d_pp.hip,
+        # wgrad_pp.hip); fp32 keeps the fold (its lock-step kernels sit at 0.79 of the f32 MFMA peak).  MISAMD_GN_FOLD=1: the fold in bf16 too (A/B switch).
+        self.materialize = dtype == torch.bfloat16 and os.environ.get("MISAMD_GN_FOLD") is None
         self.levels = len(f_maps)
         self.specs = unet3d_param_specs(in_channels, out_channels, f_maps, upsample)
         self.flat = FlatParams(self.specs, self.device, lambda n: not n.endswith("bias"))
@@ -227,6 +231,7 @@ class UNet3DEngine:
             s.sum0, s.sq0 = torch.zeros(N, cs, device=dev), torch.zeros(N, cs, device=dev)
             s.sum1, s.sq1 = torch.zeros(N, cs, device=dev), torch.zeros(N, cs, device=dev)
             s.dgam, s.dbet = torch.zeros(cs, device=dev), torch.zeros(cs, device=dev)
+            s.xn = buf(l, s.cin_pad) if (self.materialize and not s.first) else None
         self.dyn = {}      # dgrad outputs, keyed by (level, channels): shared between SingleConvs of equal shape
         for s in self.sc.values():
             if s.first:
@@ -261,6 +266,14 @@ class UNet3DEngine:
         self._gn_fwd(s, src0, c0, src1, c1)
         s.src0, s.c0, s.src1, s.c1 = src0, c0, src1, c1
         grid = (src0.shape[0], src0.shape[1], src0.shape[2], src0.shape[3])
+        if s.xn is not None:
+            if src1 is None:
+                ops.gn_apply(src0, s.cin_pad, False, grid, s.scale, s.shift, s.cin_pad, 0, s.xn)
+            else:
+                ops.gn_apply(View(src0, 0, c0), c0, False, grid, s.scale, s.shift, s.cin_pad, 0, s.xn)
+                ops.gn_apply(View(src1, 0, c1), c1, src1.shape[1] != src0.shape[1], grid, s.scale, s.shift, s.cin_pad, c0, s.xn)
+            ops.conv_igemm(s.xn, s.wf, y, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid, relu=getattr(s, "relu", True))
+            return
         ops.conv_igemm(View(src0, 0, src0.shape[-1] if src1 is None else c0), s.wf, y, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid,
                        x1=None if src1 is None else View(src1, 0, c1), relu=getattr(s, "relu", True), in_scale=s.scale, in_shift=s.shift)
 
@@ -352,8 +365,11 @@ class UNet3DEngine:
         x0v = View(src0, 0, src0.shape[-1] if src1 is None else c0)
         x1v = None if src1 is None else View(src1, 0, c1)
         dw = self.Gr[s.name + ".conv.weight"] if s.dwpad is None else s.dwpad
-        ops.wgrad(x0v, g_y, dw, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid, x1=x1v, in_scale=s.scale, in_shift=s.shift,
-                  side=self.side_reduce and s.dwpad is None)
+        if s.xn is not None:
+            ops.wgrad(s.xn, g_y, dw, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid, side=self.side_reduce and s.dwpad is None)
+        else:
+            ops.wgrad(x0v, g_y, dw, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid, x1=x1v, in_scale=s.scale, in_shift=s.shift,
+                      side=self.side_reduce and s.dwpad is None)
         if s.dwpad is not None:
             self.Gr[s.name + ".conv.weight"].copy_(s.dwpad[:, :s.cin])
         dyn = self.dyn[(self._level(s.name), s.cin_pad)]

@@ -89,6 +89,7 @@ class ResidualUNet3DEngine(UNet3DEngine):
         self.cin, self.cout, self.f_maps, self.G = in_channels, out_channels, f_maps, num_groups
         self.dtype, self.device = dtype, torch.device(device)
         self.side_reduce = os.environ.get("MISAMD_NO_SIDE_REDUCE") is None
+        self.materialize = dtype == torch.bfloat16 and os.environ.get("MISAMD_GN_FOLD") is None      # see UNet3DEngine
         self.levels = len(f_maps)
         self.specs = resunet3d_param_specs(in_channels, out_channels, f_maps, se=self.SE)
         self.flat = FlatParams(self.specs, self.device, lambda n: not n.endswith("bias"))
@@ -174,6 +175,7 @@ class ResidualUNet3DEngine(UNet3DEngine):
             s.p, s.q, s.r = torch.zeros(N, cs, device=dev), torch.zeros(N, cs, device=dev), torch.zeros(N, cs, device=dev)
             s.sum0, s.sq0 = torch.zeros(N, cs, device=dev), torch.zeros(N, cs, device=dev)
             s.sum1, s.sq1 = torch.zeros(N, cs, device=dev), torch.zeros(N, cs, device=dev)
+            s.xn = buf(self._level(s.name), s.cin_pad) if self.materialize else None
         self.dyn = {}
         for s in self.sc.values():
             key = (self._level(s.name), s.cin_pad)

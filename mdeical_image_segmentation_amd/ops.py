@@ -106,6 +106,29 @@ def conv_igemm(x0, w_packed, y0, *, ksize, Cin, Cout, grid=None, x1=None, bias=N
         check(lib.mis_conv_igemm(C.byref(d), stream_ptr()), "mis_conv_igemm")
 
 
+def dispatch_override(name, value=1):
+    """set one kernel-selection switch of the library (include/misamd.h: mis_dispatch_override; e.g. "MIS_CONV_NOPP"); value < 0: back to the environment's value;
+    name None: reset all.  Unknown names raise."""
+    check(load().mis_dispatch_override(None if name is None else name.encode(), int(value)), "mis_dispatch_override")
+
+
+class dispatch_switches:
+    """context manager: `with ops.dispatch_switches(MIS_CONV_NOPP=1): ...` - the switches are restored on exit"""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            dispatch_override(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            dispatch_override(k, -1)
+        return False
+
+
 def conv_last_dispatch():
     """name of the kernel configuration the last conv_igemm call of this thread ran (e.g. 'k3.2d.bn256.dma')"""
     return load().mis_conv_last_dispatch().decode()
@@ -397,6 +420,17 @@ def gn_fwd_finalize(sum0, sq0, C0, mult0, sum1, sq1, C1, mult1, N, G, count, gam
                                   None if sq1 is None else sq1.data_ptr(), C1, mult1, N, G, float(count), gamma.data_ptr(), beta.data_ptr(),
                                   eps, Cpad, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), stream_ptr()),
           "mis_gn_fwd_finalize")
+
+
+def gn_apply(x, Cs, up, grid, scale, shift, Ctot, c_off, y):
+    """materialise the GroupNorm output of one source: y[..., c_off:c_off+Cs] = scale * x(src voxel) + shift (mis_gn_apply); y = the destination tensor (N, D, H, W, >= Ctot)"""
+    lib = load()
+    x = _v(x)
+    N, D, H, W = grid
+    if not y.is_contiguous() or tuple(y.shape[:4]) != (N, D, H, W) or y.shape[-1] < Ctot:
+        raise MisError(f"gn_apply: destination {tuple(y.shape)} does not match grid {grid} / {Ctot} channels")
+    check(lib.mis_gn_apply(dtype_code(x.dtype), x.ptr, x.ld, Cs, 1 if up else 0, N, D, H, W, scale.data_ptr(), shift.data_ptr(), Ctot, c_off, y.data_ptr(),
+                           y.shape[-1], stream_ptr()), "mis_gn_apply")
 
 
 def gn_bwd_stats(dy, x, Cs, up, grid, S1, S2, Ctot, c_off):

@@ -154,6 +154,47 @@ def loss_and_grads(p, x, target, num_levels=4, num_groups=8, upsample="default")
     return loss.detach(), logits.detach(), {k: v.grad.detach() for k, v in ps.items()}
 
 
+# ---- bf16-STORAGE emulation (test infrastructure for the 3-D engine's bf16 mode; the 2-D twin is unet2d_oracle.unet_forward_bf16_storage) ----------------
+# The engine's bf16 mode keeps in bf16: every activation (the outputs of ReLU / max-pool), the NORMALISED operand of each convolution (mis_gn_apply writes
+# round(scale * x + shift); GroupNorm statistics are taken from the stored bf16 input in fp32), the packed conv weights and every activation gradient;
+# in fp32: the volume, the first layer's and the head's weights, the accumulators, every parameter gradient and the master weights.  Restated below on top of
+# the fp32 oracle with round-to-nearest-even at the same tensor boundaries.
+def unet3d_forward_bf16_storage(p, x, num_levels=4, num_groups=8):
+    from .unet2d_oracle import _RoundAct, _RoundWeight
+    ra, rw = _RoundAct.apply, _RoundWeight.apply
+
+    def sc(t, pre, first=False):
+        g = _groups(t.shape[1], num_groups)
+        tn = F.group_norm(t, g, p[f"{pre}.groupnorm.weight"], p[f"{pre}.groupnorm.bias"], eps=1e-5)
+        w = p[f"{pre}.conv.weight"]
+        if not first:
+            tn, w = ra(tn), rw(w)
+        return ra(F.relu(F.conv3d(tn, w, None, padding=1)))
+
+    def dc(t, pre, first=False):
+        return sc(sc(t, f"{pre}.basic_module.SingleConv1", first), f"{pre}.basic_module.SingleConv2")
+
+    feats = []
+    for i in range(num_levels):
+        if i > 0:
+            x = F.max_pool3d(x, 2)
+        x = dc(x, f"encoders.{i}", first=(i == 0))
+        feats.insert(0, x)
+    feats = feats[1:]
+    for i, enc in enumerate(feats):
+        x = F.interpolate(x, size=enc.shape[2:], mode="nearest")
+        x = dc(torch.cat((enc, x), dim=1), f"decoders.{i}")
+    return F.conv3d(x, p["final_conv.weight"], p["final_conv.bias"])
+
+
+def loss_and_grads_bf16_storage(p, x, target, num_levels=4, num_groups=8):
+    ps = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    logits = unet3d_forward_bf16_storage(ps, x, num_levels, num_groups)
+    loss = bce_dice_loss(logits, target)
+    loss.backward()
+    return loss.detach(), logits.detach(), {k: v.grad.detach() for k, v in ps.items()}
+
+
 def _res_block(x, p, pre, num_groups=8):
     """ResNetBlock with order 'gcr' (buildingblocks.py:255-325): optional 1x1x1 conv, SingleConv 'gcr', SingleConv 'gc', += residual, ReLU"""
     r = F.conv3d(x, p[f"{pre}.conv1.weight"], p[f"{pre}.conv1.bias"]) if f"{pre}.conv1.weight" in p else x

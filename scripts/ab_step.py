@@ -1,4 +1,4 @@
-"""In-process A/B of the whole 2-D train step (bs 32, 512^2, bf16) under dispatcher switches that are read per call (cdna_hip_programming.md §5.4 rule 24: boxes differ by
+"""In-process A/B of the whole 2-D train step (bs 32, 512^2, bf16) under dispatcher switches (set through mis_dispatch_override) (cdna_hip_programming.md §5.4 rule 24: boxes differ by
 several per cent, so arms are interleaved in ONE process):   python scripts/ab_step.py MIS_CONV_NOPPC=1 [NAME=VALUE ...]     (arm 0 = no switch)"""
 import os
 import sys
@@ -7,6 +7,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mdeical_image_segmentation_amd import ops  # noqa: E402
 from mdeical_image_segmentation_amd.engine2d import UNet2DEngine  # noqa: E402
 
 arms = [("default", {})] + [(a, dict([a.split("=")])) for a in sys.argv[1:]]
@@ -19,7 +20,8 @@ for _ in range(3):
 best = {n: 1e9 for n, _ in arms}
 for r in range(4):
     for name, env in arms:
-        os.environ.update(env)
+        for k, v in env.items():
+            ops.dispatch_override(k, int(v))
         eng.train_step(x, y)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -28,6 +30,6 @@ for r in range(4):
         torch.cuda.synchronize()
         best[name] = min(best[name], (time.perf_counter() - t0) / 8 * 1e3)
         for k in env:
-            del os.environ[k]
+            ops.dispatch_override(k, -1)
 for name, _ in arms:
     print(f"{name:28s} {best[name]:7.3f} ms/step  {32e3 / best[name]:7.1f} img/s")

@@ -1,5 +1,5 @@
 """A/B of mis_conv_igemm configurations on the 3x3 layer shapes of the 2-D benchmark net (bs 32, 512^2, bf16, random data), interleaved rounds in ONE
-process (cdna_hip_programming.md §5.4 rule 24).  Arms are environment switches read per call by the dispatcher.
+process (cdna_hip_programming.md §5.4 rule 24).  Arms are dispatcher switches set through mis_dispatch_override.
 
     python scripts/bench_conv_layers.py                       # column-segment kernel vs conv_pp_kernel (MIS_CONV_NOPPC=1) vs the round-1 kernels (MIS_CONV_NOPP=1)
     python scripts/bench_conv_layers.py MIS_CONV_PP_NO256=1   # extra arm(s): NAME=VALUE"""
@@ -37,7 +37,7 @@ for H, Cin, Cout, mult in LAYERS:
     for r in range(ROUNDS):
         for name, env in arms:
             for k, v in env.items():
-                os.environ[k] = v
+                ops.dispatch_override(k, int(v))
             ops.conv_igemm(x, w, y, ksize=3, Cin=Cin, Cout=Cout, bias=b, relu=True)       # warm
             cfgs[name] = ops.conv_last_dispatch()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -48,7 +48,7 @@ for H, Cin, Cout, mult in LAYERS:
             torch.cuda.synchronize()
             best[name] = min(best[name], e0.elapsed_time(e1) / REP)
             for k in env:
-                del os.environ[k]
+                ops.dispatch_override(k, -1)
     for name, _ in arms:
         tot[name] += best[name] * mult
     print(f"{H:4d}^2 {Cin:5d}->{Cout:<5d} x{mult}      " + " ".join(f"{best[n]:7.3f}ms {flops / best[n] / 1e9:6.0f}TF {cfgs[n][6:]:>6s}" for n, _ in arms), flush=True)

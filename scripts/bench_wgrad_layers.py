@@ -1,5 +1,5 @@
 """A/B of mis_wgrad configurations on the 3x3 layer shapes of the 2-D benchmark net (bs 32, 512^2, bf16, random data), interleaved rounds in ONE process.
-    python scripts/bench_wgrad_layers.py [NAME=VALUE ...]      # arms: default (ping-pong), MIS_WGRAD_NOPP=1, plus the given environment switches"""
+    python scripts/bench_wgrad_layers.py [NAME=VALUE ...]      # arms: default (ping-pong), MIS_WGRAD_NOPP=1, plus the given dispatcher switches"""
 import os
 import sys
 
@@ -32,7 +32,7 @@ for H, Cin, Cout, mult in LAYERS:
     for r in range(ROUNDS):
         for name, env in arms:
             for k, v in env.items():
-                os.environ[k] = v
+                ops.dispatch_override(k, int(v))
             ops.wgrad(x, dy, dw, ksize=3, Cin=Cin, Cout=Cout, dbias=db)
             cfgs[name] = "%s/%d" % ops.wgrad_last_dispatch()
             torch.cuda.synchronize()
@@ -44,7 +44,7 @@ for H, Cin, Cout, mult in LAYERS:
             torch.cuda.synchronize()
             best[name] = min(best[name], e0.elapsed_time(e1) / REP)
             for k in env:
-                del os.environ[k]
+                ops.dispatch_override(k, -1)
     for name, _ in arms:
         tot[name] += best[name] * mult
     print(f"{H:4d}^2 {Cin:5d}->{Cout:<5d} x{mult}      " + " ".join(f"{best[n]:7.3f}ms {flops / best[n] / 1e9:6.0f}TF {cfgs[n][3:]:>10s}" for n, _ in arms), flush=True)

@@ -22,3 +22,15 @@ def golden_dir():
 def load_golden(name):
     import numpy as np
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.fixture
+def switches():
+    """set kernel-selection switches of libmisamd for one test (mis_dispatch_override, include/misamd.h); everything is reset afterwards"""
+    from mdeical_image_segmentation_amd import ops
+
+    def set_(name, value=1):
+        ops.dispatch_override(name, value)
+
+    yield set_
+    ops.dispatch_override(None, 0)

@@ -1,7 +1,8 @@
 """Per-DISPATCH-BRANCH parity of the two MFMA kernels that carry the train step: every instantiation that
 `mis_conv_igemm` / `mis_wgrad` can select is driven by at least one case here, on ragged grids, with the epilogue / operand variants
 the engines use (bias, ReLU, ReLU mask, two destinations + pixel-unshuffle, pixel-shuffle, output channel slice), and the test ASSERTS
-which configuration ran (`mis_conv_last_dispatch`, `mis_wgrad_last_dispatch`) so a case cannot silently drift to another branch.
+which configuration ran (`mis_conv_last_dispatch`, `mis_wgrad_last_dispatch`) so a case cannot silently drift to another branch.  Non-default configurations are reached through the library's override entry point
+(`mis_dispatch_override`, the `switches` fixture), not through the environment.
 
 Reference arithmetic: reference model/unet2d/layers.py:122-126 (Conv2d k3 p1 + ReLU), :165 (ConvTranspose2d k2 s2) = ATen conv on the
 bf16-rounded (or fp32) operands with fp32 accumulation; tolerances = test_gpu_kernels.tol()."""
@@ -69,11 +70,11 @@ def _conv_ref(x, w, b, dtype):
 
 
 @pytest.mark.parametrize("case", K3_CASES, ids=lambda c: f"{'bf16' if c[0] == BF else 'f32'}-{c[1]}x{c[2]}x{c[3]}-{c[4]}to{c[5]}-{c[6]}")
-def test_conv3x3_every_branch(case, monkeypatch):
+def test_conv3x3_every_branch(case, switches):
     ops = _ops()
     dtype, N, H, W, Cin, Cout, want_cfg, env = case
     if env:
-        monkeypatch.setenv(*(env.split("=") if "=" in env else (env, "1")))
+        switches(*((env.split("=")[0], int(env.split("=")[1])) if "=" in env else (env, 1)))
     x = rnd(N, Cin, H, W, seed=110)
     w = rnd(Cout, Cin, 3, 3, seed=111, scale=(9 * Cin) ** -0.5)
     b = rnd(Cout, seed=112)
@@ -150,7 +151,7 @@ def test_gemm1x1_every_branch(case):
 
 
 WG_CASES = [
-    # (dtype, ksize, N, H, W, Cin, Cout, expected configuration, environment switch)
+    # (dtype, ksize, N, H, W, Cin, Cout, expected configuration, dispatch switch)
     (BF, 3, 2, 20, 36, 64, 64, "k3.2d.pps", ""),        # 64-column tiles: pixel-split wide wave tiles, ragged tiles, two slabs per block
     (BF, 3, 2, 20, 36, 64, 64, "k3.2d.pp", "MIS_WGRAD_PP_NOWIDE"),
     (BF, 3, 1, 9, 17, 256, 256, "k3.2d.ppw", ""),        # a single (ragged) pixel tile per block
@@ -174,11 +175,11 @@ WG_CASES = [
 
 
 @pytest.mark.parametrize("case", WG_CASES, ids=lambda c: f"{'bf16' if c[0] == BF else 'f32'}-k{c[1]}-{c[2]}x{c[3]}x{c[4]}-{c[5]}to{c[6]}-{c[8]}")
-def test_wgrad_every_branch(case, monkeypatch):
+def test_wgrad_every_branch(case, switches):
     ops = _ops()
     dtype, ks, N, H, W, Cin, Cout, want_cfg, env = case
     if env:
-        monkeypatch.setenv(env, "1")
+        switches(env, 1)
     x = rnd(N, Cin, H, W, seed=130)
     dy = rnd(N, Cout, H, W, seed=131)
     wq = torch.zeros(Cout, Cin, ks, ks, requires_grad=True)
@@ -209,3 +210,129 @@ def test_wgrad_every_branch(case, monkeypatch):
     ops.wgrad(to_nhwc(x, dtype), to_nhwc(dy, dtype), dw, ksize=ks, Cin=Cin, Cout=Cout, dw_layout=0 if ks == 3 else 1, alpha=0.5)
     want2 = wq.grad if ks == 3 else wq.grad.view(2, 2, Cout // 4, Cin).permute(3, 2, 0, 1)
     assert_close(dw, 0.5 * want2, "alpha", rtol=1e-4, atol=1e-4 * k ** 0.5)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 3-D: nn.Conv3d(k3, p1, bias=False) behind GroupNorm (reference model/unet3d/buildingblocks.py:64-66,87-92), the decoder's concat + nearest upsample
+# (:546-548, :671-673) as two-source addressing.  Two families:
+#   * the ping-pong kernels (conv3d_pp.hip `k3.3d.ppc*`, wgrad_pp.hip `k3.3d.ppw / pps`): bf16, plain single-source operand (the engines hand over the normalised
+#     tensor written by mis_gn_apply) - every instantiation (20- / 32-row tiles x 128- / 64-column blocks) on the channel plans of UNet3D's layers, ragged grids,
+#     several tiles per persistent block, ragged depth groups;
+#   * the lock-step kernels (`k3.3d.bn*`, `k3.3d.tr`, `k3.3d`): fp32 always, bf16 when the operand carries the GroupNorm fold / a second source.
+# (dtype, (N, D, H, W), Cin or (C0, C1) for [encoder | nearest-upsampled] sources + GroupNorm fold, Cout, conv configuration, wgrad configuration, switches)
+K3D_CASES = [
+    (BF, (1, 5, 20, 20), 64, 64, "k3.3d.ppc5n2", "k3.3d.pps", {}),                       # 20-row tiles fit; W ragged (16 + 4); depth groups 4 + 1
+    (BF, (2, 3, 22, 36), 192, 64, "k3.3d.ppc8n2", "k3.3d.pps", {}),                      # dec2.conv1's plan: 6 K chunks x 3 slices; 32-row tiles, ragged both ways
+    (BF, (1, 4, 22, 36), 192, 64, "k3.3d.ppc5n2", "k3.3d.pps", {"MIS_CONV3D_PF": 5}),    # the same plan on ragged 20-row tiles
+    (BF, (1, 6, 20, 24), 384, 128, "k3.3d.ppc5", "k3.3d.ppw", {}),                       # dec1.conv1
+    (BF, (1, 3, 10, 18), 768, 256, "k3.3d.ppc5", "k3.3d.ppw", {}),                       # dec0.conv1: 24 K chunks, two column tiles (spatial-major order)
+    (BF, (1, 3, 10, 18), 768, 256, "k3.3d.ppc8", "k3.3d.ppw", {"MIS_CONV3D_PF": 8}),
+    (BF, (1, 2, 9, 17), 256, 512, "k3.3d.ppc8", "k3.3d.ppw", {"MIS_CONV3D_PF": 8, "MIS_CONV3D_ZG": 1}),      # enc3.conv2: four column tiles, no depth grouping
+    (BF, (1, 3, 12, 20), 128, 384, "k3.3d.ppc5", "k3.3d.ppw", {}),                       # dgrad of dec1.conv1: three column tiles -> column-tile-major order
+    (BF, (1, 3, 12, 20), 64, 192, "k3.3d.ppc5n2", "k3.3d.pps", {}),                      # dgrad of dec2.conv1: three 64-column tiles
+    (BF, (2, 24, 40, 48), 64, 64, "k3.3d.ppc5n2", "k3.3d.pps", {}),                      # 288 tiles > 256 persistent blocks: the tile loop is taken, planes cross the sample boundary
+    (BF, (1, 40, 64, 48), 64, 128, "k3.3d.ppc8", "k3.3d.ppw", {}),                       # 240 tiles... 32-row tiles exact; interior tiles; depth groups of 4
+    (BF, (1, 1, 20, 16), 64, 64, "k3.3d.ppc5n2", "k3.3d.pps", {}),                       # exactly one tile, one plane: both neighbour planes are padding
+    (BF, (1, 7, 20, 16), 64, 128, "k3.3d.ppc5", "k3.3d.ppw", {"MIS_CONV3D_COLMAJOR": 1, "MIS_CONV3D_ZG": 3}),
+    # the kernels behind them
+    (BF, (1, 5, 20, 20), 64, 64, "k3.3d.bn64", "k3.3d.tr", {"MIS_CONV3D_NOPP": 1, "MIS_WGRAD3D_NOPP": 1}),
+    (BF, (1, 6, 20, 24), 384, 128, "k3.3d.bn128", "k3.3d.tr", {"MIS_CONV3D_NOPP": 1, "MIS_WGRAD3D_NOPP": 1}),
+    # operand with the GroupNorm fold and two sources: the lock-step kernels in both precisions
+    (BF, (2, 4, 12, 20), (64, 128), 64, "k3.3d.bn64", "k3.3d.tr", {}),
+    (BF, (1, 4, 12, 20), (128, 256), 128, "k3.3d.bn128", "k3.3d.tr", {}),
+    (BF, (1, 2, 6, 10), (256, 512), 256, "k3.3d.bn128", "k3.3d.tr", {}),
+    (F32, (2, 4, 12, 20), (64, 128), 64, "k3.3d.bn64", "k3.3d", {}),
+    (F32, (1, 4, 12, 20), (128, 256), 128, "k3.3d.bn128", "k3.3d", {}),
+    (F32, (1, 2, 6, 10), (256, 512), 256, "k3.3d.bn128", "k3.3d", {}),
+    (F32, (1, 2, 9, 17), 256, 512, "k3.3d.bn128", "k3.3d", {}),
+    (F32, (1, 5, 20, 20), 64, 64, "k3.3d.bn64", "k3.3d", {}),
+]
+
+
+def _id3(c):
+    cin = f"{c[2][0]}+{c[2][1]}" if isinstance(c[2], tuple) else str(c[2])
+    return f"{'bf16' if c[0] == BF else 'f32'}-{'x'.join(map(str, c[1]))}-{cin}to{c[3]}-{c[4]}" + "".join(f"-{k[4:]}{v}" for k, v in c[6].items())
+
+
+@pytest.mark.parametrize("case", K3D_CASES, ids=_id3)
+def test_conv3d_every_branch(case, switches):
+    ops = _ops()
+    dtype, (N, D, H, W), cin, Cout, want_conv, want_wg, sw = case
+    for k, v in sw.items():
+        switches(k, v)
+    two = isinstance(cin, tuple)
+    Cin = sum(cin) if two else cin
+    w = rnd(Cout, Cin, 3, 3, 3, seed=141, scale=(27 * Cin) ** -0.5)
+    wf = torch.empty(27, Cout, Cin, dtype=dtype, device=DEV)
+    ops.pack_conv_weight(w.to(DEV), wf, None)
+    m = rnd(N, Cout, D, H, W, seed=143)
+    dy = rnd(N, Cout, D, H, W, seed=144)
+    if two:
+        C0, C1 = cin
+        x0 = rnd(N, C0, D, H, W, seed=140)
+        x1 = rnd(N, C1, D // 2, H // 2, W // 2, seed=145)
+        scale = 1 + 0.3 * rnd(N, Cin, seed=146)
+        shift = 0.3 * rnd(N, Cin, seed=147)
+        xcat = torch.cat((q(x0, dtype), F.interpolate(q(x1, dtype), size=(D, H, W), mode="nearest")), 1)
+        xop = q(xcat * scale.view(N, Cin, 1, 1, 1) + shift.view(N, Cin, 1, 1, 1), dtype)       # the fold is rounded to the storage type before the MFMA
+        kw = dict(x1=to_nhwc(x1, dtype), in_scale=scale.to(DEV), in_shift=shift.to(DEV))
+        xd = to_nhwc(x0, dtype)
+    else:
+        x = rnd(N, Cin, D, H, W, seed=140)
+        xop = q(x, dtype)
+        kw = {}
+        xd = to_nhwc(x, dtype)
+    wq = q(w, dtype).requires_grad_(True)
+    ref = F.conv3d(xop, wq, None, padding=1)
+    ref.backward(q(dy, dtype))
+    ref = ref.detach()
+    t = tol(dtype, 27 * Cin)
+    grid = (N, D, H, W)
+    # (a) forward form: ReLU, written into a channel slice of a wider buffer
+    ybuf = torch.full((N, D, H, W, Cout + 64), float("nan"), dtype=dtype, device=DEV)
+    ops.conv_igemm(xd, wf, ops.View(ybuf, 64, Cout), ksize=3, Cin=Cin, Cout=Cout, grid=grid, relu=True, **kw)
+    cfg = ops.conv_last_dispatch()
+    assert cfg == want_conv or (cfg.startswith(want_conv) and want_conv.startswith("k3.3d.bn")), f"case meant for {want_conv} ran {cfg}"
+    assert_close(from_nhwc(ybuf[..., 64:].contiguous()), F.relu(ref), f"3-D fwd {cfg}", **t)
+    assert torch.isnan(ybuf[..., :64].float()).all(), "wrote outside the channel slice"
+    # (b) masked form (ReLU backward in the epilogue), plain destination
+    y2 = torch.full((N, D, H, W, Cout), float("nan"), dtype=dtype, device=DEV)
+    ops.conv_igemm(xd, wf, y2, ksize=3, Cin=Cin, Cout=Cout, grid=grid, mask=to_nhwc(m, dtype), **kw)
+    assert ops.conv_last_dispatch() == cfg
+    assert_close(from_nhwc(y2), ref * (q(m, dtype) > 0), f"3-D mask {cfg}", **t)
+    # (c) weight gradient of the same operand
+    dw = torch.full((Cout, Cin, 3, 3, 3), float("nan"), device=DEV)
+    ops.wgrad(xd, to_nhwc(dy, dtype), dw, ksize=3, Cin=Cin, Cout=Cout, grid=grid, **kw)
+    wcfg, nsplit = ops.wgrad_last_dispatch()
+    assert wcfg == want_wg, f"case meant for {want_wg} ran {wcfg}"
+    k = N * D * H * W
+    wt = dict(rtol=1e-4, atol=1e-4 * k ** 0.5) if not (two and dtype == BF) else dict(rtol=1e-4, atol=2e-4 * k ** 0.5)
+    assert_close(dw, wq.grad, f"3-D wgrad {wcfg} nsplit={nsplit}", **wt)
+
+
+@pytest.mark.parametrize("dtype", [BF, F32])
+def test_gn_apply_matches_the_operand_fold(dtype):
+    """mis_gn_apply (the normalised tensor the bf16 engines write once per SingleConv) == what mis_conv_igemm computes when it folds the affine into staging:
+    the two routes through a SingleConv must give BIT-identical outputs"""
+    ops = _ops()
+    N, D, H, W, C0, C1, Cout = 2, 4, 12, 20, 64, 128, 64
+    Cin = C0 + C1
+    x0, x1 = rnd(N, C0, D, H, W, seed=150), rnd(N, C1, D // 2, H // 2, W // 2, seed=151)
+    scale, shift = (1 + 0.3 * rnd(N, Cin, seed=152)).to(DEV), (0.3 * rnd(N, Cin, seed=153)).to(DEV)
+    w = rnd(Cout, Cin, 3, 3, 3, seed=154, scale=(27 * Cin) ** -0.5)
+    wf = torch.empty(27, Cout, Cin, dtype=dtype, device=DEV)
+    ops.pack_conv_weight(w.to(DEV), wf, None)
+    x0d, x1d = to_nhwc(x0, dtype), to_nhwc(x1, dtype)
+    grid = (N, D, H, W)
+    xn = torch.full((N, D, H, W, Cin), float("nan"), dtype=dtype, device=DEV)
+    ops.gn_apply(x0d, C0, False, grid, scale, shift, Cin, 0, xn)
+    ops.gn_apply(x1d, C1, True, grid, scale, shift, Cin, C0, xn)
+    xcat = torch.cat((q(x0, dtype), F.interpolate(q(x1, dtype), size=(D, H, W), mode="nearest")), 1)
+    want = torch.addcmul(shift.cpu().view(N, Cin, 1, 1, 1), xcat, scale.cpu().view(N, Cin, 1, 1, 1))
+    assert_close(from_nhwc(xn), q(want, dtype), "gn_apply", rtol=1e-2 if dtype == BF else 1e-6, atol=1e-2 if dtype == BF else 1e-6)
+    ya = torch.empty(N, D, H, W, Cout, dtype=dtype, device=DEV)
+    yb = torch.empty_like(ya)
+    with ops.dispatch_switches(MIS_CONV3D_NOPP=1):          # same kernel for both routes: only the operand path differs
+        ops.conv_igemm(x0d, wf, ya, ksize=3, Cin=Cin, Cout=Cout, grid=grid, x1=x1d, in_scale=scale, in_shift=shift, relu=True)
+        ops.conv_igemm(xn, wf, yb, ksize=3, Cin=Cin, Cout=Cout, grid=grid, relu=True)
+    assert torch.equal(ya, yb), (ya.float() - yb.float()).abs().max().item()

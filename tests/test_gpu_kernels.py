@@ -222,17 +222,10 @@ def test_conv3x3_wgrad(case, dtype, no_tr):
     wq = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
     F.conv2d(q(x, dtype), wq, None, padding=1).backward(q(dy, dtype))
     dw = torch.full((Cout, Cin, 3, 3), float("nan"), device=DEV)
-    old = os.environ.get("MIS_WGRAD_NO_TR")
-    os.environ["MIS_WGRAD_NO_TR"] = no_tr
-    try:
+    with ops.dispatch_switches(MIS_WGRAD_NO_TR=int(no_tr)):
         dbf = torch.full((Cout,), float("nan"), device=DEV)
         ops.wgrad(to_nhwc(x, dtype), to_nhwc(dy, dtype), dw, ksize=3, Cin=Cin, Cout=Cout, dbias=dbf)
         torch.cuda.synchronize()
-    finally:
-        if old is None:
-            del os.environ["MIS_WGRAD_NO_TR"]
-        else:
-            os.environ["MIS_WGRAD_NO_TR"] = old
     k = N * H * W
     assert_close(dw, wq.grad, f"wgrad {case} {dtype} no_tr={no_tr}", rtol=1e-4, atol=1e-4 * k ** 0.5)
     db = torch.full((Cout,), float("nan"), device=DEV)
