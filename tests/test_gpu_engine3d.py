@@ -38,13 +38,17 @@ def test_fp32_engine3d_matches_reference_golden():
     d = (logits.cpu() - ref).abs().max().item()
     assert d < 1e-4, f"logits max|diff| {d}"
     assert abs(loss.item() - float(g["loss"])) < 1e-4, (loss.item(), float(g["loss"]))
-    # arg-max: bit-exact on EVERY voxel, nothing excused.  The golden's closest call is a 2.4e-5 gap between the two largest logits (two voxels
-    # below 1e-4): the engine's logits must be closer to the reference than half of that for the statement to be forced rather than lucky.
-    top2 = ref.topk(2, dim=1).values
-    gap = (top2[:, 0] - top2[:, 1]).min().item()
-    assert d < 0.5 * gap, (d, gap)
-    assert int(((top2[:, 0] - top2[:, 1]) < 2 * d).sum()) == 0            # no voxel lies within the engine's own error of a tie
-    assert torch.equal(am.cpu().long(), T(g["argmax"]).long())
+    # arg-max (count what is excused).  This golden has near-ties: two of its 4096 voxels have a top-2 logit gap below 1e-4, the smallest 2.4e-5,
+    # while two correct fp32 evaluations of this net differ by ~2e-5 (the engine vs the reference's oneDNN path: measured 1.9e-5).  So: (a) the arg-max kernel is
+    # bit-exact on the engine's OWN logits everywhere (first maximum wins, torch's rule); (b) against the golden it is identical on every voxel whose gap exceeds
+    # twice the measured logit error, (c) at most the golden's 2 known near-tie voxels fall under that threshold, and there the engine picks one of the top two.
+    assert torch.equal(am.cpu().long(), logits.cpu().argmax(1))
+    top2 = ref.topk(2, dim=1)
+    near = (top2.values[:, 0] - top2.values[:, 1]) < 2 * d
+    assert int(near.sum()) <= 2, int(near.sum())
+    assert int((am.cpu().long() != T(g["argmax"]).long())[~near].sum()) == 0
+    assert bool(((am.cpu().long() == top2.indices[:, 0]) | (am.cpu().long() == top2.indices[:, 1])).all())
+    print(f"3-D golden arg-max: logits max|diff| {d:.3g}, voxels within 2x of it of a tie: {int(near.sum())} of {near.numel()}, flips elsewhere 0")
     eng.backward()
     torch.cuda.synchronize()
     gs = np.stack([stat(eng.Gr[n]) for n in names])
@@ -166,9 +170,9 @@ def test_bf16_engine3d_every_layer_replayed():
             e["dx1"] = _rel(r["dx1"], dx1.bfloat16().float())
         for k, v in e.items():
             worst[k] = max(worst.get(k, ("", 0.0)), (name, v), key=lambda kv: kv[1])
-            # relative L2 per tensor.  bf16 outputs: two correct pipelines differ by an occasional 1-ulp flip (2^-8 relative on that element): 3e-3 bounds it with room;
+            # relative L2 per tensor.  bf16 outputs: two correct pipelines differ by an occasional 1-ulp flip (2^-8 relative on that element): 2e-3 bounds it with room;
             # fp32 outputs (dW, dgamma, dbeta): summation order only, but over operands that carry those flips
-            assert v <= (3e-3 if k in ("y", "dxn", "dx0", "dx1") else 2e-3), (name, k, v)
+            assert v <= (2e-3 if k in ("y", "dxn", "dx0", "dx1") else 1e-3), (name, k, v)     # measured worst: y 4.4e-4, dW 1.2e-4, the rest < 1e-4
     print("bf16 3-D layer replay, worst rel-L2 per quantity: " + ", ".join(f"{k} {v[1]:.2e} ({v[0].split('.basic_module.')[0]})" for k, v in worst.items()))
 
 
@@ -197,7 +201,7 @@ def test_bf16_engine3d_close():
     assert worst[1] < BF16_3D_GRAD_BAR, worst
 
 
-BF16_3D_GRAD_BAR = 1.0          # placeholder until measured on the GPU (set from the first run's printout)
+BF16_3D_GRAD_BAR = 0.6          # measured on MI355X (round 3): worst 0.286 (encoders.0 SingleConv2 groupnorm.bias), final_conv.weight 4.3e-3
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
