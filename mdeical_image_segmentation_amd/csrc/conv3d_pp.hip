@@ -10,7 +10,9 @@
 // NDHWC makes the planes of a batch one contiguous sequence of H x W images, so the epilogue of the 2-D kernel serves unchanged with the plane index as its image.
 //
 // Tiles: PF = 5 (20 rows) divides the grids of the 160^3 configuration at every level (160 / 80 / 40 / 20), PF = 8 (32 rows) those of 128^3; the launcher
-// takes whichever wastes fewer rows.  NF = 4: 128-column blocks (Cout % 128 == 0), NF = 2: 64-column blocks (wave tile 16*PF px x 32 ch).
+// takes whichever wastes fewer rows.  NF = 4: 128-column blocks (Cout % 128 == 0), NF = 6: 192-column blocks (wave tile 80 px x 96 ch; the 64 -> 192 dgrad),
+// NF = 2: 64-column blocks (wave tile 16*PF px x 32 ch; PF = 10 = 40-row tiles as well: these layers carry 58 % of the net's FLOPs and are bound by their
+// fragment reads - 0.30 ds_read_b128 per MFMA at PF 10 against 0.33 at PF 8 and 0.43 at PF 5).
 // Plane walk: the tiles of ZG consecutive depth planes are interleaved (plane fastest), so the ~32 tiles an XCD runs at a time cover ZG + 2 input planes for ZG
 // output planes out of its L2 instead of 3 for 1.
 #include <stdlib.h>
@@ -22,7 +24,8 @@ template <int PF, int NF>
 __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
     using T = __bf16;
     constexpr int WAVE_N = NF * 16, BN = 2 * WAVE_N, NV = 4 * NF;
-    constexpr int WWAVES = BN / 16;                                      // waves that carry a weight DMA instruction per tap (16 rows of 64 B each)
+    constexpr int WINSTR = BN / 16;                                      // weight DMA instructions per tap (16 rows of 64 B each): 4 / 8 / 12 for 64 / 128 / 192 columns
+    constexpr int WPW = (WINSTR + 7) / 8;                                // ... per wave (the second round, NF = 6, only reaches waves 0-3)
     constexpr int TH = 4 * PF, TW = 16, HH = TH + 2, HW = 18, HP = HH * HW;
     constexpr int HITEMS = HP * 4, HINSTR = (HITEMS + 63) / 64, HBUF = HINSTR * 1024, ROWB = HW * 64;
     constexpr int HJ = (HINSTR + 7) / 8;             // halo instructions per wave per chunk
@@ -83,14 +86,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
         const int px = li + kw;
         b_off0[kw] = (wm * PF * HW + px) * 64 + ((lg ^ ((px >> 1) & 3)) << 4);
     }
-    int w_goff0;       // this wave's instruction of a tap tile: LDS rows 16*wave .. +15
-    {
-        const int slot = wave * 64 + lane;
+    int w_goff0[WPW];  // this wave's instruction(s) of a tap tile: LDS rows 16*(wave + 8r) .. +15
+#pragma unroll
+    for (int r = 0; r < WPW; ++r) {
+        const int slot = (wave + 8 * r) * 64 + lane;
         const int lrow = slot >> 2, pos = slot & 3;
         const int dc16 = pos ^ ((lrow >> 1) & 3);
         const int dwv = lrow / WAVE_N, j = lrow % WAVE_N;
         const int drow = dwv * WAVE_N + ((j & 15) >> 2) * NV + (j >> 4) * 4 + (j & 3);
-        w_goff0 = (drow * a.Cin + dc16 * 8) * 2;
+        w_goff0[r] = (drow * a.Cin + dc16 * 8) * 2;
     }
     const unsigned img_x = (unsigned)(((long long)a.H * a.W - 1) * a.x0.ld + a.Cin) * 2u;      // bytes of ONE depth plane of the input view
     const size_t plane_b = (size_t)a.H * a.W * a.x0.ld * 2;
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
     };
     const __amdgpu_buffer_rsrc_t rb = pp_make_rsrc(a.bias != nullptr ? (const void*)a.bias : a.w, a.bias != nullptr ? (unsigned)a.Cout * 4u : 0u);
     auto issue_bias = [&](int col, char* dst) {
-        if (wave < BN / 64)
+        if (wave < BN / 64)                           // (BN is a multiple of 64 in every instantiation)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (pp_lds_void_t*)(dst + wave * 256), 4, (col + wave * 64 + lane) * 4, 0, 0, 0);
     };
     // the three tap tiles (kh = 0..2) of depth slice dz, filter column kw, column tile col, channels c0..c0+31: one instruction per tap per wave
@@ -123,9 +127,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
         int soff = (int)((((long long)(dz * 9 + kw) * a.Cout + col) * a.Cin + c0) * 2);
         asm volatile("" : "+s"(soff));
         const int tapstride = 3 * a.Cout * a.Cin * 2;          // tap index = dz*9 + kh*3 + kw
-        if (wave >= WWAVES) return;                    // wave-uniform (NF = 2: the four waves of group 0 carry the whole tile)
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) pp_dma16(rw, soff + kh * tapstride + w_goff0, dst + kh * TAPB + wave * 1024);
+        for (int r = 0; r < WPW; ++r) {
+            if (wave + 8 * r >= WINSTR) return;        // wave-uniform (NF = 2: the four waves of group 0 carry the whole tile; NF = 6: waves 0-3 carry a second round)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) pp_dma16(rw, soff + kh * tapstride + w_goff0[r], dst + kh * TAPB + (wave + 8 * r) * 1024);
+        }
     };
 
     int pl, z, h0, w0, ncol0;
@@ -307,13 +314,25 @@ template <int PF, int NF> static int pp3_launch(const MisConvDesc* d, hipStream_
 }
 
 int launch_conv3d_pp(const MisConvDesc* d, hipStream_t stream, const char** tag) {
-    // rows per tile: 20 (PF 5) or 32 (PF 8), whichever pads the H axis less (ties: the taller tile - fewer fragment reads per MFMA); MIS_CONV3D_PF forces one
+    // column blocks: 128 (Cout % 128 == 0), 192 (Cout % 192 == 0: the 64 -> 192 dgrad of decoders.2 in ONE column tile instead of three 64-column ones), else 64.
+    // rows per tile: 20 (PF 5), 32 (PF 8) or - 64-column blocks only, the others have no registers for it - 40 (PF 10): whichever pads the H axis least, ties to the
+    // taller tile (fewer fragment reads and barriers per MFMA); MIS_CONV3D_PF forces one.
+    const int nf = d->Cout % 128 == 0 ? 4 : ((d->Cout % 192 == 0 && d->Cout0 % 192 == 0) ? 6 : 2);
     int pf = mis_sw(SW_CONV3D_PF);
-    if (pf != 5 && pf != 8) {
-        const int pad5 = (d->H + 19) / 20 * 20, pad8 = (d->H + 31) / 32 * 32;
-        pf = pad5 < pad8 ? 5 : 8;
+    if (!(pf == 5 || (pf == 8 && nf != 6) || (pf == 10 && nf == 2))) {
+        const int cand[3] = {5, 8, 10};
+        int best = 1 << 30;
+        pf = 5;
+        for (int i = 0; i < 3; ++i) {
+            if ((cand[i] == 10 && nf != 2) || (cand[i] == 8 && nf == 6)) continue;
+            const int th = 4 * cand[i], pad = (d->H + th - 1) / th * th;
+            if (pad <= best) {
+                best = pad;
+                pf = cand[i];
+            }
+        }
     }
-    if (d->Cout % 128 == 0) {
+    if (nf == 4) {
         if (pf == 5) {
             *tag = "k3.3d.ppc5";
             return pp3_launch<5, 4>(d, stream);
@@ -321,10 +340,18 @@ int launch_conv3d_pp(const MisConvDesc* d, hipStream_t stream, const char** tag)
         *tag = "k3.3d.ppc8";
         return pp3_launch<8, 4>(d, stream);
     }
+    if (nf == 6) {
+        *tag = "k3.3d.ppc5n6";
+        return pp3_launch<5, 6>(d, stream);
+    }
     if (pf == 5) {
         *tag = "k3.3d.ppc5n2";
         return pp3_launch<5, 2>(d, stream);
     }
-    *tag = "k3.3d.ppc8n2";
-    return pp3_launch<8, 2>(d, stream);
+    if (pf == 8) {
+        *tag = "k3.3d.ppc8n2";
+        return pp3_launch<8, 2>(d, stream);
+    }
+    *tag = "k3.3d.ppc10n2";
+    return pp3_launch<10, 2>(d, stream);
 }

@@ -147,6 +147,9 @@ class UNet3DEngine:
                         s.wf = torch.empty(27, co, s.cin_pad, dtype=dtype, device=self.device)
                         s.wd = torch.empty(27, s.cin_pad, co, dtype=dtype, device=self.device)
                         s.wpad = torch.zeros(co, s.cin_pad, 3, 3, 3, device=self.device) if s.cin_pad != ci else None
+                        # forward operand over the REAL input channels where the ping-pong kernel's 32-channel K chunks allow it (encoders.0 SingleConv2: 32 of 64):
+                        # half the MFMA work of that launch; the dgrad / weight-gradient operands stay padded (64-column / 64-channel tiles)
+                        s.wf_real = torch.empty(27, co, ci, dtype=dtype, device=self.device) if (self.materialize and s.cin_pad != ci and ci % 32 == 0) else None
                         s.dwpad = torch.zeros(co, s.cin_pad, 3, 3, 3, device=self.device) if s.cin_pad != ci else None
                     self.sc[s.name] = s
         self.partials = torch.zeros(ops.sumsq_npartials(self.flat.total), dtype=torch.float32, device=self.device)
@@ -176,6 +179,8 @@ class UNet3DEngine:
                 s.wpad[:, :s.cin] = w
                 w = s.wpad
             ops.pack_conv_weight(w, s.wf, s.wd)
+            if getattr(s, "wf_real", None) is not None:
+                ops.pack_conv_weight(self.P[s.name + ".conv.weight"], s.wf_real, None)
         for t in self.ct:       # W [Cin][Cout][27] -> [27*Cout][Cin] (row k*Cout + co), then the two packed GEMM operands
             t.w2d.view(27, t.cout, t.cin).copy_(self.P[t.name].view(t.cin, t.cout, 27).permute(2, 1, 0))
             ops.pack_conv_weight(t.w2d, t.wf, t.wd)
@@ -272,7 +277,10 @@ class UNet3DEngine:
             else:
                 ops.gn_apply(View(src0, 0, c0), c0, False, grid, s.scale, s.shift, s.cin_pad, 0, s.xn)
                 ops.gn_apply(View(src1, 0, c1), c1, src1.shape[1] != src0.shape[1], grid, s.scale, s.shift, s.cin_pad, c0, s.xn)
-            ops.conv_igemm(s.xn, s.wf, y, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid, relu=getattr(s, "relu", True))
+            if getattr(s, "wf_real", None) is not None:
+                ops.conv_igemm(View(s.xn, 0, s.cin), s.wf_real, y, ksize=3, Cin=s.cin, Cout=s.cout, grid=grid, relu=getattr(s, "relu", True))
+            else:
+                ops.conv_igemm(s.xn, s.wf, y, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid, relu=getattr(s, "relu", True))
             return
         ops.conv_igemm(View(src0, 0, src0.shape[-1] if src1 is None else c0), s.wf, y, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid,
                        x1=None if src1 is None else View(src1, 0, c1), relu=getattr(s, "relu", True), in_scale=s.scale, in_shift=s.shift)

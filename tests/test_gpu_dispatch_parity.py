@@ -229,8 +229,11 @@ K3D_CASES = [
     (BF, (1, 3, 10, 18), 768, 256, "k3.3d.ppc8", "k3.3d.ppw", {"MIS_CONV3D_PF": 8}),
     (BF, (1, 2, 9, 17), 256, 512, "k3.3d.ppc8", "k3.3d.ppw", {"MIS_CONV3D_PF": 8, "MIS_CONV3D_ZG": 1}),      # enc3.conv2: four column tiles, no depth grouping
     (BF, (1, 3, 12, 20), 128, 384, "k3.3d.ppc5", "k3.3d.ppw", {}),                       # dgrad of dec1.conv1: three column tiles -> column-tile-major order
-    (BF, (1, 3, 12, 20), 64, 192, "k3.3d.ppc5n2", "k3.3d.pps", {}),                      # dgrad of dec2.conv1: three 64-column tiles
-    (BF, (2, 24, 40, 48), 64, 64, "k3.3d.ppc5n2", "k3.3d.pps", {}),                      # 288 tiles > 256 persistent blocks: the tile loop is taken, planes cross the sample boundary
+    (BF, (1, 3, 12, 20), 64, 192, "k3.3d.ppc5n6", "k3.3d.pps", {}),                      # dgrad of dec2.conv1: ONE 192-column tile (wave tile 80 px x 96 ch)
+    (BF, (2, 5, 40, 36), 128, 192, "k3.3d.ppc5n6", "k3.3d.pps", {}),                     # 192-column blocks, 4 K chunks, 60 tiles, ragged width
+    (BF, (2, 24, 40, 48), 64, 64, "k3.3d.ppc10n2", "k3.3d.pps", {}),                     # 40-row tiles (64-column blocks only); planes cross the sample boundary
+    (BF, (1, 3, 22, 36), 64, 64, "k3.3d.ppc10n2", "k3.3d.pps", {"MIS_CONV3D_PF": 10}),   # ... on a ragged grid
+    (BF, (3, 30, 40, 48), 64, 64, "k3.3d.ppc5n2", "k3.3d.pps", {"MIS_CONV3D_PF": 5}),    # 540 tiles > 256 persistent blocks: the tile loop is taken
     (BF, (1, 40, 64, 48), 64, 128, "k3.3d.ppc8", "k3.3d.ppw", {}),                       # 240 tiles... 32-row tiles exact; interior tiles; depth groups of 4
     (BF, (1, 1, 20, 16), 64, 64, "k3.3d.ppc5n2", "k3.3d.pps", {}),                       # exactly one tile, one plane: both neighbour planes are padding
     (BF, (1, 7, 20, 16), 64, 128, "k3.3d.ppc5", "k3.3d.ppw", {"MIS_CONV3D_COLMAJOR": 1, "MIS_CONV3D_ZG": 3}),
@@ -336,3 +339,22 @@ def test_gn_apply_matches_the_operand_fold(dtype):
         ops.conv_igemm(x0d, wf, ya, ksize=3, Cin=Cin, Cout=Cout, grid=grid, x1=x1d, in_scale=scale, in_shift=shift, relu=True)
         ops.conv_igemm(xn, wf, yb, ksize=3, Cin=Cin, Cout=Cout, grid=grid, relu=True)
     assert torch.equal(ya, yb), (ya.float() - yb.float()).abs().max().item()
+
+
+@pytest.mark.parametrize("grid", [(1, 5, 20, 20), (2, 3, 40, 24)])
+def test_conv3d_pp_32_channel_slice(grid):
+    """encoders.0 SingleConv2 of the bf16 engine: 32 REAL input channels read out of a 64-channel buffer (one 32-channel K chunk per depth slice) - the padding
+    channels carry NaN here: the kernel must not touch them"""
+    ops = _ops()
+    N, D, H, W = grid
+    Cin, Cout = 32, 64
+    x = rnd(N, Cin, D, H, W, seed=160)
+    w = rnd(Cout, Cin, 3, 3, 3, seed=161, scale=(27 * Cin) ** -0.5)
+    wf = torch.empty(27, Cout, Cin, dtype=BF, device=DEV)
+    ops.pack_conv_weight(w.to(DEV), wf, None)
+    buf = torch.full((N, D, H, W, 64), float("nan"), dtype=BF, device=DEV)
+    buf[..., :Cin] = to_nhwc(x, BF)
+    y = torch.full((N, D, H, W, Cout), float("nan"), dtype=BF, device=DEV)
+    ops.conv_igemm(ops.View(buf, 0, Cin), wf, y, ksize=3, Cin=Cin, Cout=Cout, grid=grid, relu=True)
+    assert ops.conv_last_dispatch().startswith("k3.3d.ppc")
+    assert_close(from_nhwc(y), F.relu(F.conv3d(q(x, BF), q(w, BF), None, padding=1)), "3-D conv, 32-channel slice", **tol(BF, 27 * Cin))
