@@ -164,6 +164,11 @@ typedef struct MisHeadDesc {
     float* dw; float* db;
     float grad_scale;        /* dL/dloss */
     float alpha, beta;       /* BCEDice weights */
+    int phase;               /* loss 2 with backward: 0 = everything in one call; 1 = the forward part only (logits, arg-max, loss_out incl. the per-class sums);
+                                2 = the gradient part only, from loss_out[1 .. 1 + 3*C] AS THE CALLER LEFT THEM - between the two the caller may sum I_c, P_c, T_c
+                                over the ranks of a data-parallel job (36 bytes for C = 3), which makes the Dice term that of the GLOBAL batch, as the reference
+                                computes it on the gathered batch (model/unet3d/trainer.py:312-318).  In phase 2 pass beta x world_size when grad_scale carries
+                                1 / world_size: the Dice gradient from global sums is already the global derivative. */
 } MisHeadDesc;
 size_t mis_head_workspace_bytes(const MisHeadDesc* d);
 int mis_head_loss(const MisHeadDesc* d, void* stream);

@@ -80,7 +80,7 @@ class HeadDesc(C.Structure):
         ("loss_out", C.c_void_p),
         ("dy", C.c_void_p), ("dy_ld", C.c_int),
         ("dw", C.c_void_p), ("db", C.c_void_p),
-        ("grad_scale", C.c_float), ("alpha", C.c_float), ("beta", C.c_float),
+        ("grad_scale", C.c_float), ("alpha", C.c_float), ("beta", C.c_float), ("phase", C.c_int),
     ]
 
 

@@ -804,10 +804,12 @@ extern "C" int mis_conv_igemm(const MisConvDesc* d, void* stream) {
     MIS_REQUIRE(d->ksize == 3 || d->ksize == 1, MIS_EUNSUPPORTED, "conv_igemm: ksize %d", d->ksize);
     MIS_REQUIRE(d->N > 0 && d->D > 0 && d->H > 0 && d->W > 0, MIS_EINVAL, "conv_igemm: empty grid");
     MIS_REQUIRE(d->is3d || d->D == 1, MIS_EINVAL, "conv_igemm: D must be 1 for a 2-D op");
-    MIS_REQUIRE(d->Cin > 0 && d->Cin % CK == 0, MIS_EUNSUPPORTED, "conv_igemm: Cin %d must be a multiple of %d", d->Cin, CK);
+    // (the 3-D ping-pong kernel walks 32-channel K chunks in bf16: encoders.0 SingleConv2 of UNet3D reads its 32 real input channels out of a 64-channel buffer)
+    const bool pp3 = d->dtype == MIS_BF16 && d->is3d && d->ksize == 3 && !mis_sw(SW_CONV3D_NOPP) && conv3d_pp_eligible(d);
+    MIS_REQUIRE(d->Cin > 0 && (d->Cin % CK == 0 || (pp3 && d->Cin % 32 == 0)), MIS_EUNSUPPORTED, "conv_igemm: Cin %d must be a multiple of %d", d->Cin, CK);
     MIS_REQUIRE(d->Cout > 0 && d->Cout % 64 == 0, MIS_EUNSUPPORTED, "conv_igemm: Cout %d must be a multiple of 64", d->Cout);
     MIS_REQUIRE(d->x0 != nullptr && d->w != nullptr && d->y0 != nullptr, MIS_EINVAL, "conv_igemm: null pointer");
-    MIS_REQUIRE(d->Cin0 > 0 && d->Cin0 <= d->Cin && d->Cin0 % CK == 0, MIS_EINVAL, "conv_igemm: Cin0 %d", d->Cin0);
+    MIS_REQUIRE(d->Cin0 > 0 && d->Cin0 <= d->Cin && (d->Cin0 % CK == 0 || (pp3 && d->Cin0 == d->Cin)), MIS_EINVAL, "conv_igemm: Cin0 %d", d->Cin0);
     MIS_REQUIRE(d->Cin0 == d->Cin || d->x1 != nullptr, MIS_EINVAL, "conv_igemm: x1 missing");
     MIS_REQUIRE(d->Cout0 > 0 && d->Cout0 <= d->Cout && d->Cout0 % 64 == 0, MIS_EINVAL, "conv_igemm: Cout0 %d", d->Cout0);
     MIS_REQUIRE(d->Cout0 == d->Cout || d->y1 != nullptr, MIS_EINVAL, "conv_igemm: y1 missing");

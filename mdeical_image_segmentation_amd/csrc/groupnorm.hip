@@ -77,34 +77,56 @@ extern "C" int mis_gn_fwd_finalize(const float* sum0, const float* sq0, int C0, 
 // operands arrive by LDS-DMA, see a plain single-source tensor.  One 16-byte chunk per thread; the 8 readers of a coarse voxel hit L2.
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int x_ld, int Cs, int up, int N, int D, int H, int W,
-                                                       const float* __restrict__ scale, const float* __restrict__ shift, int Ctot, int c_off,
-                                                       T* __restrict__ y, int y_ld) {
-    constexpr int EPC = Tr<T>::EPC;
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int x_ld, int Cs, int up, int D, int H, int W, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int Ctot, int c_off, T* __restrict__ y, int y_ld) {
+    // a thread keeps ONE 16-byte channel chunk (its scale / shift stay in registers) and walks voxels; blockIdx.y = sample; 32-bit index arithmetic
+    // (a sample has fewer than 2^31 voxels), four voxels in flight per thread
+    constexpr int EPC = Tr<T>::EPC, UN = 4;
     const int nch = Cs / EPC;
-    const long long np = (long long)D * H * W;
-    const long long total = (long long)N * np * nch;
+    const int vpb = 256 / nch;                              // voxels per block and pass (nch <= 256)
+    const int tid = threadIdx.x;
+    const int ch = tid % nch, vl = tid / nch;
+    if (vl >= vpb) return;
+    const int n = blockIdx.y;
+    const unsigned np = (unsigned)D * H * W;
     const int sH = up ? H / 2 : H, sW = up ? W / 2 : W;
-    const long long snp = (long long)(up ? D / 2 : D) * sH * sW;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int ch = (int)(i % nch);
-        const long long pp = i / nch;
-        const int n = (int)(pp / np);
-        const long long v = pp - (long long)n * np;
-        long long sv = v;
-        if (up) {
-            const int xx = (int)(v % W);
-            const long long t = v / W;
-            const int yy = (int)(t % H), zz = (int)(t / H);
-            sv = ((long long)(zz >> 1) * sH + (yy >> 1)) * sW + (xx >> 1);
-        }
-        float f[EPC];
-        unpack_chunk<T>(*reinterpret_cast<const u32x4*>(x + ((size_t)n * snp + sv) * x_ld + (size_t)ch * EPC), f);
-        const float* sc = scale + (size_t)n * Ctot + c_off + ch * EPC;
-        const float* sh = shift + (size_t)n * Ctot + c_off + ch * EPC;
+    const size_t snp = (size_t)(up ? D / 2 : D) * sH * sW;
+    float sc[EPC], sh[EPC];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
-        *reinterpret_cast<u32x4*>(y + ((size_t)n * np + v) * y_ld + c_off + (size_t)ch * EPC) = pack_chunk<T>(f);
+    for (int e = 0; e < EPC; ++e) {
+        sc[e] = scale[(size_t)n * Ctot + c_off + ch * EPC + e];
+        sh[e] = shift[(size_t)n * Ctot + c_off + ch * EPC + e];
+    }
+    const T* xb = x + (size_t)n * snp * x_ld + (size_t)ch * EPC;
+    T* yb = y + (size_t)n * np * y_ld + c_off + (size_t)ch * EPC;
+    const unsigned stride = gridDim.x * (unsigned)vpb;
+    for (unsigned v0 = blockIdx.x * (unsigned)vpb + vl; v0 < np; v0 += UN * stride) {
+        u32x4 raw[UN];
+#pragma unroll
+        for (int k = 0; k < UN; ++k) {
+            const unsigned v = v0 + k * stride;
+            raw[k] = u32x4{0u, 0u, 0u, 0u};
+            if (v < np) {
+                unsigned sv = v;
+                if (up) {
+                    const unsigned xx = v % (unsigned)W, t = v / (unsigned)W;
+                    const unsigned yy = t % (unsigned)H, zz = t / (unsigned)H;
+                    sv = ((zz >> 1) * (unsigned)sH + (yy >> 1)) * (unsigned)sW + (xx >> 1);
+                }
+                raw[k] = *reinterpret_cast<const u32x4*>(xb + (size_t)sv * x_ld);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < UN; ++k) {
+            const unsigned v = v0 + k * stride;
+            if (v < np) {
+                float f[EPC];
+                unpack_chunk<T>(raw[k], f);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
+                *reinterpret_cast<u32x4*>(yb + (size_t)v * y_ld) = pack_chunk<T>(f);
+            }
+        }
     }
 }
 
@@ -118,14 +140,17 @@ extern "C" int mis_gn_apply(int dtype, const void* x, int x_ld, int Cs, int up, 
                     c_off + Cs <= Ctot && Ctot <= y_ld,
                 MIS_EINVAL, "gn_apply: sizes / alignment");
     MIS_REQUIRE(!up || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0), MIS_EUNSUPPORTED, "gn_apply: upsampled source needs an even grid");
-    long long blocks = ((long long)N * D * H * W * (Cs / EPC) + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    MIS_REQUIRE(Cs / EPC <= 256 && (long long)D * H * W < (1ll << 31) && N <= 65535, MIS_EUNSUPPORTED, "gn_apply: at most 256 chunks per voxel, 2^31 voxels per sample");
+    const int vpb = 256 / (Cs / EPC);
+    long long blocks = ((long long)D * H * W + 4 * vpb - 1) / (4 * vpb);
+    const long long cap = (4096 + N - 1) / N;
+    if (blocks > cap) blocks = cap;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIS_BF16)
-        hipLaunchKernelGGL(gn_apply_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, (const __bf16*)x, x_ld, Cs, up, N, D, H, W, scale, shift, Ctot, c_off,
+        hipLaunchKernelGGL(gn_apply_kernel<__bf16>, dim3((unsigned)blocks, N), dim3(256), 0, s, (const __bf16*)x, x_ld, Cs, up, D, H, W, scale, shift, Ctot, c_off,
                            (__bf16*)y, y_ld);
     else
-        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x, x_ld, Cs, up, N, D, H, W, scale, shift, Ctot, c_off,
+        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3((unsigned)blocks, N), dim3(256), 0, s, (const float*)x, x_ld, Cs, up, D, H, W, scale, shift, Ctot, c_off,
                            (float*)y, y_ld);
     MIS_LAUNCH_CHECK("gn_apply");
     return MIS_OK;

@@ -295,6 +295,12 @@ template <typename T, int C, int LOSS, int PASS> static void head_launch(const H
 template <typename T, int C> static int head_dispatch(const MisHeadDesc* d, HeadArgs& a, unsigned blocks, hipStream_t s) {
     const long long total = (long long)d->N * d->npix_per_image;
     const bool train = d->dy != nullptr;
+    if (d->phase == 2) {          // gradient part of BCE + Dice only: the sums in loss_out are the caller's (possibly all-reduced over ranks)
+        a.sums = d->loss_out + 1;
+        head_launch<T, C, 2, 1>(a, blocks, s);
+        MIS_LAUNCH_CHECK("head_pass1");
+        return head_reduce(d, (int)blocks, C, 1, total, s);
+    }
     switch (d->loss) {
         case -1: head_launch<T, C, -1, 0>(a, blocks, s); break;
         case 0:
@@ -311,7 +317,7 @@ template <typename T, int C> static int head_dispatch(const MisHeadDesc* d, Head
         const int rc = head_reduce(d, (int)blocks, C, 0, total, s);
         if (rc != MIS_OK) return rc;
     }
-    if (d->loss == 2 && train) {
+    if (d->loss == 2 && train && d->phase != 1) {
         a.sums = d->loss_out + 1;   // [bce, I_c.., P_c.., T_c..]
         head_launch<T, C, 2, 1>(a, blocks, s);
         MIS_LAUNCH_CHECK("head_pass1");
@@ -342,6 +348,7 @@ extern "C" int mis_head_loss(const MisHeadDesc* d, void* stream) {
     MIS_REQUIRE(d->loss != 3 || d->dy != nullptr, MIS_EINVAL, "head: loss 3 (external dL/dlogits) is a backward-only mode");
     MIS_REQUIRE(d->dy == nullptr || (d->dw != nullptr && d->db != nullptr && d->loss >= 0), MIS_EINVAL, "head: backward needs dw, db and a loss");
     MIS_REQUIRE(d->workspace_bytes >= mis_head_workspace_bytes(d), MIS_EINVAL, "head: workspace too small");
+    MIS_REQUIRE(d->phase == 0 || ((d->phase == 1 || d->phase == 2) && d->loss == 2 && d->dy != nullptr), MIS_EINVAL, "head: phase %d needs loss 2 with backward", d->phase);
     const int EPC = d->dtype == MIS_BF16 ? 8 : 4;
     MIS_REQUIRE(d->y_ld % EPC == 0 && (d->dy == nullptr || d->dy_ld % EPC == 0), MIS_EINVAL, "head: ld alignment");
     HeadArgs a;

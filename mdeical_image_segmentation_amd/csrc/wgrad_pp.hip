@@ -535,6 +535,253 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Row variant (round 3): the same block / wave tiles as wgrad_pp_wide_kernel, but a k-step is ONE ROW of 32 pixels (tile 32 x 4 pixels; SPLIT: 32 x 8, four rows per
+// wave group).  The x fragment of tap (kh, kw) at k-step ks is the fragment of halo row ks + kh shifted by kw columns - so the nine fragments of a k-step are three rows x
+// three shifts, and two of the three rows were already read for the previous k-step: a fragment stays in registers for the three k-steps that use it (kh = 2, 1, 0) and a
+// k-step after the first reads 3 new x fragments instead of 9 (+ 4 dY fragments): 14 transposing reads per 36 MFMAs instead of 26, 17 on average over a tile.  The wide
+// kernel is bound by its R segments (PMC r02: MFMA pipe 62 % / 50 % busy); this is the weight-gradient analogue of the column-segment recipe of conv_ppc_kernel.
+// LDS per stage: halo (6 | 10) x 34 px x 128 B + dY 128 px x 256 B | 256 px x 128 B = 58 | 75 KiB, double-buffered.  Needs W % 32 == 0 to waste nothing (the
+// dispatcher keeps the 16-wide tiles otherwise).
+template <bool SPLIT> struct W4 {
+    static constexpr int TW = 32, HW = TW + 2;
+    static constexpr int TH = SPLIT ? 8 : 4, PH = TH + 2;
+    static constexpr int CO = SPLIT ? 64 : 128;
+    static constexpr int QROW = CO * 2;                               // bytes per dY pixel row
+    static constexpr int ROWB = HW * 128;                             // bytes per halo row
+    static constexpr int PITEMS = PH * HW * 8;
+    static constexpr int PINSTR = (PITEMS + 63) / 64;                 // 26 / 43
+    static constexpr int PBUF = PINSTR * 1024;
+    static constexpr int QINSTR = TH * TW * (QROW / 16) / 64;         // 32 either way
+    static constexpr int QBUF = QINSTR * 1024;
+    static constexpr int STAGE = PBUF + QBUF;
+    static constexpr int NPJ = (PINSTR + 7) / 8;                      // halo instructions per wave: 4 / 6
+    static constexpr int NQJ = QINSTR / 8;                            // 4
+    static constexpr int PER_WAVE = NPJ + NQJ;
+};
+
+template <bool SPLIT, bool IS3D>
+__global__ __launch_bounds__(512, 2) void wgrad_pp_row_kernel(const WgArgs a) {
+    using G = W4<SPLIT>;
+    constexpr int NS = 4;                              // segments per step = the rows (k-steps) of a group's 4 x 32 pixels
+    constexpr int DPS = (G::PER_WAVE + NS - 2) / (NS - 1);   // DMA instructions per wave and R segment (none in the last one)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wi = wave & 3, wj = SPLIT ? 0 : (wave >> 2);
+    const int li = lane & 15, lg = lane >> 4;
+    const int q = li >> 2, pp = li & 3;
+
+    constexpr int KDN = IS3D ? 3 : 1;
+    const int npairs = a.nCi * a.nCo * KDN;
+    int v = xcd_remap(blockIdx.x, gridDim.x);
+    const int pair = v % npairs;
+    const int split = v / npairs;
+    const int kd = IS3D ? pair % 3 : 0;
+    const int pc = IS3D ? pair / 3 : pair;
+    const int ci_t = pc / a.nCo, co_t = pc - ci_t * a.nCo;
+    const int ci0 = ci_t * 64, co0 = co_t * G::CO;
+    const int t_begin = split * a.tps;
+    int t_end = t_begin + a.tps;
+    if (t_end > a.ntiles) t_end = a.ntiles;
+    const int tpi = a.tilesH * a.tilesW;
+    auto tile_coords = [&](int t, int& n, int& h0, int& w0) {
+        n = t / tpi;
+        const int r = t - n * tpi;
+        const int th = r / a.tilesW;
+        h0 = th * G::TH;
+        w0 = (r - th * a.tilesW) * G::TW;
+    };
+    auto src_plane = [&](int n, int& xn, bool& zok) {
+        xn = n;
+        zok = true;
+        if constexpr (IS3D) {
+            const int z = n % a.D + kd - 1;
+            zok = (unsigned)z < (unsigned)a.D;
+            xn = zok ? n + kd - 1 : n;
+        }
+    };
+
+    // fragment offsets: pixel quad s of lane group lg is quad u = (lg&1) + 2s + 4(lg>>1) of the k-step's 32 pixels = columns 4u .. 4u+3 of the row (lane groups
+    // 0,1 and 2,3 each address 8 consecutive pixels: all 64 banks once, as in the wide kernel)
+    int qoff[2], poff[2][3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int u = (lg & 1) + 2 * s + 4 * (lg >> 1);
+        const int wx = u * 4 + q;
+        if (SPLIT) qoff[s] = wx * 128 + (((pp >> 1) ^ (wx & 7)) << 4) + (pp & 1) * 8;                       // fragment fj: ^ (fj << 5)
+        else qoff[s] = wx * 256 + (((wj * 8 + (pp >> 1)) ^ ((wx & 7) << 1)) << 4) + (pp & 1) * 8;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int px = wx + kw;
+            poff[s][kw] = px * 128 + (((wi * 2 + (pp >> 1)) ^ (px & 7)) << 4) + (pp & 1) * 8;
+        }
+    }
+    unsigned prel[G::NPJ];
+    int pcoord[G::NPJ];
+#pragma unroll
+    for (int j = 0; j < G::NPJ; ++j) {
+        const int id = wave + 8 * j;
+        const int item = id * 64 + lane;
+        const int p = item >> 3, pos = item & 7;
+        const int py = p / G::HW, px = p - py * G::HW;
+        const bool have = id < G::PINSTR && item < G::PITEMS;
+        prel[j] = (unsigned)(((py * a.W + px) * a.x0.ld + ((pos ^ (px & 7)) << 3)) * 2);
+        pcoord[j] = have ? (py | (px << 8)) : -1;
+    }
+    // dY instruction i = wave + 8j.  SPLIT: tile row i >> 2, column 8 * (i & 3) + (lane >> 3), chunk position lane & 7 (XOR column & 7); (i & 3) == (wave & 3), row = (wave >> 2) + 2j.
+    //                              else: tile row i >> 3 = j, column 4 * (i & 7) + (lane >> 4) = 4 * wave + (lane >> 4), chunk position lane & 15 (XOR (column & 7) << 1).
+    const int qcol = SPLIT ? 8 * (wave & 3) + (lane >> 3) : 4 * wave + (lane >> 4);
+    const unsigned qlane = SPLIT ? (unsigned)((qcol * a.dy_ld + (((lane & 7) ^ (qcol & 7)) << 3)) * 2)
+                                 : (unsigned)((qcol * a.dy_ld + (((lane & 15) ^ ((qcol & 7) << 1)) << 3)) * 2);
+
+    const unsigned img_x = (unsigned)(((long long)a.H * a.W - 1) * a.x0.ld + a.Cin) * 2u, img_q = (unsigned)(((long long)a.H * a.W - 1) * a.dy_ld + a.Cout) * 2u;
+    const char* const xb = reinterpret_cast<const char*>(a.x0.p);
+    const char* const qb = reinterpret_cast<const char*>(a.dy);
+    auto issue = [&](auto jc, int n, int h0, int w0, char* stage, int xn, bool zok) {
+        constexpr int jj = decltype(jc)::value;
+        if constexpr (jj < G::NPJ) {
+            const int id = wave + 8 * jj;
+            if (id >= G::PINSTR) return;
+            const __amdgpu_buffer_rsrc_t rx = wp_make_rsrc(xb + (size_t)xn * a.H * a.W * a.x0.ld * 2, img_x);
+            const unsigned toff = (unsigned)((((h0 - 1) * a.W + (w0 - 1)) * a.x0.ld + ci0) * 2);
+            const bool interior = h0 >= 1 && h0 + G::TH + 1 <= a.H && w0 >= 1 && w0 + G::TW + 1 <= a.W;
+            bool ok = pcoord[jj] >= 0 && zok;
+            if (!interior) {
+                const int py = pcoord[jj] & 0xff, px = pcoord[jj] >> 8;
+                ok = ok && (unsigned)(h0 - 1 + py) < (unsigned)a.H && (unsigned)(w0 - 1 + px) < (unsigned)a.W;
+            }
+            wp_dma16(rx, ok ? (int)(toff + prel[jj]) : WP_OOB, stage + id * 1024);
+        } else {
+            const int i = wave + 8 * (jj - G::NPJ);
+            const __amdgpu_buffer_rsrc_t rq = wp_make_rsrc(qb + (size_t)n * a.H * a.W * a.dy_ld * 2, img_q);
+            const int hy = SPLIT ? (i >> 2) : (i >> 3);
+            const unsigned toff = (unsigned)((((h0 + hy) * a.W + w0) * a.dy_ld + co0) * 2);
+            const bool ok = (h0 + hy) < a.H && (w0 + qcol) < a.W;
+            wp_dma16(rq, ok ? (int)(toff + qlane) : WP_OOB, stage + G::PBUF + i * 1024);
+        }
+    };
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj) acc[t][fj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = (a.bias_partial != nullptr) && (ci_t == 0) && (wi == 0) && (!IS3D || kd == 1);
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    int n, h0, w0, xn;
+    bool zok;
+    tile_coords(t_begin, n, h0, w0);
+    src_plane(n, xn, zok);
+    wp_static_for<G::PER_WAVE>([&](auto jc) { issue(jc, n, h0, w0, smem, xn, zok); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int sel = 0;
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll 1
+    for (int t = t_begin; t < t_end; ++t) {
+        const bool has_next = t + 1 < t_end;
+        int nn = n, nh0 = h0, nw0 = w0, nxn = xn;
+        bool nzok = zok;
+        if (has_next) {
+            tile_coords(t + 1, nn, nh0, nw0);
+            src_plane(nn, nxn, nzok);
+        }
+        const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+        const uint32_t lds_p = lds0 + sel * G::STAGE + (SPLIT ? grp * (4 * G::ROWB) : 0);               // SPLIT: this group's 4 tile rows (+ 2 halo rows)
+        const uint32_t lds_q = lds0 + sel * G::STAGE + G::PBUF + (SPLIT ? grp * (4 * G::TW * G::QROW) : 0);
+        char* nstage = smem + (sel ^ 1) * G::STAGE;
+        bf16x8_t A[6][3];                              // halo row r, shift kw: live for the k-steps r - 2 .. r
+        wp_static_for<NS>([&](auto sgc) {
+            constexpr int ks = decltype(sgc)::value;
+            // ================= R segment =================
+            if constexpr (ks < NS - 1) {
+                if (has_next) {
+                    wp_static_for<DPS>([&](auto dc) {
+                        constexpr int jj = ks * DPS + decltype(dc)::value;
+                        if constexpr (jj < G::PER_WAVE) issue(std::integral_constant<int, jj>{}, nn, nh0, nw0, nstage, nxn, nzok);
+                    });
+                }
+            }
+            bf16x8_t B[4];
+            wp_static_for<4>([&](auto fjc) {
+                constexpr int fj = decltype(fjc)::value;
+                B[fj] = wp_frag<ks * (G::TW * G::QROW)>(lds_q + (qoff[0] ^ (fj << 5)), lds_q + (qoff[1] ^ (fj << 5)));
+            });
+            wp_static_for<3>([&](auto rc) {            // new halo rows of this k-step: 0, 1, 2 for the first, ks + 2 afterwards
+                constexpr int rr = decltype(rc)::value;
+                if constexpr (ks == 0 || rr == 2) {
+                    constexpr int r = ks + rr;
+                    wp_static_for<3>([&](auto kc) {
+                        constexpr int kw = decltype(kc)::value;
+                        A[r][kw] = wp_frag<r * G::ROWB>(lds_p + poff[0][kw], lds_p + poff[1][kw]);
+                    });
+                }
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_bias) {
+#pragma unroll
+                for (int fj = 0; fj < 4; ++fj) bsum[fj] += wp_sum8(B[fj]);
+            }
+            if constexpr (ks == NS - 1) {
+                if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ================= M segment =================
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int fj = 0; fj < 4; ++fj)
+                        acc[kh * 3 + kw][fj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks + kh][kw], B[fj], acc[kh * 3 + kw][fj], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            if constexpr (ks == NS - 1) {
+                if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        sel ^= 1;
+        n = nn; h0 = nh0; w0 = nw0; xn = nxn; zok = nzok;
+    }
+
+    const int se = SPLIT ? 2 * split + grp : split;            // SPLIT: one slab per wave group
+    float* out = a.partial + (size_t)se * a.TT * a.Cin * a.Cout;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj) {
+            const int co = co0 + (wj * 4 + fj) * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = ci0 + wi * 16 + lg * 4 + r;
+                out[((size_t)(kd * 9 + tap) * a.Cin + ci) * a.Cout + co] = acc[tap][fj][r];
+            }
+        }
+    if (do_bias) {
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj) {
+            float s = bsum[fj];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (lg == 0) a.bias_partial[(size_t)se * a.Cout + co0 + (wj * 4 + fj) * 16 + li] = s;
+        }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------------------
 bool wgrad_pp_eligible(const MisWgradDesc* d) {
     if (d->dtype != MIS_BF16 || d->ksize != 3) return false;
     if (d->is3d) {
@@ -552,19 +799,26 @@ bool wgrad_pp_eligible(const MisWgradDesc* d) {
     return true;
 }
 
-// kernel choice: 0 = wide (Cout % 128 == 0), 1 = pixel-split wide tile (64-column tiles), 2 = the 64 x 64 kernel with 16 x 32 wave tiles (MIS_WGRAD_PP_NOWIDE=1; 2-D only)
+// kernel choice: 0 = wide (Cout % 128 == 0), 1 = pixel-split wide tile (64-column tiles), 2 = the 64 x 64 kernel with 16 x 32 wave tiles (MIS_WGRAD_PP_NOWIDE=1; 2-D only),
+// 3 / 4 = the row variants of 0 / 1 (32-pixel-wide tiles with x-fragment reuse across k-steps): taken when the 32-wide tiles pad the W axis by at most an eighth
+// (MIS_WGRAD_PP_ROW=1: always, MIS_WGRAD_PP_NOROW=1: never)
 static int wp_kind(const MisWgradDesc* d) {
     if (!d->is3d && mis_sw(SW_WGRAD_PP_NOWIDE)) return 2;
-    return d->Cout % 128 == 0 ? 0 : 1;
+    const int base = d->Cout % 128 == 0 ? 0 : 1;
+    const bool fits = ((d->W + 31) / 32) * 32 * 8 <= d->W * 9;
+    if (!mis_sw(SW_WGRAD_PP_NOROW) && (fits || mis_sw(SW_WGRAD_PP_ROW))) return base + 3;
+    return base;
 }
 
 static void wp_plan(const MisWgradDesc* d, int* ntiles, int* tps, int* nsb, int* tilesH, int* tilesW) {
     const int kind = wp_kind(d);
-    const int th = kind == 0 ? 8 : 16;
+    const bool wide = kind == 0 || kind == 3;
+    const int th = kind == 3 ? 4 : (kind == 0 || kind == 4) ? 8 : 16;
+    const int tw = kind >= 3 ? 32 : WP_TW;
     *tilesH = (d->H + th - 1) / th;
-    *tilesW = (d->W + WP_TW - 1) / WP_TW;
+    *tilesW = (d->W + tw - 1) / tw;
     const long long nt = (long long)d->N * (d->is3d ? d->D : 1) * *tilesH * *tilesW;      // 3-D: one 2-D tile grid per depth plane
-    const long long npairs = (long long)(d->Cin / 64) * (d->Cout / (kind == 0 ? 128 : 64)) * (d->is3d ? 3 : 1);
+    const long long npairs = (long long)(d->Cin / 64) * (d->Cout / (wide ? 128 : 64)) * (d->is3d ? 3 : 1);
     long long want = 256 / npairs;                // one persistent block per CU
     if (want < 1) want = 1;
     if (want > nt) want = nt;
@@ -576,7 +830,8 @@ static void wp_plan(const MisWgradDesc* d, int* ntiles, int* tps, int* nsb, int*
 int wgrad_pp_nsplit(const MisWgradDesc* d) {
     int ntiles, tps, nsb, th, tw;
     wp_plan(d, &ntiles, &tps, &nsb, &th, &tw);
-    return wp_kind(d) == 1 ? 2 * nsb : nsb;
+    const int kind = wp_kind(d);
+    return (kind == 1 || kind == 4) ? 2 * nsb : nsb;
 }
 
 template <bool SPLIT, bool IS3D> static int wp_launch_wide(const WgArgs& a, long long grid, hipStream_t stream, const char* what) {
@@ -584,6 +839,14 @@ template <bool SPLIT, bool IS3D> static int wp_launch_wide(const WgArgs& a, long
     static std::atomic<unsigned long long> attr_done{0};
     if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&wgrad_pp_wide_kernel<SPLIT, IS3D>), lds, what)) return rc;
     hipLaunchKernelGGL((wgrad_pp_wide_kernel<SPLIT, IS3D>), dim3((unsigned)grid), dim3(512), lds, stream, a);
+    return MIS_OK;
+}
+
+template <bool SPLIT, bool IS3D> static int wp_launch_row(const WgArgs& a, long long grid, hipStream_t stream, const char* what) {
+    const size_t lds = 2 * (size_t)W4<SPLIT>::STAGE;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&wgrad_pp_row_kernel<SPLIT, IS3D>), lds, what)) return rc;
+    hipLaunchKernelGGL((wgrad_pp_row_kernel<SPLIT, IS3D>), dim3((unsigned)grid), dim3(512), lds, stream, a);
     return MIS_OK;
 }
 
@@ -599,8 +862,9 @@ int launch_wgrad_pp(const MisWgradDesc* d, float* partial, float* bias_partial, 
     const int kind = wp_kind(d);
     wp_plan(d, &a.ntiles, &a.tps, &nsb, &a.tilesH, &a.tilesW);
     MIS_REQUIRE((long long)d->N * a.D * a.tilesH * a.tilesW < (1ll << 30), MIS_EUNSUPPORTED, "wgrad(pp): too many pixel tiles");
-    a.tilesD = a.D; a.nsplit = kind == 1 ? 2 * nsb : nsb;
-    a.nCi = d->Cin / 64; a.nCo = d->Cout / (kind == 0 ? 128 : 64); a.KDn = is3d ? 3 : 1; a.TT = is3d ? 27 : 9;
+    const bool wide = kind == 0 || kind == 3;
+    a.tilesD = a.D; a.nsplit = (kind == 1 || kind == 4) ? 2 * nsb : nsb;
+    a.nCi = d->Cin / 64; a.nCo = d->Cout / (wide ? 128 : 64); a.KDn = is3d ? 3 : 1; a.TT = is3d ? 27 : 9;
     const long long grid = (long long)a.nCi * a.nCo * a.KDn * nsb;
     MIS_REQUIRE(grid < (1ll << 31), MIS_EUNSUPPORTED, "wgrad(pp): grid too large");
     if (kind == 0) {
@@ -609,6 +873,12 @@ int launch_wgrad_pp(const MisWgradDesc* d, float* partial, float* bias_partial, 
     } else if (kind == 1) {
         *tag = is3d ? "k3.3d.pps" : "k3.2d.pps";
         if (const int rc = is3d ? wp_launch_wide<true, true>(a, grid, stream, "wgrad(pps3)") : wp_launch_wide<true, false>(a, grid, stream, "wgrad(pps)")) return rc;
+    } else if (kind == 3) {
+        *tag = is3d ? "k3.3d.ppwr" : "k3.2d.ppwr";
+        if (const int rc = is3d ? wp_launch_row<false, true>(a, grid, stream, "wgrad(ppwr3)") : wp_launch_row<false, false>(a, grid, stream, "wgrad(ppwr)")) return rc;
+    } else if (kind == 4) {
+        *tag = is3d ? "k3.3d.ppsr" : "k3.2d.ppsr";
+        if (const int rc = is3d ? wp_launch_row<true, true>(a, grid, stream, "wgrad(ppsr3)") : wp_launch_row<true, false>(a, grid, stream, "wgrad(ppsr)")) return rc;
     } else {
         *tag = "k3.2d.pp";
         const size_t lds = 2 * (size_t)WP_STAGE;

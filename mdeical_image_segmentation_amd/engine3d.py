@@ -119,7 +119,9 @@ class UNet3DEngine:
             self.P[n].copy_(host[n])
         self.ck = 64 if dtype == torch.bfloat16 else 32
         self.c1 = max(f_maps[0] // 2, in_channels)                 # 32
-        self.c1p = (self.c1 + 63) // 64 * 64                       # 64: dgrad needs its GEMM-N (= Cin) in multiples of 64
+        # the first SingleConv's 32 output channels live in a 64-channel buffer when the consumer folds GroupNorm into a 64-channel K chunk (fp32 / MISAMD_GN_FOLD);
+        # with the materialised operand (bf16) only the 64-wide buffers xn / dyn carry the padding: every pass over t_enc[0] / g_t_enc[0] moves half the bytes
+        self.c1p = self.c1 if (self.materialize and self.c1 % 32 == 0) else (self.c1 + 63) // 64 * 64
         # SingleConv descriptors
         enc, dec = layer_plan(in_channels, f_maps, upsample)
         self.ct = []                                               # transposed-conv upsamplers ('deconv')
@@ -237,6 +239,8 @@ class UNet3DEngine:
             s.sum1, s.sq1 = torch.zeros(N, cs, device=dev), torch.zeros(N, cs, device=dev)
             s.dgam, s.dbet = torch.zeros(cs, device=dev), torch.zeros(cs, device=dev)
             s.xn = buf(l, s.cin_pad) if (self.materialize and not s.first) else None
+            if s.xn is not None and s.cin_pad != s.cin:
+                s.xn.zero_()                                       # the padding channels are never written: they must read as 0 in the weight gradient
         self.dyn = {}      # dgrad outputs, keyed by (level, channels): shared between SingleConvs of equal shape
         for s in self.sc.values():
             if s.first:
@@ -273,7 +277,7 @@ class UNet3DEngine:
         grid = (src0.shape[0], src0.shape[1], src0.shape[2], src0.shape[3])
         if s.xn is not None:
             if src1 is None:
-                ops.gn_apply(src0, s.cin_pad, False, grid, s.scale, s.shift, s.cin_pad, 0, s.xn)
+                ops.gn_apply(src0, src0.shape[-1], False, grid, s.scale, s.shift, s.cin_pad, 0, s.xn)
             else:
                 ops.gn_apply(View(src0, 0, c0), c0, False, grid, s.scale, s.shift, s.cin_pad, 0, s.xn)
                 ops.gn_apply(View(src1, 0, c1), c1, src1.shape[1] != src0.shape[1], grid, s.scale, s.shift, s.cin_pad, c0, s.xn)

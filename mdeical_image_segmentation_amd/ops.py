@@ -62,7 +62,9 @@ class _Timed:
     def __exit__(self, *exc):
         if PROFILE is not None and exc[0] is None:
             self.e1.record()
-            PROFILE.append((self.key, self.flops, self.e0, self.e1))
+            lib = load()            # which kernel configuration this launch ran (names the dominant kernel's symbol in bench.py's roofline)
+            tag = (lib.mis_conv_last_dispatch() if self.key[0] == "conv_igemm" else lib.mis_wgrad_last_dispatch()).decode()
+            PROFILE.append((self.key, self.flops, self.e0, self.e1, tag))
         return False
 
 
@@ -341,7 +343,7 @@ LOSS_NONE, LOSS_CE, LOSS_BCE, LOSS_BCEDICE, LOSS_EXTERNAL = -1, 0, 1, 2, 3
 
 
 def head_loss(y, w, b, *, loss, labels=None, logits=None, argmax=None, loss_out=None, dy=None, dw=None, db=None,
-              grad_scale=1.0, alpha=1.0, beta=1.0):
+              grad_scale=1.0, alpha=1.0, beta=1.0, phase=0):
     lib = load()
     y = _v(y)
     d = HeadDesc()
@@ -359,7 +361,7 @@ def head_loss(y, w, b, *, loss, labels=None, logits=None, argmax=None, loss_out=
         dy = _v(dy)
         d.dy, d.dy_ld = dy.ptr, dy.ld
         d.dw, d.db = dw.data_ptr(), db.data_ptr()
-    d.grad_scale, d.alpha, d.beta = grad_scale, alpha, beta
+    d.grad_scale, d.alpha, d.beta, d.phase = grad_scale, alpha, beta, phase
     ws = workspace(lib.mis_head_workspace_bytes(C.byref(d)), y.t.device, "head")
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     check(lib.mis_head_loss(C.byref(d), stream_ptr()), "mis_head_loss")

@@ -162,6 +162,16 @@ WG_CASES = [
     (BF, 3, 2, 150, 170, 64, 64, "k3.2d.pps", ""),       # 220 tiles, 1 pair: persistent blocks with the tile loop taken
     (BF, 3, 1, 40, 40, 128, 64, "k3.2d.pps", ""),        # two input-channel tiles: only ci tile 0 writes the bias column sums
     (BF, 3, 2, 150, 170, 64, 128, "k3.2d.ppw", ""),      # wide kernel, persistent blocks with the tile loop taken, ragged 8-row tiles
+    # row variants (32-pixel-wide tiles, x fragments reused across the k-steps of a tile): the default wherever 32-wide tiles fit the grid
+    (BF, 3, 2, 64, 64, 64, 128, "k3.2d.ppwr", ""),
+    (BF, 3, 1, 9, 32, 256, 256, "k3.2d.ppwr", ""),       # ragged 4-row tiles, 8 channel-tile pairs
+    (BF, 3, 1, 32, 32, 1024, 1024, "k3.2d.ppwr", ""),    # 128 pairs x 2 splits
+    (BF, 3, 2, 20, 36, 64, 128, "k3.2d.ppwr", "MIS_WGRAD_PP_ROW"),     # ragged in W as well (forced)
+    (BF, 3, 2, 150, 160, 64, 128, "k3.2d.ppwr", ""),     # 380 tiles over 128 blocks... the tile loop is taken
+    (BF, 3, 2, 64, 96, 64, 64, "k3.2d.ppsr", ""),        # 64-column tiles: 32 x 8-pixel tiles, four rows per wave group, two slabs per block
+    (BF, 3, 2, 20, 36, 64, 64, "k3.2d.ppsr", "MIS_WGRAD_PP_ROW"),
+    (BF, 3, 2, 150, 160, 128, 64, "k3.2d.ppsr", ""),
+    (BF, 3, 2, 64, 64, 64, 128, "k3.2d.ppw", "MIS_WGRAD_PP_NOROW"),    # the 16-wide tiles stay reachable
     (BF, 3, 2, 20, 36, 64, 64, "k3.2d.tr", "MIS_WGRAD_NOPP"),     # the kernel behind it
     (BF, 3, 1, 9, 17, 1024, 1024, "k3.2d.tr", "MIS_WGRAD_NOPP"),
     (BF, 3, 2, 40, 40, 512, 256, "k3.2d.tr", "MIS_WGRAD_NOPP"),
@@ -236,6 +246,9 @@ K3D_CASES = [
     (BF, (3, 30, 40, 48), 64, 64, "k3.3d.ppc5n2", "k3.3d.pps", {"MIS_CONV3D_PF": 5}),    # 540 tiles > 256 persistent blocks: the tile loop is taken
     (BF, (1, 40, 64, 48), 64, 128, "k3.3d.ppc8", "k3.3d.ppw", {}),                       # 240 tiles... 32-row tiles exact; interior tiles; depth groups of 4
     (BF, (1, 1, 20, 16), 64, 64, "k3.3d.ppc5n2", "k3.3d.pps", {}),                       # exactly one tile, one plane: both neighbour planes are padding
+    (BF, (1, 6, 20, 32), 64, 64, "k3.3d.ppc5n2", "k3.3d.ppsr", {}),                      # weight gradient on the row variants (32-wide tiles fit)
+    (BF, (2, 5, 12, 64), 128, 128, "k3.3d.ppc5", "k3.3d.ppwr", {}),
+    (BF, (1, 3, 10, 18), 192, 64, "k3.3d.ppc5n2", "k3.3d.ppsr", {"MIS_WGRAD_PP_ROW": 1}),        # ... ragged both ways, three input-channel tiles x three depth slices
     (BF, (1, 7, 20, 16), 64, 128, "k3.3d.ppc5", "k3.3d.ppw", {"MIS_CONV3D_COLMAJOR": 1, "MIS_CONV3D_ZG": 3}),
     # the kernels behind them
     (BF, (1, 5, 20, 20), 64, 64, "k3.3d.bn64", "k3.3d.tr", {"MIS_CONV3D_NOPP": 1, "MIS_WGRAD3D_NOPP": 1}),
