@@ -221,6 +221,12 @@ int mis_first3d_bwd(int dtype, const float* x, const float* mean /*[N]*/, const 
                     const float* beta /*[1]*/, int N, int D, int H, int W, const void* dy, int dy_ld, int Cpad, const float* w, int Cout,
                     float* workspace, float* dw, float* dgamma /*[1]*/, float* dbeta /*[1]*/, float* dxn /*optional (N,D,H,W) or NULL*/, void* stream);
 int mis_relu_mask(int dtype, const void* dy, int dy_ld, const void* y, int y_ld, void* dx, int dx_ld, long long npix, int C, void* stream);
+/* y = alpha * x * (mask > 0) on channels-last views: training-mode nn.Dropout inside a create_conv layer ('d', model/unet3d/buildingblocks.py:105-106), forward and
+ * (with dy for x) backward; the caller draws the mask */
+int mis_mask_scale(int dtype, const void* x, int x_ld, const void* mask, int mask_ld, void* y, int y_ld, long long npix, int C, float alpha, void* stream);
+/* min and max of n fp32 values -> out[0], out[1] (two-stage, workspace >= 2 * 1024 floats): data-derived bounds of `Normalize`
+ * (augment/unet3d_augment/transforms.py:575-586: np.min / np.max of the volume or of one channel) */
+int mis_minmax(const float* x, long long n, float* workspace, float* out, void* stream);
 
 /* 'deconv' upsampling of the 3-D decoders: ConvTranspose3d(k3, s2, p1, no bias) then nearest resize 2n-1 -> 2n
  * (model/unet3d/buildingblocks.py:676-728).  The contraction is mis_conv_igemm (ksize 1, 27*C columns: cols[i][k*C+c], k = (kd*3+kh)*3+kw);

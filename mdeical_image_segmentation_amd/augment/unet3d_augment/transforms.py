@@ -226,58 +226,99 @@ class ElasticDeformation:
 
 
 class Standardize:
-    """transforms.py:495-523: (m - mean) / clip(std, eps). Volume statistics are reduced on the device when not given."""
+    """transforms.py:495-523: (m - mean) / clip(std, eps). Volume statistics are reduced on the device when not given; channelwise=True: per slice of the first
+    axis (the reference's `axes[1:]`), i.e. per channel of a (C, D, H, W) volume."""
 
     def __init__(self, eps=1e-10, mean=None, std=None, channelwise=False, **kwargs):
         if mean is not None or std is not None:
             assert mean is not None and std is not None
         self.mean, self.std, self.eps, self.channelwise = mean, std, eps, channelwise
 
-    def __call__(self, m):
-        m = _dev(m)
-        if m.dtype != torch.float32:
-            raise MisError("Standardize: fp32 volumes only")
-        if self.channelwise:
-            raise NotImplementedError("Standardize(channelwise=True) is not built")
-        if self.mean is not None:
-            mean, std = float(self.mean), float(self.std)
-        else:
+    def _one(self, m, mean, std):
+        if mean is None:
             n = m.numel()
             if n % 4:
                 raise MisError("Standardize: volume size must be a multiple of 4")
             s = torch.zeros(1, 4, device=m.device)
             q = torch.zeros(1, 4, device=m.device)
-            ops.chanstats(m.view(1, 1, 1, n // 4, 4), s, q)
-            tot, tot2 = s.double().sum().item(), q.double().sum().item()
-            mean = tot / n
-            std = max(tot2 / n - mean * mean, 0.0) ** 0.5
-        std = max(std, self.eps)
+            ops.chanstats(m.reshape(1, 1, 1, n // 4, 4), s, q)
+            mean = s.double().sum().item() / n
+            # two passes like np.std (E[x^2] - mean^2 from fp32 partial sums cancels catastrophically when |mean| >> std): deviations first, then their moments
+            dev_ = torch.empty_like(m)
+            check(load().mis_aug_pointwise(m.data_ptr(), dev_.data_ptr(), n, 1.0, -mean, 0, 0.0, 0.0, 0.0, 0, stream_ptr()), "mis_aug_pointwise")
+            ops.chanstats(dev_.reshape(1, 1, 1, n // 4, 4), s, q)
+            d1, d2 = s.double().sum().item() / n, q.double().sum().item() / n
+            mean += d1
+            std = max(d2 - d1 * d1, 0.0) ** 0.5
+        std = max(float(std), self.eps)
         out = torch.empty_like(m)
         a = 1.0 / std
-        check(load().mis_aug_pointwise(m.data_ptr(), out.data_ptr(), m.numel(), a, -mean * a, 0, 0.0, 0.0, 0.0, 0, stream_ptr()), "mis_aug_pointwise")
+        check(load().mis_aug_pointwise(m.data_ptr(), out.data_ptr(), m.numel(), a, -float(mean) * a, 0, 0.0, 0.0, 0.0, 0, stream_ptr()), "mis_aug_pointwise")
         return out
-
-
-class Normalize:
-    """transforms.py:547-605 with fixed min_value / max_value (data-dependent min/max is not built)."""
-
-    def __init__(self, min_value=None, max_value=None, norm01=False, channelwise=False, eps=1e-10, **kwargs):
-        if min_value is None or max_value is None or channelwise:
-            raise NotImplementedError("on-device Normalize needs fixed scalar min_value and max_value")
-        assert max_value > min_value
-        self.min_value, self.max_value, self.norm01, self.eps = min_value, max_value, norm01, eps
 
     def __call__(self, m):
         m = _dev(m)
+        if m.dtype != torch.float32:
+            raise MisError("Standardize: fp32 volumes only")
+        if self.mean is not None:          # given statistics win over channelwise, as in the reference (:509-510); per-channel sequences broadcast over the first axis
+            mean, std = np.asarray(self.mean, dtype=np.float64).reshape(-1), np.asarray(self.std, dtype=np.float64).reshape(-1)
+            if mean.size == 1 and std.size == 1:
+                return self._one(m.contiguous(), float(mean[0]), float(std[0]))
+            if mean.size != m.shape[0] or std.size != m.shape[0]:
+                raise MisError("Standardize: mean / std must be scalars or one value per channel")
+            return torch.stack([self._one(m[c].contiguous(), float(mean[c]), float(std[c])) for c in range(m.shape[0])])
+        if self.channelwise:
+            return torch.stack([self._one(m[c].contiguous(), None, None) for c in range(m.shape[0])])
+        return self._one(m.contiguous(), None, None)
+
+
+class Normalize:
+    """transforms.py:547-605: min-max scaling to [-1, 1] (or [0, 1] with norm01) with clipping.  Bounds that are not given come from the data (np.min / np.max,
+    reduced on the device by mis_minmax); channelwise=True: bounds per slice of the first axis, given as lists in which the string 'None' (or None) means
+    "from the data", as in the reference."""
+
+    def __init__(self, min_value=None, max_value=None, norm01=False, channelwise=False, eps=1e-10, **kwargs):
+        if min_value is not None and max_value is not None and not channelwise:
+            assert max_value > min_value
+        self.min_value, self.max_value, self.norm01, self.channelwise, self.eps = min_value, max_value, norm01, channelwise, eps
+
+    @staticmethod
+    def _minmax(m):
+        ws = ops.workspace(2 * 1024 * 4, m.device, "minmax")
+        out = torch.empty(2, device=m.device)
+        check(load().mis_minmax(m.data_ptr(), m.numel(), ws.data_ptr(), out.data_ptr(), stream_ptr()), "mis_minmax")
+        lo, hi = out.cpu().tolist()
+        return lo, hi
+
+    def _one(self, m, lo, hi):
+        if lo is None or hi is None:
+            dlo, dhi = self._minmax(m)
+            lo = dlo if lo is None else lo
+            hi = dhi if hi is None else hi
         out = torch.empty_like(m)
-        a = 1.0 / (self.max_value - self.min_value + self.eps)
-        b = -self.min_value * a
-        if self.norm01:
-            args = (a, b, 1, 0.0, 1.0)
-        else:
-            args = (2 * a, 2 * b - 1, 1, -1.0, 1.0)
+        a = 1.0 / (float(hi) - float(lo) + self.eps)
+        b = -float(lo) * a
+        args = (a, b, 1, 0.0, 1.0) if self.norm01 else (2 * a, 2 * b - 1, 1, -1.0, 1.0)
         check(load().mis_aug_pointwise(m.data_ptr(), out.data_ptr(), m.numel(), *args, 0.0, 0, stream_ptr()), "mis_aug_pointwise")
         return out
+
+    def __call__(self, m):
+        m = _dev(m)
+        if m.dtype != torch.float32:
+            raise MisError("Normalize: fp32 volumes only")
+        if not self.channelwise:
+            return self._one(m.contiguous(), self.min_value, self.max_value)
+
+        def per_channel(v):
+            if v is None:
+                return [None] * m.shape[0]
+            v = list(v)
+            if len(v) != m.shape[0]:
+                raise MisError("Normalize(channelwise=True): one bound per channel expected")
+            return [None if (x is None or x == "None") else float(x) for x in v]
+
+        los, his = per_channel(self.min_value), per_channel(self.max_value)
+        return torch.stack([self._one(m[c].contiguous(), los[c], his[c]) for c in range(m.shape[0])])
 
 
 def _legacy_normal_on_device(random_state, m, std):
@@ -313,11 +354,12 @@ def _legacy_normal_on_device(random_state, m, std):
 
 class AdditiveGaussianNoise:
     """transforms.py:608-619: if uniform() < p: std = uniform(scale); m + N(0, std).
-    exact=False (default): the field comes from the counter-based generator of augment.hip (same distribution, one fused pass);
-    exact=True / "device": the reference's OWN field - numpy's MT19937 + legacy polar Box-Muller reproduced on the device, bit-comparable with the reference
-    (golden g16_gauss_noise.npz); exact="host": numpy on the host + upload (the round-1 parity mode)."""
+    exact=True / "device" (the DEFAULT since round 3: a drop-in must give the reference's results): the reference's OWN field - numpy's MT19937 + legacy polar
+    Box-Muller reproduced on the device, bit-comparable with the reference (golden g16_gauss_noise.npz), the RandomState left where the reference leaves it;
+    exact=False: opt-in fast path, the counter-based generator of augment.hip (same distribution, one fused pass, a different field);
+    exact="host": numpy on the host + upload (the round-1 parity mode)."""
 
-    def __init__(self, random_state, scale=(0.0, 1.0), execution_probability=0.1, exact=False, **kwargs):
+    def __init__(self, random_state, scale=(0.0, 1.0), execution_probability=0.1, exact=True, **kwargs):
         self.execution_probability = execution_probability
         self.random_state = random_state
         self.scale = scale

@@ -126,14 +126,67 @@ def _gn_backward(dz, x, C, G, gamma, mean, rstd):
     return dx, dgamma, dbeta
 
 
-# ---- [GroupNorm ->] Conv3d [+ bias] [-> ReLU] -----------------------------------------------------------------------------------------------------
+# ---- BatchNorm3d ('b' of create_conv, buildingblocks.py:93-104): a per-channel affine from batch (training) or running (eval) statistics -------------------------
+def _padded(v, Cp, fill=0.0):
+    out = torch.full((Cp,), fill, dtype=torch.float32, device=v.device)
+    out[:v.numel()] = v.detach().float()
+    return out
+
+
+def _bn_forward(t, C, bn):
+    """scale / shift tables [N][Cp] (the same per-channel values for every sample, so that the (n, c)-affine consumers are shared with GroupNorm), batch mean / rstd [Cp];
+    training mode updates the module's running statistics (momentum, unbiased variance) and num_batches_tracked exactly like nn.BatchNorm3d"""
+    N, Cp = t.shape[0], t.shape[-1]
+    dev = t.device
+    if bn.num_features != C or not bn.affine:
+        raise MisError(f"BatchNorm3d(num_features = {C}, affine) expected, got {bn}")
+    training = bn.training or not bn.track_running_stats
+    count = float(N * t[0, ..., 0].numel())
+    s = sq = None
+    if training:
+        s, sq = torch.empty(N, Cp, device=dev), torch.empty(N, Cp, device=dev)
+        ops.chanstats(t, s, sq)
+    rm = rv = None
+    if bn.track_running_stats:
+        rm, rv = _padded(bn.running_mean, Cp), _padded(bn.running_var, Cp, 1.0)
+    momentum = bn.momentum
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+        if momentum is None:                       # cumulative moving average (nn.BatchNorm semantics)
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    scale, shift = torch.empty(N, Cp, device=dev), torch.empty(N, Cp, device=dev)
+    mean, rstd = torch.empty(Cp, device=dev), torch.empty(Cp, device=dev)
+    ops.bn_fwd_finalize(s, sq, N, Cp, count, _padded(bn.weight, Cp), _padded(bn.bias, Cp), rm, rv, training, scale, shift, mean, rstd, eps=bn.eps,
+                        momentum=0.0 if momentum is None else momentum)
+    if training and bn.track_running_stats:
+        bn.running_mean.copy_(rm[:C])
+        bn.running_var.copy_(rv[:C])
+    return scale, shift, mean, rstd, training, count
+
+
+def _bn_backward(dz, x, C, gamma, mean, rstd, training, count):
+    """dz = dL/d(BatchNorm output), x = its input -> (dx, dgamma, dbeta)"""
+    N, Cp = x.shape[0], x.shape[-1]
+    dev = x.device
+    grid = tuple(x.shape[:4])
+    S1, S2 = torch.empty(N, Cp, device=dev), torch.empty(N, Cp, device=dev)
+    ops.gn_bwd_stats(dz, x, Cp, False, grid, S1, S2, Cp, 0)
+    p, q, r = (torch.empty(N, Cp, device=dev) for _ in range(3))
+    dgamma, dbeta = torch.empty(Cp, device=dev), torch.empty(Cp, device=dev)
+    ops.bn_bwd_finalize(S1, S2, mean, rstd, _padded(gamma, Cp), N, Cp, count, training, p, q, r, dgamma, dbeta)
+    dx = torch.empty_like(x)
+    ops.gn_bwd_apply(dz, x, Cp, False, grid, p, q, r, Cp, 0, dx)
+    return dx, dgamma[:C].contiguous(), dbeta[:C].contiguous()
+
+
+# ---- [GroupNorm | BatchNorm ->] Conv3d [+ bias] [-> ReLU] -------------------------------------------------------------------------------------------
 class _Conv(torch.autograd.Function):
     """x (N, D, H, W, Cinp) -> y (N, D, H, W, Coutp).  weight: the reference's (Cout, Cin, k, k, k) fp32 parameter, k = 3 (padding 1) or 1.  A GroupNorm in
     front of the convolution is folded into the operand staging of the forward and of the weight-gradient kernel (the normalised tensor is never written);
     a ReLU behind it is the forward's epilogue."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, cin, cout, groups, relu):
+    def forward(ctx, x, weight, bias, gamma, beta, cin, cout, groups, relu, bn=None):
         x = x.contiguous()
         dev, dt = x.device, x.dtype
         ks = weight.shape[-1]
@@ -147,7 +200,11 @@ class _Conv(torch.autograd.Function):
         wd = torch.empty(taps, cinp, coutp, dtype=dt, device=dev)
         ops.pack_conv_weight(wpad, wf, wd)
         scale = shift = mean = rstd = None
-        if gamma is not None:
+        ctx.bn = None
+        if bn is not None:
+            scale, shift, mean, rstd, training, count = _bn_forward(x, cin, bn)
+            ctx.bn = (training, count)
+        elif gamma is not None:
             scale, shift, mean, rstd = _gn_forward(x, cin, groups, gamma.detach().float(), beta.detach().float())
         bpad = None
         if bias is not None:
@@ -179,15 +236,17 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0] or gamma is not None:
             dn = torch.empty_like(x)
             ops.conv_igemm(g, wd, dn, ksize=ks, Cin=coutp, Cout=cinp)
-            if gamma is not None:
+            if ctx.bn is not None:
+                dx, dgamma, dbeta = _bn_backward(dn, x, cin, gamma, mean, rstd, *ctx.bn)
+            elif gamma is not None:
                 dx, dgamma, dbeta = _gn_backward(dn, x, cin, groups, gamma, mean, rstd)
             else:
                 dx = dn
-        return dx, dw, db, dgamma, dbeta, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None
 
 
-def conv(a, weight, bias=None, gn=None, relu=False):
-    """gn = (nn.GroupNorm in front of the convolution) or None"""
+def conv(a, weight, bias=None, gn=None, relu=False, bn=None):
+    """gn / bn = the nn.GroupNorm / nn.BatchNorm3d in front of the convolution, or None: folded into the operand staging"""
     cout, cin = weight.shape[:2]
     if cin != a.C:
         raise MisError(f"conv block: input has {a.C} channels, the weight expects {cin}")
@@ -197,16 +256,22 @@ def conv(a, weight, bias=None, gn=None, relu=False):
         gamma, beta, groups = gn.weight, gn.bias, gn.num_groups
         if gn.num_channels != cin or abs(gn.eps - 1e-5) > 0:
             raise MisError("conv block: GroupNorm(num_channels = conv in_channels, eps = 1e-5) expected")
-    return CL(_Conv.apply(a.t, weight, bias, gamma, beta, cin, cout, groups, relu), cout)
+    if bn is not None:
+        gamma, beta = bn.weight, bn.bias
+    return CL(_Conv.apply(a.t, weight, bias, gamma, beta, cin, cout, groups, relu, bn), cout)
 
 
 # ---- [GroupNorm ->] activation behind a convolution ('cge', 'cl', 'crg', ...) ------------------------------------------------------------------------
 class _NormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, C, groups, act, slope):
+    def forward(ctx, x, gamma, beta, C, groups, act, slope, bn=None):
         x = x.contiguous()
         scale = shift = mean = rstd = None
-        if gamma is not None:
+        ctx.bn = None
+        if bn is not None:
+            scale, shift, mean, rstd, training, count = _bn_forward(x, C, bn)
+            ctx.bn = (training, count)
+        elif gamma is not None:
             scale, shift, mean, rstd = _gn_forward(x, C, groups, gamma.detach().float(), beta.detach().float())
         y = torch.empty_like(x)
         ops.norm_act_fwd(x, y, scale, shift, act, slope)
@@ -225,13 +290,16 @@ class _NormAct(torch.autograd.Function):
         else:
             dz = g
         if gamma is None:
-            return dz, None, None, None, None, None, None
-        dx, dgamma, dbeta = _gn_backward(dz, x, C, groups, gamma, mean, rstd)
-        return dx, dgamma, dbeta, None, None, None, None
+            return dz, None, None, None, None, None, None, None
+        if ctx.bn is not None:
+            dx, dgamma, dbeta = _bn_backward(dz, x, C, gamma, mean, rstd, *ctx.bn)
+        else:
+            dx, dgamma, dbeta = _gn_backward(dz, x, C, groups, gamma, mean, rstd)
+        return dx, dgamma, dbeta, None, None, None, None, None
 
 
-def norm_act(a, gn=None, act=None, slope=None):
-    """act: None | 'r' | 'l' | 'e' (create_conv's letters)"""
+def norm_act(a, gn=None, act=None, slope=None, bn=None):
+    """act: None | 'r' | 'l' | 'e' (create_conv's letters); gn / bn: the normalisation in front of it (one fused pass)"""
     code, sl = (ops.ACT_NONE, 0.0) if act is None else ACT_CODES[act]
     if slope is not None:
         sl = slope
@@ -241,9 +309,56 @@ def norm_act(a, gn=None, act=None, slope=None):
         gamma, beta, groups = gn.weight, gn.bias, gn.num_groups
         if gn.num_channels != a.C:
             raise MisError(f"GroupNorm over {gn.num_channels} channels applied to {a.C}")
-    if gn is None and act is None:
+    if bn is not None:
+        gamma, beta = bn.weight, bn.bias
+    if gn is None and bn is None and act is None:
         return a
-    return CL(_NormAct.apply(a.t, gamma, beta, a.C, groups, code, sl), a.C)
+    return CL(_NormAct.apply(a.t, gamma, beta, a.C, groups, code, sl, bn), a.C)
+
+
+# ---- dropout ('d' = nn.Dropout, 'D' = nn.Dropout2d of create_conv, buildingblocks.py:105-109) -------------------------------------------------------------------
+class _Dropout(torch.autograd.Function):
+    """training-mode dropout: y = x * m / (1 - p).  The Bernoulli draws come from torch's generator on the device (torch.manual_seed governs them, as it governs the
+    reference's; the reference's CPU stream itself is not reproduced: dropout parity is statistical), the arithmetic is mis_mask_scale / mis_norm_act_fwd.
+    channelwise (Dropout2d on a 5-D input = torch's feature dropout): one draw per (sample, channel), applied as a per-(n, c) scale table."""
+
+    @staticmethod
+    def forward(ctx, x, C, p, channelwise):
+        x = x.contiguous()
+        N, Cp = x.shape[0], x.shape[-1]
+        keep = 1.0 - p
+        y = torch.empty_like(x)
+        if channelwise:
+            table = torch.zeros(N, Cp, device=x.device)
+            table[:, :C] = torch.empty(N, C, device=x.device).bernoulli_(keep) / keep
+            ops.norm_act_fwd(x, y, table, torch.zeros_like(table), ops.ACT_NONE)
+            ctx.save_for_backward(table)
+        else:
+            mask = torch.empty(x.shape, dtype=x.dtype, device=x.device).bernoulli_(keep)
+            ops.mask_scale(x, mask, y, 1.0 / keep)
+            ctx.save_for_backward(mask)
+        ctx.cfg = (channelwise, keep)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (m,) = ctx.saved_tensors
+        channelwise, keep = ctx.cfg
+        g = g.contiguous()
+        dx = torch.empty_like(g)
+        if channelwise:
+            ops.norm_act_fwd(g, dx, m, torch.zeros_like(m), ops.ACT_NONE)
+        else:
+            ops.mask_scale(g, m, dx, 1.0 / keep)
+        return dx, None, None, None
+
+
+def dropout(a, p, training, channelwise=False):
+    if not training or p <= 0.0:
+        return a
+    if p >= 1.0:
+        raise MisError("dropout with p = 1 zeroes everything: refuse")
+    return CL(_Dropout.apply(a.t, a.C, float(p), channelwise), a.C)
 
 
 # ---- pooling -------------------------------------------------------------------------------------------------------------------------------------
@@ -421,32 +536,33 @@ def conv_transpose_2x(a, weight, size):
 
 # ---- create_conv order strings -------------------------------------------------------------------------------------------------------------------------
 def run_single_conv(mod, a):
-    """mod: a SingleConv container (children named as create_conv names them, `mod.order` = the order string).  Fusions: 'g' directly in front of 'c'
-    is folded into the convolution, 'r' directly behind 'c' is its epilogue, 'g' + non-linearity behind the convolution is one pass."""
+    """mod: a SingleConv container (children named as create_conv names them, `mod.order` = the order string).  Fusions: 'g' / 'b' directly in front of 'c'
+    is folded into the convolution, 'r' directly behind 'c' is its epilogue, 'g' / 'b' + non-linearity behind the convolution is one pass."""
     order = mod.order
     i = 0
     while i < len(order):
         ch = order[i]
         nxt = order[i + 1] if i + 1 < len(order) else ""
-        if ch == "g" and nxt == "c":
+        if ch in "gb" and nxt == "c":
             relu = order[i + 2:i + 3] == "r"
-            a = conv(a, mod.conv.weight, mod.conv.bias, gn=mod.groupnorm, relu=relu)
+            kw = dict(gn=mod.groupnorm) if ch == "g" else dict(bn=mod.batchnorm)
+            a = conv(a, mod.conv.weight, mod.conv.bias, relu=relu, **kw)
             i += 3 if relu else 2
         elif ch == "c":
             relu = nxt == "r"
             a = conv(a, mod.conv.weight, mod.conv.bias, relu=relu)
             i += 2 if relu else 1
-        elif ch == "g":
+        elif ch in "gb":
             act = nxt if nxt in ACT_CODES else None
-            a = norm_act(a, gn=mod.groupnorm, act=act)
+            kw = dict(gn=mod.groupnorm) if ch == "g" else dict(bn=mod.batchnorm)
+            a = norm_act(a, act=act, **kw)
             i += 2 if act else 1
         elif ch in ACT_CODES:
             a = norm_act(a, act=ch)
             i += 1
         elif ch in "dD":
-            if mod.training and getattr(mod, "dropout_prob", 0.0) > 0:
-                raise NotImplementedError("dropout inside a conv layer ('d' / 'D') is not built on MI355X for training; eval mode is the identity")
+            a = dropout(a, getattr(mod, "dropout_prob", 0.0), mod.training, channelwise=(ch == "D"))
             i += 1
         else:
-            raise NotImplementedError(f"layer order character '{ch}' is not built on MI355X (built: g, c, r, l, e)")
+            raise NotImplementedError(f"layer order character '{ch}' is not built on MI355X (built: g, b, c, r, l, e, d, D)")
     return a

@@ -482,6 +482,51 @@ extern "C" int mis_aug_pointwise(const float* src, float* dst, long long n, floa
     return MIS_OK;
 }
 
+// min / max of a volume (Normalize with data-derived bounds): per-block partials, then one block
+__global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ x, long long n, float* __restrict__ part, int final_stage) {
+    __shared__ float smin[256], smax[256];
+    float lo = INFINITY, hi = -INFINITY;
+    if (!final_stage) {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+            const float v = x[i];
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+        }
+    } else {        // x = the partials [nblocks][2]
+        for (long long i = threadIdx.x; i < n; i += 256) {
+            lo = fminf(lo, x[2 * i]);
+            hi = fmaxf(hi, x[2 * i + 1]);
+        }
+    }
+    smin[threadIdx.x] = lo;
+    smax[threadIdx.x] = hi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + o]);
+            smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + o]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = smin[0];
+        part[2 * blockIdx.x + 1] = smax[0];
+    }
+}
+
+extern "C" int mis_minmax(const float* x, long long n, float* workspace, float* out, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(x && workspace && out && n > 0, MIS_EINVAL, "minmax: bad argument");
+    long long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(minmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, workspace, 0);
+    MIS_LAUNCH_CHECK("minmax");
+    hipLaunchKernelGGL(minmax_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, blocks, out, 1);
+    MIS_LAUNCH_CHECK("minmax(final)");
+    return MIS_OK;
+}
+
 extern "C" int mis_aug_contrast(const float* src, float* dst, long long n, float mean, float alpha, void* stream) {
     (void)hipGetLastError();
     MIS_REQUIRE(src && dst && n > 0, MIS_EINVAL, "aug_contrast: bad argument");

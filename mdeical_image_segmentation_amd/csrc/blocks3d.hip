@@ -317,6 +317,42 @@ extern "C" int mis_norm_act_bwd(int dtype, const void* dy, int dy_ld, const void
     return norm_act_common("norm_act_bwd", true, dtype, dy, dy_ld, x, x_ld, dz, dz_ld, N, npix, C, scale, shift, act, slope, stream);
 }
 
+// y = alpha * x * (mask > 0): training-mode nn.Dropout of a create_conv order ('d', reference model/unet3d/buildingblocks.py:105-106) - the Bernoulli mask is drawn by
+// the caller; the same kernel carries the gradient back (dx = alpha * dy * (mask > 0))
+template <typename T>
+__global__ __launch_bounds__(256) void mask_scale_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ m, int m_ld, T* __restrict__ y, int y_ld,
+                                                         long long npix, int C, float alpha) {
+    constexpr int EPC = Tr<T>::EPC;
+    const int nch = C / EPC;
+    const long long total = npix * nch;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        const long long pix = i / nch;
+        float f[EPC], g[EPC];
+        unpack_chunk<T>(*reinterpret_cast<const u32x4*>(x + (size_t)pix * x_ld + (size_t)ch * EPC), f);
+        unpack_chunk<T>(*reinterpret_cast<const u32x4*>(m + (size_t)pix * m_ld + (size_t)ch * EPC), g);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) f[e] = g[e] > 0.f ? alpha * f[e] : 0.f;
+        *reinterpret_cast<u32x4*>(y + (size_t)pix * y_ld + (size_t)ch * EPC) = pack_chunk<T>(f);
+    }
+}
+
+extern "C" int mis_mask_scale(int dtype, const void* x, int x_ld, const void* mask, int mask_ld, void* y, int y_ld, long long npix, int C, float alpha, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, MIS_EINVAL, "mask_scale: bad dtype %d", dtype);
+    const int EPC = dtype == MIS_BF16 ? 8 : 4;
+    MIS_REQUIRE(x && mask && y && npix > 0 && C > 0 && C % EPC == 0 && x_ld % EPC == 0 && mask_ld % EPC == 0 && y_ld % EPC == 0, MIS_EINVAL, "mask_scale: sizes / alignment");
+    long long blocks = (npix * (C / EPC) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIS_BF16)
+        hipLaunchKernelGGL(mask_scale_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, (const __bf16*)x, x_ld, (const __bf16*)mask, mask_ld, (__bf16*)y, y_ld, npix, C, alpha);
+    else
+        hipLaunchKernelGGL(mask_scale_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x, x_ld, (const float*)mask, mask_ld, (float*)y, y_ld, npix, C, alpha);
+    MIS_LAUNCH_CHECK("mask_scale");
+    return MIS_OK;
+}
+
 extern "C" int mis_gn_fwd_finalize_ld(const float* sum, const float* sq, int N, int C, int ld, int G, double count, const float* gamma,
                                       const float* beta, float eps, float* scale, float* shift, float* mean, float* rstd, void* stream) {
     (void)hipGetLastError();

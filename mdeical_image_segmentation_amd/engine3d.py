@@ -84,9 +84,15 @@ class _SC:
 
 
 class UNet3DEngine:
+    exact_dice, dice_group = False, None          # class defaults (the residual engines do not take the options)
+
     def __init__(self, in_channels=1, out_channels=3, f_maps=(64, 128, 256, 512), num_groups=8, dtype=torch.float32, device="cuda",
                  seed=None, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3, max_grad_norm=1.0, alpha=1.0, beta=1.0,
-                 upsample="default"):
+                 upsample="default", exact_dice=False, dice_group=None):
+        """exact_dice: under data parallelism (an initialised torch.distributed group) the Dice term is that of the GLOBAL batch - the 3*C per-class sums
+        (I_c, P_c, T_c: 36 bytes for C = 3) are all-reduced between the forward and the gradient part of the head, as the reference computes the loss once on the
+        gathered batch (model/unet3d/trainer.py:312-318, nn.DataParallel); default False = the DistributedDataParallel semantics (per-rank loss, averaged gradients)."""
+        self.exact_dice, self.dice_group = exact_dice, dice_group
         if upsample not in ("default", "nearest", "deconv"):
             raise MisError(f"UNet3DEngine: upsample must be 'default'/'nearest' or 'deconv', got {upsample!r}")
         self.deconv = upsample == "deconv"
@@ -358,7 +364,23 @@ class UNet3DEngine:
                   alpha=self.alpha, beta=self.beta)
         if train:
             kw.update(dy=self.g_d[L - 2], dw=self.Gr["final_conv.weight"], db=self.Gr["final_conv.bias"], grad_scale=grad_scale)
-        ops.head_loss(feat, wh, bh, **kw)
+        import torch.distributed as dist
+        if train and self.exact_dice and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.dice_group) > 1:
+            # global-batch Dice: forward part, SUM the per-class Dice sums (and the BCE means) over the ranks, redo the 40-flop loss formula on the summed values,
+            # then the gradient part from them.  grad_scale carries 1 / world for the SUM all-reduce of the gradients: the BCE term is a mean of rank means and takes
+            # it; the Dice gradient from global sums already is the global derivative, hence beta x world.
+            world = dist.get_world_size(self.dice_group)
+            ops.head_loss(feat, wh, bh, phase=1, **kw)
+            C = self.cout
+            sums = self.loss_buf[1:2 + 3 * C]                                # [bce mean, I_c, P_c, T_c]
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.dice_group)
+            sums[0:1].div_(world)
+            inter, den = sums[1:1 + C], (sums[1 + C:1 + 2 * C] + sums[1 + 2 * C:1 + 3 * C]).clamp_(min=1e-6)
+            self.loss_buf[0:1] = self.alpha * sums[0:1] + self.beta * (1.0 - (2.0 * inter / den).mean())
+            kw["beta"] = self.beta * world
+            ops.head_loss(feat, wh, bh, phase=2, **kw)
+        else:
+            ops.head_loss(feat, wh, bh, **kw)
         return self.loss_buf[:1], self.logits, self.argmax
 
     def head_backward(self, dlogits):

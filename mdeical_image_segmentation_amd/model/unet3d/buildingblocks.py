@@ -17,7 +17,7 @@ from .se import ChannelSpatialSELayer3D
 
 def create_conv(in_channels, out_channels, kernel_size, order, num_groups, padding, dropout_prob, is3d):
     """buildingblocks.py:14-113: the (name, module) list of one conv layer for an order string over 'c' conv, 'g' groupnorm, 'r' ReLU, 'l' LeakyReLU, 'e' ELU,
-    'd' / 'D' dropout.  The conv has a bias only without a norm in the order (:62).  'b' (BatchNorm3d) is not built."""
+    'b' batchnorm, 'd' / 'D' dropout.  The conv has a bias only without a norm in the order (:62)."""
     assert "c" in order, "Conv layer MUST be present"
     assert order[0] not in "rle", "Non-linearity cannot be the first operation in the layer"
     if not is3d:
@@ -46,7 +46,7 @@ def create_conv(in_channels, out_channels, kernel_size, order, num_groups, paddi
         elif char == "D":
             mods.append(("dropout2d", nn.Dropout2d(p=dropout_prob)))
         elif char == "b":
-            raise NotImplementedError("BatchNorm3d layers ('b') are not built on MI355X: use a GroupNorm order ('gcr', 'cge', ...)")
+            mods.append(("batchnorm", nn.BatchNorm3d(in_channels if i < order.index("c") else out_channels)))
         else:
             raise ValueError(f"Unsupported layer type '{char}'. MUST be one of ['b', 'g', 'r', 'l', 'e', 'c', 'd', 'D']")
     return mods

@@ -660,6 +660,13 @@ def norm_act_bwd(dy, x, dz, scale, shift, act, slope=0.0):
           "mis_norm_act_bwd")
 
 
+def mask_scale(x, mask, y, alpha):
+    """y = alpha * x * (mask > 0) (dropout: mask = the Bernoulli draws in the activation dtype)"""
+    lib = load()
+    x, mask, y = _v(x), _v(mask), _v(y)
+    check(lib.mis_mask_scale(dtype_code(x.dtype), x.ptr, x.ld, mask.ptr, mask.ld, y.ptr, y.ld, x.npix, x.C, float(alpha), stream_ptr()), "mis_mask_scale")
+
+
 def gn_fwd_finalize_ld(s, sq, N, Cc, ld, G, count, gamma, beta, scale, shift, mean, rstd, eps=1e-5):
     lib = load()
     check(lib.mis_gn_fwd_finalize_ld(s.data_ptr(), sq.data_ptr(), N, Cc, ld, G, float(count), gamma.data_ptr(), beta.data_ptr(), eps, scale.data_ptr(),

@@ -219,3 +219,56 @@ def test_unet_model_under_torch_ddp_two_ranks():
     for r, (worst, aliased) in res.items():
         assert worst < 2e-5, (r, worst)
         assert aliased, "a parameter no longer aliases the engine's flat buffer after DDP + optimizer steps"
+
+
+def _exact_dice_worker(rank, world, port, out):
+    """two ranks on cuda:0 over gloo, each with ONE volume of a 2-volume batch: with exact_dice the summed gradients and the loss are those of the single-process
+    run on the full batch (global Dice sums); without it they are not (per-rank Dice)"""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mdeical_image_segmentation_amd.ddp import GradReducer
+    from mdeical_image_segmentation_amd.engine3d import UNet3DEngine
+    torch.cuda.set_device(0)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 1, 16, 16, 16, generator=g).cuda()
+    t = (torch.rand(2, 3, 16, 16, 16, generator=g) > (0.3 + 0.4 * torch.arange(2).view(2, 1, 1, 1, 1))).float().cuda()      # unequal foreground per sample: per-rank Dice != global Dice
+    res = {}
+    for exact in (True, False):
+        eng = UNet3DEngine(1, 3, f_maps=(64, 128, 256), dtype=torch.float32, device="cuda:0", seed=0, exact_dice=exact)
+        loss, _, _ = eng.forward(x, t, train=True)                       # single process, full batch: the reference semantics
+        full_loss = loss.item()
+        eng.backward()
+        torch.cuda.synchronize()
+        ref = eng.flat.g.clone()
+        red = GradReducer(eng.flat)
+        xs, ts = x[rank:rank + 1].contiguous(), t[rank:rank + 1].contiguous()
+        # (the full-batch call above took the non-distributed branch only because its batch is what one rank would hold; the group IS initialised:
+        #  with exact=True it already all-reduced its sums over two ranks that hold the same data - which doubles I, P, T alike and leaves the Dice ratio unchanged)
+        loss, _, _ = eng.forward(xs, ts, train=True, grad_scale=1.0 / world)
+        eng.backward(stage_cb=red.stage_done)
+        red.finish()
+        torch.cuda.synchronize()
+        lt = loss.clone()
+        if not exact:
+            dist.all_reduce(lt)
+            lt /= world
+        res[exact] = ((eng.flat.g - ref).abs().max().item() / ref.abs().max().item(), abs(lt.item() - full_loss))
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_exact_dice_two_ranks_equals_the_full_batch():
+    """SURVEY §8e / reference model/unet3d/trainer.py:312-318: with `exact_dice` the 36-byte all-reduce of the Dice partial sums makes a 2-rank step equal to the
+    single-process step on the gathered batch (loss and every gradient); the default per-rank Dice (DDP semantics) measurably is not"""
+    world = 2
+    port = _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_exact_dice_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    assert set(res) == {0, 1}
+    for r, d in res.items():
+        gerr, lerr = d[True]
+        assert gerr < 2e-5 and lerr < 2e-6, (r, "exact", gerr, lerr)
+        gerr, lerr = d[False]
+        assert gerr > 1e-4 or lerr > 1e-5, (r, "per-rank Dice should differ from the global-batch Dice on this data", gerr, lerr)

@@ -156,8 +156,8 @@ def test_single_conv_bf16(monkeypatch):
 
 def test_unbuilt_orders_raise():
     b = bb()
-    with pytest.raises(NotImplementedError):
-        b.SingleConv(8, 8, order="cbr")
+    with pytest.raises(ValueError):
+        b.SingleConv(8, 8, order="cxr")
     with pytest.raises(NotImplementedError):
         b.SingleConv(8, 8, kernel_size=5, padding=2)
     m = b.SingleConv(8, 8, order="gcr")
@@ -286,3 +286,120 @@ def test_route_selection(monkeypatch):
     monkeypatch.setenv("MISAMD_3D_ROUTE", "fused")
     with pytest.raises(Exception, match="outside the fused"):
         m._route(torch.empty(1, 1, 15, 16, 16))
+
+
+# ---- against the REAL reference modules (tests/golden/g17_orders.npz, made by tests/golden/make_golden_orders.py from model/unet3d/buildingblocks.py) -----------
+# the cases above compare with a float64 copy of the MIRROR's module tree - a mis-built order would agree with itself.  Here the parameters,
+# inputs, outputs and gradients come from the reference's own create_conv / SingleConv / ResNetBlock / ResidualUNet3D(layer_order='cge').
+def _g17():
+    from conftest import load_golden
+    return load_golden("g17_orders.npz")
+
+
+def _load_params(m, g, key):
+    names = [str(n) for n in g[f"{key}/names"]]
+    assert names == [n for n, _ in m.named_parameters()], (key, "module tree differs from the reference's", names, [n for n, _ in m.named_parameters()])
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            ref = torch.from_numpy(g[f"{key}/p/{n}"])
+            assert tuple(ref.shape) == tuple(p.shape), (key, n)
+            p.copy_(ref)
+
+
+def _check_against_golden(m, g, key, tol=3e-5):
+    x = torch.from_numpy(g[f"{key}/x"]).to(DEV).requires_grad_(True)
+    y = m(x)
+    y.backward(torch.from_numpy(g[f"{key}/gy"]).to(DEV))
+    errs = {"out": rel(y, torch.from_numpy(g[f"{key}/y"])), "dx": rel(x.grad, torch.from_numpy(g[f"{key}/dx"]))}
+    for n, p in m.named_parameters():
+        errs["d" + n] = rel(p.grad, torch.from_numpy(g[f"{key}/g/{n}"]))
+    bad = {k: v for k, v in errs.items() if not v <= tol}
+    assert not bad, (key, bad)
+    return errs
+
+
+@pytest.mark.parametrize("key,order,cin,cout", [("cge", "cge", 24, 40), ("cl", "cl", 8, 16), ("crg", "crg", 16, 32), ("gcl", "gcl", 16, 24)])
+def test_single_conv_orders_vs_reference_golden(key, order, cin, cout, monkeypatch):
+    monkeypatch.setenv("MISAMD_DTYPE", "f32")
+    g = _g17()
+    m = bb().SingleConv(cin, cout, order=order, dropout_prob=0.25).to(DEV)
+    _load_params(m, g, key)
+    _check_against_golden(m.train(), g, key)
+
+
+@pytest.mark.parametrize("key,order,cin,cout", [("bcr", "bcr", 12, 20), ("cbr", "cbr", 12, 20), ("cbl", "cbl", 6, 10)])
+def test_batchnorm_orders_vs_reference_golden(key, order, cin, cout, monkeypatch):
+    """'b' = nn.BatchNorm3d (buildingblocks.py:93-104): batch statistics in training (folded into the conv's operand staging in front of it, one fused pass behind it),
+    running statistics updated with momentum 0.1 / the unbiased variance, eval mode on the running statistics"""
+    monkeypatch.setenv("MISAMD_DTYPE", "f32")
+    g = _g17()
+    m = bb().SingleConv(cin, cout, order=order).to(DEV)
+    _load_params(m, g, key)
+    _check_against_golden(m.train(), g, key)
+    for n, b in m.named_buffers():
+        ref = torch.from_numpy(g[f"{key}/b/{n}"])
+        if n.endswith("num_batches_tracked"):
+            assert int(b) == int(ref) == 1
+        else:
+            assert torch.allclose(b.cpu(), ref, rtol=1e-5, atol=1e-6), (key, n, (b.cpu() - ref).abs().max())
+    with torch.no_grad():
+        ye = m.eval()(torch.from_numpy(g[f"{key}/x"]).to(DEV))
+    assert rel(ye, torch.from_numpy(g[f"{key}/y_eval"])) <= 3e-5
+
+
+@pytest.mark.parametrize("key,order,cin,cout", [("gcrd", "gcrd", 16, 16), ("cbrD", "cbrD", 8, 12)])
+def test_dropout_orders(key, order, cin, cout, monkeypatch):
+    """'d' / 'D' (buildingblocks.py:105-109): eval mode = the identity, pinned by the reference's eval outputs and gradients; training mode: the Bernoulli stream is
+    torch's device generator, not the reference's CPU stream, so the statement is statistical - a p-fraction of elements (or of (sample, channel) slices for 'D',
+    torch's feature dropout on 5-D inputs) is zeroed, the rest is the eval output times 1 / (1 - p), and the backward pass uses the same mask"""
+    monkeypatch.setenv("MISAMD_DTYPE", "f32")
+    g = _g17()
+    p = 0.25
+    m = bb().SingleConv(cin, cout, order=order, dropout_prob=p).to(DEV)
+    _load_params(m, g, key)
+    for n, b in m.named_buffers():                      # BatchNorm running statistics as the reference's module had them
+        b.copy_(torch.from_numpy(g[f"{key}/b/{n}"]).to(b.dtype))
+    m.eval()
+    x = torch.from_numpy(g[f"{key}/x"]).to(DEV).requires_grad_(True)
+    ye = m(x)
+    ye.backward(torch.from_numpy(g[f"{key}/gy"]).to(DEV))
+    assert rel(ye, torch.from_numpy(g[f"{key}/y_eval"])) <= 3e-5 and rel(x.grad, torch.from_numpy(g[f"{key}/dx_eval"])) <= 3e-5
+    if "b" in order:
+        return                                          # training mode would also switch BatchNorm to batch statistics: the dropout arithmetic is covered by 'gcrd'
+    m.train()
+    torch.manual_seed(5)
+    x2 = x.detach().clone().requires_grad_(True)
+    yt = m(x2)
+    dropped = (yt == 0) & (ye.detach() != 0)
+    frac = dropped.float().sum().item() / (ye.detach() != 0).float().sum().item()
+    assert abs(frac - p) < 0.03, frac
+    kept = ~dropped
+    assert torch.allclose(yt[kept], ye.detach()[kept] / (1 - p), rtol=1e-5, atol=1e-6)
+    gy = torch.ones_like(yt)
+    yt.backward(gy)
+    # same mask backwards: the input gradient equals that of (mask / (1 - p)) * eval-network, i.e. vanishes where every dependent output was dropped; cheap check:
+    # total gradient mass scales like the kept fraction / (1 - p) ~ 1
+    x3 = x.detach().clone().requires_grad_(True)
+    m.eval()
+    (m(x3) * kept.float() / (1 - p)).sum().backward()
+    assert rel(x2.grad, x3.grad) <= 3e-5
+
+
+@pytest.mark.parametrize("key,order,cin,cout", [("res_cge", "cge", 12, 24), ("res_gcl", "gcl", 16, 16)])
+def test_resnet_block_vs_reference_golden(key, order, cin, cout, monkeypatch):
+    monkeypatch.setenv("MISAMD_DTYPE", "f32")
+    g = _g17()
+    m = bb().ResNetBlock(cin, cout, order=order).to(DEV)
+    _load_params(m, g, key)
+    _check_against_golden(m.train(), g, key)
+
+
+def test_residual_unet3d_cge_vs_reference_golden(monkeypatch):
+    """the whole residual U-Net with layer_order='cge' (ELU, GroupNorm behind the convolutions, transposed-conv upsampling, sum joining) on the per-block route,
+    loaded with the REAL reference net's state dict"""
+    monkeypatch.setenv("MISAMD_DTYPE", "f32")
+    from mdeical_image_segmentation_amd.model.unet3d.model import ResidualUNet3D
+    g = _g17()
+    m = ResidualUNet3D(1, 2, f_maps=[8, 16, 32], num_levels=3, layer_order="cge").to(DEV)
+    _load_params(m, g, "resunet_cge")
+    _check_against_golden(m.train(), g, "resunet_cge", tol=1e-4)
