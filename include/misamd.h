@@ -437,6 +437,19 @@ int mis_probe_mfma(int which, const float* a, const float* b, float* c, void* st
 int mis_mt19937_words(unsigned int* key_io, int* pos_io, unsigned int* out, long long n, void* stream);
 int mis_legacy_normal(const unsigned int* words, long long nattempts, const float* in, float* out, long long count, double scale, int has_gauss, double gauss0,
                       unsigned long long* result5, void* stream);
+/* The same stream from many workgroups (round 3).  mis_mt_jump: states = [S][624] generator keys; for b < njumps, states[dst0 + b] = the key J words after
+ * states[src0 + b] (per_jump_src) or after states[src0] (all jumps from one key), where g_words = the 624-word bit mask of t^(J-1) mod phi - one mask, or one per
+ * jump (per_jump_mask: g_words[b*624..]; host side: augment/unet3d_augment/mt_jump.py; MT19937 is linear over GF(2)); `parts` workgroups share the sum of a jump.
+ * mis_mt_generate: chunk c (one workgroup) walks the stream positions [c*J, (c+1)*J) from states[c]; tempered words of positions [lo, hi) go to out[position - lo];
+ * raw_block >= 0 (or used_dev, below): the untempered 624 words of that block go to raw_out (numpy's key array).  mis_legacy_normal_par = mis_legacy_normal over many workgroups
+ * (count accepted attempts per block, scan, write), same result5 protocol; workspace >= mis_legacy_normal_par_workspace_bytes(nattempts). */
+int mis_mt_jump(unsigned int* states, int src0, int dst0, int njumps, const unsigned int* g_words, int per_jump_src, int per_jump_mask, int parts, void* stream);
+int mis_mt_generate(const unsigned int* states, int nchunks, long long J, long long lo, long long hi, unsigned int* out, long long raw_block, unsigned int* raw_out,
+                    const unsigned long long* used_dev /* optional: result5 of mis_legacy_normal_par still on the device - the raw block is then the one in which numpy's
+                    position ends after used_dev[0] attempts from position pos0 (nothing is written for 0 attempts) */, long long pos0, void* stream);
+size_t mis_legacy_normal_par_workspace_bytes(long long nattempts);
+int mis_legacy_normal_par(const unsigned int* words, long long nattempts, const float* in, float* out, long long count, double scale, int has_gauss, double gauss0,
+                          void* workspace, unsigned long long* result5, void* stream);
 
 /* ---- data-parallel gradient exchange: one RCCL communicator per process (csrc/comm.cpp) ----------------------------------------------
  * Replaces nn.DataParallel in the reference's 3-D trainer (model/unet3d/trainer.py:23-24) / the DDP wrapper HF Trainer adds under torchrun (train.py).

@@ -15,7 +15,7 @@ OUT_PLAIN, OUT_SHUFFLE2, OUT_UNSHUFFLE2 = 0, 1, 2
 EXPORTS = [
     "mis_last_error", "mis_version", "mis_conv_igemm", "mis_wgrad_workspace_bytes", "mis_wgrad",
     "mis_conv_last_dispatch", "mis_wgrad_last_dispatch", "mis_wgrad_last_nsplit", "mis_dispatch_override", "mis_dispatch_switch", "mis_gn_apply",
-    "mis_mt19937_words", "mis_legacy_normal",
+    "mis_mt19937_words", "mis_legacy_normal", "mis_mt_jump", "mis_mt_generate", "mis_legacy_normal_par_workspace_bytes", "mis_legacy_normal_par",
     "mis_comm_unique_id", "mis_comm_init", "mis_comm_world", "mis_allreduce_bucket", "mis_comm_finalize",
     "mis_conv3x3_first_fwd", "mis_conv3x3_first_wgrad_workspace_bytes", "mis_conv3x3_first_wgrad",
     "mis_colsum_workspace_bytes", "mis_colsum", "mis_maxpool2_fwd", "mis_maxpool2_bwd",
@@ -157,6 +157,8 @@ def load():
     lib.mis_bcedice_workspace_bytes.argtypes = [C.c_int]
     lib.mis_seg_metrics_workspace_bytes.restype = C.c_size_t
     lib.mis_seg_metrics_workspace_bytes.argtypes = [C.c_int, C.c_longlong]
+    lib.mis_legacy_normal_par_workspace_bytes.restype = C.c_size_t
+    lib.mis_legacy_normal_par_workspace_bytes.argtypes = [C.c_longlong]
     lib.mis_aug_rotate3_workspace_bytes.restype = C.c_size_t
     lib.mis_aug_rotate3_workspace_bytes.argtypes = [C.c_longlong, C.c_int, C.c_int, C.c_int]
     vp, i, ll, f, dbl = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double
@@ -245,6 +247,9 @@ def load():
         "mis_gather3d_bwd": [i, vp, i, vp, i, i, i, i, i, i, i, i, i, vp, vp, vp, vp],
         "mis_mt19937_words": [vp, vp, vp, ll, vp],
         "mis_legacy_normal": [vp, ll, vp, vp, ll, dbl, i, dbl, vp, vp],
+        "mis_mt_jump": [vp, i, i, i, vp, i, i, i, vp],
+        "mis_mt_generate": [vp, i, ll, ll, ll, vp, ll, vp, vp, ll, vp],
+        "mis_legacy_normal_par": [vp, ll, vp, vp, ll, dbl, i, dbl, vp, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

@@ -297,9 +297,15 @@ class Normalize:
             hi = dhi if hi is None else hi
         out = torch.empty_like(m)
         a = 1.0 / (float(hi) - float(lo) + self.eps)
-        b = -float(lo) * a
+        lib = load()
+        if abs(float(lo)) > 2.0 * (float(hi) - float(lo)):
+            # bounds far from 0 relative to their distance (data-derived bounds of an offset channel): a * m - a * lo would cancel in fp32; subtract first, as numpy does
+            check(lib.mis_aug_pointwise(m.data_ptr(), out.data_ptr(), m.numel(), 1.0, -float(lo), 0, 0.0, 0.0, 0.0, 0, stream_ptr()), "mis_aug_pointwise")
+            m, b = out, 0.0
+        else:
+            b = -float(lo) * a
         args = (a, b, 1, 0.0, 1.0) if self.norm01 else (2 * a, 2 * b - 1, 1, -1.0, 1.0)
-        check(load().mis_aug_pointwise(m.data_ptr(), out.data_ptr(), m.numel(), *args, 0.0, 0, stream_ptr()), "mis_aug_pointwise")
+        check(lib.mis_aug_pointwise(m.data_ptr(), out.data_ptr(), m.numel(), *args, 0.0, 0, stream_ptr()), "mis_aug_pointwise")
         return out
 
     def __call__(self, m):
@@ -321,10 +327,24 @@ class Normalize:
         return torch.stack([self._one(m[c].contiguous(), los[c], his[c]) for c in range(m.shape[0])])
 
 
-def _legacy_normal_on_device(random_state, m, std):
-    """m + random_state.normal(0, std, size=m.shape) with the field drawn ON THE DEVICE from numpy's own stream (csrc/mt19937.hip): the generator's key / position /
-    gauss cache go to the device, MT19937 words and the polar rejection loop run there, and the host RandomState is advanced by exactly the words consumed (plus the
-    new cache content) so that every later draw of the pipeline matches the reference."""
+_POLY_DEV = {}
+_PINNED = []
+
+
+def _pinned_key(key):
+    """a pinned staging copy of a generator key (ring of 8 buffers: a buffer is reused long after the stream-ordered upload that read it has run)"""
+    if not _PINNED:
+        _PINNED.extend([torch.empty(624, dtype=torch.int32).pin_memory() for _ in range(8)] + [0])
+    i = _PINNED[-1]
+    _PINNED[-1] = (i + 1) % 8
+    buf = _PINNED[i]
+    buf.copy_(torch.from_numpy(key.view(np.int32)))
+    return buf
+
+
+def _serial_legacy_normal(random_state, m, std):
+    """the round-2 path: ONE workgroup generates the words, one draws the normals (~10 ms per 128^3); kept as the A/B arm and cross-check of the parallel path
+    (AdditiveGaussianNoise(exact="serial"))"""
     lib = load()
     name, key, pos, has_gauss, cached = random_state.get_state()
     count = m.numel()
@@ -352,27 +372,120 @@ def _legacy_normal_on_device(random_state, m, std):
     return out.view(m.shape)
 
 
+class _PendingState:
+    """what the device still owes the host RandomState after a deferred exact-noise call: result5 (attempts used, gauss cache) and the key of the block in which the
+    stream position ends, both still in HBM.  resolve() reads them (2.6 KB; by the next call the kernels have long finished, so nothing stalls) and sets the state."""
+
+    def __init__(self, random_state, name, key, pos, res, raw):
+        self.rs, self.name, self.key, self.pos, self.res, self.raw = random_state, name, key, pos, res, raw
+
+    def resolve(self):
+        r = self.res.cpu().numpy()
+        if int(r[4]) != 1:
+            raise MisError("exact Gaussian noise: the pre-drawn word stream was too short (eight sigma of slack) - the field of the previous call is incomplete; "
+                           "use defer_state=False")
+        used = int(r[0])
+        key, pos = self.key, self.pos
+        if used:
+            end = pos + 4 * used
+            blk, pos = (end // 624 - 1, 624) if end % 624 == 0 else (end // 624, end % 624)
+            if blk > 0:
+                key = self.raw.cpu().numpy().view(np.uint32)
+        self.rs.set_state((self.name, key, pos, int(r[1]), float(np.int64(r[2]).view(np.float64)) if int(r[1]) else 0.0))
+
+
+def _legacy_normal_on_device(random_state, m, std, defer=False):
+    """m + random_state.normal(0, std, size=m.shape) with the field drawn ON THE DEVICE from numpy's own stream (csrc/mt19937.hip), by many workgroups: the word stream
+    is cut into up to 64 chunks whose start keys come from GF(2) jump-ahead (mt_jump.py: one level of independent jumps from the current key), every chunk generates its words, and the polar
+    rejection loop of numpy's legacy_gauss becomes count / scan / write passes.  The host RandomState ends exactly where the reference leaves it: key of the block in
+    which the last consumed word lies (read back: 2.5 KB), position, gauss cache.  defer=True: that read-back is left to the caller (returns (field, _PendingState)):
+    no host synchronisation inside the call."""
+    from . import mt_jump
+    lib = load()
+    name, key, pos, has_gauss, cached = random_state.get_state()
+    key = np.ascontiguousarray(key, dtype=np.uint32)
+    pos = int(pos)
+    dev = m.device
+    count = m.numel()
+    flat = m.reshape(-1)
+    out = torch.empty_like(flat)
+    pairs0 = (count + 1) // 2                                 # (the chunking must not depend on the gauss cache or on pos: its jump masks are cached per size)
+    attempts = max(int(pairs0 * 1.2733 + 8.0 * math.sqrt(max(pairs0, 1) * 0.274) + 64), 1)     # acceptance pi/4 per attempt, eight sigma of slack
+    while True:
+        lo, hi = pos, pos + 4 * attempts                      # stream positions, counted from key[0]
+        nblocks = (624 + 4 * attempts + 623) // 624           # blocks touched for the worst pos
+        want = 1                                              # chunks: a power of two, at most 64, at least 8 blocks each
+        while want < 64 and nblocks > 8 * want:
+            want *= 2
+        J = 624 * ((nblocks + want - 1) // want)
+        nchunks = (nblocks * 624 + J - 1) // J
+        states = torch.empty(nchunks, 624, dtype=torch.int32, device=dev)
+        stage = _pinned_key(key)                              # pinned: the upload is stream-ordered and does not block the host
+        states[0].copy_(stage, non_blocking=True)
+        if nchunks > 1:
+            pk = (J, nchunks, str(dev))
+            if pk not in _POLY_DEV:                           # ~25 ms per chunk on the host, once per volume size
+                _POLY_DEV[pk] = torch.from_numpy(mt_jump.jump_polys_from_start(J, nchunks).view(np.int32)).to(dev)
+            # every chunk key straight from states[0]: ONE level of independent jumps, each shared by 8 workgroups
+            check(lib.mis_mt_jump(states.data_ptr(), 0, 1, nchunks - 1, _POLY_DEV[pk].data_ptr(), 0, 1, 8, stream_ptr()), "mis_mt_jump")
+        words = torch.empty(4 * attempts, dtype=torch.int32, device=dev)
+        check(lib.mis_mt_generate(states.data_ptr(), nchunks, J, lo, hi, words.data_ptr(), -1, None, None, 0, stream_ptr()), "mis_mt_generate")
+        res = torch.zeros(5, dtype=torch.int64, device=dev)
+        ws = ops.workspace(lib.mis_legacy_normal_par_workspace_bytes(attempts), dev, "legacy_normal")
+        check(lib.mis_legacy_normal_par(words.data_ptr(), attempts, flat.data_ptr(), out.data_ptr(), count, float(std), int(has_gauss), float(cached), ws.data_ptr(),
+                                        res.data_ptr(), stream_ptr()), "mis_legacy_normal_par")
+        # the key of the block in which the position ends, chosen ON THE DEVICE from the attempts used
+        raw = torch.empty(624, dtype=torch.int32, device=dev)
+        check(lib.mis_mt_generate(states.data_ptr(), nchunks, J, 0, 0, None, -1, raw.data_ptr(), res.data_ptr(), pos, stream_ptr()), "mis_mt_generate")
+        pending = _PendingState(random_state, name, key, pos, res, raw)
+        pending.keep = (stage, states, words)                 # alive until the kernels that read them have run
+        if defer:
+            return out.view(m.shape), pending
+        if int(res[4].item()) == 1:
+            break
+        attempts *= 2                                         # (practically unreachable) the word stream ran out: start again from the same state with more
+    pending.resolve()
+    return out.view(m.shape)
+
+
 class AdditiveGaussianNoise:
     """transforms.py:608-619: if uniform() < p: std = uniform(scale); m + N(0, std).
     exact=True / "device" (the DEFAULT since round 3: a drop-in must give the reference's results): the reference's OWN field - numpy's MT19937 + legacy polar
     Box-Muller reproduced on the device, bit-comparable with the reference (golden g16_gauss_noise.npz), the RandomState left where the reference leaves it;
     exact=False: opt-in fast path, the counter-based generator of augment.hip (same distribution, one fused pass, a different field);
-    exact="host": numpy on the host + upload (the round-1 parity mode)."""
+    exact="host": numpy on the host + upload (the round-1 parity mode); exact="serial": the round-2 single-workgroup device path (A/B arm)."""
 
-    def __init__(self, random_state, scale=(0.0, 1.0), execution_probability=0.1, exact=True, **kwargs):
+    def __init__(self, random_state, scale=(0.0, 1.0), execution_probability=0.1, exact=True, defer_state=False, **kwargs):
+        """defer_state (exact device path only): the read-back that advances `random_state` to where the reference leaves it is postponed to the next call of this
+        transform (or flush()), so that the call itself never synchronises with the device.  Only for a RandomState this transform owns - `Transformer` builds one per
+        transform (transforms.py:751) and switches it on; with a RandomState shared between transforms keep the default."""
         self.execution_probability = execution_probability
         self.random_state = random_state
         self.scale = scale
         self.exact = exact
+        self.defer_state = defer_state
+        self._pending = None
+
+    def flush(self):
+        """bring `random_state` up to date (deferred mode)"""
+        if self._pending is not None:
+            p, self._pending = self._pending, None
+            p.resolve()
 
     def __call__(self, m):
+        self.flush()
         if self.random_state.uniform() < self.execution_probability:
             std = self.random_state.uniform(self.scale[0], self.scale[1])
             m = _dev(m)
             if self.exact == "host":
                 noise = self.random_state.normal(0, std, size=tuple(m.shape))
                 return (m.double() + torch.from_numpy(noise).to(m.device)).float()   # upload of a host-generated field
+            if self.exact == "serial":
+                return _serial_legacy_normal(self.random_state, m.contiguous().float(), std)
             if self.exact:
+                if self.defer_state:
+                    out, self._pending = _legacy_normal_on_device(self.random_state, m.contiguous().float(), std, defer=True)
+                    return out
                 return _legacy_normal_on_device(self.random_state, m.contiguous().float(), std)
             seed = int(self.random_state.randint(0, 2 ** 31 - 1))
             out = torch.empty_like(m)
@@ -586,4 +699,6 @@ class Transformer:
         config.update(c)
         config['random_state'] = np.random.RandomState(self.seed)
         aug_class = self._transformer_class(config['name'])
+        if aug_class is AdditiveGaussianNoise:
+            config.setdefault('defer_state', True)          # the RandomState above belongs to this transform alone: its read-back can wait for the next call
         return aug_class(**config)
