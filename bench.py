@@ -296,6 +296,10 @@ def main():
                 out["extra"] = ex
             print(json.dumps(out), flush=True)
     if DDP_ON:
+        if args.comm == "native":
+            from mdeical_image_segmentation_amd.ddp import native_comm_finalize
+            torch.cuda.synchronize()
+            native_comm_finalize()
         dist.destroy_process_group()
 
 

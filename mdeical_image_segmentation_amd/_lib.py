@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmisamd.so")
+# MISAMD_LIB: load another build of the library (diagnostic builds of scripts/ppt_ablate.sh, linked to a scratch path so that they never replace the shipped one)
+LIB_PATH = os.environ.get("MISAMD_LIB") or os.path.join(_HERE, "libmisamd.so")
 
 MIS_F32, MIS_BF16 = 0, 1
 OUT_PLAIN, OUT_SHUFFLE2, OUT_UNSHUFFLE2 = 0, 1, 2

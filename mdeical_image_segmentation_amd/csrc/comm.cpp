@@ -109,9 +109,15 @@ extern "C" int mis_comm_init(const void* unique_id128, int rank, int world) {
     return MIS_OK;
 }
 
-extern "C" int mis_comm_world(void) { return g_comm != nullptr ? g_world : 0; }
+extern "C" int mis_comm_world(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_comm != nullptr ? g_world : 0;
+}
 
+// (holds g_mu like init / finalize: a finalize on another thread cannot destroy the communicator under an all-reduce that is being enqueued - ADVICE r2;
+//  the call only ENQUEUES on `stream`, so the lock is held for microseconds)
 extern "C" int mis_allreduce_bucket(float* buf, long long n, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
     if (g_comm == nullptr) {
         mis_set_error("comm: no communicator (mis_comm_init)");
         return MIS_EINVAL;

@@ -51,7 +51,8 @@ class _FusedUNet(torch.autograd.Function):
         ctx.set_materialize_grads(False)         # an unused output arrives as None, not as a tensor of zeros
         out_loss = loss.clone().reshape(()) if loss is not None else images.new_zeros(())
         out_logits = logits.clone()
-        ctx.logits = out_logits if labels is not None else None
+        # (no copy of the logits is kept for the rare external-gradient path of backward: the generation check there guarantees that the engine's own logits buffer
+        #  still holds THIS forward - ADVICE r2: a tensor stored on ctx as a plain attribute made a reference cycle through grad_fn)
         return out_loss, out_logits
 
     @staticmethod
@@ -72,7 +73,7 @@ class _FusedUNet(torch.autograd.Function):
             # rare path: something besides the fused criterion reads `logits`
             d = g_logits.to(torch.float32)
             if g_loss is not None:
-                lg, lb = ctx.logits, ctx.labels
+                lg, lb = eng.logits, ctx.labels
                 if eng.cout > 1:      # CrossEntropyLoss(mean): (softmax - onehot) / (N*H*W)   (reference unet.py:1184-1188, :1208)
                     dl = torch.softmax(lg, 1)
                     dl.scatter_add_(1, lb.unsqueeze(1), torch.full_like(dl[:, :1], -1.0))

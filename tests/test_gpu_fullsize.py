@@ -94,3 +94,33 @@ def test_ping_pong_kernels_beyond_4gib_tensors():
         acc += part
     rel = ((dw - acc).norm() / acc.norm()).item()
     assert rel < 1e-5, rel
+
+
+@pytest.mark.parametrize("kind", ["2d", "3d"])
+def test_unsynchronised_steps_with_side_stream_reductions_are_bit_reproducible(kind, monkeypatch):
+    """ADVICE r2 (csrc/wgrad.hip wg_finish): the split-K slab reductions run on a second stream, ordered behind the MFMA kernel by an event from a process-lifetime ring.
+    K back-to-back UNSYNCHRONISED train steps (nothing waits between them, so a reduction of step i may still be running when step i+1's kernels are enqueued; the two
+    workspaces alternate) must end in bit-identical parameters and gradients on every repetition.  2-D: side-stream reductions are opt-in (MISAMD_SIDE_REDUCE=1);
+    the 3-D engines use them by default - bf16 here, i.e. the ping-pong weight-gradient kernels with one slab per persistent block."""
+    monkeypatch.setenv("MISAMD_SIDE_REDUCE", "1")
+    gen = torch.Generator().manual_seed(3)
+    if kind == "2d":
+        from mdeical_image_segmentation_amd.engine2d import UNet2DEngine
+        x = torch.randn(16, 1, 256, 256, generator=gen).to(DEV)
+        y = torch.randint(0, 2, (16, 256, 256), generator=gen).to(DEV)
+        make = lambda: UNet2DEngine(1, 2, dtype=torch.bfloat16, device=DEV, seed=0, lr=1e-4)      # noqa: E731
+    else:
+        from mdeical_image_segmentation_amd.engine3d import UNet3DEngine
+        x = torch.randn(2, 1, 64, 64, 64, generator=gen).to(DEV)
+        y = (torch.rand(2, 3, 64, 64, 64, generator=gen) > 0.5).float().to(DEV)
+        make = lambda: UNet3DEngine(1, 3, dtype=torch.bfloat16, device=DEV, seed=0, lr=1e-4)      # noqa: E731
+    finals = []
+    for rep in range(3):
+        eng = make()
+        assert eng.side_reduce
+        for _ in range(6):
+            eng.train_step(x, y)
+        torch.cuda.synchronize()
+        finals.append((eng.flat.p.clone(), eng.flat.g.clone()))
+    for p, g in finals[1:]:
+        assert torch.equal(p, finals[0][0]) and torch.equal(g, finals[0][1])
