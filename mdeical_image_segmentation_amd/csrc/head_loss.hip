@@ -11,7 +11,7 @@
 // model/unet3d/predictor.py:167, metrics.py:97 (lowest index wins ties).
 #include "common.hpp"
 
-constexpr int HEAD_BLOCKS = 1024;
+constexpr int HEAD_BLOCKS = 4096;    // (1024 until round 3: 250 dependent load -> shuffle -> store iterations per thread at 160^3 = 1.16 ms for a 1.25 GB pass)
 constexpr int HEAD_PSTRIDE = 288;   // floats per block partial: [C*64 dW][C db][1 loss][3*C dice sums], padded
 
 struct HeadArgs {
