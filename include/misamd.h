@@ -101,6 +101,11 @@ typedef struct MisWgradDesc {
     void* reduce_stream;     /* optional second HIP stream: the slab reduction (HBM-bound) is enqueued there, ordered after the MFMA kernel by
                               * an event, so that it runs under the caller's next kernel on `stream`.  The caller joins reduce_stream before
                               * reading dw / dbias and before reusing the workspace. NULL: everything on `stream`. */
+    float* dw_per_sample;    /* optional [N][Cout][Cin][taps] (layout 0, bf16 3x3 / 3x3x3 ping-pong path only): the weight gradient of every SAMPLE (dw = their sum).  The
+                              * split-K ranges then never straddle a sample.  Why: a GroupNorm in front of the convolution needs sum_v dyn * x per (sample, channel) for
+                              * its backward - which equals sum_{co,tap} W[co][c][tap] * dw_n[co][c][tap] once x is expressed through the normalised operand
+                              * (mis_gn_bwd_stats_from_dw): the pass over dyn and x that mis_gn_bwd_stats makes is not needed. */
+    float* dbias_per_sample; /* optional [N][Cout]: column sums of dy per sample (with dw_per_sample) */
 } MisWgradDesc;
 size_t mis_wgrad_workspace_bytes(const MisWgradDesc* d);
 int mis_wgrad(const MisWgradDesc* d, void* stream);
@@ -207,6 +212,14 @@ int mis_gn_apply(int dtype, const void* x, int x_ld, int Cs, int up, int N, int 
 size_t mis_gn_bwd_stats_workspace_bytes(int N, int Cs);
 int mis_gn_bwd_stats(int dtype, const void* dy, int dy_ld, const void* x, int x_ld, int Cs, int up, int N, int D, int H, int W,
                      float* workspace, float* S1, float* S2, int Ctot, int c_off, void* stream);
+/* The same S1 / S2 WITHOUT reading dyn and x (bf16 engines whose conv operand is the materialised xn = scale * x + shift): from the per-sample weight gradients
+ * (MisWgradDesc::dw_per_sample) and the sums of gy = dL/d(conv output) over the whole volume (MisWgradDesc::dbias_per_sample) and its boundary faces / edges /
+ * corners - S1 = sum_{co,tap} W * G_tap, T = sum_{co,tap} W * dW_n, S2 = (T - shift * S1) / scale (see csrc/groupnorm.hip).  w, dw_per_sample: [Cout][Cw][27]
+ * (reference layout, Cw >= Cs: Cw may include channel padding), scale / shift rows of stride sld, mean [N][groups]; writes S1, S2 [N][Cs]. */
+size_t mis_gn_bwd_stats_from_dw_workspace_bytes(int N, int Cout);
+int mis_gn_bwd_stats_from_dw(int dtype, const void* gy, int gy_ld, int N, int D, int H, int W, int Cout, const float* w, const float* dw_per_sample, int Cw,
+                             const float* gy_colsum_per_sample, const float* scale, const float* shift, int sld, const float* mean, int groups, int Cs,
+                             float* workspace, float* S1, float* S2, void* stream);
 int mis_gn_bwd_finalize(const float* S1, const float* S2, const float* mean, const float* rstd, const float* gamma, int N, int C, int G,
                         double count, float* p, float* q, float* r, float* dgamma, float* dbeta, void* stream);
 /* dx = (p*sum_children(dy) + mult*(q*x + r)) [* (x > 0)] [+ add] for one source */

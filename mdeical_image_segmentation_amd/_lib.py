@@ -23,7 +23,7 @@ EXPORTS = [
     "mis_pack_conv_weight", "mis_pack_convt_weight", "mis_pack_batch", "mis_head_workspace_bytes", "mis_head_loss",
     "mis_adamw_workspace_bytes", "mis_sumsq", "mis_adamw_step", "mis_adamw_step_dev", "mis_sumsq_npartials",
     "mis_chanstats_workspace_bytes", "mis_chanstats", "mis_nchw_to_nhwc", "mis_nhwc_to_nchw", "mis_probe_mfma",
-    "mis_gn_fwd_finalize", "mis_gn_bwd_stats_workspace_bytes", "mis_gn_bwd_stats", "mis_gn_bwd_finalize", "mis_gn_bwd_apply",
+    "mis_gn_fwd_finalize", "mis_gn_bwd_stats_workspace_bytes", "mis_gn_bwd_stats", "mis_gn_bwd_stats_from_dw_workspace_bytes", "mis_gn_bwd_stats_from_dw", "mis_gn_bwd_finalize", "mis_gn_bwd_apply",
     "mis_first3d_fwd", "mis_first3d_bwd_workspace_bytes", "mis_first3d_bwd", "mis_relu_mask",
     "mis_convt3_col2im", "mis_convt3_im2col", "mis_seg_metrics_workspace_bytes", "mis_seg_metrics", "mis_iou3d_counts", "mis_se_fc_fwd", "mis_se_apply_fwd", "mis_se_bwd_workspace_bytes", "mis_se_bwd_reduce", "mis_se_fc_bwd", "mis_se_bwd_apply", "mis_patch_gather_reflect", "mis_patch_accumulate", "mis_pred_finalize", "mis_bcedice_workspace_bytes", "mis_bcedice_fwd", "mis_bcedice_bwd", "mis_loss_workspace_bytes", "mis_ce3d_fwd", "mis_ce3d_bwd", "mis_pointloss_fwd", "mis_pointloss_bwd", "mis_maxpoolk_fwd", "mis_maxpoolk_bwd", "mis_bilinear_up_fwd", "mis_bilinear_up_bwd_workspace_bytes", "mis_bilinear_up_bwd", "mis_upconv_gather_fwd_workspace_bytes", "mis_upconv_gather_fwd", "mis_upconv_gather_bwd", "mis_cgm_gate", "mis_scale_sigmoid", "mis_segloss_workspace_bytes", "mis_segloss_fwd", "mis_segloss_bwd", "mis_add_act", "mis_expand1_fwd", "mis_expand1_bwd_workspace_bytes", "mis_expand1_bwd", "mis_bn_fwd_finalize", "mis_bn_bwd_finalize", "mis_affine_act", "mis_bn_bwd_stats_workspace_bytes", "mis_bn_bwd_stats", "mis_bn_bwd_apply",
     "mis_norm_act_fwd", "mis_norm_act_bwd", "mis_mask_scale", "mis_gn_fwd_finalize_ld", "mis_gn_bwd_finalize_ld", "mis_pool3d_fwd", "mis_pool3d_bwd", "mis_gather3d_fwd", "mis_gather3d_bwd",
@@ -66,6 +66,7 @@ class WgradDesc(C.Structure):
         ("dw", C.c_void_p), ("dw_layout", C.c_int), ("alpha", C.c_float),
         ("dbias", C.c_void_p),
         ("reduce_stream", C.c_void_p),
+        ("dw_per_sample", C.c_void_p), ("dbias_per_sample", C.c_void_p),
     ]
 
 
@@ -138,6 +139,8 @@ def load():
 
     lib.mis_gn_bwd_stats_workspace_bytes.restype = C.c_size_t
     lib.mis_gn_bwd_stats_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    lib.mis_gn_bwd_stats_from_dw_workspace_bytes.restype = C.c_size_t
+    lib.mis_gn_bwd_stats_from_dw_workspace_bytes.argtypes = [C.c_int, C.c_int]
     lib.mis_first3d_bwd_workspace_bytes.restype = C.c_size_t
     lib.mis_first3d_bwd_workspace_bytes.argtypes = []
     lib.mis_bilinear_up_bwd_workspace_bytes.restype = C.c_size_t
@@ -184,6 +187,7 @@ def load():
         "mis_gn_fwd_finalize": [vp, vp, i, f, vp, vp, i, f, i, i, dbl, vp, vp, f, i, vp, vp, vp, vp, vp],
         "mis_gn_bwd_stats": [i, vp, i, vp, i, i, i, i, i, i, i, vp, vp, vp, i, i, vp],
         "mis_gn_apply": [i, vp, i, i, i, i, i, i, i, vp, vp, i, i, vp, i, vp],
+        "mis_gn_bwd_stats_from_dw": [i, vp, i, i, i, i, i, i, vp, vp, i, vp, vp, vp, i, vp, i, i, vp, vp, vp, vp],
         "mis_gn_bwd_finalize": [vp, vp, vp, vp, vp, i, i, i, dbl, vp, vp, vp, vp, vp, vp],
         "mis_gn_bwd_apply": [i, vp, i, vp, i, i, i, i, i, i, i, vp, vp, vp, i, i, i, vp, i, vp, i, vp],
         "mis_first3d_fwd": [i, vp, vp, vp, i, i, i, i, i, vp, i, vp, i, i, vp],

@@ -278,6 +278,172 @@ extern "C" int mis_gn_bwd_stats(int dtype, const void* dy, int dy_ld, const void
     return MIS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Backward statistics WITHOUT a pass over dyn and x (round 3, bf16 engines with the materialised operand xn = a*x + b):
+//   T[n,c]  = sum_v dyn[n,v,c] * xn[n,v,c] = sum_{co,tap} W[co][c][tap] * dW_n[n][co][c][tap]        (dW_n = the weight gradient of sample n, zero padding included)
+//   S1[n,c] = sum_v dyn[n,v,c]             = sum_{co,tap} W[co][c][tap] * G[n][tap][co],   G = sum of g_y over the output voxels whose tap lands inside the volume
+//   S2[n,c] = sum_v dyn * x                = (T - b * S1) / a
+// G needs the total of g_y per (sample, channel) - the weight-gradient kernel's fused column sums - and its sums over the 6 faces, 12 edges and 8 corners of the
+// volume (inclusion - exclusion over the excluded boundary planes of a tap): 4 % of the voxels.  W is taken as the kernels see it (rounded to the storage type).
+// A channel whose scale a is exactly 0 (gamma = 0) carries no information about x in xn: its S2 is set to mean * S1 (dgamma of that channel reads 0; dx is exact
+// regardless: it only needs gamma * (S2 - mean * S1) = T - beta * S1).  mis_gn_bwd_stats stays the exact route for that corner and for fp32.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int GB_BSLABS = 16;
+
+// region r = sz*9 + sy*3 + sx, s = 0: the whole axis, 1: its first index, 2: its last; r = 0 (everything) is not computed here.  grid (26, N, GB_BSLABS)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_border_sums_kernel(const T* __restrict__ gy, int gy_ld, int C, int D, int H, int W, float* __restrict__ part /*[N][27][slabs][C]*/) {
+    constexpr int EPC = Tr<T>::EPC;
+    __shared__ float red[256 * 8];
+    const int r = blockIdx.x + 1, n = blockIdx.y, slab = blockIdx.z, nslabs = gridDim.z;
+    const int sel[3] = {r / 9, (r / 3) % 3, r % 3};
+    const int L[3] = {D, H, W};
+    int ext[3], org[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        ext[a] = sel[a] == 0 ? L[a] : 1;
+        org[a] = sel[a] == 2 ? L[a] - 1 : 0;
+    }
+    const long long nvox = (long long)ext[0] * ext[1] * ext[2];
+    const int nch = C / EPC;                       // <= 256
+    const int tid = threadIdx.x, ch = tid % nch, slot = tid / nch, nslots = 256 / nch;
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    if (slot < nslots) {
+        const T* base = gy + (size_t)n * D * H * W * gy_ld + (size_t)ch * EPC;
+        for (long long i = (long long)slab * nslots + slot; i < nvox; i += (long long)nslabs * nslots) {
+            const int x = org[2] + (int)(i % ext[2]);
+            const long long t = i / ext[2];
+            const int y = org[1] + (int)(t % ext[1]), z = org[0] + (int)(t / ext[1]);
+            float f[EPC];
+            unpack_chunk<T>(*reinterpret_cast<const u32x4*>(base + (((size_t)z * H + y) * W + x) * gy_ld), f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += f[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) red[tid * EPC + e] = acc[e];
+    __syncthreads();
+    if (slot == 0) {
+        for (int k = 1; k < nslots; ++k)
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += red[(k * nch + ch) * EPC + e];
+        float* o = part + (((size_t)n * 27 + r) * nslabs + slab) * C + (size_t)ch * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o[e] = acc[e];
+    }
+}
+
+// R[n][r][co] = sum over the slabs of region r (fixed order).  grid (26, N)
+__global__ __launch_bounds__(256) void gn_border_reduce_kernel(const float* __restrict__ part, int nslabs, int C, float* __restrict__ R /*[N][27][C]*/) {
+    const int r = blockIdx.x + 1, n = blockIdx.y;
+    for (int co = threadIdx.x; co < C; co += 256) {
+        const float* p = part + (((size_t)n * 27 + r) * nslabs) * C + co;
+        double v = 0.0;
+        for (int k = 0; k < nslabs; ++k) v += (double)p[(size_t)k * C];
+        R[((size_t)n * 27 + r) * C + co] = (float)v;
+    }
+}
+
+// G[n][tap][co] = total - faces + edges - corner for the boundary planes tap excludes.  grid (27, N), 256 threads over co
+__global__ __launch_bounds__(256) void gn_border_finalize_kernel(const float* __restrict__ R, const float* __restrict__ tot /*[N][C]*/, int C, float* __restrict__ G /*[N][27][C]*/) {
+    const int tap = blockIdx.x, n = blockIdx.y;
+    const int d[3] = {tap / 9 - 1, (tap / 3) % 3 - 1, tap % 3 - 1};
+    for (int co = threadIdx.x; co < C; co += 256) {
+        double g = 0.0;
+        for (int m = 0; m < 8; ++m) {              // subsets of the axes whose boundary plane is excluded
+            int r = 0, bits = 0;
+            bool ok = true;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                int s_ = 0;
+                if ((m >> a) & 1) {
+                    if (d[a] == 0) ok = false;
+                    s_ = d[a] < 0 ? 1 : 2;
+                    ++bits;
+                }
+                r = r * 3 + s_;
+            }
+            if (!ok) continue;
+            const double v = r == 0 ? (double)tot[(size_t)n * C + co] : (double)R[((size_t)n * 27 + r) * C + co];
+            g += (bits & 1) ? -v : v;
+        }
+        G[((size_t)n * 27 + tap) * C + co] = (float)g;
+    }
+}
+
+// grid (Cs, N); one block per (n, c): reductions over (co, tap) in a fixed order
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_from_dw_kernel(const float* __restrict__ w /*[Cout][Cw][27]*/, const float* __restrict__ dwn /*[N][Cout][Cw][27]*/, int Cout,
+                                                               int Cw, const float* __restrict__ G /*[N][27][Cout]*/, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, int sld, const float* __restrict__ mean, int groups, int cpg,
+                                                               float* __restrict__ S1, float* __restrict__ S2, int Ctot) {
+    __shared__ double rT[256], rS[256];
+    const int c = blockIdx.x, n = blockIdx.y;
+    double t_ = 0.0, s_ = 0.0;
+    const int total = Cout * 27;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int co = i / 27, tap = i - co * 27;
+        float wv = w[((size_t)co * Cw + c) * 27 + tap];
+        if constexpr (sizeof(T) == 2) wv = (float)(__bf16)wv;        // the packed operand the dgrad kernel multiplies with
+        t_ += (double)wv * (double)dwn[(((size_t)n * Cout + co) * Cw + c) * 27 + tap];
+        s_ += (double)wv * (double)G[((size_t)n * 27 + tap) * Cout + co];
+    }
+    rT[threadIdx.x] = t_;
+    rS[threadIdx.x] = s_;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            rT[threadIdx.x] += rT[threadIdx.x + o];
+            rS[threadIdx.x] += rS[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double a = scale[(size_t)n * sld + c], b = shift[(size_t)n * sld + c];
+        const double s1 = rS[0], tt = rT[0];
+        const double mu = mean[n * groups + c / cpg];
+        S1[(size_t)n * Ctot + c] = (float)s1;
+        S2[(size_t)n * Ctot + c] = (float)(a != 0.0 ? (tt - b * s1) / a : mu * s1);
+    }
+}
+
+extern "C" size_t mis_gn_bwd_stats_from_dw_workspace_bytes(int N, int Cout) { return ((size_t)N * 27 * GB_BSLABS * Cout + 2 * (size_t)N * 27 * Cout) * sizeof(float); }
+
+extern "C" int mis_gn_bwd_stats_from_dw(int dtype, const void* gy, int gy_ld, int N, int D, int H, int W, int Cout, const float* w, const float* dw_per_sample, int Cw,
+                                        const float* gy_colsum_per_sample, const float* scale, const float* shift, int sld, const float* mean, int groups, int Cs,
+                                        float* workspace, float* S1, float* S2, void* stream) {
+    (void)hipGetLastError();
+    const int EPC = dtype == MIS_BF16 ? 8 : 4;
+    MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, MIS_EINVAL, "gn_bwd_stats_from_dw: bad dtype");
+    MIS_REQUIRE(gy && w && dw_per_sample && gy_colsum_per_sample && scale && shift && mean && workspace && S1 && S2, MIS_EINVAL, "gn_bwd_stats_from_dw: null pointer");
+    MIS_REQUIRE(N > 0 && N <= 65535 && D > 0 && H > 0 && W > 0 && Cout > 0 && Cout % EPC == 0 && Cout / EPC <= 256 && gy_ld % EPC == 0 && Cs > 0 && Cs <= Cw &&
+                    Cs <= sld && groups > 0 && Cs % groups == 0,
+                MIS_EINVAL, "gn_bwd_stats_from_dw: sizes");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* part = workspace;
+    float* R = workspace + (size_t)N * 27 * GB_BSLABS * Cout;
+    float* G = R + (size_t)N * 27 * Cout;
+    if (dtype == MIS_BF16)
+        hipLaunchKernelGGL(gn_border_sums_kernel<__bf16>, dim3(26, N, GB_BSLABS), dim3(256), 0, s, (const __bf16*)gy, gy_ld, Cout, D, H, W, part);
+    else
+        hipLaunchKernelGGL(gn_border_sums_kernel<float>, dim3(26, N, GB_BSLABS), dim3(256), 0, s, (const float*)gy, gy_ld, Cout, D, H, W, part);
+    MIS_LAUNCH_CHECK("gn_border_sums");
+    hipLaunchKernelGGL(gn_border_reduce_kernel, dim3(26, N), dim3(256), 0, s, (const float*)part, GB_BSLABS, Cout, R);
+    MIS_LAUNCH_CHECK("gn_border_reduce");
+    hipLaunchKernelGGL(gn_border_finalize_kernel, dim3(27, N), dim3(256), 0, s, (const float*)R, gy_colsum_per_sample, Cout, G);
+    MIS_LAUNCH_CHECK("gn_border_finalize");
+    if (dtype == MIS_BF16)
+        hipLaunchKernelGGL(gn_stats_from_dw_kernel<__bf16>, dim3(Cs, N), dim3(256), 0, s, w, dw_per_sample, Cout, Cw, (const float*)G, scale, shift, sld, mean, groups,
+                           Cs / groups, S1, S2, Cs);
+    else
+        hipLaunchKernelGGL(gn_stats_from_dw_kernel<float>, dim3(Cs, N), dim3(256), 0, s, w, dw_per_sample, Cout, Cw, (const float*)G, scale, shift, sld, mean, groups,
+                           Cs / groups, S1, S2, Cs);
+    MIS_LAUNCH_CHECK("gn_stats_from_dw");
+    return MIS_OK;
+}
+
 // per (n, g): A, B -> per (n, c): p, q, r ; dgamma, dbeta.   xmult[c] = 1 for same-grid channels, 8 for upsampled
 // (S1/S2 were summed over the SOURCE voxels with dy pre-summed over children, which is exactly the full-grid sum).
 __global__ void gn_bwd_finalize_kernel(const float* __restrict__ S1, const float* __restrict__ S2, const float* __restrict__ mean,

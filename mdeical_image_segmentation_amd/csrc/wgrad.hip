@@ -376,8 +376,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 1 : 2)) void wgrad_kernel(co
 // (32 co x 32 ci) tile for up to 9 taps at a time: slab reads are contiguous along co, dw writes are contiguous
 // along (ci, tap) for layout 0 / (c, ab) for layout 1, via an LDS transpose.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int TT, int Cin, int Cout,
-                                                           float* __restrict__ dw, int layout, float alpha) {
+                                                           float* __restrict__ dw, int layout, float alpha, size_t group_stride_partial = 0, size_t group_stride_dw = 0) {
     __shared__ float tile[32][9][33];     // [ci][tap][co]: both the fill (co fastest) and the drain ((ci,tap) fastest) are conflict free
+    partial += blockIdx.z * group_stride_partial;      // blockIdx.z = slab group (per-sample gradients: one group of slabs and one output per sample)
+    dw += blockIdx.z * group_stride_dw;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
     const size_t slab = (size_t)TT * Cin * Cout;
@@ -421,7 +423,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 // Stage 0 of the slab reduction when there are many splits: slab z <- sum of slabs {z, z+Z, z+2Z, ...} (in place,
 // element-wise, float4, fixed order), so that the transposing kernel below only has Z <= 16 slabs left to add.
-__global__ __launch_bounds__(256) void wgrad_prereduce_kernel(float* __restrict__ partial, int nsplit, int Z, size_t E4) {
+__global__ __launch_bounds__(256) void wgrad_prereduce_kernel(float* __restrict__ partial, int nsplit, int Z, size_t E4, size_t group_stride = 0) {
+    partial += blockIdx.z * group_stride;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int z = blockIdx.y;
     if (i >= E4) return;
@@ -436,7 +439,9 @@ __global__ __launch_bounds__(256) void wgrad_prereduce_kernel(float* __restrict_
 
 // db[c] = alpha * sum over splits (and over the 4 (a,b) column groups for the transposed conv); one wave per output
 __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ bp, int nsplit, int Cout, int fold, float alpha,
-                                                                float* __restrict__ db) {
+                                                                float* __restrict__ db, size_t group_stride_bp = 0, size_t group_stride_db = 0) {
+    bp += blockIdx.z * group_stride_bp;
+    db += blockIdx.z * group_stride_db;
     const int cq = Cout / fold;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -448,6 +453,15 @@ __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __r
     }
     s = wave_sum(s);
     if (lane == 0) db[c] = alpha * s;
+}
+
+// dw = sum over samples of the per-sample gradients (fixed order)
+__global__ __launch_bounds__(256) void wgrad_sum_samples_kernel(const float* __restrict__ dwn, int N, size_t E, float* __restrict__ dw) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= E) return;
+    float s = dwn[i];
+    for (int n = 1; n < N; ++n) s += dwn[(size_t)n * E + i];
+    dw[i] = s;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -528,8 +542,34 @@ static int wg_finish(const MisWgradDesc* d, const WgPlan& p, float* bias_partial
         MIS_REQUIRE(ok, MIS_EHIP, "wgrad: could not order the reduction stream after the MFMA kernel");
         stream = side;
     }
-    int nslab = p.nsplit;
     const size_t E = (size_t)p.TT * d->Cin * d->Cout;     // multiple of 4 (channel tiles are multiples of 32)
+    if (d->dw_per_sample != nullptr) {
+        // per-sample gradients: the slabs of sample n are [n * k, (n + 1) * k) (wgrad_pp.hip's per-sample split plan); each group is reduced like the whole, then summed
+        const int k = p.nsplit / d->N;
+        int ns = k;
+        if (ns > 1) {       // down to ONE slab per sample with the wide element-wise kernel: the transposing kernel below has few blocks for small layers
+            hipLaunchKernelGGL(wgrad_prereduce_kernel, dim3((unsigned)((E / 4 + 255) / 256), 1, d->N), dim3(256), 0, stream, d->workspace, ns, 1, E / 4, (size_t)k * E);
+            MIS_LAUNCH_CHECK("wgrad_prereduce");
+            ns = 1;
+        }
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((d->Cout + 31) / 32, (d->Cin + 31) / 32, d->N), dim3(256), 0, stream, (const float*)d->workspace, ns, p.TT, d->Cin,
+                           d->Cout, d->dw_per_sample, 0, d->alpha, (size_t)k * E, E);
+        MIS_LAUNCH_CHECK("wgrad_reduce");
+        if (d->dbias_per_sample != nullptr) {
+            hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((d->Cout + 3) / 4, 1, d->N), dim3(256), 0, stream, (const float*)bias_partial, k, d->Cout, 1, d->alpha,
+                               d->dbias_per_sample, (size_t)k * d->Cout, (size_t)d->Cout);
+            MIS_LAUNCH_CHECK("wgrad_bias_reduce");
+        }
+        hipLaunchKernelGGL(wgrad_sum_samples_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, (const float*)d->dw_per_sample, d->N, E, d->dw);
+        MIS_LAUNCH_CHECK("wgrad_sum_samples");
+        if (d->dbias != nullptr) {
+            hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((d->Cout + 3) / 4), dim3(256), 0, stream, (const float*)bias_partial, p.nsplit, d->Cout, 1, d->alpha,
+                               d->dbias);
+            MIS_LAUNCH_CHECK("wgrad_bias_reduce");
+        }
+        return MIS_OK;
+    }
+    int nslab = p.nsplit;
     if (nslab > 4) {
         const int Z = 4;
         hipLaunchKernelGGL(wgrad_prereduce_kernel, dim3((unsigned)((E / 4 + 255) / 256), Z), dim3(256), 0, stream, d->workspace, nslab, Z,
@@ -559,7 +599,7 @@ static int wg_launch(const MisWgradDesc* d, const WgPlan& p, hipStream_t stream)
     a.dy = d->dy; a.dy_ld = d->dy_ld; a.partial = d->workspace;
     a.bias_partial = d->dbias != nullptr ? d->workspace + (size_t)p.nsplit * p.TT * d->Cin * d->Cout : nullptr;
     a.tilesD = p.tilesD; a.tilesH = p.tilesH; a.tilesW = p.tilesW; a.ntiles = p.ntiles; a.nsplit = p.nsplit; a.tps = p.tps;
-    a.nCi = p.nCi; a.nCo = p.nCo; a.KDn = p.KDn; a.TT = p.TT;
+    a.nCi = p.nCi; a.nCo = p.nCo; a.KDn = p.KDn; a.TT = p.TT; a.spb = 0; a.tpsamp = 0;
     const size_t lds = WIDE ? (size_t)(G::PHP + G::M) * 288 : (size_t)G::PHP * PSTR + (size_t)G::M * (sizeof(T) == 2 ? PSTR : 288);
     static std::atomic<unsigned long long> attr_done{0};
     if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&wgrad_kernel<T, G, USE_TR, WIDE>), lds, "wgrad")) return rc;
@@ -620,9 +660,12 @@ extern "C" int mis_wgrad(const MisWgradDesc* d, void* stream) {
         MIS_REQUIRE(okD && okH && okW, MIS_EUNSUPPORTED, "wgrad: source grid must equal the pixel grid or be exactly half of it");
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    MIS_REQUIRE(d->dw_per_sample == nullptr || (p.pp && d->dw_layout == 0 && wgrad_pp_splits_per_sample(d) > 0 && p.nsplit % d->N == 0), MIS_EUNSUPPORTED,
+                "wgrad: per-sample gradients need the bf16 3x3 / 3x3x3 ping-pong path (layout 0)");
+    MIS_REQUIRE(d->dbias_per_sample == nullptr || d->dw_per_sample != nullptr, MIS_EINVAL, "wgrad: dbias_per_sample needs dw_per_sample");
     if (p.pp) {
         g_wgrad_last_nsplit = p.nsplit;
-        float* bias_partial = d->dbias != nullptr ? d->workspace + (size_t)p.nsplit * p.TT * d->Cin * d->Cout : nullptr;
+        float* bias_partial = (d->dbias != nullptr || d->dbias_per_sample != nullptr) ? d->workspace + (size_t)p.nsplit * p.TT * d->Cin * d->Cout : nullptr;
         rc = launch_wgrad_pp(d, d->workspace, bias_partial, s, &g_wgrad_last);
         if (rc != MIS_OK) return rc;
         return wg_finish(d, p, bias_partial, s);

@@ -345,9 +345,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
     const int pc = IS3D ? pair / 3 : pair;
     const int ci_t = pc / a.nCo, co_t = pc - ci_t * a.nCo;
     const int ci0 = ci_t * 64, co0 = co_t * G::CO;
-    const int t_begin = split * a.tps;
+    int t_begin = split * a.tps;
     int t_end = t_begin + a.tps;
     if (t_end > a.ntiles) t_end = a.ntiles;
+    if (a.spb > 0) {               // per-sample split-K: this split's tile range lies inside ONE sample
+        const int smp = split / a.spb;
+        t_begin = smp * a.tpsamp + (split - smp * a.spb) * a.tps;
+        t_end = t_begin + a.tps;
+        if (t_end > (smp + 1) * a.tpsamp) t_end = (smp + 1) * a.tpsamp;
+    }
     const int tpi = a.tilesH * a.tilesW;
     auto tile_coords = [&](int t, int& n, int& h0, int& w0) {
         n = t / tpi;
@@ -430,8 +436,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int fj = 0; fj < 4; ++fj) acc[t][fj] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = (a.bias_partial != nullptr) && (ci_t == 0) && (wi == 0) && (!IS3D || kd == 1);     // one wave per group (3-D: of the centre-slice block)
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    // bias gradient / column sums of dY: wave wi of a group sums dY fragment fj = wi with ONE extra MFMA per k-step against an all-ones A operand (every row of the
+    // result is the column sum) - the VALU version (8 unpack + add per fragment on one wave per group) stretched that wave's R segment and with it every barrier
+    const bool do_bias = (a.bias_partial != nullptr) && (ci_t == 0) && (!IS3D || kd == 1);     // block-uniform (3-D: the centre-slice block, whose input plane always exists)
+    f32x4 bacc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16x8_t ones8 = __builtin_bit_cast(bf16x8_t, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
 
     int n, h0, w0, xn;
     bool zok;
@@ -481,10 +490,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
             });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            if (do_bias) {
-#pragma unroll
-                for (int fj = 0; fj < 4; ++fj) bsum[fj] += wp_sum8(B[fj]);
-            }
             if constexpr (ks == NS - 1) {
                 if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -497,6 +502,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
             for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
                 for (int fj = 0; fj < 4; ++fj) acc[tap][fj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[tap], B[fj], acc[tap][fj], 0, 0, 0);
+            if (do_bias) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, wi == 0 ? B[0] : (wi == 1 ? B[1] : (wi == 2 ? B[2] : B[3])), bacc, 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             if constexpr (ks == NS - 1) {
                 if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -522,15 +528,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
                 out[((size_t)(kd * 9 + tap) * a.Cin + ci) * a.Cout + co] = acc[tap][fj][r];
             }
         }
-    if (do_bias) {
-#pragma unroll
-        for (int fj = 0; fj < 4; ++fj) {
-            float s = bsum[fj];
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            if (lg == 0) a.bias_partial[(size_t)se * a.Cout + co0 + (wj * 4 + fj) * 16 + li] = s;
-        }
-    }
+    if (do_bias && lg == 0) a.bias_partial[(size_t)se * a.Cout + co0 + (wj * 4 + wi) * 16 + li] = bacc[0];      // row 0 of the ones x dY product: fragment fj = wi
     if (grp == 0) __builtin_amdgcn_s_barrier();
 }
 
@@ -582,9 +580,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_row_kernel(const WgArgs a) {
     const int pc = IS3D ? pair / 3 : pair;
     const int ci_t = pc / a.nCo, co_t = pc - ci_t * a.nCo;
     const int ci0 = ci_t * 64, co0 = co_t * G::CO;
-    const int t_begin = split * a.tps;
+    int t_begin = split * a.tps;
     int t_end = t_begin + a.tps;
     if (t_end > a.ntiles) t_end = a.ntiles;
+    if (a.spb > 0) {               // per-sample split-K: this split's tile range lies inside ONE sample
+        const int smp = split / a.spb;
+        t_begin = smp * a.tpsamp + (split - smp * a.spb) * a.tps;
+        t_end = t_begin + a.tps;
+        if (t_end > (smp + 1) * a.tpsamp) t_end = (smp + 1) * a.tpsamp;
+    }
     const int tpi = a.tilesH * a.tilesW;
     auto tile_coords = [&](int t, int& n, int& h0, int& w0) {
         n = t / tpi;
@@ -668,8 +672,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_row_kernel(const WgArgs a) {
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int fj = 0; fj < 4; ++fj) acc[t][fj] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = (a.bias_partial != nullptr) && (ci_t == 0) && (wi == 0) && (!IS3D || kd == 1);
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    // bias gradient / column sums of dY: wave wi of a group sums dY fragment fj = wi with ONE extra MFMA per k-step against an all-ones A operand (every row of the
+    // result is the column sum) - the VALU version (8 unpack + add per fragment on one wave per group) stretched that wave's R segment and with it every barrier
+    const bool do_bias = (a.bias_partial != nullptr) && (ci_t == 0) && (!IS3D || kd == 1);     // block-uniform (3-D: the centre-slice block, whose input plane always exists)
+    f32x4 bacc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16x8_t ones8 = __builtin_bit_cast(bf16x8_t, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
 
     int n, h0, w0, xn;
     bool zok;
@@ -725,10 +732,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_row_kernel(const WgArgs a) {
             });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            if (do_bias) {
-#pragma unroll
-                for (int fj = 0; fj < 4; ++fj) bsum[fj] += wp_sum8(B[fj]);
-            }
             if constexpr (ks == NS - 1) {
                 if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -744,6 +747,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_row_kernel(const WgArgs a) {
 #pragma unroll
                     for (int fj = 0; fj < 4; ++fj)
                         acc[kh * 3 + kw][fj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks + kh][kw], B[fj], acc[kh * 3 + kw][fj], 0, 0, 0);
+            if (do_bias) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, wi == 0 ? B[0] : (wi == 1 ? B[1] : (wi == 2 ? B[2] : B[3])), bacc, 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             if constexpr (ks == NS - 1) {
                 if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -769,15 +773,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_row_kernel(const WgArgs a) {
                 out[((size_t)(kd * 9 + tap) * a.Cin + ci) * a.Cout + co] = acc[tap][fj][r];
             }
         }
-    if (do_bias) {
-#pragma unroll
-        for (int fj = 0; fj < 4; ++fj) {
-            float s = bsum[fj];
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            if (lg == 0) a.bias_partial[(size_t)se * a.Cout + co0 + (wj * 4 + fj) * 16 + li] = s;
-        }
-    }
+    if (do_bias && lg == 0) a.bias_partial[(size_t)se * a.Cout + co0 + (wj * 4 + wi) * 16 + li] = bacc[0];      // row 0 of the ones x dY product: fragment fj = wi
     if (grp == 0) __builtin_amdgcn_s_barrier();
 }
 
@@ -810,21 +806,37 @@ static int wp_kind(const MisWgradDesc* d) {
     return base;
 }
 
-static void wp_plan(const MisWgradDesc* d, int* ntiles, int* tps, int* nsb, int* tilesH, int* tilesW) {
+static bool wp_per_sample(const MisWgradDesc* d) { return d->dw_per_sample != nullptr && wp_kind(d) != 2; }
+
+// spb: splits per sample when the descriptor asks for per-sample weight gradients (the split ranges then never straddle a sample), else 0
+static void wp_plan(const MisWgradDesc* d, int* ntiles, int* tps, int* nsb, int* tilesH, int* tilesW, int* spb = nullptr, int* tpsamp = nullptr) {
     const int kind = wp_kind(d);
     const bool wide = kind == 0 || kind == 3;
     const int th = kind == 3 ? 4 : (kind == 0 || kind == 4) ? 8 : 16;
     const int tw = kind >= 3 ? 32 : WP_TW;
     *tilesH = (d->H + th - 1) / th;
     *tilesW = (d->W + tw - 1) / tw;
-    const long long nt = (long long)d->N * (d->is3d ? d->D : 1) * *tilesH * *tilesW;      // 3-D: one 2-D tile grid per depth plane
+    const long long per = (long long)(d->is3d ? d->D : 1) * *tilesH * *tilesW;      // tiles per sample (3-D: one 2-D tile grid per depth plane)
+    const long long nt = (long long)d->N * per;
     const long long npairs = (long long)(d->Cin / 64) * (d->Cout / (wide ? 128 : 64)) * (d->is3d ? 3 : 1);
     long long want = 256 / npairs;                // one persistent block per CU
     if (want < 1) want = 1;
     if (want > nt) want = nt;
+    *ntiles = (int)nt;
+    if (spb != nullptr) *spb = 0;
+    if (tpsamp != nullptr) *tpsamp = (int)per;
+    if (wp_per_sample(d)) {
+        long long k = want / d->N;                // splits per sample
+        if (k < 1) k = 1;
+        if (k > per) k = per;
+        *tps = (int)((per + k - 1) / k);
+        k = (per + *tps - 1) / *tps;              // every split non-empty
+        *nsb = (int)(k * d->N);
+        if (spb != nullptr) *spb = (int)k;
+        return;
+    }
     *tps = (int)((nt + want - 1) / want);
     *nsb = (int)((nt + *tps - 1) / *tps);
-    *ntiles = (int)nt;
 }
 
 int wgrad_pp_nsplit(const MisWgradDesc* d) {
@@ -832,6 +844,12 @@ int wgrad_pp_nsplit(const MisWgradDesc* d) {
     wp_plan(d, &ntiles, &tps, &nsb, &th, &tw);
     const int kind = wp_kind(d);
     return (kind == 1 || kind == 4) ? 2 * nsb : nsb;
+}
+
+int wgrad_pp_splits_per_sample(const MisWgradDesc* d) {
+    int ntiles, tps, nsb, th, tw, spb = 0;
+    wp_plan(d, &ntiles, &tps, &nsb, &th, &tw, &spb);
+    return spb;
 }
 
 template <bool SPLIT, bool IS3D> static int wp_launch_wide(const WgArgs& a, long long grid, hipStream_t stream, const char* what) {
@@ -860,7 +878,7 @@ int launch_wgrad_pp(const MisWgradDesc* d, float* partial, float* bias_partial, 
     a.dy = d->dy; a.dy_ld = d->dy_ld; a.partial = partial; a.bias_partial = bias_partial;
     int nsb;
     const int kind = wp_kind(d);
-    wp_plan(d, &a.ntiles, &a.tps, &nsb, &a.tilesH, &a.tilesW);
+    wp_plan(d, &a.ntiles, &a.tps, &nsb, &a.tilesH, &a.tilesW, &a.spb, &a.tpsamp);
     MIS_REQUIRE((long long)d->N * a.D * a.tilesH * a.tilesW < (1ll << 30), MIS_EUNSUPPORTED, "wgrad(pp): too many pixel tiles");
     const bool wide = kind == 0 || kind == 3;
     a.tilesD = a.D; a.nsplit = (kind == 1 || kind == 4) ? 2 * nsb : nsb;

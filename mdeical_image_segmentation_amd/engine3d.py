@@ -112,6 +112,9 @@ class UNet3DEngine:
         # convolution and the weight gradient as a plain single-source tensor - which is what lets them run on the all-DMA ping-pong kernels (conv3d_pp.hip,
         # wgrad_pp.hip); fp32 keeps the fold (its lock-step kernels sit at 0.79 of the f32 MFMA peak).  MISAMD_GN_FOLD=1: the fold in bf16 too (A/B switch).
         self.materialize = dtype == torch.bfloat16 and os.environ.get("MISAMD_GN_FOLD") is None
+        # ... and with xn at hand the GroupNorm backward statistics (sum dyn, sum dyn * x per sample and channel) follow from the per-sample weight gradients and the
+        # border sums of g_y (mis_gn_bwd_stats_from_dw) instead of a pass over dyn and x (2 x 1-3 GB per full-resolution layer).  MISAMD_GN_STATS_KERNEL=1: that pass.
+        self.gn_from_dw = self.materialize and os.environ.get("MISAMD_GN_STATS_KERNEL") is None
         self.levels = len(f_maps)
         self.specs = unet3d_param_specs(in_channels, out_channels, f_maps, upsample)
         self.flat = FlatParams(self.specs, self.device, lambda n: not n.endswith("bias"))
@@ -251,6 +254,9 @@ class UNet3DEngine:
             s.sum1, s.sq1 = torch.zeros(N, cs, device=dev), torch.zeros(N, cs, device=dev)
             s.dgam, s.dbet = torch.zeros(cs, device=dev), torch.zeros(cs, device=dev)
             s.xn = buf(l, s.cin_pad) if (self.materialize and not s.first) else None
+            if s.xn is not None and getattr(self, "gn_from_dw", False):
+                s.dwn = torch.empty(N, s.cout, s.cin_pad, 3, 3, 3, device=dev)
+                s.gysum = torch.empty(N, s.cout, device=dev)
             if s.xn is not None and s.cin_pad != s.cin:
                 s.xn.zero_()                                       # the padding channels are never written: they must read as 0 in the weight gradient
         self.dyn = {}      # dgrad outputs, keyed by (level, channels): shared between SingleConvs of equal shape
@@ -405,8 +411,12 @@ class UNet3DEngine:
         x0v = View(src0, 0, src0.shape[-1] if src1 is None else c0)
         x1v = None if src1 is None else View(src1, 0, c1)
         dw = self.Gr[s.name + ".conv.weight"] if s.dwpad is None else s.dwpad
+        from_dw = s.xn is not None and getattr(s, "dwn", None) is not None
         if s.xn is not None:
-            ops.wgrad(s.xn, g_y, dw, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid, side=self.side_reduce and s.dwpad is None)
+            # (per-sample gradients feed this layer's GroupNorm backward right after the dgrad: their reductions stay on the main stream - ~75 MB of slabs per layer -
+            #  a side-stream reduction is starved by the persistent dgrad kernel and would be waited for)
+            ops.wgrad(s.xn, g_y, dw, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid, side=self.side_reduce and s.dwpad is None and not from_dw,
+                      dw_per_sample=s.dwn if from_dw else None, dbias_per_sample=s.gysum if from_dw else None)
         else:
             ops.wgrad(x0v, g_y, dw, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid, x1=x1v, in_scale=s.scale, in_shift=s.shift,
                       side=self.side_reduce and s.dwpad is None)
@@ -415,9 +425,13 @@ class UNet3DEngine:
         dyn = self.dyn[(self._level(s.name), s.cin_pad)]
         ops.conv_igemm(g_y, s.wd, dyn, ksize=3, Cin=s.cout, Cout=s.cin_pad, grid=grid)
         ctot = c0 + c1
-        ops.gn_bwd_stats(dyn, View(src0, 0, c0), c0, False, grid, s.S1, s.S2, ctot, 0)
-        if src1 is not None:
-            ops.gn_bwd_stats(dyn, View(src1, 0, c1), c1, up1, grid, s.S1, s.S2, ctot, c0)
+        if from_dw:
+            ops.gn_bwd_stats_from_dw(g_y, self.P[s.name + ".conv.weight"] if s.wpad is None else s.wpad, s.dwn, s.gysum, s.scale, s.shift, s.mean, s.groups, ctot,
+                                     s.S1, s.S2)
+        else:
+            ops.gn_bwd_stats(dyn, View(src0, 0, c0), c0, False, grid, s.S1, s.S2, ctot, 0)
+            if src1 is not None:
+                ops.gn_bwd_stats(dyn, View(src1, 0, c1), c1, up1, grid, s.S1, s.S2, ctot, c0)
         ops.gn_bwd_finalize(s.S1, s.S2, s.mean, s.rstd, self.P[s.name + ".groupnorm.weight"], N, ctot, s.groups, D * H * W,
                             s.p, s.q, s.r, self.Gr[s.name + ".groupnorm.weight"], self.Gr[s.name + ".groupnorm.bias"])
         ops.gn_bwd_apply(dyn, View(src0, 0, c0), c0, False, grid, s.p, s.q, s.r, ctot, 0, View(dx0, 0, c0), relu_mask=mask0, add=add0)

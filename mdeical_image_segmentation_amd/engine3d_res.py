@@ -90,6 +90,7 @@ class ResidualUNet3DEngine(UNet3DEngine):
         self.dtype, self.device = dtype, torch.device(device)
         self.side_reduce = os.environ.get("MISAMD_NO_SIDE_REDUCE") is None
         self.materialize = dtype == torch.bfloat16 and os.environ.get("MISAMD_GN_FOLD") is None      # see UNet3DEngine
+        self.gn_from_dw = False                                                                      # (the residual engines keep the statistics kernel)
         self.levels = len(f_maps)
         self.specs = resunet3d_param_specs(in_channels, out_channels, f_maps, se=self.SE)
         self.flat = FlatParams(self.specs, self.device, lambda n: not n.endswith("bias"))

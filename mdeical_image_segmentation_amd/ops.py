@@ -186,7 +186,8 @@ def wgrad_join(device=None):
         torch.cuda.current_stream(dev).wait_stream(st["stream"])
 
 
-def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alpha=1.0, in_scale=None, in_shift=None, dbias=None, side=False):
+def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alpha=1.0, in_scale=None, in_shift=None, dbias=None, side=False,
+          dw_per_sample=None, dbias_per_sample=None):
     """side=True: the reduction kernels go to a second stream (see _SideReduce); the caller must call wgrad_join() before using dw."""
     lib = load()
     x0 = _v(x0)
@@ -209,6 +210,8 @@ def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alph
     d.dy, d.dy_ld = dy.ptr, dy.ld
     d.dw, d.dw_layout, d.alpha = dw.data_ptr(), dw_layout, alpha
     d.dbias = None if dbias is None else dbias.data_ptr()
+    d.dw_per_sample = None if dw_per_sample is None else dw_per_sample.data_ptr()
+    d.dbias_per_sample = None if dbias_per_sample is None else dbias_per_sample.data_ptr()
     need = lib.mis_wgrad_workspace_bytes(C.byref(d))
     if need == 0:
         check(-1, "mis_wgrad_workspace_bytes")
@@ -443,6 +446,18 @@ def gn_bwd_stats(dy, x, Cs, up, grid, S1, S2, Ctot, c_off):
     ws = workspace(lib.mis_gn_bwd_stats_workspace_bytes(N, Cs), x.t.device, "gnbwd")
     check(lib.mis_gn_bwd_stats(dtype_code(x.dtype), dy.ptr, dy.ld, x.ptr, x.ld, Cs, 1 if up else 0, N, D, H, W, ws.data_ptr(),
                                S1.data_ptr(), S2.data_ptr(), Ctot, c_off, stream_ptr()), "mis_gn_bwd_stats")
+
+
+def gn_bwd_stats_from_dw(gy, w, dw_per_sample, gy_colsum, scale, shift, mean, groups, Cs, S1, S2):
+    """S1 / S2 of the GroupNorm backward from the per-sample weight gradients and border sums of gy (mis_gn_bwd_stats_from_dw): no pass over dyn and x.
+    gy: View (N, D, H, W, Cout); w, dw_per_sample[n]: (Cout, Cw, 3, 3, 3) fp32; scale / shift: (N, >= Cs); mean: (N, groups)"""
+    lib = load()
+    gy = _v(gy)
+    Cout, Cw = w.shape[0], w.shape[1]
+    ws = workspace(lib.mis_gn_bwd_stats_from_dw_workspace_bytes(gy.N, Cout), gy.t.device, "gn_from_dw")
+    check(lib.mis_gn_bwd_stats_from_dw(dtype_code(gy.dtype), gy.ptr, gy.ld, gy.N, gy.D, gy.H, gy.W, Cout, w.data_ptr(), dw_per_sample.data_ptr(), Cw,
+                                       gy_colsum.data_ptr(), scale.data_ptr(), shift.data_ptr(), scale.shape[-1], mean.data_ptr(), groups, Cs, ws.data_ptr(),
+                                       S1.data_ptr(), S2.data_ptr(), stream_ptr()), "mis_gn_bwd_stats_from_dw")
 
 
 def gn_bwd_finalize(S1, S2, mean, rstd, gamma, N, Cc, G, count, p, q, r, dgamma, dbeta):

@@ -371,3 +371,71 @@ def test_conv3d_pp_32_channel_slice(grid):
     ops.conv_igemm(ops.View(buf, 0, Cin), wf, y, ksize=3, Cin=Cin, Cout=Cout, grid=grid, relu=True)
     assert ops.conv_last_dispatch().startswith("k3.3d.ppc")
     assert_close(from_nhwc(y), F.relu(F.conv3d(q(x, BF), q(w, BF), None, padding=1)), "3-D conv, 32-channel slice", **tol(BF, 27 * Cin))
+
+
+@pytest.mark.parametrize("grid,C0,C1,Cout", [((2, 6, 20, 36), 64, 128, 64), ((2, 4, 12, 32), 64, 0, 128), ((3, 5, 10, 18), 32, 0, 64)])
+def test_gn_bwd_stats_from_per_sample_dw(grid, C0, C1, Cout):
+    """mis_gn_bwd_stats_from_dw (round 3): S1 = sum_v dyn and S2 = sum_v dyn * x per (sample, channel) from the per-sample weight gradients of the ping-pong wgrad
+    kernel and the border sums of g_y - against float64 sums over the exact (unrounded) dyn = conv_transpose(g_y, W), and against the statistics kernel that reads the
+    bf16-stored dyn.  Two-source operand (encoder | nearest-upsampled), a single source, and the padded 32-of-64-channel case of encoders.0."""
+    ops = _ops()
+    N, D, H, W = grid
+    Cin = C0 + C1
+    Cp = (Cin + 63) // 64 * 64
+    x0 = rnd(N, C0, D, H, W, seed=170)
+    scale = 1 + 0.3 * rnd(N, Cp, seed=171)
+    shift = 0.3 * rnd(N, Cp, seed=172)
+    scale[:, Cin:] = 0
+    shift[:, Cin:] = 0
+    srcs = [q(x0, BF)]
+    if C1:
+        x1 = rnd(N, C1, D // 2, H // 2, W // 2, seed=173)
+        srcs.append(F.interpolate(q(x1, BF), size=(D, H, W), mode="nearest"))
+    xc = torch.cat(srcs, 1)
+    w = rnd(Cout, Cin, 3, 3, 3, seed=174, scale=(27 * Cin) ** -0.5)
+    wpad = torch.zeros(Cout, Cp, 3, 3, 3)
+    wpad[:, :Cin] = w
+    gy = rnd(N, Cout, D, H, W, seed=175)
+    # device: xn by mis_gn_apply, per-sample wgrad, stats from dW
+    xn = torch.zeros(N, D, H, W, Cp, dtype=BF, device=DEV)
+    sc, sh = scale.to(DEV), shift.to(DEV)
+    ops.gn_apply(to_nhwc(x0, BF), C0, False, grid, sc, sh, Cp, 0, xn)
+    if C1:
+        ops.gn_apply(to_nhwc(x1, BF), C1, True, grid, sc, sh, Cp, C0, xn)
+    gyd = to_nhwc(gy, BF)
+    dw = torch.empty(Cout, Cp, 3, 3, 3, device=DEV)
+    dwn = torch.empty(N, Cout, Cp, 3, 3, 3, device=DEV)
+    gys = torch.empty(N, Cout, device=DEV)
+    ops.wgrad(xn, gyd, dw, ksize=3, Cin=Cp, Cout=Cout, grid=grid, dw_per_sample=dwn, dbias_per_sample=gys)
+    assert ops.wgrad_last_dispatch()[0].startswith("k3.3d.pp")
+    assert_close(dwn.sum(0), dw, "sum of the per-sample gradients", rtol=1e-5, atol=1e-5)
+    assert_close(gys, q(gy, BF).sum((2, 3, 4)), "per-sample column sums of gy", rtol=1e-4, atol=2e-3)
+    xnq = from_nhwc(xn)[:, :Cin]
+    for n in range(N):          # each sample's gradient = the wgrad of that sample alone
+        wz = torch.zeros(Cout, Cin, 3, 3, 3, requires_grad=True)
+        F.conv3d(xnq[n:n + 1], wz, None, padding=1).backward(q(gy, BF)[n:n + 1])
+        assert_close(dwn[n, :, :Cin], wz.grad, f"dW of sample {n}", rtol=1e-4, atol=1e-4 * (D * H * W) ** 0.5)
+    G = 8
+    mean = torch.zeros(N, G, device=DEV)                     # (only used for channels whose scale is 0)
+    S1, S2 = torch.full((N, Cin), float("nan"), device=DEV), torch.full((N, Cin), float("nan"), device=DEV)
+    ops.gn_bwd_stats_from_dw(gyd, wpad.to(DEV), dwn, gys, sc, sh, mean, G, Cin, S1, S2)
+    # float64 reference on the exact dyn
+    dyn = F.conv_transpose3d(q(gy, BF).double(), q(w, BF).double(), padding=1)
+    r1, r2 = dyn.sum((2, 3, 4)), (dyn * xc.double()).sum((2, 3, 4))
+    den = dyn.abs().sum((2, 3, 4)).clamp_min(1e-30)          # sums of signed terms: errors are judged against the sum of magnitudes
+    e1 = ((S1.cpu().double() - r1).abs() / den).max().item()
+    e2 = ((S2.cpu().double() - r2).abs() / (dyn.abs() * xc.double().abs()).sum((2, 3, 4)).clamp_min(1e-30)).max().item()
+    assert e1 < 2e-4 and e2 < 2e-3, (e1, e2)                 # (S2 goes through xn, which is rounded to bf16: 2^-9 per element, averaged over the volume)
+    # the statistics kernel on the bf16-stored dyn agrees to its own rounding
+    wd = torch.empty(27, Cp, Cout, dtype=BF, device=DEV)
+    wf = torch.empty(27, Cout, Cp, dtype=BF, device=DEV)
+    ops.pack_conv_weight(wpad.to(DEV), wf, wd)
+    dynd = torch.empty(N, D, H, W, Cp, dtype=BF, device=DEV)
+    ops.conv_igemm(gyd, wd, dynd, ksize=3, Cin=Cout, Cout=Cp, grid=grid)
+    K1, K2 = torch.zeros(N, Cin, device=DEV), torch.zeros(N, Cin, device=DEV)
+    ops.gn_bwd_stats(dynd, to_nhwc(x0, BF), C0, False, grid, K1, K2, Cin, 0)
+    if C1:
+        ops.gn_bwd_stats(dynd, to_nhwc(x1, BF), C1, True, grid, K1, K2, Cin, C0)
+    k1 = ((K1.cpu().double() - r1).abs() / den).max().item()
+    print(f"S1 / S2 vs float64: from dW {e1:.2e} / {e2:.2e}; statistics kernel S1 {k1:.2e}")
+    assert k1 < 2e-3
