@@ -101,6 +101,22 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
     const char* const xb = reinterpret_cast<const char*>(a.x0.p);
     const __amdgpu_buffer_rsrc_t rw = pp_make_rsrc(a.w, (unsigned)((long long)27 * a.Cout * a.Cin * 2));
 
+    // Every instruction of an R segment costs the wave issue slots it shares with its partner's MFMA cluster: where registers allow (the instantiations below 200
+    // VGPRs) the per-lane source offset and halo coordinates of the wave's halo instructions are computed ONCE (conv_pp_kernel's HPRE), ~25 VALU fewer per issue.
+    constexpr bool HPRE = (NF * PF <= 20);
+    unsigned h_rel[HPRE ? HJ : 1];
+    int h_coord[HPRE ? HJ : 1];                   // halo row | halo column << 8; -1: no item
+    if constexpr (HPRE) {
+#pragma unroll
+        for (int j = 0; j < HJ; ++j) {
+            const int id = j * 8 + wave;
+            const int item = id * 64 + lane;
+            const int p = item >> 2, pos = item & 3;
+            const int py = p / HW, px = p - py * HW;
+            h_rel[j] = (unsigned)(((py * a.W + px) * a.x0.ld + ((pos ^ ((px >> 1) & 3)) << 3)) * 2);
+            h_coord[j] = (id < HINSTR && item < HITEMS) ? (py | (px << 8)) : -1;
+        }
+    }
     // halo DMA j of this wave (instruction id = j*8 + wave) from plane `spl` (valid = the plane exists; otherwise the image is zero-filled)
     auto issue_halo = [&](auto jc, int spl, bool valid, int h0, int w0, int c0, char* dst) {
         constexpr int j = decltype(jc)::value;
@@ -108,6 +124,16 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
         if (id >= HINSTR) return;                     // wave-uniform
         const __amdgpu_buffer_rsrc_t rx = pp_make_rsrc(xb + (size_t)(valid ? spl : 0) * plane_b, img_x);
         unsigned toff = (unsigned)((((h0 - 1) * a.W + (w0 - 1)) * a.x0.ld + c0) * 2);
+        if constexpr (HPRE) {
+            const bool interior = h0 >= 1 && h0 + TH + 1 <= a.H && w0 >= 1 && w0 + TW + 1 <= a.W;        // block-uniform
+            bool ok = valid && h_coord[j] >= 0;
+            if (!interior) {
+                const int py = h_coord[j] & 0xff, px = h_coord[j] >> 8;
+                ok = ok && (unsigned)(h0 - 1 + py) < (unsigned)a.H && (unsigned)(w0 - 1 + px) < (unsigned)a.W;
+            }
+            pp_dma16(rx, ok ? (int)(toff + h_rel[j]) : PP_OOB, dst + id * 1024);
+            return;
+        }
         asm volatile("" : "+s"(toff));
         int item = id * 64 + lane;
         asm volatile("" : "+v"(item));

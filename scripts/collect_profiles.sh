@@ -1,0 +1,32 @@
+#!/bin/bash
+# Collect the per-round profile set on the GPU box (one gpurun call; repo root = $GRAFT_REPO_ROOT or the script's parent):
+#   bash scripts/collect_profiles.sh r03         -> gpurun_out/prof_r03/{bench.json, kernel_stats.csv, bench_under_rocprof.json, pmc_summary.json, traffic.json,
+#                                                   3d_bf16_160_kernel_stats.csv, 3d_bf16_160_bench_under_rocprof.json, 3d_bf16_160_pmc_summary.json}
+# rocprofv3 runs the program itself after `--` (python3 bench.py ...), counters in their own passes (--pmc with --kernel-trace only), as profiles/README.md prescribes.
+set -e
+TAG=${1:-rXX}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+B2D="--steps 3 --warmup 1 --no-cpu-baseline --no-extra"
+B3D="--workload 3d --dtype bf16 --size 160 --steps 3 --warmup 1 --no-cpu-baseline --no-extra"
+echo "[1/8] full default bench line"; python3 $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+echo "[2/8] 2-D kernel stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks2d -- python3 $ROOT/bench.py $B2D > $OUT/bench_under_rocprof.json 2> $OUT/ks2d.err
+cp $(ls $OUT/ks2d/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
+P2D="--steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-kernel-timing"
+echo "[3/8] 2-D PMC: SQ"; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py $P2D > /dev/null 2> $OUT/pmc_sq.err
+echo "[4/8] 2-D PMC: FETCH"; rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $P2D > /dev/null 2> $OUT/pmc_fetch.err
+echo "[5/8] 2-D PMC: WRITE"; rocprofv3 --pmc WRITE_SIZE SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py $P2D > /dev/null 2> $OUT/pmc_write.err
+python3 $ROOT/scripts/pmc_summary.py $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_summary.json
+(cd $ROOT && python3 scripts/make_traffic.py $OUT/pmc_summary.json ${TAG}_pmc_summary.json > $OUT/traffic.json)
+echo "[6/8] 3-D kernel stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks3d -- python3 $ROOT/bench.py $B3D > $OUT/3d_bf16_160_bench_under_rocprof.json 2> $OUT/ks3d.err
+cp $(ls $OUT/ks3d/*/*kernel_stats.csv | head -1) $OUT/3d_bf16_160_kernel_stats.csv
+P3D="--workload 3d --dtype bf16 --size 160 --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-kernel-timing"
+echo "[7/8] 3-D PMC: SQ"; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc3d_sq -- python3 $ROOT/bench.py $P3D > /dev/null 2> $OUT/pmc3d_sq.err
+echo "[8/8] 3-D PMC: FETCH / WRITE"; rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc3d_fetch -- python3 $ROOT/bench.py $P3D > /dev/null 2> $OUT/pmc3d_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc3d_write -- python3 $ROOT/bench.py $P3D > /dev/null 2> $OUT/pmc3d_write.err
+python3 $ROOT/scripts/pmc_summary.py $OUT/pmc3d_sq $OUT/pmc3d_fetch $OUT/pmc3d_write > $OUT/3d_bf16_160_pmc_summary.json
+# the raw counter dumps are large: keep the summaries only
+rm -rf $OUT/ks2d $OUT/ks3d $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc3d_sq $OUT/pmc3d_fetch $OUT/pmc3d_write
+ls -la $OUT
