@@ -2,7 +2,7 @@
 HBM bytes per launch of the bench's dominant kernel KEYS, launch-weighted over the kernel symbols that make up a key, stamped with the hash of the
 kernel sources (so bench.py only reports the figure for the build it was measured on).
 
-    python scripts/make_traffic.py profiles/r02_pmc_summary.json > profiles/traffic.json"""
+    python scripts/make_traffic.py profiles/r03_pmc_summary.json [name of the committed summary] > profiles/traffic.json"""
 import json
 import os
 import sys
@@ -12,14 +12,15 @@ from mdeical_image_segmentation_amd import _lib  # noqa: E402
 
 KEYS = {   # bench key -> kernel symbols (prefix match on the rocprof name) whose launches carry that key at the benchmark shapes
     "conv_igemm/bf16/k3/2d/bn128": ["void conv_ppc_kernel<8, 4>", "void conv_pp_kernel<8>", "void conv_pp_kernel<4>"],
-    "wgrad/bf16/k3/2d": ["void wgrad_pp_wide_kernel<", "wgrad_pp_wide_kernel", "void wgrad_pp_kernel<2>"],
+    "wgrad/bf16/k3/2d": ["void wgrad_pp_row_kernel<", "void wgrad_pp_wide_kernel<", "wgrad_pp_wide_kernel", "void wgrad_pp_kernel<2>"],
     "conv_igemm/bf16/k3/2d/bn64": ["conv64_ws_kernel"],
 }
 
 
-def main(path):
+def main(path, profile_name=None):
     summ = json.load(open(path))
-    out = {"source_hash": _lib.source_hash(_lib.TRAFFIC_SOURCES), "hashed_sources": list(_lib.TRAFFIC_SOURCES), "batch": 32, "size": 512, "profile": os.path.basename(path), "kernels": {}}
+    out = {"source_hash": _lib.source_hash(_lib.TRAFFIC_SOURCES), "hashed_sources": list(_lib.TRAFFIC_SOURCES), "batch": 32, "size": 512,
+           "profile": profile_name or os.path.basename(path), "kernels": {}}
     for key, syms in KEYS.items():
         rd = wr = n = 0.0
         used = []
@@ -37,4 +38,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(*sys.argv[1:3])
