@@ -826,8 +826,19 @@ static void wp_plan(const MisWgradDesc* d, int* ntiles, int* tps, int* nsb, int*
     if (spb != nullptr) *spb = 0;
     if (tpsamp != nullptr) *tpsamp = (int)per;
     if (wp_per_sample(d)) {
-        long long k = want / d->N;                // splits per sample
-        if (k < 1) k = 1;
+        // splits per sample: the count that minimises (rounds of 256 blocks) / (splits) - e.g. 72 pairs x 2 samples: 3 per sample (432 blocks, two rounds of a third
+        // of the tiles each) matches the 3 splits of the batch-wide plan, where 1 per sample would leave 112 CUs idle; ties go to the smaller count (fewer slabs)
+        long long k = 1;
+        double best = 1e30;
+        for (long long c = 1; c <= 4 && c <= per; ++c) {
+            const long long blocks = npairs * c * d->N;
+            const double cost = (double)((blocks + 255) / 256) / (double)(c * d->N);
+            if (cost < best * 0.999) {
+                best = cost;
+                k = c;
+            }
+        }
+        if (want / d->N > k) k = want / d->N;     // few pairs: one persistent block per CU, as in the batch-wide plan
         if (k > per) k = per;
         *tps = (int)((per + k - 1) / k);
         k = (per + *tps - 1) / *tps;              // every split non-empty
