@@ -93,7 +93,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
         const int lrow = slot >> 2, pos = slot & 3;
         const int dc16 = pos ^ ((lrow >> 1) & 3);
         const int dwv = lrow / WAVE_N, j = lrow % WAVE_N;
-        const int drow = dwv * WAVE_N + ((j & 15) >> 2) * NV + (j >> 4) * 4 + (j & 3);
+        const int drow = dwv * WAVE_N + ((j >> 5) * 32) + ((j & 15) >> 2) * 8 + ((j >> 4) & 1) * 4 + (j & 3);       // channel order of pp_epilogue_plain (see conv_ppc_kernel)
         w_goff0[r] = (drow * a.Cin + dc16 * 8) * 2;
     }
     const unsigned img_x = (unsigned)(((long long)a.H * a.W - 1) * a.x0.ld + a.Cin) * 2u;      // bytes of ONE depth plane of the input view
@@ -145,8 +145,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
     };
     const __amdgpu_buffer_rsrc_t rb = pp_make_rsrc(a.bias != nullptr ? (const void*)a.bias : a.w, a.bias != nullptr ? (unsigned)a.Cout * 4u : 0u);
     auto issue_bias = [&](int col, char* dst) {
-        if (wave < BN / 64)                           // (BN is a multiple of 64 in every instantiation)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (pp_lds_void_t*)(dst + wave * 256), 4, (col + wave * 64 + lane) * 4, 0, 0, 0);
+        if (wave < BN / 64) {                         // (BN is a multiple of 64 in every instantiation)
+            int l;                                    // lane index re-derived rather than held (or spilled) across the tile loop, as in conv_ppc_kernel
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (pp_lds_void_t*)(dst + wave * 256), 4, (col + wave * 64 + l) * 4, 0, 0, 0);
+        }
     };
     // the three tap tiles (kh = 0..2) of depth slice dz, filter column kw, column tile col, channels c0..c0+31: one instruction per tap per wave
     auto issue_weights = [&](int dz, int kw, int col, int c0, char* dst) {
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
             dz = ndz;
             c0 = nc0;
         }
-        pp_epilogue<NF, PF>(a, acc, (uint32_t)(uintptr_t)bbase + bsel * (BN * 4), pl, h0, w0, ncol0, wm, wn, li, lg);
+        pp_epilogue_plain<NF, PF>(a, acc, (uint32_t)(uintptr_t)bbase + bsel * (BN * 4), pl, h0, w0, ncol0, wm, wn);
         pl = npl; z = nz; h0 = nh0; w0 = nw0; ncol0 = ncolN;
         bsel ^= 1;
         if (has_next) issue_bias(ncol0, bbase + bsel * (BN * 4));
@@ -303,6 +306,11 @@ bool conv3d_pp_eligible(const MisConvDesc* d) {
     // 32-bit buffer offsets, computed in (signed) int: ONE depth plane of the input view and the packed weights must each span less than 2 GiB
     if ((((long long)d->H * d->W - 1) * d->x0_ld + d->Cin) * 2 >= (1ll << 31) - 65536) return false;
     if ((long long)27 * d->Cout * d->Cin * 2 >= (1ll << 31) - 65536) return false;
+    // pp_epilogue_plain: one depth plane of each destination view / of the mask within 32-bit buffer offsets
+    const long long img = (long long)d->H * d->W, lim = (1ll << 32) - 65536;
+    if (((img - 1) * d->y0_ld + d->Cout0) * 2 >= lim) return false;
+    if (d->Cout0 < d->Cout && (d->y1 == nullptr || ((img - 1) * d->y1_ld + (d->Cout - d->Cout0)) * 2 >= lim)) return false;
+    if (d->mask != nullptr && ((img - 1) * d->mask_ld + d->Cout) * 2 >= lim) return false;
     return true;
 }
 

@@ -28,6 +28,7 @@ struct ConvArgs {
 // conv_pp.hip: the ping-pong 3x3 kernel for the bf16 2-D layers (returns MIS_OK after the launch, or an error); `eligible` says whether a
 // descriptor can take that path at all (dispatch in conv_igemm.hip decides)
 bool conv_pp_eligible(const MisConvDesc* d);
+bool conv_ppc64_auto(const MisConvDesc* d);            // 64-column blocks of the column-segment kernel chosen by default (Cin >= 128)
 bool conv_pp_rs64_eligible(const MisConvDesc* d);      // 64 -> 64 channels: the register-stationary ping-pong kernel
 int launch_conv_pp(const MisConvDesc* d, hipStream_t stream, const char** tag);
 // conv3d_pp.hip: the same structure for the bf16 3x3x3 layers (single source, no operand affine)

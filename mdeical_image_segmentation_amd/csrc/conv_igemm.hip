@@ -731,7 +731,7 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
                 // 64-column layers stay on the weight-stationary / bn64 configurations: the ping-pong kernel with 64-column blocks (wave tile 64 px x 32 ch: 12 fragment
                 // reads per 16 MFMAs) is bound by its R segments - measured 629 vs 959 TFLOP/s (64->64 at 512^2) and 784 vs 916 (128->64); MIS_CONV_PP64=1 selects it
                 const bool pp64 = mis_sw(SW_CONV_PP64) || mis_sw(SW_CONV_PPC64);
-                if (pp && conv_pp_eligible(d) && (d->Cout % 128 == 0 || pp64 || conv_pp_rs64_eligible(d))) {      // (rs64: opt-in, MIS_CONV_RS64=1)
+                if (pp && conv_pp_eligible(d) && (d->Cout % 128 == 0 || pp64 || conv_ppc64_auto(d) || conv_pp_rs64_eligible(d))) {      // (rs64: opt-in, MIS_CONV_RS64=1)
                     const char* tag = "";
                     const int rc = launch_conv_pp(d, s, &tag);
                     g_conv_last = tag;

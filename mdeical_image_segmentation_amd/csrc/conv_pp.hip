@@ -411,6 +411,9 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
     const int tstride = (int)gridDim.x;
     int tile = xcd_remap(blockIdx.x, gridDim.x);
     if (tile >= total_tiles) return;                 // block-uniform
+#ifdef PPT_DESYNC           // diagnostic build: blocks of one XCD start PPT_DESYNC x 64 cycles apart, so that their tile boundaries (store bursts) do not coincide
+    for (int i = (int)((blockIdx.x >> 3) & 31); i > 0; --i) __builtin_amdgcn_s_sleep(PPT_DESYNC);
+#endif
     const int nchunks = a.Cin >> 5;
     const int tpi = a.tilesH * a.tilesW;
     // tile order (a.tilesD, set by the launcher): 1 = column-tile major (all spatial tiles of one column tile, then the next: the weight tile is shared by every running block);
@@ -446,7 +449,9 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
         const int lrow = slot >> 2, pos = slot & 3;
         const int dc16 = pos ^ ((lrow >> 1) & 3);
         const int dwv = lrow / WAVE_N, j = lrow % WAVE_N;
-        const int drow = dwv * WAVE_N + ((j & 15) >> 2) * NV + (j >> 4) * 4 + (j & 3);
+        // MFMA row i = lg*4 + q of fragment f is output channel (f>>1)*32 + lg*8 + (f&1)*4 + q of the wave's slice: a lane holds 8 consecutive channels per fragment PAIR, and the
+        // four lane groups of a pixel cover 64 contiguous bytes with ONE store instruction (pp_epilogue_plain)
+        const int drow = dwv * WAVE_N + ((j >> 5) * 32) + ((j & 15) >> 2) * 8 + ((j >> 4) & 1) * 4 + (j & 3);
         w_goff0 = (drow * a.Cin + dc16 * 8) * 2;
     }
     const unsigned img_x = (unsigned)(((long long)a.H * a.W - 1) * a.x0.ld + a.Cin) * 2u;
@@ -461,8 +466,12 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
         const __amdgpu_buffer_rsrc_t rx = pp_make_rsrc(xb + (size_t)n * a.H * a.W * a.x0.ld * 2, img_x);
         unsigned toff = (unsigned)((((h0 - 1) * a.W + (w0 - 1)) * a.x0.ld + c0) * 2);
         asm volatile("" : "+s"(toff));
-        int item = id * 64 + lane;
-        asm volatile("" : "+v"(item));
+        // the lane index is re-derived at every issue (two v_mbcnt, volatile so that it is not hoisted): with `lane` as input hipcc keeps id*64 + lane per instruction
+        // across the tile loop, and at 256 VGPRs that meant SPILLING them - a scratch reload + s_waitcnt vmcnt(0) in front of two of the five halo issues of every
+        // chunk, i.e. a full wait for the weight DMAs issued a few instructions earlier
+        int item;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(item));
+        item += id * 64;
         const int p = item >> 2, pos = item & 3;
         const int py = p / HW, px = p - py * HW;
         const unsigned rel = (unsigned)(((py * a.W + px) * a.x0.ld + ((pos ^ ((px >> 1) & 3)) << 3)) * 2);
@@ -471,8 +480,11 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
     };
     const __amdgpu_buffer_rsrc_t rb = pp_make_rsrc(a.bias != nullptr ? (const void*)a.bias : a.w, a.bias != nullptr ? (unsigned)a.Cout * 4u : 0u);
     auto issue_bias = [&](int col, char* dst) {
-        if (wave < BN / 64)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (pp_lds_void_t*)(dst + wave * 256), 4, (col + wave * 64 + lane) * 4, 0, 0, 0);
+        if (wave < BN / 64) {
+            int l;                                    // lane index re-derived (see issue_halo: a spilled `lane` here meant a scratch reload + vmcnt(0) right behind the tile's stores)
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (pp_lds_void_t*)(dst + wave * 256), 4, (col + wave * 64 + l) * 4, 0, 0, 0);
+        }
     };
     // the three tap tiles (kh = 0..2) of filter column kw, column tile col, channels c0..c0+31: one instruction per tap per wave
     auto issue_weights = [&](int kw, int col, int c0, char* dst) {
@@ -570,7 +582,9 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 // ================= M segment: 3 taps x NF x PF MFMAs =================
+                #ifndef PPT_NO_PRIO
                 __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -602,13 +616,29 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
             });
             hsel ^= 1;
         }
-        pp_epilogue<NF, PF>(a, acc, (uint32_t)(uintptr_t)bbase + bsel * (BN * 4), n, h0, w0, ncol0, wm, wn, li, lg);
+#if !defined(PPT_NO_EPI)
+#ifdef PPT_EPI_PRIO
+        __builtin_amdgcn_s_setprio(PPT_EPI_PRIO);
+#endif
+        pp_epilogue_plain<NF, PF>(a, acc, (uint32_t)(uintptr_t)bbase + bsel * (BN * 4), n, h0, w0, ncol0, wm, wn);
+#ifdef PPT_EPI_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#else                       // diagnostic build: no epilogue at all (the accumulators run on; they are summed into one conditional store after the tile loop)
+#endif
         n = nn; h0 = nh0; w0 = nw0; ncol0 = ncolN;
         bsel ^= 1;
         if (has_next) issue_bias(ncol0, bbase + bsel * (BN * 4));
         __builtin_amdgcn_sched_barrier(0);
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's last barrier
+#ifdef PPT_NO_EPI
+    {
+        f32x4 s4 = acc[0][0];
+        pp_static_for<NF>([&](auto fc) { pp_static_for<PF>([&](auto pc) { s4 += acc[decltype(fc)::value][decltype(pc)::value]; }); });
+        if (s4[0] == 123.456f) *reinterpret_cast<f32x4*>(a.y0) = s4;
+    }
+#endif
 }
 
 template <int PF, int NF> static int pp_launch_col(const MisConvDesc* d, hipStream_t stream) {
@@ -847,6 +877,28 @@ template <int NF> static int pp_launch(const MisConvDesc* d, hipStream_t stream)
     return MIS_OK;
 }
 
+// pp_epilogue_plain: plain or pixel-unshuffled NHWC destinations, and ONE image of each destination view / of the mask spans less than 4 GiB - 64 KiB (32-bit buffer offsets)
+static bool ppc_plain_ok(const MisConvDesc* d) {
+    const long long img = (long long)d->H * d->W;
+    const long long lim = (1ll << 32) - 65536;
+    auto view_ok = [&](int mode, int ld, int cview) {
+        if (mode == MIS_OUT_PLAIN) return ((img - 1) * ld + cview) * 2 < lim;
+        if (mode == MIS_OUT_UNSHUFFLE2) return d->H % 2 == 0 && d->W % 2 == 0 && ((img / 4 - 1) * ld + 4ll * cview) * 2 < lim;
+        return false;
+    };
+    if (!view_ok(d->y0_mode, d->y0_ld, d->Cout0)) return false;
+    if (d->Cout0 < d->Cout && (d->y1 == nullptr || !view_ok(d->y1_mode, d->y1_ld, d->Cout - d->Cout0))) return false;
+    if (d->mask != nullptr && ((img - 1) * d->mask_ld + d->Cout) * 2 >= lim) return false;
+    return true;
+}
+
+// 64-column blocks of the column-segment kernel by default: Cout = 64 (or any multiple of 64 that is not one of 128) with at least 128 input channels, on grids whose
+// 32-row tiles waste at most 15 % (measured in one process, scripts/bench_conv_layers.py: 128->64 at 512^2 1.249 vs 1.379 ms for bn64.persist.dma, at 256^2 0.320 vs 0.336;
+// 64->64 stays on the weight-stationary kernel, 0.633 vs 0.751 ms)
+bool conv_ppc64_auto(const MisConvDesc* d) {
+    return conv_pp_eligible(d) && d->Cout % 128 != 0 && d->Cin >= 128 && !mis_sw(SW_CONV_NOPPC) && ppc_plain_ok(d) && ((d->H + 31) / 32) * 32 * 100 <= d->H * 115;
+}
+
 bool conv_pp_rs64_eligible(const MisConvDesc* d) {
     return conv_pp_eligible(d) && d->Cin == 64 && d->Cout == 64 && d->Cout0 == 64 && d->y0_mode == MIS_OUT_PLAIN && mis_sw(SW_CONV_RS64);      // opt-in: measured 0.700 vs 0.654 ms against conv64_ws_kernel
 }
@@ -858,11 +910,11 @@ int launch_conv_pp(const MisConvDesc* d, hipStream_t stream, const char** tag) {
     }
     // Cout % 128 == 0: the column-segment kernel, unless its 32-row tiles waste more than 15 % of the rows (MIS_CONV_PPC=1 takes it regardless) or MIS_CONV_NOPPC is set
     // (the parity tests reach every kernel on small grids that way)
-    if (d->Cout % 128 == 0 && !mis_sw(SW_CONV_NOPPC) && (((d->H + 31) / 32) * 32 * 100 <= d->H * 115 || mis_sw(SW_CONV_PPC))) {
+    if (d->Cout % 128 == 0 && !mis_sw(SW_CONV_NOPPC) && ppc_plain_ok(d) && (((d->H + 31) / 32) * 32 * 100 <= d->H * 115 || mis_sw(SW_CONV_PPC))) {
         *tag = "k3.2d.ppc8";
         return pp_launch_col<8, 4>(d, stream);
     }
-    if (d->Cout % 64 == 0 && mis_sw(SW_CONV_PPC64)) {      // 64-column blocks of the same kernel (opt-in A/B switch)
+    if (d->Cout % 64 == 0 && (mis_sw(SW_CONV_PPC64) || conv_ppc64_auto(d)) && ppc_plain_ok(d)) {      // 64-column blocks of the same kernel (MIS_CONV_PPC64=1: wherever eligible)
         *tag = "k3.2d.ppc8n2";
         return pp_launch_col<8, 2>(d, stream);
     }

@@ -111,8 +111,124 @@ __device__ __forceinline__ void pp_epilogue(const ConvArgs& a, f32x4 (&acc)[NF][
                 const size_t opix = ((size_t)n * oh + (y >> 1)) * ow + (x >> 1);
                 dst = ybase + opix * yld + ((y & 1) * 2 + (x & 1)) * cview + lcol;
             }
+#ifndef PPT_NO_STORE
 #pragma unroll
             for (int i = 0; i < NV; i += EPC) *reinterpret_cast<u32x4*>(dst + i) = pack_chunk<T>(o + i);
+#else
+            if (o[0] == 123.456f) *reinterpret_cast<u32x4*>(dst) = pack_chunk<T>(o);          // diagnostic build: keeps the arithmetic, drops the stores
+#endif
+        }
+    }
+}
+
+// ---- epilogue of the column-segment kernels (plain NHWC destinations only): the same arithmetic as pp_epilogue - accumulator + bias, ReLU, ReLU mask of another tensor,
+// round to bf16 - in a third of the instructions.  Measured on conv_ppc_kernel<8, 4> (scripts/ppt_ablate.sh, PPT_NO_EPI): the epilogue's VECTOR instructions, not its stores, were
+// the per-tile overhead that made the short-K layers slow (128->128 at 256^2: 0.600 ms with, 0.465 ms without the epilogue; removing only the stores changed nothing) - every
+// instruction of an R slot costs ~10 cycles next to the partner's MFMA cluster, and hipcc's code for pp_epilogue is ~110 of them per pixel row (one v_cvt per VALUE plus shift / or,
+// canonicalising v_max pairs, 64-bit address arithmetic per row).  Here, per pixel row of NV values: NV/2 v_pk_add_f32, NV/2 v_cvt_pk_bf16_f32 (two values each), NV/2
+// v_pk_max_i16 (ReLU on the PACKED bf16 pair: as int16 a negative float is a negative integer; the lower bound is 0x8000 = "no ReLU" otherwise), and buffer stores whose address is a
+// per-lane offset computed once + a scalar row offset; the ReLU mask is applied to the packed pair too (min(m, 1) -> max(., 0) -> multiply, all 16-bit packed).  The bias comes
+// out of LDS once per tile.  NaNs are not preserved through the packed ReLU (a negative-signed NaN becomes 0), as with fmaxf.
+typedef float pp_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pp_bf16x2 __attribute__((ext_vector_type(2)));
+typedef short pp_i16x2 __attribute__((ext_vector_type(2)));
+
+template <int NF, int PF>
+__device__ __forceinline__ void pp_epilogue_plain(const ConvArgs& a, f32x4 (&acc)[NF][PF], uint32_t bias_lds, int n, int h0, int w0, int ncol0, int wm, int wn) {
+    constexpr int NV = 4 * NF, WAVE_N = NF * 16, NS = NF / 2;          // NS 16-byte stores per pixel
+    static_assert(NF % 2 == 0, "");
+    // lane coordinates re-derived here (volatile: not hoisted), so that nothing per-lane of the epilogue is held - or, at 256 VGPRs, spilled - across the tile loop
+    int lane_;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_));
+    const int li = lane_ & 15, lg = lane_ >> 4;
+    const int colw = ncol0 + wn * WAVE_N;          // wave-uniform first column
+    const bool to0 = colw < a.Cout0;
+    const char* const ybase = reinterpret_cast<const char*>(to0 ? a.y0 : a.y1);
+    const int yld = to0 ? a.y0_ld : a.y1_ld;
+    const int cview = to0 ? a.Cout0 : a.Cout - a.Cout0;
+    const int lcolw = to0 ? colw : colw - a.Cout0;
+    u32x4 braw[NF];
+    pp_static_for<NF>([&](auto fc) {
+        constexpr int f = decltype(fc)::value;
+        braw[f] = pp_lds_read128<(f >> 1) * 128 + (f & 1) * 16>(bias_lds + (wn * WAVE_N + lg * 8) * 4);
+    });
+    // one buffer resource per image (plane): 32-bit offsets span one image of the destination / the mask (the launchers check < 4 GiB - 64 KiB).  A pixel-UNSHUFFLED
+    // destination (MIS_OUT_UNSHUFFLE2: pixel (y, x) -> pixel (y/2, x/2) of a half-resolution image, channel block (y&1)*2 + (x&1)) is the same store with other constants:
+    // the x part goes into the per-lane offset, the y part into the scalar row offset
+    const size_t img = (size_t)a.H * a.W;
+    const bool uns = (to0 ? a.y0_mode : a.y1_mode) == MIS_OUT_UNSHUFFLE2;      // wave-uniform
+    const int ow = a.W >> 1;
+    const size_t yimg = uns ? (size_t)(a.H >> 1) * ow : img;
+    const __amdgpu_buffer_rsrc_t ry = pp_make_rsrc(ybase + (size_t)n * yimg * yld * 2, (unsigned)(((yimg - 1) * yld + (uns ? 4 * cview : cview)) * 2));
+    const int x = w0 + li;
+    const int xpart = uns ? (x >> 1) * yld + (x & 1) * cview : x * yld;
+    const int yv = x < a.W ? (xpart + lcolw + lg * 8) * 2 : PP_OOB;          // a store past num_records is dropped: the ragged right edge
+    const bool masked = a.mask != nullptr;
+    const __amdgpu_buffer_rsrc_t rm = pp_make_rsrc(reinterpret_cast<const char*>(masked ? a.mask : a.y0) + (masked ? (size_t)n * img * a.mask_ld * 2 : 0),
+                                                   masked ? (unsigned)(((img - 1) * a.mask_ld + a.Cout) * 2) : 0u);
+    const int mv = x < a.W ? (x * a.mask_ld + colw + lg * 8) * 2 : PP_OOB;
+    const unsigned yrow = (unsigned)(uns ? ow : a.W) * yld * 2, mrow = (unsigned)a.W * a.mask_ld * 2;
+    const unsigned yodd = uns ? (unsigned)cview * 4u : 0u;                    // byte offset of the odd rows' channel blocks
+    const int yr0 = h0 + wm * PF;
+    const uint32_t lowb = a.relu ? 0u : 0x80008000u;       // lower bound of the packed ReLU; a SCALAR operand of the asm below (no register held across the tile loop)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    pp_f32x2 bias2[NF][2];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t u0 = braw[f][2 * h], u1 = braw[f][2 * h + 1];
+            bias2[f][h] = pp_f32x2{__uint_as_float(u0), __uint_as_float(u1)};
+        }
+    constexpr int MG = PF % 4 == 0 ? 4 : (PF % 5 == 0 ? 5 : (PF % 2 == 0 ? 2 : 1));      // pixel rows whose mask loads are in flight together
+#pragma unroll
+    for (int pg = 0; pg < PF; pg += MG) {
+        u32x4 mk[MG][NS];
+        if (masked) {
+#pragma unroll
+            for (int r = 0; r < MG; ++r)
+#pragma unroll
+                for (int i = 0; i < NS; ++i)
+                    mk[r][i] = __builtin_amdgcn_raw_buffer_load_b128(rm, mv + i * 64, (int)((unsigned)(yr0 + pg + r) * mrow), 0);      // rows past H: offset past num_records reads 0
+        }
+#pragma unroll
+        for (int r = 0; r < MG; ++r) {
+            const int pf = pg + r;
+            const int y = yr0 + pf;                // wave-uniform
+            u32x4 d[NS];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const pp_f32x2 s2 = pp_f32x2{acc[f][pf][2 * h], acc[f][pf][2 * h + 1]} + bias2[f][h];
+                    uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(s2, pp_bf16x2));
+                    asm("v_pk_max_i16 %0, %1, %2" : "=v"(pk) : "v"(pk), "s"(lowb));
+                    d[f / 2][(f & 1) * 2 + h] = pk;
+                }
+#ifndef PPT_EPI_NOZERO
+                acc[f][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+            }
+            if (masked) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t t = mk[r][i][q], du = d[i][q];          // per 16-bit half: 1 where the mask value is a positive float, else 0 (hipcc's own lowering of this is
+                        asm("v_pk_min_i16 %0, %1, 1 op_sel_hi:[1,0]\n\tv_pk_max_i16 %0, %0, 0 op_sel_hi:[1,0]\n\tv_pk_mul_lo_u16 %0, %0, %2" : "=&v"(t) : "v"(t), "v"(du));      // compare + select + permute)
+                        d[i][q] = t;
+                    }
+            }
+#ifdef PPT_EPI_NOSTORE
+            if (y < a.H && d[0][0] == 0x12345678u) {
+#else
+            if (y < a.H) {
+#endif
+#pragma unroll
+                for (int i = 0; i < NS; ++i)
+                    __builtin_amdgcn_raw_buffer_store_b128(d[i], ry, yv + i * 64, (int)(uns ? (unsigned)(y >> 1) * yrow + (unsigned)(y & 1) * yodd : (unsigned)y * yrow), 0);
+            }
         }
     }
 }

@@ -12,10 +12,10 @@ SCRATCH=$(mktemp -d /tmp/ppt_ablate.XXXXXX)
 trap 'rm -rf "$SCRATCH"' EXIT
 out=gpurun_out/ppt_ablate.log
 : > $out
-for m in NONE PPT_NO_MFMA PPT_NO_DMA; do
+for m in ${PPT_MODES:-NONE PPT_NO_MFMA PPT_NO_DMA}; do
   /opt/rocm/bin/hipcc $FLAGS -D$m -c $CS/conv_pp.hip -o $SCRATCH/conv_pp_abl.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $SCRATCH/libmisamd_abl.so $OBJS $SCRATCH/conv_pp_abl.o -ldl
   echo "== $m" >> $out
-  MISAMD_LIB=$SCRATCH/libmisamd_abl.so python scripts/bench_one_conv.py 64 512 512 128 256 256 256 128 128 >> $out 2>&1
+  MISAMD_LIB=$SCRATCH/libmisamd_abl.so python scripts/bench_one_conv.py ${PPT_LAYERS:-512 64 128 256 128 128 128 256 256} >> $out 2>&1
 done
 cat $out

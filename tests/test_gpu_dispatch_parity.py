@@ -53,7 +53,8 @@ K3_CASES = [
     (BF, 1, 70, 90, 128, 64, "k3.2d.pp64", "MIS_CONV_PP64"),
     (BF, 2, 20, 36, 64, 64, "k3.2d.pp64", "MIS_CONV_PP64"),
     (BF, 3, 150, 170, 64, 64, "k3.2d.pp64", "MIS_CONV_PP64"),          # 330 tiles > 256 blocks: one K chunk per tile, tile loop taken
-    (BF, 1, 70, 90, 128, 64, "k3.2d.ppc8n2", "MIS_CONV_PPC64"),        # 64-column blocks of the column-segment kernel (opt-in)
+    (BF, 2, 64, 50, 128, 64, "k3.2d.ppc8n2", ""),                      # 64-column blocks of the column-segment kernel: the default for Cin >= 128 on grids that fill 32-row tiles
+    (BF, 1, 70, 90, 128, 64, "k3.2d.ppc8n2", "MIS_CONV_PPC64"),        # ... and wherever eligible with the switch
     (BF, 2, 20, 36, 64, 64, "k3.2d.ppc8n2", "MIS_CONV_PPC64"),
     (BF, 3, 150, 170, 64, 64, "k3.2d.ppc8n2", "MIS_CONV_PPC64"),       # 165 tiles
     (BF, 9, 150, 170, 64, 64, "k3.2d.ppc8n2", "MIS_CONV_PPC64"),       # 495 tiles > 256 persistent blocks
