@@ -67,6 +67,12 @@ typedef struct MisConvDesc {
     void* y0; int y0_ld; int y0_mode;
     void* y1; int y1_ld; int y1_mode;
     int Cout0;
+    /* ReLU bits (bf16, 2-D, Cout % 64 == 0; layout: csrc/relu_bits.hpp, size mis_relu_bits_bytes(N, H, W, Cout)): one bit per output element.
+     * relu_bits (out, with relu = 1, one plain destination): bit = (stored output > 0), written from the epilogue - the mask the ReLU backward of this layer needs.
+     * mask_bits (in, instead of `mask`): out *= bit of a tensor of the output's shape - the same result as `mask` with the bf16 tensor the bits were taken from,
+     * at 1/16 of its traffic.  Both NULL by default. */
+    void* relu_bits;
+    const void* mask_bits;
 } MisConvDesc;
 int mis_conv_igemm(const MisConvDesc* d, void* stream);
 /* Name of the kernel configuration the calling thread's last mis_conv_igemm ran, e.g. "k3.2d.bn256.dma" (diagnostic: the parity tests assert
@@ -117,6 +123,13 @@ int mis_wgrad_last_nsplit(void);
  * model/unet2d/layers.py:122 for down_conv.0.first. */
 int mis_conv3x3_first_fwd(int dtype, const float* x_nchw, int N, int Cin, int H, int W, const float* w /*[64][Cin][3][3]*/,
                           const float* bias, void* y, int y_ld, int Cout, void* stream);
+/* ... the same with the ReLU bits of the output written from the epilogue (bf16; relu_bits may be NULL) */
+int mis_conv3x3_first_fwd_rb(int dtype, const float* x_nchw, int N, int Cin, int H, int W, const float* w, const float* bias, void* y, int y_ld, int Cout,
+                             void* relu_bits, void* stream);
+/* ReLU bits of a bf16 NHWC tensor (N, H, W, C), C % 64 == 0: bits = (y > 0), in the layout of csrc/relu_bits.hpp (stand-alone producer; the convolutions write
+ * them from their epilogues). */
+size_t mis_relu_bits_bytes(int N, int H, int W, int C);
+int mis_relu_bits(const void* y, int y_ld, int N, int H, int W, int C, void* bits, void* stream);
 size_t mis_conv3x3_first_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout);
 int mis_conv3x3_first_wgrad(int dtype, const float* x_nchw, int N, int Cin, int H, int W, const void* dy, int dy_ld, int Cout,
                             float* workspace, float* dw, float* db, void* stream);

@@ -18,7 +18,7 @@ EXPORTS = [
     "mis_conv_last_dispatch", "mis_wgrad_last_dispatch", "mis_wgrad_last_nsplit", "mis_dispatch_override", "mis_dispatch_switch", "mis_gn_apply",
     "mis_mt19937_words", "mis_legacy_normal", "mis_mt_jump", "mis_mt_generate", "mis_legacy_normal_par_workspace_bytes", "mis_legacy_normal_par",
     "mis_comm_unique_id", "mis_comm_init", "mis_comm_world", "mis_allreduce_bucket", "mis_comm_finalize",
-    "mis_conv3x3_first_fwd", "mis_conv3x3_first_wgrad_workspace_bytes", "mis_conv3x3_first_wgrad",
+    "mis_conv3x3_first_fwd", "mis_conv3x3_first_fwd_rb", "mis_relu_bits_bytes", "mis_relu_bits", "mis_conv3x3_first_wgrad_workspace_bytes", "mis_conv3x3_first_wgrad",
     "mis_colsum_workspace_bytes", "mis_colsum", "mis_maxpool2_fwd", "mis_maxpool2_bwd",
     "mis_pack_conv_weight", "mis_pack_convt_weight", "mis_pack_batch", "mis_head_workspace_bytes", "mis_head_loss",
     "mis_adamw_workspace_bytes", "mis_sumsq", "mis_adamw_step", "mis_adamw_step_dev", "mis_sumsq_npartials",
@@ -49,6 +49,7 @@ class ConvDesc(C.Structure):
         ("y0", C.c_void_p), ("y0_ld", C.c_int), ("y0_mode", C.c_int),
         ("y1", C.c_void_p), ("y1_ld", C.c_int), ("y1_mode", C.c_int),
         ("Cout0", C.c_int),
+        ("relu_bits", C.c_void_p), ("mask_bits", C.c_void_p),
     ]
 
 
@@ -126,6 +127,8 @@ def load():
     for name in ("mis_wgrad_workspace_bytes", "mis_head_workspace_bytes"):
         getattr(lib, name).restype = C.c_size_t
         getattr(lib, name).argtypes = [C.c_void_p]
+    lib.mis_relu_bits_bytes.restype = C.c_size_t
+    lib.mis_relu_bits_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.mis_conv3x3_first_wgrad_workspace_bytes.restype = C.c_size_t
     lib.mis_conv3x3_first_wgrad_workspace_bytes.argtypes = [C.c_int] * 5
     lib.mis_colsum_workspace_bytes.restype = C.c_size_t
@@ -170,6 +173,8 @@ def load():
         "mis_conv_igemm": [vp, vp],
         "mis_wgrad": [vp, vp],
         "mis_conv3x3_first_fwd": [i, vp, i, i, i, i, vp, vp, vp, i, i, vp],
+        "mis_conv3x3_first_fwd_rb": [i, vp, i, i, i, i, vp, vp, vp, i, i, vp, vp],
+        "mis_relu_bits": [vp, i, i, i, i, i, vp, vp],
         "mis_conv3x3_first_wgrad": [i, vp, i, i, i, i, vp, i, i, vp, vp, vp, vp],
         "mis_colsum": [i, vp, i, ll, i, i, f, vp, vp, vp],
         "mis_maxpool2_fwd": [i, vp, i, vp, i, i, i, i, i, i, vp],

@@ -20,7 +20,7 @@
 #include "conv_pp_common.hpp"
 #include "dispatch_cfg.hpp"
 
-template <int PF, int NF>
+template <int PF, int NF, int EM>
 __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
     using T = __bf16;
     constexpr int WAVE_N = NF * 16, BN = 2 * WAVE_N, NV = 4 * NF;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
             dz = ndz;
             c0 = nc0;
         }
-        pp_epilogue_plain<NF, PF>(a, acc, (uint32_t)(uintptr_t)bbase + bsel * (BN * 4), pl, h0, w0, ncol0, wm, wn);
+        pp_epilogue_plain<NF, PF, EM, false>(a, acc, (uint32_t)(uintptr_t)bbase + bsel * (BN * 4), pl, h0, w0, ncol0, wm, wn, u32x4{0u, 0u, 0u, 0u});
         pl = npl; z = nz; h0 = nh0; w0 = nw0; ncol0 = ncolN;
         bsel ^= 1;
         if (has_next) issue_bias(ncol0, bbase + bsel * (BN * 4));
@@ -314,7 +314,12 @@ bool conv3d_pp_eligible(const MisConvDesc* d) {
     return true;
 }
 
-template <int PF, int NF> static int pp3_launch(const MisConvDesc* d, hipStream_t stream) {
+template <int PF, int NF, int EM> static int pp3_launch_em(const MisConvDesc* d, hipStream_t stream);
+template <int PF, int NF> static int pp3_launch(const MisConvDesc* d, hipStream_t stream) {      // one instantiation per epilogue mask path (3-D: none or the bf16 mask)
+    if (d->mask != nullptr) return pp3_launch_em<PF, NF, PP_EM_MASK>(d, stream);
+    return pp3_launch_em<PF, NF, PP_EM_NONE>(d, stream);
+}
+template <int PF, int NF, int EM> static int pp3_launch_em(const MisConvDesc* d, hipStream_t stream) {
     constexpr int BN = 2 * NF * 16;
     constexpr int TH = 4 * PF, HINSTR = ((TH + 2) * 18 * 4 + 63) / 64;
     ConvArgs a;
@@ -322,7 +327,7 @@ template <int PF, int NF> static int pp3_launch(const MisConvDesc* d, hipStream_
     a.x0 = SrcView{d->x0, d->x0_ld, d->x0_D, d->x0_H, d->x0_W};
     a.x1 = SrcView{nullptr, 0, 0, 0, 0};
     a.in_scale = nullptr; a.in_shift = nullptr;
-    a.w = d->w; a.bias = d->bias; a.relu = d->relu; a.mask = d->mask; a.mask_ld = d->mask_ld;
+    a.w = d->w; a.bias = d->bias; a.relu = d->relu; a.mask = d->mask; a.mask_ld = d->mask_ld; a.relu_bits = nullptr; a.mask_bits = reinterpret_cast<const unsigned char*>(d->mask_bits);
     a.y0 = d->y0; a.y0_ld = d->y0_ld; a.y0_mode = d->y0_mode;
     a.y1 = d->y1; a.y1_ld = d->y1_ld; a.y1_mode = d->y1_mode;
     a.tilesD = d->D;
@@ -340,9 +345,9 @@ template <int PF, int NF> static int pp3_launch(const MisConvDesc* d, hipStream_
     a.nSp = (int)nsp;
     const size_t lds = 2 * (size_t)HINSTR * 1024 + 2 * (size_t)3 * BN * 64 + 2 * (size_t)BN * 4;
     static std::atomic<unsigned long long> attr_done{0};
-    if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv3d_ppc_kernel<PF, NF>), lds, "conv_igemm(3d pp)")) return rc;
+    if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv3d_ppc_kernel<PF, NF, EM>), lds, "conv_igemm(3d pp)")) return rc;
     const long long total = nsp * a.nCt;
-    hipLaunchKernelGGL((conv3d_ppc_kernel<PF, NF>), dim3((unsigned)(total > 256 ? 256 : total)), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((conv3d_ppc_kernel<PF, NF, EM>), dim3((unsigned)(total > 256 ? 256 : total)), dim3(512), lds, stream, a);
     MIS_LAUNCH_CHECK("conv_igemm(3d pp)");
     return MIS_OK;
 }

@@ -22,14 +22,18 @@ struct ConvArgs {
     void* y1;
     int y1_ld, y1_mode;
     int tilesD, tilesH, tilesW, nSp, nCt;
+    unsigned char* relu_bits;          // ReLU bits of the output (relu_bits.hpp) or nullptr
+    const unsigned char* mask_bits;    // ReLU bits applied to the output instead of `mask`, or nullptr
     int order, zg;     // conv3d_pp.hip: tile order (1 = column-tile major, 2 = spatial major) and depth-group size of the plane walk
 };
 
+extern thread_local bool g_conv_bits_fused;            // conv_igemm.hip: the launched kernel writes relu_bits itself
 // conv_pp.hip: the ping-pong 3x3 kernel for the bf16 2-D layers (returns MIS_OK after the launch, or an error); `eligible` says whether a
 // descriptor can take that path at all (dispatch in conv_igemm.hip decides)
 bool conv_pp_eligible(const MisConvDesc* d);
 bool conv_ppc64_auto(const MisConvDesc* d);            // 64-column blocks of the column-segment kernel chosen by default (Cin >= 128)
 bool conv_pp_rs64_eligible(const MisConvDesc* d);      // 64 -> 64 channels: the register-stationary ping-pong kernel
+int conv_ppc_choice(const MisConvDesc* d);            // 4 / 2: launch_conv_pp runs conv_ppc_kernel<8, 4 / 2> (the kernels that read / write ReLU bits in their epilogue); 0: another kernel
 int launch_conv_pp(const MisConvDesc* d, hipStream_t stream, const char** tag);
 // conv3d_pp.hip: the same structure for the bf16 3x3x3 layers (single source, no operand affine)
 bool conv3d_pp_eligible(const MisConvDesc* d);

@@ -20,6 +20,7 @@
 #include "common.hpp"
 #include "conv_args.hpp"
 #include "dispatch_cfg.hpp"
+#include "relu_bits.hpp"
 
 #ifndef MIS_WDMA_EXPLICIT_DRAIN
 #define MIS_WDMA_EXPLICIT_DRAIN 1
@@ -387,6 +388,16 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const ConvArgs a) {
                             for (int e = 0; e < EPC; ++e) o[i + e] = (mf[e] > 0.f) ? o[i + e] : 0.f;
                         }
                     }
+                    if constexpr (sizeof(T) == 2) {
+                        if (a.mask_bits != nullptr) {          // ReLU bits instead of the bf16 mask tensor (relu_bits.hpp): one byte per 8 columns of this pixel
+#pragma unroll
+                            for (int i = 0; i < NV; i += 8) {
+                                const unsigned b = a.mask_bits[rb_byte_offset((a.H + 7) >> 3, a.W, a.Cout >> 6, n, y, x, (col + i) >> 3)];
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) o[i + e] = ((b >> e) & 1u) ? o[i + e] : 0.f;
+                            }
+                        }
+                    }
                     T* dst;
                     if (ymode == MIS_OUT_PLAIN) {
                         dst = ybase + pix * yld + lcol;
@@ -446,6 +457,17 @@ __device__ __forceinline__ uint32_t mask_bf16x2(uint32_t v, uint32_t m) {   // v
     return __builtin_bit_cast(uint32_t, (u16x2_t)(__builtin_bit_cast(u16x2_t, v) * pos));
 }
 
+// v where bit 2q / 2q + 1 of byte R (0..3) of the ReLU-bits word mw is set (low / high half), else 0
+__device__ __forceinline__ uint32_t maskbits_bf16x2(uint32_t v, uint32_t mw, int R, int Q) {      // (R, Q: constants after unrolling)
+    const uint32_t sh = (uint32_t)((R & 1) * 8 + 2 * Q) * 0x00010001u + 0x00010000u;      // shift the byte's 16-bit half by (s, s + 1) into the two result halves
+    uint32_t t;
+    if (R < 2) asm("v_pk_lshrrev_b16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "s"(sh), "v"(mw));
+    else asm("v_pk_lshrrev_b16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(t) : "s"(sh), "v"(mw));
+    t &= 0x00010001u;
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(t) : "v"(v), "v"(t));
+    return t;
+}
+
 __global__ __launch_bounds__(512, 2) void conv64_ws_kernel(const ConvArgs a) {
     using T = __bf16;
     constexpr int EPC = 8, NF = 4, PF = 4, NV = 16;
@@ -468,7 +490,9 @@ __global__ __launch_bounds__(512, 2) void conv64_ws_kernel(const ConvArgs a) {
         for (int k = 0; k < 9; ++k) {
             const int it = tid + k * WS64::NT;                 // 4608 items = 9 taps x 64 rows x 8 chunks
             const int tap = it >> 9, r = (it >> 3) & 63, c16 = it & 7;
-            const int aa = r / NV, ff = (r >> 2) % NF, bb = r & 3;
+            // output channel r = (f >> 1) * 32 + lg * 8 + (f & 1) * 4 + q sits in MFMA row lg * 4 + q of fragment f (the channel order of the column-segment kernels, conv_pp.hip:
+            // a lane holds channels lg*8..+7 and 32 + lg*8..+7, each store instruction covers 64 contiguous bytes per pixel, and the lane's ReLU bits are its own bytes)
+            const int ff = (r >> 5) * 2 + ((r >> 2) & 1), aa = (r >> 3) & 3, bb = r & 3;
             const int lrow = ff * 16 + aa * 4 + bb;
             const u32x4 v = *reinterpret_cast<const u32x4*>(wp + ((size_t)tap * 64 + r) * 64 + c16 * EPC);
             lds_write_b128(wlds, tap * 8192 + lrow * 128 + ((c16 ^ (lrow & 7)) << 4), v);
@@ -542,15 +566,15 @@ __global__ __launch_bounds__(512, 2) void conv64_ws_kernel(const ConvArgs a) {
     }
     constexpr int ROWB = WS64::HW * 128;   // 2304
 
-    // lane (li, lg) owns, per pixel row pf, channels lg*16 .. lg*16+15 of pixel (h0 + wm*4 + pf, w0 + li)
-    const int col = lg * NV;
+    // lane (li, lg) owns, per pixel row pf, channels lg*8 .. +7 (fragments 0, 1) and 32 + lg*8 .. +7 (fragments 2, 3) of pixel (h0 + wm*4 + pf, w0 + li)
+    const int col = lg * 8;
     const uint32_t orel = (uint32_t)(((wm * 4) * a.W + li) * a.y0_ld + col) * 2u;       // bytes from the tile's first output pixel
     const uint32_t mrel = (uint32_t)(((wm * 4) * a.W + li) * a.mask_ld + col) * 2u;
     f32x4 bv[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         bv[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.bias != nullptr) bv[f] = *reinterpret_cast<const f32x4*>(a.bias + col + f * 4);
+        if (a.bias != nullptr) bv[f] = *reinterpret_cast<const f32x4*>(a.bias + (f >> 1) * 32 + col + (f & 1) * 4);
     }
     f32x4 acc[NF][PF];
 #pragma unroll
@@ -572,6 +596,14 @@ __global__ __launch_bounds__(512, 2) void conv64_ws_kernel(const ConvArgs a) {
         __syncthreads();                       // this tile's halo (and, first time, the filter) is in LDS
         STAMP(0)
         if (has_next) h_load(nn, nh0, nw0);    // in flight during the 288 MFMAs below
+        // ReLU bits of this lane's 4 rows (relu_bits.hpp): bytes [lg][i][(wm & 1) * 4 .. + 3] of the record of (n, row block, column, the one 64-channel block) - two dwords,
+        // in flight during the MFMAs as well
+        uint32_t mbw[2] = {0u, 0u};
+        if (a.mask_bits != nullptr && w0 + li < a.W && h0 + wm * 4 < a.H) {
+            const uint32_t* bp = reinterpret_cast<const uint32_t*>(a.mask_bits + ((((size_t)n * ((a.H + 7) >> 3) + ((h0 + wm * 4) >> 3)) * a.W + (w0 + li)) * 64 + lg * 16 + (wm & 1) * 4));
+            mbw[0] = bp[0];
+            mbw[1] = bp[2];
+        }
         __builtin_amdgcn_sched_barrier(0);
         STAMP(1)
 #pragma unroll 1
@@ -623,16 +655,22 @@ __global__ __launch_bounds__(512, 2) void conv64_ws_kernel(const ConvArgs a) {
                     }
                     if (a.mask != nullptr) {
                         const u32x4* mp = reinterpret_cast<const u32x4*>(mbase + (mrel + (uint32_t)(pf * a.W * a.mask_ld * 2)));
-                        const u32x4 m0 = mp[0], m1 = mp[1];
+                        const u32x4 m0 = mp[0], m1 = mp[4];           // (pieces are 64 bytes apart)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             o[0][i] = mask_bf16x2(o[0][i], m0[i]);
                             o[1][i] = mask_bf16x2(o[1][i], m1[i]);
                         }
                     }
+                    if (a.mask_bits != nullptr) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) o[i][q] = maskbits_bf16x2(o[i][q], mbw[i], pf, q);
+                    }
                     u32x4* dst = reinterpret_cast<u32x4*>(obase + (orel + (uint32_t)(pf * a.W * a.y0_ld * 2)));
                     dst[0] = o[0];
-                    dst[1] = o[1];
+                    dst[4] = o[1];
                 }
             }
         }
@@ -656,7 +694,7 @@ static int launch_ws64(const MisConvDesc* d, hipStream_t stream) {
     a.x0 = SrcView{d->x0, d->x0_ld, 1, d->x0_H, d->x0_W};
     a.x1 = SrcView{nullptr, 0, 0, 0, 0};
     a.in_scale = nullptr; a.in_shift = nullptr;
-    a.w = d->w; a.bias = d->bias; a.relu = d->relu; a.mask = d->mask; a.mask_ld = d->mask_ld;
+    a.w = d->w; a.bias = d->bias; a.relu = d->relu; a.mask = d->mask; a.mask_ld = d->mask_ld; a.relu_bits = nullptr; a.mask_bits = reinterpret_cast<const unsigned char*>(d->mask_bits);
     a.y0 = d->y0; a.y0_ld = d->y0_ld; a.y0_mode = MIS_OUT_PLAIN;
     a.y1 = nullptr; a.y1_ld = 0; a.y1_mode = 0;
 #ifdef MIS_WS64_STAMPS
@@ -690,7 +728,7 @@ static int launch_cfg(const MisConvDesc* d, hipStream_t stream) {
     a.x0 = SrcView{d->x0, d->x0_ld, d->x0_D, d->x0_H, d->x0_W};
     a.x1 = SrcView{d->x1, d->x1_ld, d->x1_D, d->x1_H, d->x1_W};
     a.in_scale = d->in_scale; a.in_shift = d->in_shift;
-    a.w = d->w; a.bias = d->bias; a.relu = d->relu; a.mask = d->mask; a.mask_ld = d->mask_ld;
+    a.w = d->w; a.bias = d->bias; a.relu = d->relu; a.mask = d->mask; a.mask_ld = d->mask_ld; a.relu_bits = nullptr; a.mask_bits = reinterpret_cast<const unsigned char*>(d->mask_bits);
     a.y0 = d->y0; a.y0_ld = d->y0_ld; a.y0_mode = d->y0_mode;
     a.y1 = d->y1; a.y1_ld = d->y1_ld; a.y1_mode = d->y1_mode;
     a.tilesD = (d->D + G::TD - 1) / G::TD;
@@ -711,6 +749,7 @@ static int launch_cfg(const MisConvDesc* d, hipStream_t stream) {
 
 // name of the kernel configuration the last mis_conv_igemm call of this thread ran (tests assert that a parity case reaches the branch it is meant for)
 static thread_local const char* g_conv_last = "";
+thread_local bool g_conv_bits_fused = false;       // set by a launcher whose kernel writes MisConvDesc::relu_bits from its epilogue (conv_pp.hip)
 extern "C" const char* mis_conv_last_dispatch(void) { return g_conv_last; }
 #define RUN(tag, ...)          \
     do {                       \
@@ -731,7 +770,7 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
                 // 64-column layers stay on the weight-stationary / bn64 configurations: the ping-pong kernel with 64-column blocks (wave tile 64 px x 32 ch: 12 fragment
                 // reads per 16 MFMAs) is bound by its R segments - measured 629 vs 959 TFLOP/s (64->64 at 512^2) and 784 vs 916 (128->64); MIS_CONV_PP64=1 selects it
                 const bool pp64 = mis_sw(SW_CONV_PP64) || mis_sw(SW_CONV_PPC64);
-                if (pp && conv_pp_eligible(d) && (d->Cout % 128 == 0 || pp64 || conv_ppc64_auto(d) || conv_pp_rs64_eligible(d))) {      // (rs64: opt-in, MIS_CONV_RS64=1)
+                if (pp && conv_pp_eligible(d) && (d->Cout % 128 == 0 || pp64 || conv_ppc64_auto(d) || conv_pp_rs64_eligible(d)) && (d->mask_bits == nullptr || conv_ppc_choice(d) != 0)) {      // (rs64: opt-in, MIS_CONV_RS64=1)
                     const char* tag = "";
                     const int rc = launch_conv_pp(d, s, &tag);
                     g_conv_last = tag;
@@ -842,7 +881,16 @@ extern "C" int mis_conv_igemm(const MisConvDesc* d, void* stream) {
         if (modes[i] == MIS_OUT_UNSHUFFLE2)
             MIS_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0, MIS_EUNSUPPORTED, "conv_igemm: unshuffle needs even H, W");
     }
+    if (d->relu_bits != nullptr || d->mask_bits != nullptr) {
+        MIS_REQUIRE(d->dtype == MIS_BF16 && !d->is3d && d->D == 1, MIS_EUNSUPPORTED, "conv_igemm: ReLU bits are a bf16 2-D feature");
+        MIS_REQUIRE(d->mask_bits == nullptr || d->mask == nullptr, MIS_EINVAL, "conv_igemm: mask and mask_bits are alternatives");
+        MIS_REQUIRE(d->relu_bits == nullptr || (d->relu && d->Cout0 == d->Cout && d->y0_mode == MIS_OUT_PLAIN), MIS_EUNSUPPORTED,
+                    "conv_igemm: relu_bits needs relu = 1 and one plain destination");
+    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (d->dtype == MIS_BF16) return dispatch<__bf16>(d, s);
-    return dispatch<float>(d, s);
+    g_conv_bits_fused = false;
+    const int rc = d->dtype == MIS_BF16 ? dispatch<__bf16>(d, s) : dispatch<float>(d, s);
+    // a kernel without the fused producer (everything but the column-segment kernels): the stand-alone pass over the stored output
+    if (rc == MIS_OK && d->relu_bits != nullptr && !g_conv_bits_fused) return mis_relu_bits(d->y0, d->y0_ld, d->N, d->H, d->W, d->Cout, d->relu_bits, stream);
+    return rc;
 }

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
 // DMA schedule per wave: weights 3 instructions per segment (group 0 in its R for the next segment, group 1 in its M for the segment after the next one, as in conv_pp_kernel);
 // halo of the next chunk: instructions j = 0..2 in the R of column 0, j = 3.. in the R of column 1, none in column 2 (so that everything has had a slot pair to land before the
 // chunk's last barrier); every wait is a counted vmcnt that leaves exactly the halo instructions issued in the same segment in flight.
-template <int PF, int NF>
+template <int PF, int NF, int EM>
 __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
     using T = __bf16;
     constexpr int WAVE_N = NF * 16, BN = 2 * WAVE_N, NV = 4 * NF;       // NF = 4: 128-column blocks; NF = 2: 64-column blocks (wave tile 128 px x 32 ch)
@@ -519,6 +519,10 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
         const bool has_next = tile + tstride < total_tiles;
         int nn = n, nh0 = h0, nw0 = w0, ncolN = ncol0;
         if (has_next) decode(tile + tstride, nn, nh0, nw0, ncolN);
+        // EM == PP_EM_BITS: the mask of this tile's epilogue - one 16-byte (8-byte) load per lane, issued here, ahead of the whole K loop (inside the chunk loop the
+        // load's destination would be loop-carried and hipcc guards it with an s_waitcnt vmcnt(0) at the loop header, i.e. in front of every chunk's prefetches)
+        u32x4 mbits = u32x4{0u, 0u, 0u, 0u};
+        if constexpr (EM == PP_EM_BITS) mbits = pp_mask_bits_load<NF, PF>(a, n, h0, w0, ncol0, wm, wn);
 #pragma unroll 1
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             const int c0 = chunk << 5;
@@ -620,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
 #ifdef PPT_EPI_PRIO
         __builtin_amdgcn_s_setprio(PPT_EPI_PRIO);
 #endif
-        pp_epilogue_plain<NF, PF>(a, acc, (uint32_t)(uintptr_t)bbase + bsel * (BN * 4), n, h0, w0, ncol0, wm, wn);
+        pp_epilogue_plain<NF, PF, EM>(a, acc, (uint32_t)(uintptr_t)bbase + bsel * (BN * 4), n, h0, w0, ncol0, wm, wn, mbits);
 #ifdef PPT_EPI_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -641,7 +645,13 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
 #endif
 }
 
-template <int PF, int NF> static int pp_launch_col(const MisConvDesc* d, hipStream_t stream) {
+template <int PF, int NF, int EM> static int pp_launch_col_em(const MisConvDesc* d, hipStream_t stream);
+template <int PF, int NF> static int pp_launch_col(const MisConvDesc* d, hipStream_t stream) {      // one instantiation per epilogue mask path (pp_epilogue_plain)
+    if (d->mask_bits != nullptr) return pp_launch_col_em<PF, NF, PP_EM_BITS>(d, stream);
+    if (d->mask != nullptr) return pp_launch_col_em<PF, NF, PP_EM_MASK>(d, stream);
+    return pp_launch_col_em<PF, NF, PP_EM_NONE>(d, stream);
+}
+template <int PF, int NF, int EM> static int pp_launch_col_em(const MisConvDesc* d, hipStream_t stream) {
     constexpr int BN = 2 * NF * 16;
     constexpr int TH = 4 * PF, HINSTR = ((TH + 2) * 18 * 4 + 63) / 64;
     ConvArgs a;
@@ -649,9 +659,11 @@ template <int PF, int NF> static int pp_launch_col(const MisConvDesc* d, hipStre
     a.x0 = SrcView{d->x0, d->x0_ld, 1, d->x0_H, d->x0_W};
     a.x1 = SrcView{nullptr, 0, 0, 0, 0};
     a.in_scale = nullptr; a.in_shift = nullptr;
-    a.w = d->w; a.bias = d->bias; a.relu = d->relu; a.mask = d->mask; a.mask_ld = d->mask_ld;
+    a.w = d->w; a.bias = d->bias; a.relu = d->relu; a.mask = d->mask; a.mask_ld = d->mask_ld; a.relu_bits = nullptr; a.mask_bits = reinterpret_cast<const unsigned char*>(d->mask_bits);
     a.y0 = d->y0; a.y0_ld = d->y0_ld; a.y0_mode = d->y0_mode;
     a.y1 = d->y1; a.y1_ld = d->y1_ld; a.y1_mode = d->y1_mode;
+    a.relu_bits = reinterpret_cast<unsigned char*>(d->relu_bits);      // written from the epilogue (pp_epilogue_plain)
+    g_conv_bits_fused = d->relu_bits != nullptr;
     a.tilesH = (d->H + TH - 1) / TH;
     a.tilesW = (d->W + 15) / 16;
     const long long nsp = (long long)d->N * a.tilesH * a.tilesW;
@@ -662,9 +674,9 @@ template <int PF, int NF> static int pp_launch_col(const MisConvDesc* d, hipStre
     a.nSp = (int)nsp;
     const size_t lds = 2 * (size_t)HINSTR * 1024 + 2 * (size_t)3 * BN * 64 + 2 * (size_t)BN * 4;
     static std::atomic<unsigned long long> attr_done{0};
-    if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv_ppc_kernel<PF, NF>), lds, "conv_igemm(ppc)")) return rc;
+    if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv_ppc_kernel<PF, NF, EM>), lds, "conv_igemm(ppc)")) return rc;
     const long long total = nsp * a.nCt;
-    hipLaunchKernelGGL((conv_ppc_kernel<PF, NF>), dim3((unsigned)(total > 256 ? 256 : total)), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((conv_ppc_kernel<PF, NF, EM>), dim3((unsigned)(total > 256 ? 256 : total)), dim3(512), lds, stream, a);
     MIS_LAUNCH_CHECK("conv_igemm(ppc)");
     return MIS_OK;
 }
@@ -819,7 +831,7 @@ static int pp_launch_rs64(const MisConvDesc* d, hipStream_t stream) {
     a.x0 = SrcView{d->x0, d->x0_ld, 1, d->x0_H, d->x0_W};
     a.x1 = SrcView{nullptr, 0, 0, 0, 0};
     a.in_scale = nullptr; a.in_shift = nullptr;
-    a.w = d->w; a.bias = d->bias; a.relu = d->relu; a.mask = d->mask; a.mask_ld = d->mask_ld;
+    a.w = d->w; a.bias = d->bias; a.relu = d->relu; a.mask = d->mask; a.mask_ld = d->mask_ld; a.relu_bits = nullptr; a.mask_bits = reinterpret_cast<const unsigned char*>(d->mask_bits);
     a.y0 = d->y0; a.y0_ld = d->y0_ld; a.y0_mode = d->y0_mode;
     a.y1 = nullptr; a.y1_ld = 0; a.y1_mode = 0;
     a.tilesD = 1;
@@ -858,7 +870,7 @@ template <int NF> static int pp_launch(const MisConvDesc* d, hipStream_t stream)
     a.x0 = SrcView{d->x0, d->x0_ld, 1, d->x0_H, d->x0_W};
     a.x1 = SrcView{nullptr, 0, 0, 0, 0};
     a.in_scale = nullptr; a.in_shift = nullptr;
-    a.w = d->w; a.bias = d->bias; a.relu = d->relu; a.mask = d->mask; a.mask_ld = d->mask_ld;
+    a.w = d->w; a.bias = d->bias; a.relu = d->relu; a.mask = d->mask; a.mask_ld = d->mask_ld; a.relu_bits = nullptr; a.mask_bits = reinterpret_cast<const unsigned char*>(d->mask_bits);
     a.y0 = d->y0; a.y0_ld = d->y0_ld; a.y0_mode = d->y0_mode;
     a.y1 = d->y1; a.y1_ld = d->y1_ld; a.y1_mode = d->y1_mode;
     a.tilesD = 1;
@@ -889,6 +901,7 @@ static bool ppc_plain_ok(const MisConvDesc* d) {
     if (!view_ok(d->y0_mode, d->y0_ld, d->Cout0)) return false;
     if (d->Cout0 < d->Cout && (d->y1 == nullptr || !view_ok(d->y1_mode, d->y1_ld, d->Cout - d->Cout0))) return false;
     if (d->mask != nullptr && ((img - 1) * d->mask_ld + d->Cout) * 2 >= lim) return false;
+    if ((d->relu_bits != nullptr || d->mask_bits != nullptr) && (long long)rb_bytes(d->N, d->H, d->W, d->Cout) >= lim) return false;      // ReLU bits: one 32-bit-offset resource
     return true;
 }
 
@@ -903,20 +916,30 @@ bool conv_pp_rs64_eligible(const MisConvDesc* d) {
     return conv_pp_eligible(d) && d->Cin == 64 && d->Cout == 64 && d->Cout0 == 64 && d->y0_mode == MIS_OUT_PLAIN && mis_sw(SW_CONV_RS64);      // opt-in: measured 0.700 vs 0.654 ms against conv64_ws_kernel
 }
 
+// which column-segment configuration launch_conv_pp takes for a descriptor conv_pp_eligible accepts: 4 / 2 = conv_ppc_kernel<8, 4 / 2>, 0 = none (conv_pp_kernel / rs64)
+//   Cout % 128 == 0: 128-column blocks, unless the 32-row tiles waste more than 15 % of the rows (MIS_CONV_PPC=1 takes it regardless) or MIS_CONV_NOPPC is set
+//   (the parity tests reach every kernel on small grids that way); else 64-column blocks where conv_ppc64_auto says so (MIS_CONV_PPC64=1: wherever eligible)
+int conv_ppc_choice(const MisConvDesc* d) {
+    if (conv_pp_rs64_eligible(d)) return 0;
+    if (d->Cout % 128 == 0 && !mis_sw(SW_CONV_NOPPC) && ppc_plain_ok(d) && (((d->H + 31) / 32) * 32 * 100 <= d->H * 115 || mis_sw(SW_CONV_PPC))) return 4;
+    if (d->Cout % 64 == 0 && (mis_sw(SW_CONV_PPC64) || conv_ppc64_auto(d)) && ppc_plain_ok(d)) return 2;
+    return 0;
+}
+
 int launch_conv_pp(const MisConvDesc* d, hipStream_t stream, const char** tag) {
-    if (conv_pp_rs64_eligible(d)) {
-        *tag = "k3.2d.rs64";
-        return pp_launch_rs64(d, stream);
-    }
-    // Cout % 128 == 0: the column-segment kernel, unless its 32-row tiles waste more than 15 % of the rows (MIS_CONV_PPC=1 takes it regardless) or MIS_CONV_NOPPC is set
-    // (the parity tests reach every kernel on small grids that way)
-    if (d->Cout % 128 == 0 && !mis_sw(SW_CONV_NOPPC) && ppc_plain_ok(d) && (((d->H + 31) / 32) * 32 * 100 <= d->H * 115 || mis_sw(SW_CONV_PPC))) {
+    const int ppc = conv_ppc_choice(d);
+    if (ppc == 4) {
         *tag = "k3.2d.ppc8";
         return pp_launch_col<8, 4>(d, stream);
     }
-    if (d->Cout % 64 == 0 && (mis_sw(SW_CONV_PPC64) || conv_ppc64_auto(d)) && ppc_plain_ok(d)) {      // 64-column blocks of the same kernel (MIS_CONV_PPC64=1: wherever eligible)
+    if (ppc == 2) {
         *tag = "k3.2d.ppc8n2";
         return pp_launch_col<8, 2>(d, stream);
+    }
+    MIS_REQUIRE(d->mask_bits == nullptr, MIS_EUNSUPPORTED, "conv_igemm(pp): ReLU bits are read by the column-segment kernels only");      // (dispatch never sends one here)
+    if (conv_pp_rs64_eligible(d)) {
+        *tag = "k3.2d.rs64";
+        return pp_launch_rs64(d, stream);
     }
     if (d->Cout % 256 == 0 && d->Cout0 % 128 == 0) {
         const int no256 = mis_sw(SW_CONV_PP_NO256);

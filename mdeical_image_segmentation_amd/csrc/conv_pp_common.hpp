@@ -5,6 +5,7 @@
 #include <utility>
 
 #include "conv_args.hpp"
+#include "relu_bits.hpp"
 
 typedef __attribute__((address_space(3))) void pp_lds_void_t;
 typedef __attribute__((address_space(1))) const void pp_glob_void_t;
@@ -133,9 +134,43 @@ typedef float pp_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 pp_bf16x2 __attribute__((ext_vector_type(2)));
 typedef short pp_i16x2 __attribute__((ext_vector_type(2)));
 
+// ReLU bits (relu_bits.hpp) of a lane's part of a tile, 8-row wave tiles only: NF = 4: the 16 bytes [lg][0..1][row 0..7] of record (n, row block, x, 64-channel block);
+// NF = 2 (32-channel wave slice): the 8 bytes [lg][half][0..7].  Returns the per-lane byte offset into the bit tensor (32-bit: the launchers check its size), or PP_OOB.
 template <int NF, int PF>
-__device__ __forceinline__ void pp_epilogue_plain(const ConvArgs& a, f32x4 (&acc)[NF][PF], uint32_t bias_lds, int n, int h0, int w0, int ncol0, int wm, int wn) {
+__device__ __forceinline__ int pp_bits_voff(const ConvArgs& a, int n, int h0, int w0, int ncol0, int wm, int wn, int li, int lg) {
+    const int colw = ncol0 + wn * NF * 16;
+    const int x = w0 + li, yb = (h0 + wm * PF) >> 3, H8 = (a.H + 7) >> 3;
+    const unsigned rec = (unsigned)(((n * H8 + yb) * a.W + x) * (a.Cout >> 6) + (colw >> 6));
+    return (x < a.W && yb < H8) ? (int)(rec * 64u + (unsigned)(lg * 16 + (NF == 2 ? ((colw >> 5) & 1) * 8 : 0))) : PP_OOB;
+}
+
+// EM (compile time: each kernel instantiation carries ONE mask path - with all of them in one body the 256-VGPR kernels spilled, scalars first):
+//   PP_EM_NONE no mask (the forward form; writes a.relu_bits when asked to), PP_EM_MASK a.mask (bf16 tensor), PP_EM_BITS a.mask_bits (ReLU bits)
+constexpr int PP_EM_NONE = 0, PP_EM_MASK = 1, PP_EM_BITS = 2;
+// this lane's ReLU-bits bytes of tile (n, h0, w0, ncol0) (see pp_bits_voff): the kernels issue this a K chunk before the tile's epilogue, which takes the result as `mb`
+template <int NF, int PF>
+__device__ __forceinline__ u32x4 pp_mask_bits_load(const ConvArgs& a, int n, int h0, int w0, int ncol0, int wm, int wn) {
+    int lane_;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_));
+    const int bvoff = pp_bits_voff<NF, PF>(a, n, h0, w0, ncol0, wm, wn, lane_ & 15, lane_ >> 4);
+    const __amdgpu_buffer_rsrc_t rbm = pp_make_rsrc(a.mask_bits, (unsigned)rb_bytes(a.N, a.H, a.W, a.Cout));
+    u32x4 mb = u32x4{0u, 0u, 0u, 0u};
+    if constexpr (NF == 4) {
+        mb = __builtin_amdgcn_raw_buffer_load_b128(rbm, bvoff, 0, 0);
+    } else {
+        const u32x2 m2 = __builtin_amdgcn_raw_buffer_load_b64(rbm, bvoff, 0, 0);
+        mb[0] = m2[0];
+        mb[1] = m2[1];
+    }
+    return mb;
+}
+
+template <int NF, int PF, int EM, bool RB = true>
+__device__ __forceinline__ void pp_epilogue_plain(const ConvArgs& a, f32x4 (&acc)[NF][PF], uint32_t bias_lds, int n, int h0, int w0, int ncol0, int wm, int wn,
+                                                  const u32x4& mb_pre) {
     constexpr int NV = 4 * NF, WAVE_N = NF * 16, NS = NF / 2;          // NS 16-byte stores per pixel
+    constexpr bool BITS = RB && PF == 8 && (NF == 4 || NF == 2);        // ReLU bits: the 2-D instantiations (8-row wave tiles); RB = false: the 3-D kernels
+    static_assert(EM != PP_EM_BITS || BITS, "");
     static_assert(NF % 2 == 0, "");
     // lane coordinates re-derived here (volatile: not hoisted), so that nothing per-lane of the epilogue is held - or, at 256 VGPRs, spilled - across the tile loop
     int lane_;
@@ -163,14 +198,25 @@ __device__ __forceinline__ void pp_epilogue_plain(const ConvArgs& a, f32x4 (&acc
     const int x = w0 + li;
     const int xpart = uns ? (x >> 1) * yld + (x & 1) * cview : x * yld;
     const int yv = x < a.W ? (xpart + lcolw + lg * 8) * 2 : PP_OOB;          // a store past num_records is dropped: the ragged right edge
-    const bool masked = a.mask != nullptr;
+    constexpr bool masked = EM == PP_EM_MASK;
     const __amdgpu_buffer_rsrc_t rm = pp_make_rsrc(reinterpret_cast<const char*>(masked ? a.mask : a.y0) + (masked ? (size_t)n * img * a.mask_ld * 2 : 0),
-                                                   masked ? (unsigned)(((img - 1) * a.mask_ld + a.Cout) * 2) : 0u);
+                                                   masked ? (unsigned)(((img - 1) * a.mask_ld + a.Cout) * 2) : 0u);      // (dead unless EM == PP_EM_MASK)
     const int mv = x < a.W ? (x * a.mask_ld + colw + lg * 8) * 2 : PP_OOB;
     const unsigned yrow = (unsigned)(uns ? ow : a.W) * yld * 2, mrow = (unsigned)a.W * a.mask_ld * 2;
     const unsigned yodd = uns ? (unsigned)cview * 4u : 0u;                    // byte offset of the odd rows' channel blocks
+    const int ush = uns ? 1 : 0;                                              // row y -> row y >> ush of the destination (+ yodd for odd y when unshuffling)
     const int yr0 = h0 + wm * PF;
     const uint32_t lowb = a.relu ? 0u : 0x80008000u;       // lower bound of the packed ReLU; a SCALAR operand of the asm below (no register held across the tile loop)
+    // ReLU bits instead of the bf16 mask: this lane's rows of the tile are ONE load, issued by the kernel a K chunk ago (NF = 4: 16 bytes, byte i*8 + r = row r of store
+    // piece i; NF = 2: 8 bytes)
+    const u32x4 mb = mb_pre;
+    u32x4 ob = u32x4{0u, 0u, 0u, 0u};                       // ... and the ones this tile produces, assembled row by row
+    constexpr bool bmask = EM == PP_EM_BITS;
+    const bool bout = BITS && EM == PP_EM_NONE && a.relu_bits != nullptr;
+    int bvoff = 0;
+    if constexpr (BITS) {
+        if (bout) bvoff = pp_bits_voff<NF, PF>(a, n, h0, w0, ncol0, wm, wn, li, lg);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     pp_f32x2 bias2[NF][2];
@@ -181,16 +227,16 @@ __device__ __forceinline__ void pp_epilogue_plain(const ConvArgs& a, f32x4 (&acc
             const uint32_t u0 = braw[f][2 * h], u1 = braw[f][2 * h + 1];
             bias2[f][h] = pp_f32x2{__uint_as_float(u0), __uint_as_float(u1)};
         }
-    constexpr int MG = PF % 4 == 0 ? 4 : (PF % 5 == 0 ? 5 : (PF % 2 == 0 ? 2 : 1));      // pixel rows whose mask loads are in flight together
+    constexpr int MG = PF % 4 == 0 ? 2 : (PF % 5 == 0 ? 5 : (PF % 2 == 0 ? 2 : 1));      // pixel rows whose mask loads are in flight together (the 2-D net masks with ReLU bits)
 #pragma unroll
     for (int pg = 0; pg < PF; pg += MG) {
-        u32x4 mk[MG][NS];
-        if (masked) {
+        u32x4 mk[masked ? MG : 1][NS];
+        if constexpr (masked) {
 #pragma unroll
             for (int r = 0; r < MG; ++r)
 #pragma unroll
                 for (int i = 0; i < NS; ++i)
-                    mk[r][i] = __builtin_amdgcn_raw_buffer_load_b128(rm, mv + i * 64, (int)((unsigned)(yr0 + pg + r) * mrow), 0);      // rows past H: offset past num_records reads 0
+                    mk[r][i] = __builtin_amdgcn_raw_buffer_load_b128(rm, mv + i * 64, __builtin_amdgcn_readfirstlane((int)((unsigned)(yr0 + pg + r) * mrow)), 0);      // rows past H: offset past num_records reads 0
         }
 #pragma unroll
         for (int r = 0; r < MG; ++r) {
@@ -210,7 +256,7 @@ __device__ __forceinline__ void pp_epilogue_plain(const ConvArgs& a, f32x4 (&acc
                 acc[f][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
             }
-            if (masked) {
+            if constexpr (masked) {
 #pragma unroll
                 for (int i = 0; i < NS; ++i)
 #pragma unroll
@@ -220,15 +266,54 @@ __device__ __forceinline__ void pp_epilogue_plain(const ConvArgs& a, f32x4 (&acc
                         d[i][q] = t;
                     }
             }
+            if constexpr (BITS) {
+                if constexpr (bmask) {
+                    // dword q of piece i holds channels 2q, 2q + 1 of the piece: their bits are bits 2q, 2q + 1 of byte i*8 + pf.  v_pk_lshrrev_b16 shifts the byte's
+                    // 16-bit half by (s, s + 1) into the two result halves; & 0x00010001 leaves the multipliers (1 or 0 per half)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const uint32_t mw = mb[i * 2 + (pf >> 2)], du = d[i][q];
+                            const uint32_t sh = (uint32_t)((pf & 1) * 8 + 2 * q) * 0x00010001u + 0x00010000u;
+                            uint32_t t;
+                            if ((pf & 3) < 2) asm("v_pk_lshrrev_b16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "s"(sh), "v"(mw));
+                            else asm("v_pk_lshrrev_b16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(t) : "s"(sh), "v"(mw));
+                            t &= 0x00010001u;
+                            asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(t) : "v"(du), "v"(t));
+                            d[i][q] = t;
+                        }
+                }
+                if (bout) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        uint32_t t[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(t[q]) : "v"(d[i][q]));      // per half: 1 if the stored value is > 0 (it is >= 0)
+                        uint32_t m = t[0] | (t[1] << 2) | (t[2] << 4) | (t[3] << 6);      // even channels at bits 0,2,4,6; odd ones at 16,18,20,22
+                        m |= m >> 15;
+                        const uint32_t prev = ob[i * 2 + (pf >> 2)];
+                        ob[i * 2 + (pf >> 2)] = (pf & 3) == 0 ? (m & 0xffu) : (prev | ((m & 0xffu) << ((pf & 3) * 8)));
+                    }
+                }
+            }
 #ifdef PPT_EPI_NOSTORE
             if (y < a.H && d[0][0] == 0x12345678u) {
 #else
             if (y < a.H) {
 #endif
+                // (readfirstlane: the offset is wave-uniform, but hipcc evaluates the selects on the VALU and would wrap every store in a waterfall loop)
+                const int srow = __builtin_amdgcn_readfirstlane((int)((unsigned)(y >> ush) * yrow + (unsigned)(y & ush) * yodd));
 #pragma unroll
-                for (int i = 0; i < NS; ++i)
-                    __builtin_amdgcn_raw_buffer_store_b128(d[i], ry, yv + i * 64, (int)(uns ? (unsigned)(y >> 1) * yrow + (unsigned)(y & 1) * yodd : (unsigned)y * yrow), 0);
+                for (int i = 0; i < NS; ++i) __builtin_amdgcn_raw_buffer_store_b128(d[i], ry, yv + i * 64, srow, 0);
             }
+        }
+    }
+    if constexpr (BITS) {
+        if (bout) {          // rows past H of the last row block carry garbage bits: never read
+            const __amdgpu_buffer_rsrc_t rbo = pp_make_rsrc(a.relu_bits, (unsigned)rb_bytes(a.N, a.H, a.W, a.Cout));
+            if constexpr (NF == 4) __builtin_amdgcn_raw_buffer_store_b128(ob, rbo, bvoff, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b64(u32x2{ob[0], ob[1]}, rbo, bvoff, 0, 0);
         }
     }
 }

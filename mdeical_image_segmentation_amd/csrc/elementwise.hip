@@ -5,6 +5,7 @@
 
 #include "common.hpp"
 #include "dispatch_cfg.hpp"
+#include "relu_bits.hpp"
 
 // =========================================================================================================
 // First layer: x fp32 NCHW (Cin <= 4) -> y NHWC [pixel][64], 3x3 pad 1, bias, ReLU.   reference: layers.py:122-123
@@ -63,7 +64,8 @@ __global__ __launch_bounds__(256) void first_conv_fwd_kernel(const float* __rest
 // from LDS is used 4 times.  No per-tap global loads or bounds checks; the kernel is bound by its 128-byte-per-pixel output stream.
 template <typename T>
 __global__ __launch_bounds__(256) void first_conv_fwd_tiled_kernel(const float* __restrict__ x, int N, int Cin, int H, int W,
-                                                                   const float* __restrict__ w, const float* __restrict__ bias, T* y, int y_ld) {
+                                                                   const float* __restrict__ w, const float* __restrict__ bias, T* y, int y_ld,
+                                                                   unsigned char* __restrict__ rbits) {
     constexpr int TH = 2, TW = 64, HH = TH + 2, HW = TW + 2;
     __shared__ __attribute__((aligned(16))) float wl[36 * 64];
     __shared__ __attribute__((aligned(16))) float bl[64];
@@ -136,7 +138,9 @@ __global__ __launch_bounds__(256) void first_conv_fwd_tiled_kernel(const float* 
                 for (int j = 0; j < 8; ++j) acc[v][j] = fmaxf(acc[v][j], 0.f);
                 T* dst = y + (((size_t)n * H + yy) * W + xx) * y_ld + cg * 8;
                 if constexpr (sizeof(T) == 2) {
-                    *reinterpret_cast<u32x4*>(dst) = pack_chunk<__bf16>(acc[v]);
+                    const u32x4 pk = pack_chunk<__bf16>(acc[v]);
+                    *reinterpret_cast<u32x4*>(dst) = pk;
+                    if (rbits != nullptr) rbits[rb_byte_offset((H + 7) >> 3, W, 1, n, yy, xx, cg)] = rb_byte_of(pk);      // ReLU bits of the STORED values (relu_bits.hpp)
                 } else {
                     *reinterpret_cast<u32x4*>(dst) = pack_chunk<float>(acc[v]);
                     *reinterpret_cast<u32x4*>(dst + 4) = pack_chunk<float>(acc[v] + 4);
@@ -146,8 +150,50 @@ __global__ __launch_bounds__(256) void first_conv_fwd_tiled_kernel(const float* 
     }
 }
 
+// ReLU bits of a bf16 NHWC tensor (relu_bits.hpp): the stand-alone producer - what mis_conv_igemm runs behind a kernel that cannot write them from its epilogue,
+// and the reference the tests compare the fused producers with.  One thread per (pixel, 8 channels).
+__global__ __launch_bounds__(256) void relu_bits_kernel(const __bf16* __restrict__ y, int y_ld, int N, int H, int W, int C, unsigned char* __restrict__ bits) {
+    const int c8n = C >> 3;
+    const long long total = (long long)N * H * W * c8n;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c8 = (int)(i % c8n);
+        const long long pix = i / c8n;
+        const int x = (int)(pix % W);
+        const long long r = pix / W;
+        const int yy = (int)(r % H), n = (int)(r / H);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(y + pix * y_ld + c8 * 8);
+        bits[rb_byte_offset((H + 7) >> 3, W, C >> 6, n, yy, x, c8)] = rb_byte_of(v);
+    }
+}
+
+extern "C" size_t mis_relu_bits_bytes(int N, int H, int W, int C) { return rb_bytes(N, H, W, C); }
+
+extern "C" int mis_relu_bits(const void* y, int y_ld, int N, int H, int W, int C, void* bits, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(y && bits && N > 0 && H > 0 && W > 0, MIS_EINVAL, "relu_bits: bad argument");
+    MIS_REQUIRE(C > 0 && C % 64 == 0 && y_ld % 8 == 0, MIS_EUNSUPPORTED, "relu_bits: C must be a multiple of 64 and y_ld of 8 (got %d, %d)", C, y_ld);
+    long long blocks = ((long long)N * H * W * (C >> 3) + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(relu_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const __bf16*)y, y_ld, N, H, W, C,
+                       (unsigned char*)bits);
+    MIS_LAUNCH_CHECK("relu_bits");
+    return MIS_OK;
+}
+
+static int first_fwd_impl(int dtype, const float* x, int N, int Cin, int H, int W, const float* w, const float* bias, void* y, int y_ld, int Cout, void* relu_bits,
+                          void* stream);
 extern "C" int mis_conv3x3_first_fwd(int dtype, const float* x, int N, int Cin, int H, int W, const float* w, const float* bias, void* y,
                                      int y_ld, int Cout, void* stream) {
+    return first_fwd_impl(dtype, x, N, Cin, H, W, w, bias, y, y_ld, Cout, nullptr, stream);
+}
+// ... and the same with the ReLU bits of the output (relu_bits.hpp; bf16 only) written from the epilogue
+extern "C" int mis_conv3x3_first_fwd_rb(int dtype, const float* x, int N, int Cin, int H, int W, const float* w, const float* bias, void* y,
+                                        int y_ld, int Cout, void* relu_bits, void* stream) {
+    MIS_REQUIRE(relu_bits == nullptr || dtype == MIS_BF16, MIS_EUNSUPPORTED, "first_fwd: ReLU bits are a bf16 feature");
+    return first_fwd_impl(dtype, x, N, Cin, H, W, w, bias, y, y_ld, Cout, relu_bits, stream);
+}
+static int first_fwd_impl(int dtype, const float* x, int N, int Cin, int H, int W, const float* w, const float* bias, void* y, int y_ld, int Cout, void* relu_bits,
+                          void* stream) {
     (void)hipGetLastError();   // drop any stale (already handled) error of this thread
     MIS_REQUIRE(Cout == 64, MIS_EUNSUPPORTED, "first_fwd: Cout must be 64 (got %d)", Cout);
     MIS_REQUIRE(Cin >= 1 && Cin <= 4, MIS_EUNSUPPORTED, "first_fwd: Cin must be 1..4 (got %d)", Cin);
@@ -160,9 +206,10 @@ extern "C" int mis_conv3x3_first_fwd(int dtype, const float* x, int N, int Cin, 
         long long tiles = (long long)N * ((H + 1) / 2) * ((W + 63) / 64);
         if (tiles > 4096) tiles = 4096;
         if (dtype == MIS_BF16)
-            hipLaunchKernelGGL(first_conv_fwd_tiled_kernel<__bf16>, dim3((unsigned)tiles), dim3(256), 0, s, x, N, Cin, H, W, w, bias, (__bf16*)y, y_ld);
+            hipLaunchKernelGGL(first_conv_fwd_tiled_kernel<__bf16>, dim3((unsigned)tiles), dim3(256), 0, s, x, N, Cin, H, W, w, bias, (__bf16*)y, y_ld,
+                               (unsigned char*)relu_bits);
         else
-            hipLaunchKernelGGL(first_conv_fwd_tiled_kernel<float>, dim3((unsigned)tiles), dim3(256), 0, s, x, N, Cin, H, W, w, bias, (float*)y, y_ld);
+            hipLaunchKernelGGL(first_conv_fwd_tiled_kernel<float>, dim3((unsigned)tiles), dim3(256), 0, s, x, N, Cin, H, W, w, bias, (float*)y, y_ld, nullptr);
         MIS_LAUNCH_CHECK("first_conv_fwd(tiled)");
         return MIS_OK;
     }
@@ -173,6 +220,7 @@ extern "C" int mis_conv3x3_first_fwd(int dtype, const float* x, int N, int Cin, 
     else
         hipLaunchKernelGGL(first_conv_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, x, N, Cin, H, W, w, bias, (float*)y, y_ld);
     MIS_LAUNCH_CHECK("first_conv_fwd");
+    if (relu_bits != nullptr) return mis_relu_bits(y, y_ld, N, H, W, 64, relu_bits, stream);      // the untiled (A/B) kernel has no fused producer
     return MIS_OK;
 }
 

@@ -207,11 +207,26 @@ class UNet2DEngine:
             self.dys.append(buf(h // 2, w // 2, 4 * c))
         self.logits = torch.empty(N, self.cout, H, W, dtype=torch.float32, device=dev)
         self.argmax = torch.empty(N, H, W, dtype=torch.uint8, device=dev)
+        # ReLU bits (csrc/relu_bits.hpp) of every activation whose sign the backward pass needs as a ReLU mask: written by the producing convolution's epilogue, read by
+        # the masked dgrad instead of the bf16 tensor (1/16 of the bytes; MISAMD_BF16_MASK=1: the bf16 masks, the pre-round-3 path)
+        self.use_bits = dt == torch.bfloat16 and not os.environ.get("MISAMD_BF16_MASK")
+        self.rb = {}
+        if self.use_bits:
+            def bits(t):
+                n_, h_, w_, c_ = t.shape
+                return torch.empty(ops.relu_bits_bytes(n_, h_, w_, c_), dtype=torch.uint8, device=dev)
+            for l in range(4):
+                self.rb[("t1", l)] = bits(self.t1[l])
+            for j in range(4):
+                self.rb[("u1", j)] = bits(self.u1[j])
+                if j < 3:
+                    self.rb[("u2", j)] = bits(self.u2[j])
+            self.rb["m1"], self.rb["m2"] = bits(self.m1), bits(self.m2)
         self._shape = (N, H, W)
 
     # ---- forward ---------------------------------------------------------------------------------------
-    def _conv(self, x, name, y, cin, cout, mask=None):
-        ops.conv_igemm(x, self.wf[name], y, ksize=3, Cin=cin, Cout=cout, bias=self.P[name + ".bias"], relu=True)
+    def _conv(self, x, name, y, cin, cout, rb=None):
+        ops.conv_igemm(x, self.wf[name], y, ksize=3, Cin=cin, Cout=cout, bias=self.P[name + ".bias"], relu=True, relu_bits=self.rb.get(rb))
 
     def forward(self, images, labels=None, train=True, grad_scale=1.0):
         """images: fp32 NCHW on the device; labels: int64 (N,H,W) for CE / fp32 (N,1,H,W) for BCE.
@@ -227,21 +242,21 @@ class UNet2DEngine:
         for l, c in enumerate(FEATS):
             skip = View(self.cat[l], c, c)
             if l == 0:
-                ops.first_conv_fwd(images, P["down_conv.0.first.weight"], P["down_conv.0.first.bias"], self.t1[0])
+                ops.first_conv_fwd(images, P["down_conv.0.first.weight"], P["down_conv.0.first.bias"], self.t1[0], relu_bits=self.rb.get(("t1", 0)))
             else:
-                self._conv(self.pooled[l - 1], f"down_conv.{l}.first", self.t1[l], FEATS[l - 1], c)
+                self._conv(self.pooled[l - 1], f"down_conv.{l}.first", self.t1[l], FEATS[l - 1], c, rb=("t1", l))
             self._conv(self.t1[l], f"down_conv.{l}.second", skip, c, c)
             ops.maxpool2_fwd(skip, self.pooled[l])
-        self._conv(self.pooled[3], "middle_conv.first", self.m1, 512, 1024)
-        self._conv(self.m1, "middle_conv.second", self.m2, 1024, 1024)
+        self._conv(self.pooled[3], "middle_conv.first", self.m1, 512, 1024, rb="m1")
+        self._conv(self.m1, "middle_conv.second", self.m2, 1024, 1024, rb="m2")
         x = self.m2
         for j in range(4):
             l = 3 - j
             c = FEATS[l]
             ops.conv_igemm(x, self.wf[f"up_sample.{j}.up"], View(self.cat[l], 0, c), ksize=1, Cin=2 * c, Cout=4 * c,
                            bias=P[f"up_sample.{j}.up.bias"], relu=False, y0_mode=OUT_SHUFFLE2)
-            self._conv(self.cat[l], f"up_conv.{j}.first", self.u1[j], 2 * c, c)
-            self._conv(self.u1[j], f"up_conv.{j}.second", self.u2[j], c, c)
+            self._conv(self.cat[l], f"up_conv.{j}.first", self.u1[j], 2 * c, c, rb=("u1", j))
+            self._conv(self.u1[j], f"up_conv.{j}.second", self.u2[j], c, c, rb=("u2", j))
             x = self.u2[j]
         wh = P["final_conv.weight"].view(self.cout, 64)
         bh = P["final_conv.bias"]
@@ -274,12 +289,17 @@ class UNet2DEngine:
                       dy=self.g_u2[3], dw=self.G["final_conv.weight"], db=self.G["final_conv.bias"])
 
     # ---- backward --------------------------------------------------------------------------------------
+    def _mask(self, t, key):
+        """the ReLU mask of activation t as conv_igemm keywords: its bits when the forward pass wrote them, else the bf16 tensor itself"""
+        b = self.rb.get(key)
+        return dict(mask=t) if b is None else dict(mask_bits=b)
+
     def _bwd_conv(self, x, dy, name, cin, cout, dx=None, mask=None, dx1=None, cout0=None, dx_mode=OUT_PLAIN):
-        """grads of y = relu(conv3x3(x) + b) given dy = dL/d(pre-activation)."""
+        """grads of y = relu(conv3x3(x) + b) given dy = dL/d(pre-activation); mask: (activation, key of its ReLU bits) of the layer below."""
         ops.wgrad(x, dy, self.G[name + ".weight"], ksize=3, Cin=cin, Cout=cout, dbias=self.G[name + ".bias"], side=self.side_reduce)
         if dx is not None:
-            ops.conv_igemm(dy, self.wd_[name], dx, ksize=3, Cin=cout, Cout=cin, mask=mask, y0_mode=dx_mode, y1=dx1,
-                           Cout0=cout0)
+            ops.conv_igemm(dy, self.wd_[name], dx, ksize=3, Cin=cout, Cout=cin, y0_mode=dx_mode, y1=dx1,
+                           Cout0=cout0, **({} if mask is None else self._mask(*mask)))
 
     def backward(self, stage_cb=None):
         """Run after forward(train=True): fills self.G (reference-layout fp32 grads).
@@ -296,7 +316,7 @@ class UNet2DEngine:
             c = FEATS[l]
             x_in = self.m2 if j == 0 else self.u2[j - 1]
             g_in = self.g_m2 if j == 0 else self.g_u2[j - 1]
-            self._bwd_conv(self.u1[j], self.g_u2[j], f"up_conv.{j}.second", c, c, dx=self.g_u1[j], mask=self.u1[j])
+            self._bwd_conv(self.u1[j], self.g_u2[j], f"up_conv.{j}.second", c, c, dx=self.g_u1[j], mask=(self.u1[j], ("u1", j)))
             # first conv of the block reads the concat buffer: gradient of the up-sampled half goes out
             # pixel-unshuffled (N, h/2, w/2, 4c), gradient of the skip half goes to g_skip[l]
             self._bwd_conv(self.cat[l], self.g_u1[j], f"up_conv.{j}.first", 2 * c, c, dx=self.dys[j], dx1=self.g_skip[l],
@@ -304,16 +324,16 @@ class UNet2DEngine:
             up = f"up_sample.{j}.up"
             ops.wgrad(x_in, self.dys[j], self.G[up + ".weight"], ksize=1, Cin=2 * c, Cout=4 * c, dw_layout=1,
                       dbias=self.G[up + ".bias"], side=self.side_reduce)
-            ops.conv_igemm(self.dys[j], self.wd_[up], g_in, ksize=1, Cin=4 * c, Cout=2 * c, mask=x_in)
+            ops.conv_igemm(self.dys[j], self.wd_[up], g_in, ksize=1, Cin=4 * c, Cout=2 * c, **self._mask(x_in, "m2" if j == 0 else ("u2", j - 1)))
             cb([f"up_conv.{j}", f"up_sample.{j}"])
-        self._bwd_conv(self.m1, self.g_m2, "middle_conv.second", 1024, 1024, dx=self.g_m1, mask=self.m1)
+        self._bwd_conv(self.m1, self.g_m2, "middle_conv.second", 1024, 1024, dx=self.g_m1, mask=(self.m1, "m1"))
         self._bwd_conv(self.pooled[3], self.g_m1, "middle_conv.first", 512, 1024, dx=self.g_pooled[3])
         cb(["middle_conv"])
         for l in range(3, -1, -1):
             c = FEATS[l]
             skip = View(self.cat[l], c, c)
             ops.maxpool2_bwd(skip, self.g_pooled[l], self.g_skip[l], add=self.g_skip[l], relu_mask=True)
-            self._bwd_conv(self.t1[l], self.g_skip[l], f"down_conv.{l}.second", c, c, dx=self.g_t1[l], mask=self.t1[l])
+            self._bwd_conv(self.t1[l], self.g_skip[l], f"down_conv.{l}.second", c, c, dx=self.g_t1[l], mask=(self.t1[l], ("t1", l)))
             if l > 0:
                 self._bwd_conv(self.pooled[l - 1], self.g_t1[l], f"down_conv.{l}.first", FEATS[l - 1], c, dx=self.g_pooled[l - 1])
             else:

@@ -69,8 +69,9 @@ class _Timed:
 
 
 def conv_igemm(x0, w_packed, y0, *, ksize, Cin, Cout, grid=None, x1=None, bias=None, relu=False, mask=None,
-               y0_mode=OUT_PLAIN, y1=None, y1_mode=OUT_PLAIN, Cout0=None, in_scale=None, in_shift=None):
-    """grid = (N, D, H, W) of the GEMM rows; defaults to x0's grid."""
+               y0_mode=OUT_PLAIN, y1=None, y1_mode=OUT_PLAIN, Cout0=None, in_scale=None, in_shift=None, relu_bits=None, mask_bits=None):
+    """grid = (N, D, H, W) of the GEMM rows; defaults to x0's grid.
+    relu_bits (out, uint8 tensor of relu_bits_bytes(N, H, W, Cout) bytes, with relu=True): bit = (output > 0); mask_bits (in): such bits applied instead of `mask`."""
     lib = load()
     x0 = _v(x0)
     y0 = _v(y0)
@@ -97,6 +98,8 @@ def conv_igemm(x0, w_packed, y0, *, ksize, Cin, Cout, grid=None, x1=None, bias=N
         mask = _v(mask)
         d.mask, d.mask_ld = mask.ptr, mask.ld
     d.y0, d.y0_ld, d.y0_mode = y0.ptr, y0.ld, y0_mode
+    d.relu_bits = None if relu_bits is None else relu_bits.data_ptr()
+    d.mask_bits = None if mask_bits is None else mask_bits.data_ptr()
     d.Cout0 = Cout if Cout0 is None else Cout0
     if y1 is not None:
         y1 = _v(y1)
@@ -241,13 +244,25 @@ def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alph
         st["events"][slot] = ev
 
 
-def first_conv_fwd(x_nchw, w, bias, y):
+def first_conv_fwd(x_nchw, w, bias, y, relu_bits=None):
     lib = load()
     y = _v(y)
     N, Cin, H, W = x_nchw.shape
-    check(lib.mis_conv3x3_first_fwd(dtype_code(y.dtype), x_nchw.data_ptr(), N, Cin, H, W, w.data_ptr(),
-                                    None if bias is None else bias.data_ptr(), y.ptr, y.ld, y.C, stream_ptr()),
+    check(lib.mis_conv3x3_first_fwd_rb(dtype_code(y.dtype), x_nchw.data_ptr(), N, Cin, H, W, w.data_ptr(),
+                                       None if bias is None else bias.data_ptr(), y.ptr, y.ld, y.C,
+                                       None if relu_bits is None else relu_bits.data_ptr(), stream_ptr()),
           "mis_conv3x3_first_fwd")
+
+
+def relu_bits_bytes(N, H, W, C):
+    """size in bytes of the ReLU-bits tensor of a bf16 (N, H, W, C) activation (csrc/relu_bits.hpp; C % 64 == 0)"""
+    return int(load().mis_relu_bits_bytes(int(N), int(H), int(W), int(C)))
+
+
+def relu_bits(y, bits):
+    """bits = (y > 0), one bit per element of the bf16 NHWC view y, in the layout the convolutions' `mask_bits` reads (the stand-alone producer)"""
+    y = _v(y)
+    check(load().mis_relu_bits(y.ptr, y.ld, y.N, y.H, y.W, y.C, bits.data_ptr(), stream_ptr()), "mis_relu_bits")
 
 
 def first_conv_wgrad(x_nchw, dy, dw, db):

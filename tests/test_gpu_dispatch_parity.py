@@ -66,6 +66,36 @@ K3_CASES = [
 ]
 
 
+def _decode_relu_bits(bits, N, H, W, C):
+    """the ReLU-bits layout of csrc/relu_bits.hpp back to a bool (N, H, W, C) tensor: records [4][2][8 rows] bytes per (n, block of 8 rows, x, block of 64 channels);
+    channel group g = (c >> 3) & 7 sits at [g & 3][g >> 2], bit c & 7"""
+    H8 = (H + 7) // 8
+    r = bits.view(N, H8, W, C // 64, 4, 2, 8)                                  # [u16idx][byteidx][row]
+    r = r.permute(0, 1, 6, 2, 3, 5, 4).reshape(N, H8 * 8, W, C // 64, 8)         # (n, y, x, cb, g = byteidx*4 + u16idx)
+    b = (r.unsqueeze(-1) >> torch.arange(8, device=bits.device, dtype=torch.uint8)) & 1
+    return b.reshape(N, H8 * 8, W, C).bool()[:, :H]
+
+
+def _bits_of(ops, t_nhwc):
+    N, H, W, C = t_nhwc.shape
+    bits = torch.zeros(ops.relu_bits_bytes(N, H, W, C), dtype=torch.uint8, device=DEV)
+    ops.relu_bits(t_nhwc, bits)
+    return bits
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 16, 64), (1, 13, 7, 128), (3, 33, 20, 192)])
+def test_relu_bits_layout(shape):
+    """mis_relu_bits against the layout's definition, signed zeros and ragged row blocks included"""
+    ops = _ops()
+    N, H, W, C = shape
+    y = torch.randn(N, H, W, C, generator=torch.Generator().manual_seed(7)).clamp_(min=0)
+    y[0, 0, 0, :8] = torch.tensor([0.0, -0.0, 1e-30, -1.0, 2.0, 0.0, 3.0, -0.0])
+    yd = y.to(torch.bfloat16).to(DEV)
+    assert ops.relu_bits_bytes(N, H, W, C) == N * ((H + 7) // 8) * W * C
+    got = _decode_relu_bits(_bits_of(ops, yd), N, H, W, C)
+    assert torch.equal(got, yd.float() > 0)
+
+
 def _conv_ref(x, w, b, dtype):
     return F.conv2d(q(x, dtype), q(w, dtype), b, padding=w.shape[-1] // 2)
 
@@ -97,6 +127,23 @@ def test_conv3x3_every_branch(case, switches):
     ops.conv_igemm(xd, wf, y2, ksize=3, Cin=Cin, Cout=Cout, mask=to_nhwc(m, dtype))
     assert ops.conv_last_dispatch() == cfg
     assert_close(from_nhwc(y2), ref * (q(m, dtype) > 0), f"mask {cfg}", **t)
+    if dtype == BF:
+        # (b') the same mask as ReLU BITS: bit-for-bit the masked result (the kernels that cannot read bits hand the call to one that can)
+        y3 = torch.full((N, H, W, Cout), float("nan"), dtype=dtype, device=DEV)
+        ops.conv_igemm(xd, wf, y3, ksize=3, Cin=Cin, Cout=Cout, mask_bits=_bits_of(ops, to_nhwc(m, dtype)))
+        cfg_bits = ops.conv_last_dispatch()
+        assert_close(from_nhwc(y3), ref * (q(m, dtype) > 0), f"mask_bits {cfg_bits}", **t)
+        if cfg_bits == cfg:          # same kernel, same sums
+            assert torch.equal(y3.view(torch.int16), y2.view(torch.int16)), f"mask_bits differs from the bf16 mask ({cfg})"
+        else:                        # the pre-column-segment ping-pong kernels do not read bits: the dispatcher must have chosen another kernel, not dropped the mask
+            assert "pp" in cfg or "rs64" in cfg, f"{cfg} handed a mask_bits call to {cfg_bits}"
+        # (a') the forward form also writes the ReLU bits of its output
+        y4 = torch.full((N, H, W, Cout), float("nan"), dtype=dtype, device=DEV)
+        rb = torch.full((ops.relu_bits_bytes(N, H, W, Cout),), 0xA5, dtype=torch.uint8, device=DEV)
+        ops.conv_igemm(xd, wf, y4, ksize=3, Cin=Cin, Cout=Cout, bias=b.to(DEV), relu=True, relu_bits=rb)
+        assert ops.conv_last_dispatch() == cfg
+        assert torch.equal(y4.view(torch.int16), ybuf[..., 64:].contiguous().view(torch.int16))
+        assert torch.equal(_decode_relu_bits(rb, N, H, W, Cout), y4.float() > 0), f"relu_bits {cfg}"
     # (c) two destinations (dgrad of up_conv.*.first): first half pixel-unshuffled, second half plain
     if Cout % 128 == 0 and (Cout // 2) % (128 if ("bn256" in cfg or "pp256" in cfg) else 64) == 0 and H % 2 == 0 and W % 2 == 0:
         h = Cout // 2
@@ -139,6 +186,11 @@ def test_gemm1x1_every_branch(case):
     cfg = ops.conv_last_dispatch()
     assert cfg.startswith(want_cfg), f"case meant for {want_cfg} ran {cfg}"
     assert_close(from_nhwc(y), ref * (q(m, dtype) > 0), f"1x1 mask {cfg}", **t)
+    if dtype == BF:
+        yb = torch.full((N, H, W, Cout), float("nan"), dtype=dtype, device=DEV)
+        ops.conv_igemm(xd, wf, yb, ksize=1, Cin=Cin, Cout=Cout, mask_bits=_bits_of(ops, to_nhwc(m, dtype)))
+        assert ops.conv_last_dispatch() == cfg
+        assert torch.equal(yb.view(torch.int16), y.view(torch.int16)), f"1x1 mask_bits differs from the bf16 mask ({cfg})"
     if Cout % 256 == 0:
         cq = Cout // 4
         b = rnd(cq, seed=122)

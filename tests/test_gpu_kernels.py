@@ -247,6 +247,14 @@ def test_first_layer(cin, dtype):
     ref = F.conv2d(x, w, b, padding=1)
     assert_close(from_nhwc(y), F.relu(ref).detach(), f"first conv fwd cin={cin} {dtype}",
                  **(dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)))
+    if dtype == torch.bfloat16:          # the ReLU bits of the stored output, written from the same epilogue (both kernels; layout decoded by the dispatch-parity helper)
+        from test_gpu_dispatch_parity import _decode_relu_bits
+        for sw in ({}, {"MIS_FIRST2D_UNTILED": 1}):
+            with ops.dispatch_switches(**sw):
+                y2 = torch.full((N, H, W, 64), float("nan"), dtype=dtype, device=DEV)
+                rb = torch.full((ops.relu_bits_bytes(N, H, W, 64),), 0x5A, dtype=torch.uint8, device=DEV)
+                ops.first_conv_fwd(x.to(DEV), w.detach().to(DEV), b.detach().to(DEV), y2, relu_bits=rb)
+            assert torch.equal(_decode_relu_bits(rb, N, H, W, 64), y2.float() > 0), f"first conv relu bits {sw}"
     dy = rnd(N, 64, H, W, seed=53)
     ref.backward(q(dy, dtype))
     dw = torch.full((64, cin, 3, 3), float("nan"), device=DEV)
