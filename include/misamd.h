@@ -145,6 +145,12 @@ int mis_maxpool2_fwd(int dtype, const void* x, int x_ld, void* y, int y_ld, int 
 /* dx = relu_mask(x) * (scatter(dy to the first max of each window) + (add ? add : 0)); dx may alias add. */
 int mis_maxpool2_bwd(int dtype, const void* x, int x_ld, const void* dy, int dy_ld, const void* add, int add_ld, void* dx, int dx_ld,
                      int N, int D, int H, int W, int C, int relu_mask, void* stream);
+/* 2-D max-pool with "pool bits": the forward pass also writes one byte per POOLED element (N, H/2, W/2, C; even H, W) = [bit k: window position k = kh*2 + kw is
+ * the arg-max, first maximum in scan order] | [bit 4 + k: the input at position k is > 0]; the backward pass takes those bytes instead of the input tensor:
+ * dx = (x > 0) * (add + scatter(dy)), the same result as mis_maxpool2_bwd(relu_mask = 1) without reading x. */
+int mis_maxpool2_fwd_pb(int dtype, const void* x, int x_ld, void* y, int y_ld, int N, int H, int W, int C, void* pbits, void* stream);
+int mis_maxpool2_bwd_pb(int dtype, const void* pbits, const void* dy, int dy_ld, const void* add, int add_ld, void* dx, int dx_ld, int N, int H, int W, int C,
+                        void* stream);
 
 /* Weight repack: fp32 master in the reference layout -> packed operand layouts of mis_conv_igemm. */
 /* conv: w [Cout][Cin][taps] -> fwd pack [tap][Cout][Cin] and (optional) dgrad pack [tap'][Cin][Cout] with tap' mirrored */

@@ -19,7 +19,7 @@ EXPORTS = [
     "mis_mt19937_words", "mis_legacy_normal", "mis_mt_jump", "mis_mt_generate", "mis_legacy_normal_par_workspace_bytes", "mis_legacy_normal_par",
     "mis_comm_unique_id", "mis_comm_init", "mis_comm_world", "mis_allreduce_bucket", "mis_comm_finalize",
     "mis_conv3x3_first_fwd", "mis_conv3x3_first_fwd_rb", "mis_relu_bits_bytes", "mis_relu_bits", "mis_conv3x3_first_wgrad_workspace_bytes", "mis_conv3x3_first_wgrad",
-    "mis_colsum_workspace_bytes", "mis_colsum", "mis_maxpool2_fwd", "mis_maxpool2_bwd",
+    "mis_colsum_workspace_bytes", "mis_colsum", "mis_maxpool2_fwd", "mis_maxpool2_bwd", "mis_maxpool2_fwd_pb", "mis_maxpool2_bwd_pb",
     "mis_pack_conv_weight", "mis_pack_convt_weight", "mis_pack_batch", "mis_head_workspace_bytes", "mis_head_loss",
     "mis_adamw_workspace_bytes", "mis_sumsq", "mis_adamw_step", "mis_adamw_step_dev", "mis_sumsq_npartials",
     "mis_chanstats_workspace_bytes", "mis_chanstats", "mis_nchw_to_nhwc", "mis_nhwc_to_nchw", "mis_probe_mfma",
@@ -178,6 +178,8 @@ def load():
         "mis_conv3x3_first_wgrad": [i, vp, i, i, i, i, vp, i, i, vp, vp, vp, vp],
         "mis_colsum": [i, vp, i, ll, i, i, f, vp, vp, vp],
         "mis_maxpool2_fwd": [i, vp, i, vp, i, i, i, i, i, i, vp],
+        "mis_maxpool2_fwd_pb": [i, vp, i, vp, i, i, i, i, i, vp, vp],
+        "mis_maxpool2_bwd_pb": [i, vp, vp, i, vp, i, vp, i, i, i, i, i, vp],
         "mis_maxpool2_bwd": [i, vp, i, vp, i, vp, i, vp, i, i, i, i, i, i, i, vp],
         "mis_pack_conv_weight": [i, vp, i, i, i, vp, vp, vp],
         "mis_pack_convt_weight": [i, vp, i, i, vp, vp, vp],

@@ -822,6 +822,96 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
     }
 }
 
+// ---- 2-D max-pool with "pool bits" (round 3): the forward pass also writes, per POOLED element, one byte = [bit k: window position k = kh*2 + kw is the arg-max
+// (first maximum in scan order)] | [bit 4 + k: the input at position k is > 0]; the backward pass then needs neither the input tensor (a third of its traffic in the
+// 2-D net: dx = relu_mask(x) * (add + scatter(dy))) nor the comparison.  pbits: (N, H/2, W/2, C) bytes; even H and W.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_pb_kernel(const T* __restrict__ x, int x_ld, T* __restrict__ y, int y_ld, int N, int H, int W, int C,
+                                                             unsigned char* __restrict__ pbits) {
+    constexpr int EPC = Tr<T>::EPC;
+    const int OH = H / 2, OW = W / 2;
+    const int nch = C / EPC;
+    const long long total = (long long)N * OH * OW * nch;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        const long long opix = i / nch;
+        const int ox = (int)(opix % OW);
+        const long long r = opix / OW;
+        const int oy = (int)(r % OH), n = (int)(r / OH);
+        float m[EPC];
+        unsigned bits[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            m[e] = -INFINITY;
+            bits[e] = 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t pix = ((size_t)n * H + 2 * oy + (k >> 1)) * W + 2 * ox + (k & 1);
+            float f[EPC];
+            unpack_chunk<T>(*reinterpret_cast<const u32x4*>(x + pix * x_ld + (size_t)ch * EPC), f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                if (f[e] > m[e]) {                    // strict: the first maximum wins, as in maxpool_bwd_kernel / PyTorch
+                    m[e] = f[e];
+                    bits[e] = (bits[e] & 0xf0u) | (1u << k);
+                }
+                if (f[e] > 0.f) bits[e] |= 0x10u << k;
+            }
+        }
+        *reinterpret_cast<u32x4*>(y + (size_t)opix * y_ld + (size_t)ch * EPC) = pack_chunk<T>(m);
+        unsigned char* bp = pbits + (size_t)opix * C + (size_t)ch * EPC;
+        if constexpr (EPC == 8) {
+            *reinterpret_cast<u32x2*>(bp) = u32x2{bits[0] | (bits[1] << 8) | (bits[2] << 16) | (bits[3] << 24), bits[4] | (bits[5] << 8) | (bits[6] << 16) | (bits[7] << 24)};
+        } else {
+            *reinterpret_cast<uint32_t*>(bp) = bits[0] | (bits[1] << 8) | (bits[2] << 16) | (bits[3] << 24);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_pb_kernel(const unsigned char* __restrict__ pbits, const T* __restrict__ dy, int dy_ld, const T* add, int add_ld,
+                                                             T* dx, int dx_ld, int N, int H, int W, int C) {
+    constexpr int EPC = Tr<T>::EPC;
+    const int OH = H / 2, OW = W / 2;
+    const int nch = C / EPC;
+    const long long total = (long long)N * OH * OW * nch;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        const long long opix = i / nch;
+        const int ox = (int)(opix % OW);
+        const long long r = opix / OW;
+        const int oy = (int)(r % OH), n = (int)(r / OH);
+        float g[EPC];
+        unpack_chunk<T>(*reinterpret_cast<const u32x4*>(dy + (size_t)opix * dy_ld + (size_t)ch * EPC), g);
+        unsigned bits[EPC];
+        const unsigned char* bp = pbits + (size_t)opix * C + (size_t)ch * EPC;
+        if constexpr (EPC == 8) {
+            const u32x2 b2 = *reinterpret_cast<const u32x2*>(bp);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bits[e] = (b2[e >> 2] >> ((e & 3) * 8)) & 0xffu;
+        } else {
+            const uint32_t b1 = *reinterpret_cast<const uint32_t*>(bp);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bits[e] = (b1 >> (e * 8)) & 0xffu;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t pix = ((size_t)n * H + 2 * oy + (k >> 1)) * W + 2 * ox + (k & 1);
+            float o[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o[e] = 0.f;
+            if (add != nullptr) unpack_chunk<T>(*reinterpret_cast<const u32x4*>(add + pix * add_ld + (size_t)ch * EPC), o);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                if ((bits[e] >> k) & 1u) o[e] += g[e];
+                if (!((bits[e] >> (4 + k)) & 1u)) o[e] = 0.f;
+            }
+            *reinterpret_cast<u32x4*>(dx + pix * dx_ld + (size_t)ch * EPC) = pack_chunk<T>(o);
+        }
+    }
+}
+
 static unsigned capped_grid(long long total, int per_block) {
     long long b = (total + per_block - 1) / per_block;
     if (b > 256 * 16) b = 256 * 16;
@@ -843,6 +933,43 @@ extern "C" int mis_maxpool2_fwd(int dtype, const void* x, int x_ld, void* y, int
     else { if (is3d) MP_FWD(float, true); else MP_FWD(float, false); }
 #undef MP_FWD
     MIS_LAUNCH_CHECK("maxpool_fwd");
+    return MIS_OK;
+}
+
+extern "C" int mis_maxpool2_fwd_pb(int dtype, const void* x, int x_ld, void* y, int y_ld, int N, int H, int W, int C, void* pbits, void* stream) {
+    (void)hipGetLastError();
+    const int EPC = dtype == MIS_BF16 ? 8 : 4;
+    MIS_REQUIRE(x && y && pbits && N > 0 && H > 1 && W > 1, MIS_EINVAL, "maxpool_fwd_pb: bad argument");
+    MIS_REQUIRE(H % 2 == 0 && W % 2 == 0, MIS_EUNSUPPORTED, "maxpool_fwd_pb: even H and W (got %d x %d)", H, W);
+    MIS_REQUIRE(C % EPC == 0 && x_ld % EPC == 0 && y_ld % EPC == 0, MIS_EINVAL, "maxpool_fwd_pb: alignment");
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / EPC);
+    const unsigned g = capped_grid(total, 256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIS_BF16)
+        hipLaunchKernelGGL(maxpool_fwd_pb_kernel<__bf16>, dim3(g), dim3(256), 0, s, (const __bf16*)x, x_ld, (__bf16*)y, y_ld, N, H, W, C, (unsigned char*)pbits);
+    else
+        hipLaunchKernelGGL(maxpool_fwd_pb_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x, x_ld, (float*)y, y_ld, N, H, W, C, (unsigned char*)pbits);
+    MIS_LAUNCH_CHECK("maxpool_fwd_pb");
+    return MIS_OK;
+}
+
+extern "C" int mis_maxpool2_bwd_pb(int dtype, const void* pbits, const void* dy, int dy_ld, const void* add, int add_ld, void* dx, int dx_ld, int N, int H, int W,
+                                   int C, void* stream) {
+    (void)hipGetLastError();
+    const int EPC = dtype == MIS_BF16 ? 8 : 4;
+    MIS_REQUIRE(pbits && dy && dx && N > 0 && H > 1 && W > 1, MIS_EINVAL, "maxpool_bwd_pb: bad argument");
+    MIS_REQUIRE(H % 2 == 0 && W % 2 == 0, MIS_EUNSUPPORTED, "maxpool_bwd_pb: even H and W (got %d x %d)", H, W);
+    MIS_REQUIRE(C % EPC == 0 && dy_ld % EPC == 0 && dx_ld % EPC == 0 && (add == nullptr || add_ld % EPC == 0), MIS_EINVAL, "maxpool_bwd_pb: alignment");
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / EPC);
+    const unsigned g = capped_grid(total, 256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIS_BF16)
+        hipLaunchKernelGGL(maxpool_bwd_pb_kernel<__bf16>, dim3(g), dim3(256), 0, s, (const unsigned char*)pbits, (const __bf16*)dy, dy_ld, (const __bf16*)add, add_ld,
+                           (__bf16*)dx, dx_ld, N, H, W, C);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_pb_kernel<float>, dim3(g), dim3(256), 0, s, (const unsigned char*)pbits, (const float*)dy, dy_ld, (const float*)add, add_ld,
+                           (float*)dx, dx_ld, N, H, W, C);
+    MIS_LAUNCH_CHECK("maxpool_bwd_pb");
     return MIS_OK;
 }
 

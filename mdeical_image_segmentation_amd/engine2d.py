@@ -222,6 +222,9 @@ class UNet2DEngine:
                 if j < 3:
                     self.rb[("u2", j)] = bits(self.u2[j])
             self.rb["m1"], self.rb["m2"] = bits(self.m1), bits(self.m2)
+        # "pool bits" (mis_maxpool2_fwd_pb): arg-max position + input sign per pooled element, so that the pooling backward does not read the skip tensor again
+        self.pb = [None] * 4 if os.environ.get("MISAMD_NO_POOL_BITS") else [torch.empty(N, (H >> l) // 2, (W >> l) // 2, c, dtype=torch.uint8, device=dev)
+                                                                           for l, c in enumerate(FEATS)]
         self._shape = (N, H, W)
 
     # ---- forward ---------------------------------------------------------------------------------------
@@ -246,7 +249,7 @@ class UNet2DEngine:
             else:
                 self._conv(self.pooled[l - 1], f"down_conv.{l}.first", self.t1[l], FEATS[l - 1], c, rb=("t1", l))
             self._conv(self.t1[l], f"down_conv.{l}.second", skip, c, c)
-            ops.maxpool2_fwd(skip, self.pooled[l])
+            ops.maxpool2_fwd(skip, self.pooled[l], pbits=self.pb[l] if train else None)
         self._conv(self.pooled[3], "middle_conv.first", self.m1, 512, 1024, rb="m1")
         self._conv(self.m1, "middle_conv.second", self.m2, 1024, 1024, rb="m2")
         x = self.m2
@@ -332,7 +335,7 @@ class UNet2DEngine:
         for l in range(3, -1, -1):
             c = FEATS[l]
             skip = View(self.cat[l], c, c)
-            ops.maxpool2_bwd(skip, self.g_pooled[l], self.g_skip[l], add=self.g_skip[l], relu_mask=True)
+            ops.maxpool2_bwd(skip, self.g_pooled[l], self.g_skip[l], add=self.g_skip[l], relu_mask=True, pbits=self.pb[l])
             self._bwd_conv(self.t1[l], self.g_skip[l], f"down_conv.{l}.second", c, c, dx=self.g_t1[l], mask=(self.t1[l], ("t1", l)))
             if l > 0:
                 self._bwd_conv(self.pooled[l - 1], self.g_t1[l], f"down_conv.{l}.first", FEATS[l - 1], c, dx=self.g_pooled[l - 1])

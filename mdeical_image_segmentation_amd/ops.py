@@ -292,18 +292,29 @@ def chanstats(x, s, sq):
                             stream_ptr()), "mis_chanstats")
 
 
-def maxpool2_fwd(x, y):
+def maxpool2_fwd(x, y, pbits=None):
+    """pbits (2-D, even H and W): uint8 (N, H/2, W/2, C) "pool bits" for maxpool2_bwd(pbits=...) - arg-max position and input sign per pooled element"""
     lib = load()
     x, y = _v(x), _v(y)
+    if pbits is not None:
+        check(lib.mis_maxpool2_fwd_pb(dtype_code(x.dtype), x.ptr, x.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, pbits.data_ptr(), stream_ptr()), "mis_maxpool2_fwd_pb")
+        return
     check(lib.mis_maxpool2_fwd(dtype_code(x.dtype), x.ptr, x.ld, y.ptr, y.ld, x.N, x.D, x.H, x.W, x.C, stream_ptr()),
           "mis_maxpool2_fwd")
 
 
-def maxpool2_bwd(x, dy, dx, add=None, relu_mask=True):
+def maxpool2_bwd(x, dy, dx, add=None, relu_mask=True, pbits=None):
+    """pbits (from maxpool2_fwd): the backward pass with the ReLU mask, without reading x (x may then be None)"""
     lib = load()
-    x, dy, dx = _v(x), _v(dy), _v(dx)
+    dy, dx = _v(dy), _v(dx)
     if add is not None:
         add = _v(add)
+    if pbits is not None:
+        assert relu_mask, "pool bits carry the ReLU mask"
+        check(lib.mis_maxpool2_bwd_pb(dtype_code(dx.dtype), pbits.data_ptr(), dy.ptr, dy.ld, None if add is None else add.ptr, 0 if add is None else add.ld,
+                                      dx.ptr, dx.ld, dx.N, dx.H, dx.W, dx.C, stream_ptr()), "mis_maxpool2_bwd_pb")
+        return
+    x = _v(x)
     check(lib.mis_maxpool2_bwd(dtype_code(x.dtype), x.ptr, x.ld, dy.ptr, dy.ld, None if add is None else add.ptr,
                                0 if add is None else add.ld, dx.ptr, dx.ld, x.N, x.D, x.H, x.W, x.C, 1 if relu_mask else 0,
                                stream_ptr()), "mis_maxpool2_bwd")

@@ -291,6 +291,21 @@ def test_maxpool_fwd_bwd_ties(dtype):
         dx2 = torch.zeros(2, 10, 14, 8, device=DEV)
         ops.maxpool2_bwd(xd, to_nhwc(torch.cat([torch.from_numpy(g["ds_gy"])] * 2, 1), dtype), dx2, add=None, relu_mask=False)
         assert torch.equal(from_nhwc(dx2)[:, :4], torch.from_numpy(g["ds_gx"])), "maxpool bwd vs golden (ties)"
+    # the "pool bits" pair (arg-max position + input sign per pooled element instead of re-reading x): bit for bit the results above, ties included
+    yb = torch.full_like(y, float("nan"))
+    pb = torch.full((2, 5, 7, 8), 0xFF, dtype=torch.uint8, device=DEV)
+    ops.maxpool2_fwd(xd, yb, pbits=pb)
+    assert torch.equal(yb, y), "maxpool fwd with pool bits"
+    sel, pos = pb & 0xF, pb >> 4
+    assert torch.equal((sel == 1).int() + (sel == 2).int() + (sel == 4).int() + (sel == 8).int(), torch.ones_like(sel, dtype=torch.int32)), "one arg-max per window"
+    xw = to_nhwc(x, dtype).float().view(2, 5, 2, 7, 2, 8).permute(0, 1, 3, 5, 2, 4).reshape(2, 5, 7, 8, 4)       # window position k = kh*2 + kw last
+    assert torch.equal(pos, ((xw > 0).to(torch.uint8) << torch.arange(4, device=DEV, dtype=torch.uint8)).sum(-1).to(torch.uint8)), "sign bits"
+    for with_add in (True, False):
+        dxa = to_nhwc(add, dtype)
+        ops.maxpool2_bwd(xd, to_nhwc(gy, dtype), dxa, add=dxa if with_add else None, relu_mask=True)
+        dxb = to_nhwc(add, dtype)
+        ops.maxpool2_bwd(None, to_nhwc(gy, dtype), dxb, add=dxb if with_add else None, relu_mask=True, pbits=pb)
+        assert torch.equal(dxa, dxb), f"maxpool bwd with pool bits (add={with_add})"
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
