@@ -130,14 +130,18 @@ def live_fractions(tensors):
 
 # dispatch configuration (mis_conv_last_dispatch / mis_wgrad_last_dispatch) -> the kernel symbol rocprofv3 shows for it
 SYMBOLS = {
-    "k3.2d.ppc8": "conv_ppc_kernel<8, 4>", "k3.2d.ppc8n2": "conv_ppc_kernel<8, 2>", "k3.2d.pp256": "conv_pp_kernel<8>", "k3.2d.pp128": "conv_pp_kernel<4>",
+    "k3.2d.pp256": "conv_pp_kernel<8>", "k3.2d.pp128": "conv_pp_kernel<4>",
     "k3.2d.pp64": "conv_pp_kernel<2>", "k3.2d.ws64": "conv64_ws_kernel", "k3.2d.rs64": "conv_pp_rs64_kernel",
-    "k3.3d.ppc5": "conv3d_ppc_kernel<5, 4>", "k3.3d.ppc8": "conv3d_ppc_kernel<8, 4>", "k3.3d.ppc5n6": "conv3d_ppc_kernel<5, 6>",
-    "k3.3d.ppc5n2": "conv3d_ppc_kernel<5, 2>", "k3.3d.ppc8n2": "conv3d_ppc_kernel<8, 2>", "k3.3d.ppc10n2": "conv3d_ppc_kernel<10, 2>",
     "k3.2d.ppw": "wgrad_pp_wide_kernel<false, false>", "k3.2d.pps": "wgrad_pp_wide_kernel<true, false>", "k3.2d.ppwr": "wgrad_pp_row_kernel<false, false>",
     "k3.2d.ppsr": "wgrad_pp_row_kernel<true, false>", "k3.3d.ppw": "wgrad_pp_wide_kernel<false, true>", "k3.3d.pps": "wgrad_pp_wide_kernel<true, true>",
     "k3.3d.ppwr": "wgrad_pp_row_kernel<false, true>", "k3.3d.ppsr": "wgrad_pp_row_kernel<true, true>", "k3.2d.pp": "wgrad_pp_kernel<2>",
 }
+# the column-segment kernels: one instantiation per epilogue mask path (template argument 0 = none, 1 = bf16 mask ".mask", 2 = ReLU bits ".bits")
+for _t, _k in (("k3.2d.ppc8", "conv_ppc_kernel<8, 4"), ("k3.2d.ppc8n2", "conv_ppc_kernel<8, 2"), ("k3.3d.ppc5", "conv3d_ppc_kernel<5, 4"),
+               ("k3.3d.ppc8", "conv3d_ppc_kernel<8, 4"), ("k3.3d.ppc5n6", "conv3d_ppc_kernel<5, 6"), ("k3.3d.ppc5n2", "conv3d_ppc_kernel<5, 2"),
+               ("k3.3d.ppc8n2", "conv3d_ppc_kernel<8, 2"), ("k3.3d.ppc10n2", "conv3d_ppc_kernel<10, 2")):
+    for _sfx, _em in (("", 0), (".mask", 1), (".bits", 2)):
+        SYMBOLS[_t + _sfx] = f"{_k}, {_em}>"
 
 
 def kernel_tables(prof, steps, peak):

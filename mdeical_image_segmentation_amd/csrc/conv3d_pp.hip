@@ -373,24 +373,24 @@ int launch_conv3d_pp(const MisConvDesc* d, hipStream_t stream, const char** tag)
     }
     if (nf == 4) {
         if (pf == 5) {
-            *tag = "k3.3d.ppc5";
+            *tag = d->mask != nullptr ? "k3.3d.ppc5.mask" : "k3.3d.ppc5";
             return pp3_launch<5, 4>(d, stream);
         }
-        *tag = "k3.3d.ppc8";
+        *tag = d->mask != nullptr ? "k3.3d.ppc8.mask" : "k3.3d.ppc8";
         return pp3_launch<8, 4>(d, stream);
     }
     if (nf == 6) {
-        *tag = "k3.3d.ppc5n6";
+        *tag = d->mask != nullptr ? "k3.3d.ppc5n6.mask" : "k3.3d.ppc5n6";
         return pp3_launch<5, 6>(d, stream);
     }
     if (pf == 5) {
-        *tag = "k3.3d.ppc5n2";
+        *tag = d->mask != nullptr ? "k3.3d.ppc5n2.mask" : "k3.3d.ppc5n2";
         return pp3_launch<5, 2>(d, stream);
     }
     if (pf == 8) {
-        *tag = "k3.3d.ppc8n2";
+        *tag = d->mask != nullptr ? "k3.3d.ppc8n2.mask" : "k3.3d.ppc8n2";
         return pp3_launch<8, 2>(d, stream);
     }
-    *tag = "k3.3d.ppc10n2";
+    *tag = d->mask != nullptr ? "k3.3d.ppc10n2.mask" : "k3.3d.ppc10n2";
     return pp3_launch<10, 2>(d, stream);
 }

@@ -928,12 +928,13 @@ int conv_ppc_choice(const MisConvDesc* d) {
 
 int launch_conv_pp(const MisConvDesc* d, hipStream_t stream, const char** tag) {
     const int ppc = conv_ppc_choice(d);
+    // (the tag names the instantiation: one per epilogue mask path, ".mask" = bf16 mask tensor, ".bits" = ReLU bits)
     if (ppc == 4) {
-        *tag = "k3.2d.ppc8";
+        *tag = d->mask_bits != nullptr ? "k3.2d.ppc8.bits" : (d->mask != nullptr ? "k3.2d.ppc8.mask" : "k3.2d.ppc8");
         return pp_launch_col<8, 4>(d, stream);
     }
     if (ppc == 2) {
-        *tag = "k3.2d.ppc8n2";
+        *tag = d->mask_bits != nullptr ? "k3.2d.ppc8n2.bits" : (d->mask != nullptr ? "k3.2d.ppc8n2.mask" : "k3.2d.ppc8n2");
         return pp_launch_col<8, 2>(d, stream);
     }
     MIS_REQUIRE(d->mask_bits == nullptr, MIS_EUNSUPPORTED, "conv_igemm(pp): ReLU bits are read by the column-segment kernels only");      // (dispatch never sends one here)

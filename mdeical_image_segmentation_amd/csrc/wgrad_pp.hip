@@ -707,6 +707,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_row_kernel(const WgArgs a) {
         wp_static_for<NS>([&](auto sgc) {
             constexpr int ks = decltype(sgc)::value;
             // ================= R segment =================
+#ifndef WPT_NO_DMA          // (WPT_NO_*: timing ablations of a diagnostic build, scripts/wgrad_ablate.sh - results are garbage, never shipped)
             if constexpr (ks < NS - 1) {
                 if (has_next) {
                     wp_static_for<DPS>([&](auto dc) {
@@ -715,6 +716,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_row_kernel(const WgArgs a) {
                     });
                 }
             }
+#endif
             bf16x8_t B[4];
             wp_static_for<4>([&](auto fjc) {
                 constexpr int fj = decltype(fjc)::value;
@@ -740,6 +742,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_row_kernel(const WgArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             // ================= M segment =================
             __builtin_amdgcn_s_setprio(1);
+#ifdef WPT_NO_MFMA
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks][0], B[0], acc[0][0], 0, 0, 0);
+            for (int kh = 0; kh < 3; ++kh)
+                for (int kw = 0; kw < 3; ++kw)
+                    for (int fj = 0; fj < 4; ++fj) asm volatile("" ::"v"(A[ks + kh][kw]), "v"(B[fj]));
+#else
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -747,6 +755,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_row_kernel(const WgArgs a) {
 #pragma unroll
                     for (int fj = 0; fj < 4; ++fj)
                         acc[kh * 3 + kw][fj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks + kh][kw], B[fj], acc[kh * 3 + kw][fj], 0, 0, 0);
+#endif
             if (do_bias) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, wi == 0 ? B[0] : (wi == 1 ? B[1] : (wi == 2 ? B[2] : B[3])), bacc, 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             if constexpr (ks == NS - 1) {
