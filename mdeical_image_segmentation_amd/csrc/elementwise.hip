@@ -286,11 +286,13 @@ __global__ __launch_bounds__(256) void first_conv_wgrad_kernel(const float* __re
     for (int i = tid; i < 640; i += 256) out[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
 }
 
-// Tiled variant (same 2 x 64 pixel tiles, halo of input channel blockIdx.y in LDS, 4 pixels x 8 channels of dy per thread).
+// Tiled variant: 8 x 64 pixel tiles (round 3; 2 x 64 before: two block barriers and one exposed round of loads per 128 pixels made the kernel latency-bound at half of the
+// HBM rate), halo of input channel blockIdx.y in LDS, per thread 4 pixels x 8 channels of dy for each of the tile's four row pairs - the row pairs are unrolled, so the
+// next pair's loads are in flight under the current pair's 288 FMAs.
 template <typename T>
 __global__ __launch_bounds__(256) void first_conv_wgrad_tiled_kernel(const float* __restrict__ x, int N, int Cin, int H, int W, const T* dy, int dy_ld,
                                                                      float* __restrict__ partial /*[blocks][Cin][10][64]*/) {
-    constexpr int TH = 2, TW = 64, HH = TH + 2, HW = TW + 2;
+    constexpr int TH = 8, TW = 64, HH = TH + 2, HW = TW + 2, RP = TH / 2;
     __shared__ __attribute__((aligned(16))) float xs[HH][HW + 2];
     __shared__ float red[4][10 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -320,42 +322,54 @@ __global__ __launch_bounds__(256) void first_conv_wgrad_tiled_kernel(const float
             if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = x[((long long)n * Cin + ci) * HWp + (long long)sy * W + sx];
             xs[py][px] = v;
         }
-        float g[4][8];
-        const int yy = h0 + r;
+        u32x4 raw[RP][4][sizeof(T) == 2 ? 1 : 2];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int xx = w0 + wq + v;
+        for (int rp = 0; rp < RP; ++rp) {
+            const int yy = h0 + 2 * rp + r;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[v][j] = 0.f;
-            if (yy < H && xx < W) {
-                const T* src = dy + (((size_t)n * H + yy) * W + xx) * dy_ld + cg * 8;
-                if constexpr (sizeof(T) == 2) {
-                    unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(src), g[v]);
-                } else {
-                    unpack_chunk<float>(*reinterpret_cast<const u32x4*>(src), g[v]);
-                    unpack_chunk<float>(*reinterpret_cast<const u32x4*>(src + 4), g[v] + 4);
+            for (int v = 0; v < 4; ++v) {
+                const int xx = w0 + wq + v;
+#pragma unroll
+                for (int k = 0; k < (sizeof(T) == 2 ? 1 : 2); ++k) raw[rp][v][k] = u32x4{0u, 0u, 0u, 0u};
+                if (yy < H && xx < W) {
+                    const T* src = dy + (((size_t)n * H + yy) * W + xx) * dy_ld + cg * 8;
+                    raw[rp][v][0] = *reinterpret_cast<const u32x4*>(src);
+                    if constexpr (sizeof(T) == 4) raw[rp][v][1] = *reinterpret_cast<const u32x4*>(src + 4);
                 }
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            float xr[6];
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(&xs[r + kh][wq]);
-            xr[0] = lo[0]; xr[1] = lo[1]; xr[2] = lo[2]; xr[3] = lo[3];
-            xr[4] = xs[r + kh][wq + 4];
-            xr[5] = xs[r + kh][wq + 5];
+        for (int rp = 0; rp < RP; ++rp) {
+            float g[4][8];
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw)
+            for (int v = 0; v < 4; ++v) {
+                if constexpr (sizeof(T) == 2) {
+                    unpack_chunk<__bf16>(raw[rp][v][0], g[v]);
+                } else {
+                    unpack_chunk<float>(raw[rp][v][0], g[v]);
+                    unpack_chunk<float>(raw[rp][v][1], g[v] + 4);
+                }
+            }
 #pragma unroll
-                for (int v = 0; v < 4; ++v)
+            for (int kh = 0; kh < 3; ++kh) {
+                float xr[6];
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(&xs[2 * rp + r + kh][wq]);
+                xr[0] = lo[0]; xr[1] = lo[1]; xr[2] = lo[2]; xr[3] = lo[3];
+                xr[4] = xs[2 * rp + r + kh][wq + 4];
+                xr[5] = xs[2 * rp + r + kh][wq + 5];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[kh * 3 + kw][j] = fmaf(xr[v + kw], g[v][j], acc[kh * 3 + kw][j]);
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[kh * 3 + kw][j] = fmaf(xr[v + kw], g[v][j], acc[kh * 3 + kw][j]);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[9][j] += g[v][j];
         }
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[9][j] += g[v][j];
     }
 #pragma unroll
     for (int t = 0; t < 10; ++t)
@@ -415,7 +429,7 @@ extern "C" int mis_conv3x3_first_wgrad(int dtype, const float* x, int N, int Cin
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int tiled = !mis_sw(SW_FIRST2D_UNTILED);
     if (tiled) {
-        const long long tiles = (long long)N * ((H + 1) / 2) * ((W + 63) / 64);
+        const long long tiles = (long long)N * ((H + 7) / 8) * ((W + 63) / 64);
         blocks = tiles < FW_BLOCKS ? tiles : FW_BLOCKS;
         if (dtype == MIS_BF16)
             hipLaunchKernelGGL(first_conv_wgrad_tiled_kernel<__bf16>, dim3((unsigned)blocks, Cin), dim3(256), 0, s, x, N, Cin, H, W, (const __bf16*)dy,
