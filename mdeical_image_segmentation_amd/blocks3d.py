@@ -47,8 +47,8 @@ class CL:
 def _need_cuda(x):
     if x.device.type != "cuda":
         raise MisError(f"the 3-D building blocks run on MI355X only: got a tensor on {x.device} (no CPU fallback)")
-    if x.dim() != 5:
-        raise MisError(f"expected a (N, C, D, H, W) tensor, got {tuple(x.shape)}")
+    if x.dim() not in (4, 5):
+        raise MisError(f"expected a (N, C, D, H, W) tensor (or (N, C, H, W) for the 2-D variants of the blocks), got {tuple(x.shape)}")
 
 
 # ---- layout ------------------------------------------------------------------------------------------------------------------------------
@@ -91,12 +91,16 @@ class _FromCL(torch.autograd.Function):
 
 
 def to_cl(x, dtype=None):
+    """(N, C, D, H, W) -> channels-last activation; a 2-D tensor (N, C, H, W) (UNet2D / ResidualUNet2D, is3d=False blocks) travels as a volume of depth 1"""
     _need_cuda(x)
+    if x.dim() == 4:
+        x = x.unsqueeze(2)
     return CL(_ToCL.apply(x, compute_dtype() if dtype is None else dtype), x.shape[1])
 
 
-def from_cl(a):
-    return _FromCL.apply(a.t, a.C)
+def from_cl(a, two_d=False):
+    y = _FromCL.apply(a.t, a.C)
+    return y.squeeze(2) if two_d else y
 
 
 # ---- GroupNorm statistics shared by the two normalising functions ----------------------------------------------------------------------------
@@ -190,12 +194,15 @@ class _Conv(torch.autograd.Function):
         x = x.contiguous()
         dev, dt = x.device, x.dtype
         ks = weight.shape[-1]
+        nd = weight.dim() - 2                                  # 3: Conv3d; 2: Conv2d (is3d=False blocks) on a depth-1 volume, run by the 2-D kernels on (N, H, W, C) views
         cinp, coutp = x.shape[-1], pad64(cout)
-        if tuple(weight.shape) != (cout, cin) + (ks,) * 3 or ks not in (1, 3) or cinp != pad64(cin):
+        if nd not in (2, 3) or tuple(weight.shape) != (cout, cin) + (ks,) * nd or ks not in (1, 3) or cinp != pad64(cin):
             raise MisError(f"conv block: weight {tuple(weight.shape)} does not fit {cin} -> {cout} channels (kernel 1 or 3)")
-        wpad = torch.zeros(coutp, cinp, ks, ks, ks, device=dev)
+        if nd == 2 and x.shape[1] != 1:
+            raise MisError(f"conv block: a Conv2d weight needs a depth-1 activation, got grid {tuple(x.shape[1:4])}")
+        wpad = torch.zeros(coutp, cinp, *((ks,) * nd), device=dev)
         wpad[:cout, :cin] = weight.detach()
-        taps = ks ** 3
+        taps = ks ** nd
         wf = torch.empty(taps, coutp, cinp, dtype=dt, device=dev)
         wd = torch.empty(taps, cinp, coutp, dtype=dt, device=dev)
         ops.pack_conv_weight(wpad, wf, wd)
@@ -211,15 +218,16 @@ class _Conv(torch.autograd.Function):
             bpad = torch.zeros(coutp, device=dev)
             bpad[:cout] = bias.detach()
         y = torch.empty(*x.shape[:4], coutp, dtype=dt, device=dev)
-        ops.conv_igemm(x, wf, y, ksize=ks, Cin=cinp, Cout=coutp, bias=bpad, relu=relu, in_scale=scale, in_shift=shift)
+        v = (lambda t: t) if nd == 3 else (lambda t: t.view(t.shape[0], *t.shape[2:]))      # depth-1 volume -> image
+        ops.conv_igemm(v(x), wf, v(y), ksize=ks, Cin=cinp, Cout=coutp, bias=bpad, relu=relu, in_scale=scale, in_shift=shift)
         ctx.save_for_backward(x, y if relu else None, wd, scale, shift, mean, rstd, None if gamma is None else gamma.detach().float())
-        ctx.cfg = (cin, cout, groups, relu, ks, bias is not None)
+        ctx.cfg = (cin, cout, groups, relu, ks, bias is not None, nd)
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, y, wd, scale, shift, mean, rstd, gamma = ctx.saved_tensors
-        cin, cout, groups, relu, ks, has_bias = ctx.cfg
+        cin, cout, groups, relu, ks, has_bias, nd = ctx.cfg
         dev = x.device
         cinp, coutp = x.shape[-1], g.shape[-1]
         g = g.contiguous()
@@ -227,15 +235,16 @@ class _Conv(torch.autograd.Function):
             gm = torch.empty_like(g)
             ops.relu_mask(g, y, gm)
             g = gm
-        dwp = torch.empty(coutp, cinp, ks, ks, ks, device=dev)
+        v = (lambda t: t) if nd == 3 else (lambda t: t.view(t.shape[0], *t.shape[2:]))
+        dwp = torch.empty(coutp, cinp, *((ks,) * nd), device=dev)
         dbp = torch.empty(coutp, device=dev) if has_bias else None
-        ops.wgrad(x, g, dwp, ksize=ks, Cin=cinp, Cout=coutp, in_scale=scale, in_shift=shift, dbias=dbp)
+        ops.wgrad(v(x), v(g), dwp, ksize=ks, Cin=cinp, Cout=coutp, in_scale=scale, in_shift=shift, dbias=dbp)
         dw = dwp[:cout, :cin].contiguous()
         db = dbp[:cout].contiguous() if has_bias else None
         dx = dgamma = dbeta = None
         if ctx.needs_input_grad[0] or gamma is not None:
             dn = torch.empty_like(x)
-            ops.conv_igemm(g, wd, dn, ksize=ks, Cin=coutp, Cout=cinp)
+            ops.conv_igemm(v(g), wd, v(dn), ksize=ks, Cin=coutp, Cout=cinp)
             if ctx.bn is not None:
                 dx, dgamma, dbeta = _bn_backward(dn, x, cin, gamma, mean, rstd, *ctx.bn)
             elif gamma is not None:
@@ -526,6 +535,14 @@ class _ConvT2x(torch.autograd.Function):
 
 
 def conv_transpose_2x(a, weight, size):
+    if weight.dim() == 4:
+        # ConvTranspose2d(k3, s2, p1) of the is3d=False blocks on a depth-1 volume: the 3-D operator with the 2-D filter as its centre depth slice gives exactly that
+        # at output depth 0 (z = 2*iz - 1 + kd admits only kd = 1), and the kernels' nearest resize (2d-1 -> 2d per axis) duplicates it into depth 1: keep depth 0
+        if a.grid[1] != 1 or size[0] != 1:
+            raise MisError(f"transposed conv: a ConvTranspose2d weight needs depth-1 activations, got {a.grid[1:]} -> {tuple(size)}")
+        w3 = torch.nn.functional.pad(weight.unsqueeze(2), (0, 0, 0, 0, 1, 1))
+        up = conv_transpose_2x(a, w3, (2,) + tuple(size[1:]))
+        return CL(up.t[:, 0:1], up.C)
     cin, cout = weight.shape[:2]
     if cin != a.C:
         raise MisError(f"transposed conv: input has {a.C} channels, the weight expects {cin}")

@@ -20,8 +20,6 @@ def create_conv(in_channels, out_channels, kernel_size, order, num_groups, paddi
     'b' batchnorm, 'd' / 'D' dropout.  The conv has a bias only without a norm in the order (:62)."""
     assert "c" in order, "Conv layer MUST be present"
     assert order[0] not in "rle", "Non-linearity cannot be the first operation in the layer"
-    if not is3d:
-        raise NotImplementedError("2-D variants of the 3-D building blocks (is3d=False) are outside the accelerated path (SURVEY.md §8f4)")
     if not ((kernel_size == 3 and padding == 1) or (kernel_size == 1 and padding == 0)):
         raise NotImplementedError("the MI355X convolution kernels are built for kernel 3 / padding 1 and kernel 1 / padding 0")
     mods = []
@@ -34,7 +32,7 @@ def create_conv(in_channels, out_channels, kernel_size, order, num_groups, paddi
             mods.append(("ELU", nn.ELU(inplace=True)))
         elif char == "c":
             bias = not ("g" in order or "b" in order)
-            mods.append(("conv", nn.Conv3d(in_channels, out_channels, kernel_size, padding=padding, bias=bias)))
+            mods.append(("conv", (nn.Conv3d if is3d else nn.Conv2d)(in_channels, out_channels, kernel_size, padding=padding, bias=bias)))     # (:65-68)
         elif char == "g":
             num_channels = in_channels if i < order.index("c") else out_channels
             groups = 1 if num_channels < num_groups else num_groups
@@ -46,17 +44,18 @@ def create_conv(in_channels, out_channels, kernel_size, order, num_groups, paddi
         elif char == "D":
             mods.append(("dropout2d", nn.Dropout2d(p=dropout_prob)))
         elif char == "b":
-            mods.append(("batchnorm", nn.BatchNorm3d(in_channels if i < order.index("c") else out_channels)))
+            mods.append(("batchnorm", (nn.BatchNorm3d if is3d else nn.BatchNorm2d)(in_channels if i < order.index("c") else out_channels)))      # (:97-104)
         else:
             raise ValueError(f"Unsupported layer type '{char}'. MUST be one of ['b', 'g', 'r', 'l', 'e', 'c', 'd', 'D']")
     return mods
 
 
 class _Block:
-    """forward(x): (N, C, D, H, W) fp32 on the GPU -> the same layout, through the channels-last HIP route (`_cl`)"""
+    """forward(x): (N, C, D, H, W) fp32 on the GPU (is3d=False blocks: (N, C, H, W), carried as a depth-1 volume) -> the same layout, through the channels-last HIP
+    route (`_cl`)"""
 
     def forward(self, x):
-        return B.from_cl(self._cl(B.to_cl(x)))
+        return B.from_cl(self._cl(B.to_cl(x)), two_d=x.dim() == 4)
 
 
 class SingleConv(_Block, nn.Sequential):
@@ -102,9 +101,7 @@ class ResNetBlock(_Block, nn.Module):
 
     def __init__(self, in_channels, out_channels, kernel_size=3, order="cge", num_groups=8, is3d=True, **kwargs):
         super().__init__()
-        if not is3d:
-            raise NotImplementedError("2-D variants of the 3-D building blocks (is3d=False) are outside the accelerated path (SURVEY.md §8f4)")
-        self.conv1 = nn.Conv3d(in_channels, out_channels, 1) if in_channels != out_channels else nn.Identity()
+        self.conv1 = (nn.Conv3d if is3d else nn.Conv2d)(in_channels, out_channels, 1) if in_channels != out_channels else nn.Identity()     # (:262-268)
         self.conv2 = SingleConv(out_channels, out_channels, kernel_size=kernel_size, order=order, num_groups=num_groups, is3d=is3d)
         n_order = order
         for c in "rel":
@@ -149,10 +146,10 @@ class Encoder(_Block, nn.Module):
                  basic_module=DoubleConv, conv_layer_order="gcr", num_groups=8, padding=1, upscale=2, dropout_prob=0.1, is3d=True):
         super().__init__()
         assert pool_type in ["max", "avg"]
-        if not is3d:
-            raise NotImplementedError("2-D variants of the 3-D building blocks (is3d=False) are outside the accelerated path (SURVEY.md §8f4)")
-        if apply_pooling:
-            self.pooling = (nn.MaxPool3d if pool_type == "max" else nn.AvgPool3d)(kernel_size=pool_kernel_size)
+        self._is3d = is3d
+        if apply_pooling:                                    # (:409-418: MaxPool3d / AvgPool3d, or their 2-D twins)
+            cls = (nn.MaxPool3d if pool_type == "max" else nn.AvgPool3d) if is3d else (nn.MaxPool2d if pool_type == "max" else nn.AvgPool2d)
+            self.pooling = cls(kernel_size=pool_kernel_size)
         else:
             self.pooling = None
         self.basic_module = basic_module(in_channels, out_channels, encoder=True, kernel_size=conv_kernel_size, order=conv_layer_order,
@@ -160,7 +157,10 @@ class Encoder(_Block, nn.Module):
 
     def _cl(self, a):
         if self.pooling is not None:
-            a = B.pool(a, self.pooling.kernel_size, avg=isinstance(self.pooling, nn.AvgPool3d))
+            k = self.pooling.kernel_size
+            if not self._is3d:                               # a 2-D window on the depth-1 volume
+                k = (1,) + ((k, k) if isinstance(k, int) else tuple(k))
+            a = B.pool(a, k, avg=isinstance(self.pooling, (nn.AvgPool3d, nn.AvgPool2d)))
         return self.basic_module._cl(a)
 
 
@@ -169,7 +169,8 @@ class AbstractUpsampling(nn.Module):
 
     def forward(self, encoder_features, x):
         size = tuple(encoder_features.shape[2:])
-        return B.from_cl(self._cl(B.to_cl(x), size))
+        two_d = x.dim() == 4
+        return B.from_cl(self._cl(B.to_cl(x), (1,) + size if two_d else size), two_d=two_d)
 
 
 class InterpolateUpsampling(AbstractUpsampling):
@@ -192,13 +193,16 @@ class TransposeConvUpsampling(AbstractUpsampling):
             self.is3d = is3d
 
         def forward(self, x, size):
-            return B.from_cl(B.conv_transpose_2x(B.to_cl(x), self.conv_transposed.weight, tuple(size)))
+            two_d = x.dim() == 4
+            size = (1,) + tuple(size) if two_d else tuple(size)
+            return B.from_cl(B.conv_transpose_2x(B.to_cl(x), self.conv_transposed.weight, size), two_d=two_d)
 
     def __init__(self, in_channels, out_channels, kernel_size=3, scale_factor=2, is3d=True):
         super().__init__()
-        if not is3d or kernel_size != 3 or scale_factor != 2:
-            raise NotImplementedError("only ConvTranspose3d(k3, s2, p1) upsampling is built")
-        self.upsample = self.Upsample(nn.ConvTranspose3d(in_channels, out_channels, kernel_size=3, stride=2, padding=1, bias=False), is3d)
+        if kernel_size != 3 or scale_factor != 2:
+            raise NotImplementedError("only ConvTranspose3d / ConvTranspose2d(k3, s2, p1) upsampling is built")
+        ct = nn.ConvTranspose3d if is3d else nn.ConvTranspose2d          # (:700-718)
+        self.upsample = self.Upsample(ct(in_channels, out_channels, kernel_size=3, stride=2, padding=1, bias=False), is3d)
 
     def _cl(self, a, size):
         return B.conv_transpose_2x(a, self.upsample.conv_transposed.weight, size)
@@ -244,7 +248,7 @@ class Decoder(nn.Module):
         return self.basic_module._cl(joined)
 
     def forward(self, encoder_features, x):
-        return B.from_cl(self._cl(B.to_cl(encoder_features), B.to_cl(x)))
+        return B.from_cl(self._cl(B.to_cl(encoder_features), B.to_cl(x)), two_d=x.dim() == 4)
 
 
 def create_encoders(in_channels, f_maps, basic_module, conv_kernel_size, conv_padding, conv_upscale, dropout_prob, layer_order, num_groups,

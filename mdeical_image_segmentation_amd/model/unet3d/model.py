@@ -62,15 +62,16 @@ class AbstractUNet(nn.Module):
         if isinstance(f_maps, int):
             f_maps = number_of_features_per_level(f_maps, num_levels=num_levels)
         assert isinstance(f_maps, (list, tuple)) and len(f_maps) > 1, "Required at least 2 levels in the U-Net"
-        if not is3d or basic_module not in (DoubleConv, ResNetBlock, ResNetBlockSE):
-            raise NotImplementedError("the 3-D U-Nets with DoubleConv (UNet3D), ResNetBlock (ResidualUNet3D) or ResNetBlockSE basic modules are built")
+        if basic_module not in (DoubleConv, ResNetBlock, ResNetBlockSE) or (not is3d and basic_module is ResNetBlockSE):
+            raise NotImplementedError("U-Nets with DoubleConv (UNet3D / UNet2D), ResNetBlock (ResidualUNet3D / ResidualUNet2D) or ResNetBlockSE (3-D) basic modules are built")
+        self._is3d = is3d
         self._residual = basic_module in (ResNetBlock, ResNetBlockSE)
         self._se = basic_module is ResNetBlockSE
         self.encoders = create_encoders(in_channels, f_maps, basic_module, conv_kernel_size, conv_padding, conv_upscale, dropout_prob,
                                         layer_order, num_groups, pool_kernel_size, is3d)
         self.decoders = create_decoders(f_maps, basic_module, conv_kernel_size, conv_padding, layer_order, num_groups, upsample,
                                         dropout_prob, is3d)
-        self.final_conv = nn.Conv3d(f_maps[0], out_channels, 1)
+        self.final_conv = (nn.Conv3d if is3d else nn.Conv2d)(f_maps[0], out_channels, 1)      # (model.py:89-92)
         if is_segmentation:
             self.final_activation = nn.Sigmoid() if final_sigmoid else nn.Softmax(dim=1)
         else:
@@ -78,7 +79,7 @@ class AbstractUNet(nn.Module):
         self._cfg = (in_channels, out_channels, list(f_maps), num_groups, "deconv" if upsample == "deconv" else "default")
         ups_ok = upsample in ("default", "deconv") if self._residual else upsample in ("default", "nearest", "deconv")
         # what the whole-network engines cover (engine3d.UNet3DEngine.__init__ / engine3d_res): everything else takes the per-block route
-        self._fused_cfg_ok = (in_channels == 1 and 1 <= out_channels <= 4 and f_maps[0] == 64 and all(f % 64 == 0 for f in f_maps) and
+        self._fused_cfg_ok = (is3d and in_channels == 1 and 1 <= out_channels <= 4 and f_maps[0] == 64 and all(f % 64 == 0 for f in f_maps) and
                               layer_order == "gcr" and conv_kernel_size == 3 and conv_padding == 1 and conv_upscale == 2 and
                               pool_kernel_size in (2, (2, 2, 2)) and ups_ok)
         self._compute_dtype = compute_dtype
@@ -105,14 +106,16 @@ class AbstractUNet(nn.Module):
             raise MisError(f"UNet3D runs on MI355X only: got input on {x.device} (no CPU fallback)")
         if any(p.device != x.device for p in self.parameters()):
             self.to(x.device)
-        a = B.to_cl(x, _dtype_from(self._compute_dtype))
+        if x.dim() != (5 if self._is3d else 4):
+            raise MisError(f"{type(self).__name__} expects a {'(N, C, D, H, W)' if self._is3d else '(N, C, H, W)'} input, got {tuple(x.shape)}")
+        a = B.to_cl(x, _dtype_from(self._compute_dtype))          # (a 2-D input travels as a depth-1 volume: blocks3d.to_cl)
         feats = []
         for enc in self.encoders:
             a = enc._cl(a)
             feats.insert(0, a)
         for dec, skip in zip(self.decoders, feats[1:]):
             a = dec._cl(skip, a)
-        return B.from_cl(B.conv(a, self.final_conv.weight, self.final_conv.bias))
+        return B.from_cl(B.conv(a, self.final_conv.weight, self.final_conv.bias), two_d=not self._is3d)
 
     def _engine_for(self, x):
         if x.device.type != "cuda":
@@ -175,16 +178,27 @@ class ResidualUNetSE3D(AbstractUNet):
                          dropout_prob=dropout_prob, is3d=True, compute_dtype=kwargs.get("compute_dtype"))
 
 
-def _stub(name):
-    class _S(nn.Module):
-        def __init__(self, *a, **k):
-            raise NotImplementedError(f"{name} is outside the accelerated hot path (SURVEY.md §8f4)")
-    _S.__name__ = name
-    return _S
+class UNet2D(AbstractUNet):
+    """model.py:283-320: the same encoder / decoder tree over Conv2d / MaxPool2d (is3d=False).  Runs on the per-block HIP route: images travel as depth-1 volumes,
+    the 3x3 convolutions are the 2-D implicit-GEMM kernels on (N, H, W, C) views of them"""
+
+    def __init__(self, in_channels, out_channels, final_sigmoid=True, f_maps=64, layer_order="gcr", num_groups=8, num_levels=4,
+                 is_segmentation=True, conv_padding=1, conv_upscale=2, upsample="default", dropout_prob=0.1, **kwargs):
+        super().__init__(in_channels=in_channels, out_channels=out_channels, final_sigmoid=final_sigmoid, basic_module=DoubleConv,
+                         f_maps=f_maps, layer_order=layer_order, num_groups=num_groups, num_levels=num_levels,
+                         is_segmentation=is_segmentation, conv_padding=conv_padding, conv_upscale=conv_upscale, upsample=upsample,
+                         dropout_prob=dropout_prob, is3d=False, compute_dtype=kwargs.get("compute_dtype"))
 
 
-UNet2D = _stub("UNet2D")
-ResidualUNet2D = _stub("ResidualUNet2D")
+class ResidualUNet2D(AbstractUNet):
+    """model.py:323-359: ResNetBlock basic modules, sum joining, ConvTranspose2d(k3, s2, p1) upsampling, is3d=False"""
+
+    def __init__(self, in_channels, out_channels, final_sigmoid=True, f_maps=64, layer_order="gcr", num_groups=8, num_levels=5,
+                 is_segmentation=True, conv_padding=1, conv_upscale=2, upsample="default", dropout_prob=0.1, **kwargs):
+        super().__init__(in_channels=in_channels, out_channels=out_channels, final_sigmoid=final_sigmoid, basic_module=ResNetBlock,
+                         f_maps=f_maps, layer_order=layer_order, num_groups=num_groups, num_levels=num_levels,
+                         is_segmentation=is_segmentation, conv_padding=conv_padding, conv_upscale=conv_upscale, upsample=upsample,
+                         dropout_prob=dropout_prob, is3d=False, compute_dtype=kwargs.get("compute_dtype"))
 
 
 def get_model(model_config):
@@ -196,4 +210,8 @@ def get_model(model_config):
         return ResidualUNet3D(**cfg)
     if name == "ResidualUNetSE3D":
         return ResidualUNetSE3D(**cfg)
-    raise NotImplementedError(f"get_model: UNet3D, ResidualUNet3D and ResidualUNetSE3D are built, got {name}")
+    if name == "UNet2D":
+        return UNet2D(**cfg)
+    if name == "ResidualUNet2D":
+        return ResidualUNet2D(**cfg)
+    raise NotImplementedError(f"get_model: UNet3D, ResidualUNet3D, ResidualUNetSE3D, UNet2D and ResidualUNet2D are built, got {name}")

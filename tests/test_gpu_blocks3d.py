@@ -403,3 +403,55 @@ def test_residual_unet3d_cge_vs_reference_golden(monkeypatch):
     m = ResidualUNet3D(1, 2, f_maps=[8, 16, 32], num_levels=3, layer_order="cge").to(DEV)
     _load_params(m, g, "resunet_cge")
     _check_against_golden(m.train(), g, "resunet_cge", tol=1e-4)
+
+
+# ---- the is3d=False variants (UNet2D / ResidualUNet2D of model/unet3d/model.py:283-359 and their blocks) against the REAL reference (tests/golden/g18_unet2d_blocks.npz,
+# made by tests/golden/make_golden_unet2d_blocks.py): images travel as depth-1 volumes, Conv2d weights run the 2-D implicit-GEMM kernels --------------------------------
+def _g18():
+    from conftest import load_golden
+    return load_golden("g18_unet2d_blocks.npz")
+
+
+@pytest.mark.parametrize("key,order,cin,cout", [("sc_gcr", "gcr", 16, 24), ("sc_cbr", "cbr", 12, 20)])
+def test_single_conv_2d_vs_reference_golden(key, order, cin, cout, monkeypatch):
+    monkeypatch.setenv("MISAMD_DTYPE", "f32")
+    g = _g18()
+    m = bb().SingleConv(cin, cout, order=order, is3d=False).to(DEV)
+    assert isinstance(m.conv, torch.nn.Conv2d)
+    _load_params(m, g, key)
+    _check_against_golden(m.train(), g, key)
+    if "b" in order:
+        assert isinstance(m.batchnorm, torch.nn.BatchNorm2d)
+        with torch.no_grad():
+            ye = m.eval()(torch.from_numpy(g[f"{key}/x"]).to(DEV))
+        assert rel(ye, torch.from_numpy(g[f"{key}/y_eval"])) <= 3e-5
+
+
+def test_encoder_and_resnet_block_2d_vs_reference_golden(monkeypatch):
+    monkeypatch.setenv("MISAMD_DTYPE", "f32")
+    g = _g18()
+    b = bb()
+    enc = b.Encoder(8, 16, basic_module=b.DoubleConv, conv_layer_order="gcr", num_groups=4, is3d=False).to(DEV)
+    assert isinstance(enc.pooling, torch.nn.MaxPool2d)
+    _load_params(enc, g, "enc2d")
+    _check_against_golden(enc.train(), g, "enc2d")
+    res = b.ResNetBlock(12, 24, order="cge", is3d=False).to(DEV)
+    assert isinstance(res.conv1, torch.nn.Conv2d)
+    _load_params(res, g, "res2d")
+    _check_against_golden(res.train(), g, "res2d")
+
+
+@pytest.mark.parametrize("name,key,shape", [("UNet2D", "unet2d", (2, 1, 16, 24)), ("ResidualUNet2D", "resunet2d", (1, 1, 16, 16))])
+def test_unet2d_networks_vs_reference_golden(name, key, shape, monkeypatch):
+    """UNet2D (DoubleConv, nearest upsampling + concat) and ResidualUNet2D (ResNetBlock, ConvTranspose2d(k3, s2, p1) upsampling + sum) with the reference nets' state
+    dicts: logits, input gradient and every parameter gradient"""
+    monkeypatch.setenv("MISAMD_DTYPE", "f32")
+    from mdeical_image_segmentation_amd.model.unet3d import model as M
+    g = _g18()
+    net = getattr(M, name)(1, 2, f_maps=[8, 16, 32], num_groups=4, num_levels=3).to(DEV)
+    assert M.get_model(dict(name=name, in_channels=1, out_channels=2, f_maps=[8, 16, 32], num_groups=4, num_levels=3)).__class__ is net.__class__
+    _load_params(net, g, key)
+    assert tuple(g[f"{key}/x"].shape) == shape
+    _check_against_golden(net.train(), g, key, tol=1e-4)
+    with pytest.raises(Exception, match="expects"):
+        net(torch.zeros(1, 1, 1, 16, 16, device=DEV))
