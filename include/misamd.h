@@ -299,6 +299,9 @@ int mis_aug_rotate0(const void* src, void* dst, long long nvol, int D, int H, in
 size_t mis_aug_rotate3_workspace_bytes(long long nvol, int D, int H, int W);
 int mis_aug_rotate3(const float* src, float* dst, double* workspace, long long nvol, int D, int H, int W, int a0, int a1,
                     const double* m4 /*host*/, const double* off2 /*host*/, void* stream);
+/* ... and for the other spline orders of scipy.ndimage.rotate: order 1 (linear), 2, 4, 5 (order 3 forwards to mis_aug_rotate3); mode 'reflect'; same workspace */
+int mis_aug_rotate_spline(const float* src, float* dst, double* workspace, long long nvol, int D, int H, int W, int a0, int a1, const double* m4,
+                          const double* off2, int order, void* stream);
 /* ElasticDeformation (transforms.py:138-191): one axis of scipy.ndimage.gaussian_filter(mode='reflect') on float64 fields (weights = the
  * normalised kernel of radius int(4*sigma+0.5), on the device), and scipy.ndimage.map_coordinates(order 0 | 3, mode='reflect') at the voxel
  * grid displaced by alpha * (fz, fy, fx) (fz may be NULL). */

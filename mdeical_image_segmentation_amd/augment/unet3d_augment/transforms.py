@@ -116,12 +116,11 @@ class RandomRotate:
     def __call__(self, m):
         axis = self.axes[self.random_state.randint(len(self.axes))]
         angle = self.random_state.randint(-self.angle_spectrum, self.angle_spectrum)
-        if self.order not in (0, 3) or self.mode != 'reflect':
-            raise NotImplementedError("on-device RandomRotate: order 0 (class default) and 3 (the configs' raw setting) with "
-                                      "mode='reflect' are built")
+        if self.order not in (0, 1, 2, 3, 4, 5) or self.mode != 'reflect':
+            raise NotImplementedError("on-device RandomRotate: spline orders 0 .. 5 with mode='reflect' (the reference's default and the configs' setting) are built")
         m = _dev(m)
-        if self.order == 3 and m.dtype != torch.float32:
-            raise MisError("RandomRotate(order=3): fp32 volumes only (labels use order 0)")
+        if self.order >= 1 and m.dtype != torch.float32:
+            raise MisError(f"RandomRotate(order={self.order}): fp32 volumes only (labels use order 0)")
         D, H, W = m.shape[-3:]
         a0, a1 = sorted(int(a) for a in axis)
         # exactly scipy.ndimage.rotate's host arithmetic
@@ -135,10 +134,14 @@ class RandomRotate:
         o2 = (C.c_double * 2)(off[0], off[1])
         out = torch.empty_like(m)
         nvol = m.numel() // (D * H * W)
-        if self.order == 3:
+        if self.order >= 1:
             lib = load()
             ws = ops.workspace(lib.mis_aug_rotate3_workspace_bytes(nvol, D, H, W), m.device, "rotate3")
-            check(lib.mis_aug_rotate3(m.data_ptr(), out.data_ptr(), ws.data_ptr(), nvol, D, H, W, a0, a1, m4, o2, stream_ptr()), "mis_aug_rotate3")
+            if self.order == 3:
+                check(lib.mis_aug_rotate3(m.data_ptr(), out.data_ptr(), ws.data_ptr(), nvol, D, H, W, a0, a1, m4, o2, stream_ptr()), "mis_aug_rotate3")
+            else:
+                check(lib.mis_aug_rotate_spline(m.data_ptr(), out.data_ptr(), ws.data_ptr(), nvol, D, H, W, a0, a1, m4, o2, int(self.order), stream_ptr()),
+                      "mis_aug_rotate_spline")
             return out
         check(load().mis_aug_rotate0(m.data_ptr(), out.data_ptr(), nvol, D, H, W, a0, a1, m4, o2, m.element_size(), stream_ptr()),
               "mis_aug_rotate0")

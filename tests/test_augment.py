@@ -148,7 +148,39 @@ def test_device_rotate_at_full_size_matches_oracle_and_noise_statistics():
         ref = ao.rotate3(vol, angle, axis)
         assert np.abs(out - ref).max() < 5e-7, (seed, axis, angle, np.abs(out - ref).max())
     with pytest.raises(NotImplementedError):
-        tr.RandomRotate(np.random.RandomState(1), order=2)(vol)
+        tr.RandomRotate(np.random.RandomState(1), order=3, mode="constant")(vol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", [1, 2, 4, 5])
+def test_random_rotate_other_spline_orders(order):
+    """RandomRotate(order = 1, 2, 4, 5; mode 'reflect') against the call the reference makes (transforms.py:109-111: scipy.ndimage.rotate(m, angle, axes, reshape=False,
+    order, mode, cval=-1)): the same random draws, float64 spline arithmetic rounded to fp32 once - equal up to that rounding; a line of length 1 along a rotation axis is
+    its own coefficient"""
+    from scipy import ndimage
+    from mdeical_image_segmentation_amd.augment.unet3d_augment import transforms as tr
+    vol = (np.random.RandomState(21).rand(20, 33, 47).astype(np.float32) * 3 - 1)
+    for seed in (1, 2, 3, 4):
+        rs = np.random.RandomState(seed)
+        axes = [(1, 0), (2, 1), (2, 0)]
+        axis = axes[rs.randint(len(axes))]
+        angle = rs.randint(-30, 30)
+        ref = ndimage.rotate(vol, angle, axes=axis, reshape=False, order=order, mode="reflect", cval=-1)
+        out = tr.RandomRotate(np.random.RandomState(seed), order=order)(vol).cpu().numpy()
+        err = np.abs(out - ref).max()
+        assert err < 1e-6, (order, seed, axis, angle, err)
+        assert (out == ref).mean() > 0.98, (order, seed, (out == ref).mean())
+    c4 = np.random.RandomState(5).rand(2, 6, 9, 1).astype(np.float32)           # channel-first 4-D input, a rotation axis of length 1
+    ref = np.stack([ndimage.rotate(c, 17, axes=(2, 1), reshape=False, order=order, mode="reflect", cval=-1) for c in c4])
+    rs = np.random.RandomState(0)
+    for seed in range(200):                                                   # a seed whose draw is (axis index 0 of the one given, angle 17)
+        rs = np.random.RandomState(seed)
+        if rs.randint(1) == 0 and rs.randint(-30, 30) == 17:
+            out = tr.RandomRotate(np.random.RandomState(seed), axes=[(2, 1)], order=order)(c4).cpu().numpy()
+            assert np.abs(out - ref).max() < 1e-6
+            break
+    else:
+        raise AssertionError("no seed with angle 17 among 200")
 
 
 @pytest.mark.gpu
