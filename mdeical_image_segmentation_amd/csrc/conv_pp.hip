@@ -523,8 +523,12 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
         // load's destination would be loop-carried and hipcc guards it with an s_waitcnt vmcnt(0) at the loop header, i.e. in front of every chunk's prefetches)
         u32x4 mbits = u32x4{0u, 0u, 0u, 0u};
         if constexpr (EM == PP_EM_BITS) mbits = pp_mask_bits_load<NF, PF>(a, n, h0, w0, ncol0, wm, wn);
-#pragma unroll 1
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
+        // the next tile's bias slice is read at that tile's START (first segment): fetched now, into the half of the bias region this tile's first segment is done with
+        // by the time the DMA lands (issued behind that segment's barrier pair at the earliest - see the chunk-0 code)
+        // The K loop: chunk 0 runs a copy of the segment code whose first filter row's MFMAs take the BIAS as their C operand (`first`), so that the accumulators are
+        // neither zeroed nor biased by vector instructions anywhere (pp_epilogue_plain<..., BINIT>).
+        auto run_chunk = [&](auto firstc, const int chunk) __attribute__((always_inline)) {
+            constexpr bool first = decltype(firstc)::value;
             const int c0 = chunk << 5;
             const bool last_chunk = chunk + 1 == nchunks;
             const bool hnext = !last_chunk || has_next;
@@ -556,6 +560,17 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
                 }
 #endif
                 u32x4 A[3][NF], Brow[PF + 2];
+                f32x4 bq[NF];          // first && kw == 0: the tile's bias, 4 values per fragment (the C operand of the first filter row's MFMAs)
+                if constexpr (first && kw == 0) {
+                    int l_;
+                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
+                    const uint32_t ba = (uint32_t)(uintptr_t)bbase + bsel * (BN * 4) + (wn * WAVE_N + (l_ >> 4) * 8) * 4;
+                    pp_static_for<NF>([&](auto fc) {
+                        constexpr int f = decltype(fc)::value;
+                        const u32x4 r = pp_lds_read128<(f >> 1) * 128 + (f & 1) * 16>(ba);
+                        bq[f] = __builtin_bit_cast(f32x4, r);
+                    });
+                }
                 pp_static_for<3>([&](auto hc) {
                     constexpr int kh = decltype(hc)::value;
                     pp_static_for<NF>([&](auto fc) {
@@ -595,7 +610,12 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
                     for (int f = 0; f < NF; ++f) {
 #ifndef PPT_NO_MFMA
 #pragma unroll
-                        for (int pf = 0; pf < PF; ++pf) mma_b128<T>(acc[f][pf], A[kh][f], Brow[pf + kh]);
+                        for (int pf = 0; pf < PF; ++pf) {
+                            if constexpr (first && kw == 0) {
+                                if (kh == 0) acc[f][pf] = bq[f];          // (folds into the MFMA's C operand: no copy is emitted when the compiler keeps bq in place)
+                            }
+                            mma_b128<T>(acc[f][pf], A[kh][f], Brow[pf + kh]);
+                        }
 #endif
 #ifndef PPT_NO_DMA
                         if (kh == 0 && f == 0) {
@@ -619,12 +639,18 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
                 wsel ^= 1;
             });
             hsel ^= 1;
-        }
+        };
+        run_chunk(std::true_type{}, 0);
+        // the next tile's bias slice -> the other half of the bias region (last read in the previous tile's chunk 0); it lands under the rest of this tile's K loop and is
+        // read in the next tile's first segment (nchunks >= 2: at least three segments and their counted waits / barriers in between)
+        if (has_next) issue_bias(ncolN, bbase + (bsel ^ 1) * (BN * 4));
+#pragma unroll 1
+        for (int chunk = 1; chunk < nchunks; ++chunk) run_chunk(std::false_type{}, chunk);
 #if !defined(PPT_NO_EPI)
 #ifdef PPT_EPI_PRIO
         __builtin_amdgcn_s_setprio(PPT_EPI_PRIO);
 #endif
-        pp_epilogue_plain<NF, PF, EM>(a, acc, (uint32_t)(uintptr_t)bbase + bsel * (BN * 4), n, h0, w0, ncol0, wm, wn, mbits);
+        pp_epilogue_plain<NF, PF, EM, true, true>(a, acc, 0u, n, h0, w0, ncol0, wm, wn, mbits);
 #ifdef PPT_EPI_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -632,7 +658,6 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
 #endif
         n = nn; h0 = nh0; w0 = nw0; ncol0 = ncolN;
         bsel ^= 1;
-        if (has_next) issue_bias(ncol0, bbase + bsel * (BN * 4));
         __builtin_amdgcn_sched_barrier(0);
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's last barrier

@@ -165,7 +165,9 @@ __device__ __forceinline__ u32x4 pp_mask_bits_load(const ConvArgs& a, int n, int
     return mb;
 }
 
-template <int NF, int PF, int EM, bool RB = true>
+// BINIT (conv_ppc_kernel): the bias went into the accumulators as the C operand of the tile's first MFMAs and the next tile's first MFMAs overwrite them - the epilogue
+// neither adds the bias nor re-arms the accumulators (192 of its ~330 vector instructions per tile and wave).
+template <int NF, int PF, int EM, bool RB = true, bool BINIT = false>
 __device__ __forceinline__ void pp_epilogue_plain(const ConvArgs& a, f32x4 (&acc)[NF][PF], uint32_t bias_lds, int n, int h0, int w0, int ncol0, int wm, int wn,
                                                   const u32x4& mb_pre) {
     constexpr int NV = 4 * NF, WAVE_N = NF * 16, NS = NF / 2;          // NS 16-byte stores per pixel
@@ -183,10 +185,12 @@ __device__ __forceinline__ void pp_epilogue_plain(const ConvArgs& a, f32x4 (&acc
     const int cview = to0 ? a.Cout0 : a.Cout - a.Cout0;
     const int lcolw = to0 ? colw : colw - a.Cout0;
     u32x4 braw[NF];
-    pp_static_for<NF>([&](auto fc) {
-        constexpr int f = decltype(fc)::value;
-        braw[f] = pp_lds_read128<(f >> 1) * 128 + (f & 1) * 16>(bias_lds + (wn * WAVE_N + lg * 8) * 4);
-    });
+    if constexpr (!BINIT) {
+        pp_static_for<NF>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            braw[f] = pp_lds_read128<(f >> 1) * 128 + (f & 1) * 16>(bias_lds + (wn * WAVE_N + lg * 8) * 4);
+        });
+    }
     // one buffer resource per image (plane): 32-bit offsets span one image of the destination / the mask (the launchers check < 4 GiB - 64 KiB).  A pixel-UNSHUFFLED
     // destination (MIS_OUT_UNSHUFFLE2: pixel (y, x) -> pixel (y/2, x/2) of a half-resolution image, channel block (y&1)*2 + (x&1)) is the same store with other constants:
     // the x part goes into the per-lane offset, the y part into the scalar row offset
@@ -217,16 +221,18 @@ __device__ __forceinline__ void pp_epilogue_plain(const ConvArgs& a, f32x4 (&acc
     if constexpr (BITS) {
         if (bout) bvoff = pp_bits_voff<NF, PF>(a, n, h0, w0, ncol0, wm, wn, li, lg);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
     pp_f32x2 bias2[NF][2];
+    if constexpr (!BINIT) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int f = 0; f < NF; ++f)
+        for (int f = 0; f < NF; ++f)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const uint32_t u0 = braw[f][2 * h], u1 = braw[f][2 * h + 1];
-            bias2[f][h] = pp_f32x2{__uint_as_float(u0), __uint_as_float(u1)};
-        }
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t u0 = braw[f][2 * h], u1 = braw[f][2 * h + 1];
+                bias2[f][h] = pp_f32x2{__uint_as_float(u0), __uint_as_float(u1)};
+            }
+    }
     constexpr int MG = PF % 4 == 0 ? 2 : (PF % 5 == 0 ? 5 : (PF % 2 == 0 ? 2 : 1));      // pixel rows whose mask loads are in flight together (the 2-D net masks with ReLU bits)
 #pragma unroll
     for (int pg = 0; pg < PF; pg += MG) {
@@ -247,13 +253,14 @@ __device__ __forceinline__ void pp_epilogue_plain(const ConvArgs& a, f32x4 (&acc
             for (int f = 0; f < NF; ++f) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const pp_f32x2 s2 = pp_f32x2{acc[f][pf][2 * h], acc[f][pf][2 * h + 1]} + bias2[f][h];
+                    pp_f32x2 s2 = pp_f32x2{acc[f][pf][2 * h], acc[f][pf][2 * h + 1]};
+                    if constexpr (!BINIT) s2 += bias2[f][h];
                     uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(s2, pp_bf16x2));
                     asm("v_pk_max_i16 %0, %1, %2" : "=v"(pk) : "v"(pk), "s"(lowb));
                     d[f / 2][(f & 1) * 2 + h] = pk;
                 }
 #ifndef PPT_EPI_NOZERO
-                acc[f][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (!BINIT) acc[f][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
             }
             if constexpr (masked) {
