@@ -308,6 +308,9 @@ def main():
 
 
 # ------------------------------------------------------------------------------------------------------------------
+LAST_STEP_TRACE = None
+
+
 def _timed_loop(step, steps, warmup, world, dist, dev, timing):
     from mdeical_image_segmentation_amd import ops
 
@@ -323,15 +326,27 @@ def _timed_loop(step, steps, warmup, world, dist, dev, timing):
     # steps (first, middle, last) - still inside the timed region - and leave the others untouched
     timed_steps = sorted({0, steps // 2, steps - 1}) if timing else []
     prof = []
+    if timing:
+        # the brackets' events are created and recorded once BEFORE the timed region (ops.prepare_events): created inside it, the ~130 events of the first bracketed
+        # step made that step host-bound (49-67 ms instead of 33.5: the `step_trace` of a run shows it), i.e. the 10-step default under-reported by 5-9 %
+        ops.prepare_events(3 * 2 * 100)
     fence()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]       # one event per step boundary: shows a ramp (clocks, host) if there is one
+    host = []
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(steps):
         if i in timed_steps:
             ops.PROFILE = prof
         step(i)
         ops.PROFILE = None
+        marks[i + 1].record()
+        host.append(time.perf_counter())
     fence()
     dt = time.perf_counter() - t0
+    global LAST_STEP_TRACE
+    LAST_STEP_TRACE = {"gpu_ms_each": [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(steps)],
+                       "host_enqueue_ms_each": [round((host[i] - (host[i - 1] if i else t0)) * 1e3, 2) for i in range(steps)]}
     prof = (prof, len(timed_steps)) if timing else None
     if DDP_ON:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -404,7 +419,7 @@ def run2d(args, rank, world, dev, dist, *, dtype, batch, size, steps, warmup, ti
             "config": {"workload": f"unet2d {cin}-ch->{ncls}-class, bs={batch}/GPU {size}x{size}, "
                                    f"fwd+CE loss+bwd+clip_grad_norm(1.0)+AdamW(lr {args.lr:g} constant, wd 1e-3 on weights), PyTorch-default init (seed 0), N(0,1) images",
                        "global_batch": world * batch, "parallelism": f"dp{world}", "final_loss": loss_list[-1] if loss_list else None},
-            "loss_per_step": loss_list,
+            "loss_per_step": loss_list, "step_trace": LAST_STEP_TRACE,
             "act_nonzero_frac": {"before_timed_steps": live0, "after_timed_steps": live1},
         }
         out["model_tflops"] = round(value * (FLOP_PER_IMAGE_512 if args.net == "1x2" else FLOP_PER_IMAGE_512_3X4) * (size / 512.0) ** 2 / 1e12, 1)
@@ -510,7 +525,7 @@ def run3d(args, rank, world, dev, dist, *, dtype, batch, size, steps, warmup, ti
                                       f"Gaussian noise from the reference's own MT19937 stream; one batch ahead on a second HIP stream) + "
                                       f"fwd+BCEDice+bwd+clip+AdamW(lr {args.lr:g}), random-init weights",
                           "global_batch": world * batch, "parallelism": f"dp{world}", "final_loss": loss_list[-1] if loss_list else None},
-               "loss_per_step": loss_list}
+               "loss_per_step": loss_list, "step_trace": LAST_STEP_TRACE}
         out["model_tflops"] = round(value * FLOP_PER_VOLUME_128 * (size / 128.0) ** 3 / 1e12, 1)
         if prof:
             peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS

@@ -49,14 +49,31 @@ def _v(x):
 PROFILE = None
 
 
+EVENT_POOL = []          # pre-created, once-recorded timing events for the per-launch brackets (prepare_events)
+
+
+def prepare_events(n):
+    """create n timing events and record each once, OUTSIDE any timed region: the first record of a torch event creates its HIP event, and on this stack the first
+    ~130 creations of a process cost 0.3-0.45 ms each - a bench step whose launches are bracketed with fresh events was host-bound for 35-60 ms"""
+    while len(EVENT_POOL) < n:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        EVENT_POOL.append(e)
+    torch.cuda.synchronize()
+
+
+def _event():
+    return EVENT_POOL.pop() if EVENT_POOL else torch.cuda.Event(enable_timing=True)
+
+
 class _Timed:
     def __init__(self, key, flops):
         self.key, self.flops = key, flops
 
     def __enter__(self):
         if PROFILE is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0 = _event()
+            self.e1 = _event()
             self.e0.record()
 
     def __exit__(self, *exc):
