@@ -494,7 +494,6 @@ def run3d(args, rank, world, dev, dist, *, dtype, batch, size, steps, warmup, ti
         k = state["n"] & 1
         state["n"] += 1
         main = torch.cuda.current_stream(dev)
-        augment_into(k ^ 1)                                 # next step's batch, on the side stream
         main.wait_event(ready[k])
         xa, ta = bufs[k]
         eng.forward(xa, ta, train=True, grad_scale=1.0 / world)
@@ -507,6 +506,10 @@ def run3d(args, rank, world, dev, dist, *, dtype, batch, size, steps, warmup, ti
             reducer.finish()
         free[k].record(main)                                # (the first layer's weight gradient read the augmented volume)
         eng.optimizer_step()
+        # the next step's batch, on the side stream - enqueued AFTER this step's kernels: the transforms block the host on small read-backs (the noise transform advances
+        # its numpy RandomState from a device result), and with the augmentation enqueued first the host sat in those waits while the main stream ran dry - the device
+        # idled ~3 ms at every step boundary (`step_trace`: host enqueue 52 ms per step = the whole step).  Now the host waits while the device works on this step.
+        augment_into(k ^ 1)
 
     warmup = max(warmup, 1)
     step(-1)
