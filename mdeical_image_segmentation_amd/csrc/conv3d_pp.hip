@@ -188,8 +188,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
         int npl = pl, nz = z, nh0 = h0, nw0 = w0, ncolN = ncol0;
         if (has_next) decode(tile + tstride, npl, nz, nh0, nw0, ncolN);
         int dz = 0, c0 = 0;
-#pragma unroll 1
-        for (int vc = 0; vc < nvc; ++vc) {
+        // The K loop: pair 0 runs a copy of the segment code whose first filter row's MFMAs take the BIAS as their C operand (`first`) - no accumulator zeroing and no
+        // bias add by vector instructions anywhere (pp_epilogue_plain<..., BINIT>; the same peeling as conv_ppc_kernel, conv_pp.hip)
+        auto run_pair = [&](auto firstc, const int vc) __attribute__((always_inline)) {
+            constexpr bool first = decltype(firstc)::value;
             // the (dz, chunk) pair after this one within the tile
             int ndz = dz, nc0 = c0 + 32;
             if (nc0 == a.Cin) {
@@ -229,6 +231,17 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
                         pp_static_for<NH>([&](auto jc) { issue_halo(std::integral_constant<int, (kw == 0 ? 0 : HJ0) + decltype(jc)::value>{}, hpl, hval, hh0, hw0, hc0, hbn); });
                 }
                 u32x4 A[3][NF], Brow[PF + 2];
+                f32x4 bq[NF];          // first && kw == 0: the tile's bias, 4 values per fragment (the C operand of the first filter row's MFMAs)
+                if constexpr (first && kw == 0) {
+                    int l_;
+                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
+                    const uint32_t ba = (uint32_t)(uintptr_t)bbase + bsel * (BN * 4) + (wn * WAVE_N + (l_ >> 4) * 8) * 4;
+                    pp_static_for<NF>([&](auto fc) {
+                        constexpr int f = decltype(fc)::value;
+                        const u32x4 r = pp_lds_read128<(f >> 1) * 128 + (f & 1) * 16>(ba);
+                        bq[f] = __builtin_bit_cast(f32x4, r);
+                    });
+                }
                 pp_static_for<3>([&](auto hc) {
                     constexpr int kh = decltype(hc)::value;
                     pp_static_for<NF>([&](auto fc) {
@@ -236,9 +249,16 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
                         A[kh][f] = pp_lds_read128<kh * TAPB + f * 1024>(wb + a_off0);
                     });
                 });
+                uint32_t ba_rows = hb + b_off0[kw];
+                if constexpr (NF * PF >= 32) {          // 256-VGPR instantiations: the offset is re-derived (volatile lane index) instead of held across the loops - held, it spilled
+                    int l_;
+                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
+                    const int px = (l_ & 15) + kw;
+                    ba_rows = hb + (wm * PF * HW + px) * 64 + (((l_ >> 4) ^ ((px >> 1) & 3)) << 4);
+                }
                 pp_static_for<PF + 2>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
-                    Brow[r] = pp_lds_read128<r * ROWB>(hb + b_off0[kw]);
+                    Brow[r] = pp_lds_read128<r * ROWB>(ba_rows);
                 });
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -263,7 +283,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int f = 0; f < NF; ++f) {
 #pragma unroll
-                        for (int pf = 0; pf < PF; ++pf) mma_b128<T>(acc[f][pf], A[kh][f], Brow[pf + kh]);
+                        for (int pf = 0; pf < PF; ++pf) {
+                            if constexpr (first && kw == 0) {
+                                if (kh == 0) acc[f][pf] = bq[f];          // (becomes the MFMA's C operand)
+                            }
+                            mma_b128<T>(acc[f][pf], A[kh][f], Brow[pf + kh]);
+                        }
                         if (kh == 0 && f == 0) {
                             if (grp == 1 && w2next) issue_weights(w2dz, w2kw, w2col, w2c0, wb_self);
                         }
@@ -286,11 +311,26 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
             hsel ^= 1;
             dz = ndz;
             c0 = nc0;
+        };
+        // (the 256-VGPR instantiations, PF 8 x 128 columns, keep the vector-instruction bias add: with the bias quads live through the peeled pair they spill)
+        constexpr bool BINIT = NF * PF < 32;
+        if constexpr (BINIT) {
+            run_pair(std::true_type{}, 0);
+            // the next tile's bias slice -> the other half of the bias region (last read in the previous tile's first pair); it lands under the rest of this tile's K
+            // loop (nvc >= 3) and is read in the next tile's first segment
+            if (has_next) issue_bias(ncolN, bbase + (bsel ^ 1) * (BN * 4));
+#pragma unroll 1
+            for (int vc = 1; vc < nvc; ++vc) run_pair(std::false_type{}, vc);
+        } else {
+#pragma unroll 1
+            for (int vc = 0; vc < nvc; ++vc) run_pair(std::false_type{}, vc);
         }
-        pp_epilogue_plain<NF, PF, EM, false>(a, acc, (uint32_t)(uintptr_t)bbase + bsel * (BN * 4), pl, h0, w0, ncol0, wm, wn, u32x4{0u, 0u, 0u, 0u});
+        pp_epilogue_plain<NF, PF, EM, false, BINIT>(a, acc, (uint32_t)(uintptr_t)bbase + bsel * (BN * 4), pl, h0, w0, ncol0, wm, wn, u32x4{0u, 0u, 0u, 0u});
         pl = npl; z = nz; h0 = nh0; w0 = nw0; ncol0 = ncolN;
         bsel ^= 1;
-        if (has_next) issue_bias(ncol0, bbase + bsel * (BN * 4));
+        if constexpr (!BINIT) {
+            if (has_next) issue_bias(ncol0, bbase + bsel * (BN * 4));
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's last barrier
