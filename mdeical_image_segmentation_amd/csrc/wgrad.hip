@@ -375,16 +375,22 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 1 : 2)) void wgrad_kernel(co
 // Sum the split-K slabs in a fixed order and convert [tap][ci][co] -> the reference layout.  A block owns a
 // (32 co x 32 ci) tile for up to 9 taps at a time: slab reads are contiguous along co, dw writes are contiguous
 // along (ci, tap) for layout 0 / (c, ab) for layout 1, via an LDS transpose.
+// tsplit > 1 (small layers: a 64 -> 64 layer has 2 x 2 tiles, i.e. FOUR blocks walking 9 taps x nsplit slabs one after the other - 40 us of latency for 150 KB): the taps
+// are dealt out over blockIdx.z, one tap group of TT / tsplit taps per block.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int TT, int Cin, int Cout,
-                                                           float* __restrict__ dw, int layout, float alpha, size_t group_stride_partial = 0, size_t group_stride_dw = 0) {
+                                                           float* __restrict__ dw, int layout, float alpha, size_t group_stride_partial = 0, size_t group_stride_dw = 0,
+                                                           int tsplit = 1) {
     __shared__ float tile[32][9][33];     // [ci][tap][co]: both the fill (co fastest) and the drain ((ci,tap) fastest) are conflict free
-    partial += blockIdx.z * group_stride_partial;      // blockIdx.z = slab group (per-sample gradients: one group of slabs and one output per sample)
-    dw += blockIdx.z * group_stride_dw;
+    const int zg = blockIdx.z / tsplit, tz = blockIdx.z - zg * tsplit;
+    partial += zg * group_stride_partial;      // zg = slab group (per-sample gradients: one group of slabs and one output per sample)
+    dw += zg * group_stride_dw;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
     const size_t slab = (size_t)TT * Cin * Cout;
-    for (int t0 = 0; t0 < TT; t0 += 9) {
-        const int nt = (TT - t0) < 9 ? (TT - t0) : 9;
+    const int tper = TT / tsplit;                // (tsplit divides TT)
+    const int tbeg = tz * tper, tend = tbeg + tper;
+    for (int t0 = tbeg; t0 < tend; t0 += 9) {
+        const int nt = (tend - t0) < 9 ? (tend - t0) : 9;
         __syncthreads();
         for (int t = 0; t < nt; ++t)
             for (int r = ty; r < 32; r += 8) {
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                 if (co >= Cout) continue;
                 for (int e = tx; e < 32 * nt; e += 32) {
                     const int cil = e / nt, t = e - cil * nt;
-                    if (ci0 + cil < Cin) dw[((size_t)co * Cin + ci0 + cil) * TT + t0 + t] = tile[cil][t][r];
+                    if (ci0 + cil < Cin) dw[((size_t)co * Cin + ci0 + cil) * TT + t0 + t] = tile[cil][t][r];      // (contiguous over (ci, tap) when the block owns all taps)
                 }
             }
         } else {
@@ -552,8 +558,10 @@ static int wg_finish(const MisWgradDesc* d, const WgPlan& p, float* bias_partial
             MIS_LAUNCH_CHECK("wgrad_prereduce");
             ns = 1;
         }
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((d->Cout + 31) / 32, (d->Cin + 31) / 32, d->N), dim3(256), 0, stream, (const float*)d->workspace, ns, p.TT, d->Cin,
-                           d->Cout, d->dw_per_sample, 0, d->alpha, (size_t)k * E, E);
+        const int tiles2s = ((d->Cout + 31) / 32) * ((d->Cin + 31) / 32) * d->N;
+        const int tsplit_s = (p.TT > 1 && tiles2s * 4 <= 256) ? p.TT : ((p.TT == 27 && tiles2s * 4 <= 768) ? 3 : 1);       // few tiles: one tap (or one depth slice) per block
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((d->Cout + 31) / 32, (d->Cin + 31) / 32, d->N * tsplit_s), dim3(256), 0, stream, (const float*)d->workspace, ns, p.TT,
+                           d->Cin, d->Cout, d->dw_per_sample, 0, d->alpha, (size_t)k * E, E, tsplit_s);
         MIS_LAUNCH_CHECK("wgrad_reduce");
         if (d->dbias_per_sample != nullptr) {
             hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((d->Cout + 3) / 4, 1, d->N), dim3(256), 0, stream, (const float*)bias_partial, k, d->Cout, 1, d->alpha,
@@ -577,8 +585,11 @@ static int wg_finish(const MisWgradDesc* d, const WgPlan& p, float* bias_partial
         MIS_LAUNCH_CHECK("wgrad_prereduce");
         nslab = Z;
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((d->Cout + 31) / 32, (d->Cin + 31) / 32), dim3(256), 0, stream,
-                       (const float*)d->workspace, nslab, p.TT, d->Cin, d->Cout, d->dw, d->dw_layout, d->alpha);
+    // few (co, ci) tiles: one tap per block (9 or 27 times the blocks)
+    const int tiles2 = ((d->Cout + 31) / 32) * ((d->Cin + 31) / 32);
+    const int tsplit = d->dw_layout != 0 || p.TT == 1 ? 1 : (tiles2 * 4 <= 256 ? p.TT : ((p.TT == 27 && tiles2 * 4 <= 768) ? 3 : 1));
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((d->Cout + 31) / 32, (d->Cin + 31) / 32, tsplit), dim3(256), 0, stream,
+                       (const float*)d->workspace, nslab, p.TT, d->Cin, d->Cout, d->dw, d->dw_layout, d->alpha, (size_t)0, (size_t)0, tsplit);
     MIS_LAUNCH_CHECK("wgrad_reduce");
     if (d->dbias != nullptr) {
         const int fold = d->dw_layout == 1 ? 4 : 1;
