@@ -395,17 +395,19 @@ __global__ __launch_bounds__(256) void first_conv_wgrad_tiled_kernel(const float
 
 __global__ void first_conv_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, int Cin, float* __restrict__ dw,
                                                float* __restrict__ db) {
-    // 4 lanes per (ci, t, co): each sums every 4th block slab in a fixed order, then two shuffles
+    // 16 lanes per (ci, t, co): each sums every 16th block slab in a fixed order, then four shuffles (4 lanes per output left each lane 256 dependent loads: 92 us)
     const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int idx = gidx >> 2, part = gidx & 3;
+    const int idx = gidx >> 4, part = gidx & 15;
     const bool live = idx < Cin * 640;
     const int ci = live ? idx / 640 : 0, r = live ? idx - ci * 640 : 0;
     const int t = r >> 6, co = r & 63;
     float s = 0.f;
     if (live)
-        for (int b = part; b < nblocks; b += 4) s += partial[((size_t)b * Cin + ci) * 640 + r];
+        for (int b = part; b < nblocks; b += 16) s += partial[((size_t)b * Cin + ci) * 640 + r];
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
     if (!live || part != 0) return;
     if (t < 9) dw[(co * Cin + ci) * 9 + t] = s;
     else if (ci == 0 && db != nullptr) db[co] = s;
@@ -444,7 +446,7 @@ extern "C" int mis_conv3x3_first_wgrad(int dtype, const float* x, int N, int Cin
         hipLaunchKernelGGL(first_conv_wgrad_kernel<float>, dim3((unsigned)blocks, Cin), dim3(256), 0, s, x, N, Cin, H, W, (const float*)dy,
                            dy_ld, workspace);
     MIS_LAUNCH_CHECK("first_conv_wgrad");
-    hipLaunchKernelGGL(first_conv_wgrad_reduce_kernel, dim3((Cin * 640 * 4 + 255) / 256), dim3(256), 0, s, (const float*)workspace, (int)blocks,
+    hipLaunchKernelGGL(first_conv_wgrad_reduce_kernel, dim3((Cin * 640 * 16 + 255) / 256), dim3(256), 0, s, (const float*)workspace, (int)blocks,
                        Cin, dw, db);
     MIS_LAUNCH_CHECK("first_conv_wgrad_reduce");
     return MIS_OK;
