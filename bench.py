@@ -142,6 +142,8 @@ for _t, _k in (("k3.2d.ppc8", "conv_ppc_kernel<8, 4"), ("k3.2d.ppc8n2", "conv_pp
                ("k3.3d.ppc8n2", "conv3d_ppc_kernel<8, 2"), ("k3.3d.ppc10n2", "conv3d_ppc_kernel<10, 2")):
     for _sfx, _em in (("", 0), (".mask", 1), (".bits", 2)):
         SYMBOLS[_t + _sfx] = f"{_k}, {_em}>"
+for _sfx, _em in (("", 0), (".mask", 1), (".bits", 2)):
+    SYMBOLS["k1.2d.pp" + _sfx] = f"gemm1_pp_kernel<{_em}>"
 
 
 def kernel_tables(prof, steps, peak):

@@ -38,3 +38,6 @@ int launch_conv_pp(const MisConvDesc* d, hipStream_t stream, const char** tag);
 // conv3d_pp.hip: the same structure for the bf16 3x3x3 layers (single source, no operand affine)
 bool conv3d_pp_eligible(const MisConvDesc* d);
 int launch_conv3d_pp(const MisConvDesc* d, hipStream_t stream, const char** tag);
+// gemm1_pp.hip: the ping-pong 1x1 GEMM for the bf16 2-D transposed-convolution GEMMs (plain or pixel-shuffled destination, optional mask / ReLU bits)
+bool gemm1_pp_eligible(const MisConvDesc* d);
+int launch_gemm1_pp(const MisConvDesc* d, hipStream_t stream, const char** tag);

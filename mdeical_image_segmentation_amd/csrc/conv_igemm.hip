@@ -820,6 +820,15 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
         const int k1v2 = !mis_sw(SW_CONV_K1V1);
         const int k1p = !mis_sw(SW_CONV_K1NOPERSIST);
         if constexpr (sizeof(T) == 2) {
+            // the transposed convolution's GEMMs (plain / pixel-shuffled destination, Cin % 64 == 0, Cout % 128 == 0): the ping-pong 1x1 kernel (gemm1_pp.hip)
+            if (!mis_sw(SW_GEMM1_NOPP) && gemm1_pp_eligible(d)) {
+                const char* tag = "";
+                const int rc = launch_gemm1_pp(d, s, &tag);
+                g_conv_last = tag;
+                return rc;
+            }
+        }
+        if constexpr (sizeof(T) == 2) {
             // deep 1x1 GEMMs (transposed-conv forward / dgrad): 256 output columns per block = twice the MFMA work per staged pixel tile and barrier
             const int k1nf8 = !mis_sw(SW_CONV_K1_NO256);
             if (k1nf8 && k1v2 && d->Cout % 256 == 0 && d->Cin >= 4 * (int)Tr<T>::CK)

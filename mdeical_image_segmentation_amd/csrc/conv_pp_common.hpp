@@ -195,20 +195,28 @@ __device__ __forceinline__ void pp_epilogue_plain(const ConvArgs& a, f32x4 (&acc
     // destination (MIS_OUT_UNSHUFFLE2: pixel (y, x) -> pixel (y/2, x/2) of a half-resolution image, channel block (y&1)*2 + (x&1)) is the same store with other constants:
     // the x part goes into the per-lane offset, the y part into the scalar row offset
     const size_t img = (size_t)a.H * a.W;
-    const bool uns = (to0 ? a.y0_mode : a.y1_mode) == MIS_OUT_UNSHUFFLE2;      // wave-uniform
+    const int ymode = to0 ? a.y0_mode : a.y1_mode;                              // wave-uniform
+    const bool uns = ymode == MIS_OUT_UNSHUFFLE2;
+    // a pixel-SHUFFLED destination (MIS_OUT_SHUFFLE2, the transposed convolution's forward GEMM: column ab*Cq + c of pixel (y, x) -> channel c of pixel (2y + a, 2x + b) of an
+    // image of twice the size; Cq % 64 == 0, so a wave's 64 columns share one (a, b)): again the same store with other constants
+    const bool shf = ymode == MIS_OUT_SHUFFLE2;
+    const int cqs = cview >> 2;
+    const int abq = shf ? lcolw / cqs : 0;
+    const int lcols = shf ? lcolw - abq * cqs : lcolw;
     const int ow = a.W >> 1;
-    const size_t yimg = uns ? (size_t)(a.H >> 1) * ow : img;
-    const __amdgpu_buffer_rsrc_t ry = pp_make_rsrc(ybase + (size_t)n * yimg * yld * 2, (unsigned)(((yimg - 1) * yld + (uns ? 4 * cview : cview)) * 2));
+    const size_t yimg = uns ? (size_t)(a.H >> 1) * ow : (shf ? 4 * img : img);
+    const __amdgpu_buffer_rsrc_t ry = pp_make_rsrc(ybase + (size_t)n * yimg * yld * 2, (unsigned)(((yimg - 1) * yld + (uns ? 4 * cview : (shf ? cqs : cview))) * 2));
     const int x = w0 + li;
-    const int xpart = uns ? (x >> 1) * yld + (x & 1) * cview : x * yld;
-    const int yv = x < a.W ? (xpart + lcolw + lg * 8) * 2 : PP_OOB;          // a store past num_records is dropped: the ragged right edge
+    const int xpart = uns ? (x >> 1) * yld + (x & 1) * cview : (shf ? (2 * x + (abq & 1)) * yld : x * yld);
+    const int yv = x < a.W ? (xpart + lcols + lg * 8) * 2 : PP_OOB;          // a store past num_records is dropped: the ragged right edge
     constexpr bool masked = EM == PP_EM_MASK;
     const __amdgpu_buffer_rsrc_t rm = pp_make_rsrc(reinterpret_cast<const char*>(masked ? a.mask : a.y0) + (masked ? (size_t)n * img * a.mask_ld * 2 : 0),
                                                    masked ? (unsigned)(((img - 1) * a.mask_ld + a.Cout) * 2) : 0u);      // (dead unless EM == PP_EM_MASK)
     const int mv = x < a.W ? (x * a.mask_ld + colw + lg * 8) * 2 : PP_OOB;
-    const unsigned yrow = (unsigned)(uns ? ow : a.W) * yld * 2, mrow = (unsigned)a.W * a.mask_ld * 2;
+    const unsigned yrow = (unsigned)(uns ? ow : (shf ? 2 * a.W : a.W)) * yld * 2, mrow = (unsigned)a.W * a.mask_ld * 2;
     const unsigned yodd = uns ? (unsigned)cview * 4u : 0u;                    // byte offset of the odd rows' channel blocks
     const int ush = uns ? 1 : 0;                                              // row y -> row y >> ush of the destination (+ yodd for odd y when unshuffling)
+    const int ysh = shf ? 1 : 0, yadd = shf ? (abq >> 1) : 0;                 // ... or row 2y + a when shuffling
     const int yr0 = h0 + wm * PF;
     const uint32_t lowb = a.relu ? 0u : 0x80008000u;       // lower bound of the packed ReLU; a SCALAR operand of the asm below (no register held across the tile loop)
     // ReLU bits instead of the bf16 mask: this lane's rows of the tile are ONE load, issued by the kernel a K chunk ago (NF = 4: 16 bytes, byte i*8 + r = row r of store
@@ -310,7 +318,7 @@ __device__ __forceinline__ void pp_epilogue_plain(const ConvArgs& a, f32x4 (&acc
             if (y < a.H) {
 #endif
                 // (readfirstlane: the offset is wave-uniform, but hipcc evaluates the selects on the VALU and would wrap every store in a waterfall loop)
-                const int srow = __builtin_amdgcn_readfirstlane((int)((unsigned)(y >> ush) * yrow + (unsigned)(y & ush) * yodd));
+                const int srow = __builtin_amdgcn_readfirstlane((int)((unsigned)(((y >> ush) << ysh) + yadd) * yrow + (unsigned)(y & ush) * yodd));
 #pragma unroll
                 for (int i = 0; i < NS; ++i) __builtin_amdgcn_raw_buffer_store_b128(d[i], ry, yv + i * 64, srow, 0);
             }

@@ -169,17 +169,26 @@ K1_CASES = [
     (BF, 2, 100, 150, 128, 256, "k1.2d.bn128.persist"),   # 280 tiles > 256 blocks
     (BF, 2, 10, 18, 512, 128, "k1.2d.bn128.dma"),
     (BF, 2, 10, 18, 128, 64, "k1.2d.bn64"),
+    # the ping-pong 1x1 kernel (32-row tiles must fit the grid): ragged in W / in both, two K steps, 64 K steps, more tiles than blocks
+    (BF, 2, 64, 50, 128, 256, "k1.2d.pp"),
+    (BF, 2, 60, 70, 256, 512, "k1.2d.pp"),
+    (BF, 3, 96, 40, 64, 128, "k1.2d.pp"),
+    (BF, 1, 32, 16, 2048, 1024, "k1.2d.pp"),
+    (BF, 4, 128, 176, 64, 256, "k1.2d.pp"),
+    (BF, 2, 64, 50, 128, 256, "k1.2d.bn128.persist", "MIS_GEMM1_NOPP"),     # ... and the kernel behind it
     (F32, 2, 10, 18, 64, 256, "k1.2d.bn128.persist"),
     (F32, 2, 10, 18, 256, 128, "k1.2d.bn128.dma"),
     (F32, 2, 10, 18, 64, 64, "k1.2d.bn64"),
 ]
 
 
-@pytest.mark.parametrize("case", K1_CASES, ids=lambda c: f"{'bf16' if c[0] == BF else 'f32'}-{c[1]}x{c[2]}x{c[3]}-{c[4]}to{c[5]}")
-def test_gemm1x1_every_branch(case):
+@pytest.mark.parametrize("case", K1_CASES, ids=lambda c: f"{'bf16' if c[0] == BF else 'f32'}-{c[1]}x{c[2]}x{c[3]}-{c[4]}to{c[5]}{'-' + c[7] if len(c) > 7 else ''}")
+def test_gemm1x1_every_branch(case, switches):
     """the two 1x1 GEMMs of ConvTranspose2d(k2, s2): forward (bias + pixel-shuffle store into a concat slice) and dgrad (ReLU mask)"""
     ops = _ops()
-    dtype, N, H, W, Cin, Cout, want_cfg = case
+    dtype, N, H, W, Cin, Cout, want_cfg = case[:7]
+    if len(case) > 7:
+        switches(case[7], 1)
     x = rnd(N, Cin, H, W, seed=120)
     w = rnd(Cout, Cin, 1, 1, seed=121, scale=Cin ** -0.5)
     xd = to_nhwc(x, dtype)
