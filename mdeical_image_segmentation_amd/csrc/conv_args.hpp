@@ -35,6 +35,8 @@ bool conv_ppc64_auto(const MisConvDesc* d);            // 64-column blocks of th
 bool conv_pp_rs64_eligible(const MisConvDesc* d);      // 64 -> 64 channels: the register-stationary ping-pong kernel
 int conv_ppc_choice(const MisConvDesc* d);            // 4 / 2: launch_conv_pp runs conv_ppc_kernel<8, 4 / 2> (the kernels that read / write ReLU bits in their epilogue); 0: another kernel
 int launch_conv_pp(const MisConvDesc* d, hipStream_t stream, const char** tag);
+// conv_ppd.hip: the deep-prefetch form of conv_ppc_kernel<8, 2> (conv_ppc_choice(d) == 2 descriptors with Cin % 64 == 0)
+int launch_conv_ppd(const MisConvDesc* d, hipStream_t stream, const char** tag);
 // conv3d_pp.hip: the same structure for the bf16 3x3x3 layers (single source, no operand affine)
 bool conv3d_pp_eligible(const MisConvDesc* d);
 int launch_conv3d_pp(const MisConvDesc* d, hipStream_t stream, const char** tag);

@@ -934,7 +934,7 @@ static bool ppc_plain_ok(const MisConvDesc* d) {
 // 32-row tiles waste at most 15 % (measured in one process, scripts/bench_conv_layers.py: 128->64 at 512^2 1.249 vs 1.379 ms for bn64.persist.dma, at 256^2 0.320 vs 0.336;
 // 64->64 stays on the weight-stationary kernel, 0.633 vs 0.751 ms)
 bool conv_ppc64_auto(const MisConvDesc* d) {
-    return conv_pp_eligible(d) && d->Cout % 128 != 0 && d->Cin >= 128 && !mis_sw(SW_CONV_NOPPC) && ppc_plain_ok(d) && ((d->H + 31) / 32) * 32 * 100 <= d->H * 115;
+    return conv_pp_eligible(d) && d->Cout % 128 != 0 && (d->Cin >= 128 || !mis_sw(SW_CONV_NOPPD)) && !mis_sw(SW_CONV_NOPPC) && ppc_plain_ok(d) && ((d->H + 31) / 32) * 32 * 100 <= d->H * 115;
 }
 
 bool conv_pp_rs64_eligible(const MisConvDesc* d) {
@@ -947,7 +947,7 @@ bool conv_pp_rs64_eligible(const MisConvDesc* d) {
 int conv_ppc_choice(const MisConvDesc* d) {
     if (conv_pp_rs64_eligible(d)) return 0;
     if (d->Cout % 128 == 0 && !mis_sw(SW_CONV_NOPPC) && ppc_plain_ok(d) && (((d->H + 31) / 32) * 32 * 100 <= d->H * 115 || mis_sw(SW_CONV_PPC))) return 4;
-    if (d->Cout % 64 == 0 && (mis_sw(SW_CONV_PPC64) || conv_ppc64_auto(d)) && ppc_plain_ok(d)) return 2;
+    if (d->Cout % 64 == 0 && (mis_sw(SW_CONV_PPC64) || (conv_ppc64_auto(d) && !mis_sw(SW_CONV_PP64))) && ppc_plain_ok(d)) return 2;
     return 0;
 }
 
@@ -958,6 +958,7 @@ int launch_conv_pp(const MisConvDesc* d, hipStream_t stream, const char** tag) {
         *tag = d->mask_bits != nullptr ? "k3.2d.ppc8.bits" : (d->mask != nullptr ? "k3.2d.ppc8.mask" : "k3.2d.ppc8");
         return pp_launch_col<8, 4>(d, stream);
     }
+    if (ppc == 2 && !mis_sw(SW_CONV_NOPPD)) return launch_conv_ppd(d, stream, tag);          // (Cin % 64 == 0: conv_pp_eligible)
     if (ppc == 2) {
         *tag = d->mask_bits != nullptr ? "k3.2d.ppc8n2.bits" : (d->mask != nullptr ? "k3.2d.ppc8n2.mask" : "k3.2d.ppc8n2");
         return pp_launch_col<8, 2>(d, stream);

@@ -46,19 +46,29 @@ K3_CASES = [
     # 64-column layers: the weight-stationary / bn64 configurations; the ping-pong kernel with 64-column blocks is selectable (MIS_CONV_PP64=1; slower)
     (BF, 1, 70, 90, 128, 64, "k3.2d.bn64.persist", ""),  # 32x16-pixel persistent tiles
     (BF, 2, 20, 36, 128, 64, "k3.2d.bn64.v1", ""),       # small grid: 64-column 4-wave config
-    (BF, 2, 256, 256, 64, 64, "k3.2d.ws64", ""),         # weight-stationary (LDS) kernel
+    (BF, 2, 256, 256, 64, 64, "k3.2d.ws64", "MIS_CONV_NOPPD"),         # weight-stationary (LDS) kernel (the default before the deep-prefetch kernel)
     (BF, 2, 256, 256, 64, 64, "k3.2d.rs64", "MIS_CONV_RS64"),          # 64 -> 64: register-stationary ping-pong kernel (filter in VGPRs; opt-in, slower)
     (BF, 3, 150, 170, 64, 64, "k3.2d.rs64", "MIS_CONV_RS64"),          # ragged, 330 tiles > 256 blocks
     (BF, 1, 20, 36, 64, 64, "k3.2d.rs64", "MIS_CONV_RS64"),
     (BF, 1, 70, 90, 128, 64, "k3.2d.pp64", "MIS_CONV_PP64"),
     (BF, 2, 20, 36, 64, 64, "k3.2d.pp64", "MIS_CONV_PP64"),
     (BF, 3, 150, 170, 64, 64, "k3.2d.pp64", "MIS_CONV_PP64"),          # 330 tiles > 256 blocks: one K chunk per tile, tile loop taken
-    (BF, 2, 64, 50, 128, 64, "k3.2d.ppc8n2", ""),                      # 64-column blocks of the column-segment kernel: the default for Cin >= 128 on grids that fill 32-row tiles
-    (BF, 1, 70, 90, 128, 64, "k3.2d.ppc8n2", "MIS_CONV_PPC64"),        # ... and wherever eligible with the switch
-    (BF, 2, 20, 36, 64, 64, "k3.2d.ppc8n2", "MIS_CONV_PPC64"),
-    (BF, 3, 150, 170, 64, 64, "k3.2d.ppc8n2", "MIS_CONV_PPC64"),       # 165 tiles
-    (BF, 9, 150, 170, 64, 64, "k3.2d.ppc8n2", "MIS_CONV_PPC64"),       # 495 tiles > 256 persistent blocks
-    (BF, 1, 40, 40, 64, 192, "k3.2d.ppc8n2", "MIS_CONV_PPC64"),        # three column tiles
+    # 64-column blocks, deep-prefetch form (conv_ppd.hip): the default for Cout % 128 != 0 on grids that fill 32-row tiles
+    (BF, 2, 64, 50, 128, 64, "k3.2d.ppd8", ""),                        # four K chunks, ragged in W
+    (BF, 2, 256, 256, 64, 64, "k3.2d.ppd8", ""),                       # two K chunks: every halo prefetch crosses a tile boundary
+    (BF, 3, 150, 170, 64, 64, "k3.2d.ppd8", ""),                       # ragged both ways, 165 tiles
+    (BF, 9, 150, 170, 64, 64, "k3.2d.ppd8", ""),                       # 495 tiles > 256 persistent blocks
+    (BF, 1, 70, 90, 128, 64, "k3.2d.ppd8", "MIS_CONV_PPC64"),          # ... and wherever eligible with the switch
+    (BF, 2, 20, 36, 64, 64, "k3.2d.ppd8", "MIS_CONV_PPC64"),           # a single ragged tile per block
+    (BF, 1, 40, 40, 64, 192, "k3.2d.ppd8", "MIS_CONV_PPC64"),          # three column tiles
+    (BF, 1, 33, 17, 256, 64, "k3.2d.ppd8", "MIS_CONV_PPC64"),          # eight K chunks, 2 x 2 ragged tiles
+    # ... and the kernel it replaces (same tiles, one prefetch stream per wave: conv_ppc_kernel<8, 2>)
+    (BF, 2, 64, 50, 128, 64, "k3.2d.ppc8n2", "MIS_CONV_NOPPD"),
+    (BF, 1, 70, 90, 128, 64, "k3.2d.ppc8n2", "MIS_CONV_PPC64,MIS_CONV_NOPPD"),
+    (BF, 2, 20, 36, 64, 64, "k3.2d.ppc8n2", "MIS_CONV_PPC64,MIS_CONV_NOPPD"),
+    (BF, 3, 150, 170, 64, 64, "k3.2d.ppc8n2", "MIS_CONV_PPC64,MIS_CONV_NOPPD"),       # 165 tiles
+    (BF, 9, 150, 170, 64, 64, "k3.2d.ppc8n2", "MIS_CONV_PPC64,MIS_CONV_NOPPD"),       # 495 tiles > 256 persistent blocks
+    (BF, 1, 40, 40, 64, 192, "k3.2d.ppc8n2", "MIS_CONV_PPC64,MIS_CONV_NOPPD"),        # three column tiles
     (F32, 2, 20, 36, 64, 128, "k3.2d.bn128.persist", ""),
     (F32, 1, 9, 17, 128, 256, "k3.2d.bn128.dma", ""),
     (F32, 1, 70, 90, 64, 64, "k3.2d.bn64.persist", ""),
@@ -110,8 +120,8 @@ def _conv_ref(x, w, b, dtype):
 def test_conv3x3_every_branch(case, switches):
     ops = _ops()
     dtype, N, H, W, Cin, Cout, want_cfg, env = case
-    if env:
-        switches(*((env.split("=")[0], int(env.split("=")[1])) if "=" in env else (env, 1)))
+    for e in filter(None, env.split(",")):
+        switches(*((e.split("=")[0], int(e.split("=")[1])) if "=" in e else (e, 1)))
     x = rnd(N, Cin, H, W, seed=110)
     w = rnd(Cout, Cin, 3, 3, seed=111, scale=(9 * Cin) ** -0.5)
     b = rnd(Cout, seed=112)

@@ -118,10 +118,11 @@ def test_conv3x3_fwd(case, dtype):
 
 
 @pytest.mark.parametrize("shape", [(2, 256, 256), (3, 250, 203), (1, 512, 272)])
-def test_conv3x3_weight_stationary_64_to_64(shape):
-    """bf16 64 -> 64 layers of at least 128K pixels run the weight-stationary persistent kernel (conv64_ws_kernel): ragged
-    32x16 tiles, bias + ReLU, ReLU mask (dgrad form) and an output that is a channel slice of a wider buffer."""
+def test_conv3x3_weight_stationary_64_to_64(shape, switches):
+    """bf16 64 -> 64 layers of at least 128K pixels run the weight-stationary persistent kernel (conv64_ws_kernel) when the deep-prefetch
+    column-segment kernel is switched off: ragged 32x16 tiles, bias + ReLU, ReLU mask (dgrad form) and an output that is a channel slice of a wider buffer."""
     ops = _ops()
+    switches("MIS_CONV_NOPPD", 1)
     dtype = torch.bfloat16
     N, H, W = shape
     x = rnd(N, 64, H, W, seed=30)
@@ -133,6 +134,7 @@ def test_conv3x3_weight_stationary_64_to_64(shape):
     ybuf = torch.full((N, H, W, 128), float("nan"), dtype=dtype, device=DEV)
     ops.conv_igemm(xd, wf, ops.View(ybuf, 64, 64), ksize=3, Cin=64, Cout=64, bias=b.to(DEV), relu=True)
     want = F.relu(F.conv2d(q(x, dtype), q(w, dtype), b, padding=1))
+    assert ops.conv_last_dispatch() == "k3.2d.ws64"
     assert_close(from_nhwc(ybuf[..., 64:].contiguous()), want, f"ws64 fwd {shape}", **tol(dtype, 9 * 64))
     assert torch.isnan(ybuf[..., :64].float()).all(), "ws64 wrote outside its channel slice"
     m = rnd(N, 64, H, W, seed=33)
