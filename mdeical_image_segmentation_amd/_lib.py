@@ -273,7 +273,7 @@ def load():
 
 
 # the sources that define the kernels whose HBM traffic profiles/traffic.json records (the 3x3 convolution / weight-gradient kernels of the benchmark)
-TRAFFIC_SOURCES = ("common.hpp", "conv_args.hpp", "conv_pp_common.hpp", "conv_igemm.hip", "conv_pp.hip", "wgrad_args.hpp", "wgrad.hip", "wgrad_pp.hip")
+TRAFFIC_SOURCES = ("common.hpp", "conv_args.hpp", "conv_pp_common.hpp", "conv_igemm.hip", "conv_pp.hip", "conv_ppd.hip", "gemm1_pp.hip", "wgrad_args.hpp", "wgrad.hip", "wgrad_pp.hip")
 
 
 def source_hash(only=None):
