@@ -474,7 +474,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
                 if (has_next) {
                     wp_static_for<DPS>([&](auto dc) {
                         constexpr int jj = ks * DPS + decltype(dc)::value;
+#ifdef WPT_SAME_TILE        // diagnostic: every prefetch re-reads the tile the block started with - the same DMA count from L2-resident lines (loaded-latency share of a step)
+                        if constexpr (jj < G::PER_WAVE) issue(std::integral_constant<int, jj>{}, n, h0, w0, nstage, xn, zok);
+#else
                         if constexpr (jj < G::PER_WAVE) issue(std::integral_constant<int, jj>{}, nn, nh0, nw0, nstage, nxn, nzok);
+#endif
                     });
                 }
             }
@@ -512,7 +516,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         });
         sel ^= 1;
+#ifndef WPT_SAME_TILE
         n = nn; h0 = nh0; w0 = nw0; xn = nxn; zok = nzok;
+#endif
     }
 
     const int se = SPLIT ? 2 * split + grp : split;            // SPLIT: one slab per wave group
@@ -712,7 +718,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_row_kernel(const WgArgs a) {
                 if (has_next) {
                     wp_static_for<DPS>([&](auto dc) {
                         constexpr int jj = ks * DPS + decltype(dc)::value;
+#ifdef WPT_SAME_TILE        // diagnostic: every prefetch re-reads the tile the block started with - the same DMA count from L2-resident lines (loaded-latency share of a step)
+                        if constexpr (jj < G::PER_WAVE) issue(std::integral_constant<int, jj>{}, n, h0, w0, nstage, xn, zok);
+#else
                         if constexpr (jj < G::PER_WAVE) issue(std::integral_constant<int, jj>{}, nn, nh0, nw0, nstage, nxn, nzok);
+#endif
                     });
                 }
             }
@@ -766,7 +776,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_row_kernel(const WgArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         });
         sel ^= 1;
+#ifndef WPT_SAME_TILE
         n = nn; h0 = nh0; w0 = nw0; xn = nxn; zok = nzok;
+#endif
     }
 
     const int se = SPLIT ? 2 * split + grp : split;            // SPLIT: one slab per wave group
@@ -783,6 +795,259 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_row_kernel(const WgArgs a) {
             }
         }
     if (do_bias && lg == 0) a.bias_partial[(size_t)se * a.Cout + co0 + (wj * 4 + wi) * 16 + li] = bacc[0];      // row 0 of the ones x dY product: fragment fj = wi
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Streaming variant of the row kernel (end of round 3; 2-D, Cout % 128 == 0, H % 4 == 0, W % 32 == 0): the same block / wave tiles, fragments and arithmetic as
+// wgrad_pp_row_kernel<false>, but a block walks DOWN a 32-pixel-wide strip of the image and its operands stream through a ring of ROW slots instead of two tile stages.
+// Why: with every prefetch redirected to L2-resident lines (diagnostic build WPT_SAME_TILE) the row kernel's launches of a train step take 8.27 instead of 9.59 ms - a
+// seventh of its time is loaded HBM latency that a prefetch distance of ONE 32 x 4-pixel tile (58 KB, issued over the three segments before the wait) cannot cover, and
+// its 6-row halo per 4-row tile fetches every input row 1.5 times.
+//   * stream element j of a strip segment of R output rows [ya, ya + R): input row ya - 1 + j (34 px x 64 ci, 128-byte pixels) + dY row ya + j - 2 (32 px x 128 co,
+//     256-byte pixels; none for j < 2), j = 0 .. R + 1 - 13 DMA instructions (waves 0-4: 2, waves 5-7: 1), one 13 KiB slot of a 12-slot ring;
+//   * step j reads element j's three input fragments (kw = 0..2) into the register row j % 3 and, from j = 2 on, its four dY fragments, and runs k-step j - 2: the
+//     36 MFMAs of output row ya + j - 2 against register rows (j - 2, j - 1, j) = taps kh = 0, 1, 2.  Every step is the row kernel's LIGHT k-step (14 transposing reads);
+//     each input row is fetched once per strip segment (R + 2 rows per R);
+//   * each wave's only vector-memory traffic is this stream, so its in-order vmcnt counter works as a FIFO: element j + 11 is issued at step j, and the wait before
+//     step j + 1 leaves ten elements (130 KB per CU) in flight.
+// Tile order: the split-K plan is the row kernel's (32 x 4-pixel tiles, a.tps per block) with the tiles of an image numbered column-major, so a block's range is a run
+// of whole or partial strips; each run restarts the register rows (two MFMA-free warm-up steps).
+namespace {
+constexpr int WS_HROW = 5 * 1024;                   // input-row image: 34 px x 128 B = 4352 B in 5 DMA instructions (the last a quarter full)
+constexpr int WS_QROW = 8 * 1024;                   // dY-row image: 32 px x 256 B
+constexpr int WS_SLOT = WS_HROW + WS_QROW;
+constexpr int WS_NSLOT = 12;
+constexpr int WS_D = WS_NSLOT - 1;                  // prefetch distance in elements
+}   // namespace
+
+__global__ __launch_bounds__(512, 2) void wgrad_pp_stream_kernel(const WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wi = wave & 3, wj = wave >> 2;
+    const int li = lane & 15, lg = lane >> 4;
+    const int q = li >> 2, pp = li & 3;
+
+    const int npairs = a.nCi * a.nCo;
+    const int v = xcd_remap(blockIdx.x, gridDim.x);
+    const int pair = v % npairs;
+    const int split = v / npairs;
+    const int ci_t = pair / a.nCo, co_t = pair - ci_t * a.nCo;
+    const int ci0 = ci_t * 64, co0 = co_t * 128;
+    int t_begin = split * a.tps;
+    int t_end = t_begin + a.tps;
+    if (t_end > a.ntiles) t_end = a.ntiles;
+    if (a.spb > 0) {               // per-sample split-K: this split's tile range lies inside ONE sample
+        const int smp = split / a.spb;
+        t_begin = smp * a.tpsamp + (split - smp * a.spb) * a.tps;
+        t_end = t_begin + a.tps;
+        if (t_end > (smp + 1) * a.tpsamp) t_end = (smp + 1) * a.tpsamp;
+    }
+    const int tpi = a.tilesH * a.tilesW;
+    // segment starting at tile t (column-major tiles within an image): sample, first column, first row, rows
+    auto segment = [&](int t, int& n, int& w0, int& ya, int& R) {
+        n = t / tpi;
+        const int r = t - n * tpi;
+        const int tw = r / a.tilesH, th = r - tw * a.tilesH;
+        w0 = tw * 32;
+        ya = th * 4;
+        int nt = a.tilesH - th;
+        if (nt > t_end - t) nt = t_end - t;
+        R = nt * 4;
+    };
+
+    // fragment offsets inside a slot (wgrad_pp_row_kernel<false>: one row)
+    int qoff[2], poff[2][3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int u = (lg & 1) + 2 * s + 4 * (lg >> 1);
+        const int wx = u * 4 + q;
+        qoff[s] = WS_HROW + wx * 256 + (((wj * 8 + (pp >> 1)) ^ ((wx & 7) << 1)) << 4) + (pp & 1) * 8;                       // fragment fj: ^ (fj << 5)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int px = wx + kw;
+            poff[s][kw] = px * 128 + (((wi * 2 + (pp >> 1)) ^ (px & 7)) << 4) + (pp & 1) * 8;
+        }
+    }
+    // DMA lane parts.  Input row, instruction `wave` (waves 0-4): item = wave*64 + lane -> halo column item >> 3, chunk position item & 7 (XOR column & 7).
+    // dY row, instruction `wave`: column 4*wave + (lane >> 4), chunk position lane & 15 (XOR (column & 7) << 1).
+    const int hitem = wave * 64 + lane;
+    const int hpx = hitem < 34 * 8 ? (hitem >> 3) : 0x40000000;
+    const unsigned hrel = (unsigned)((((hitem >> 3) * a.x0.ld) + (((hitem & 7) ^ ((hitem >> 3) & 7)) << 3)) * 2);
+    const int qcol = 4 * wave + (lane >> 4);
+    const unsigned qrel = (unsigned)((qcol * a.dy_ld + (((lane & 15) ^ ((qcol & 7) << 1)) << 3)) * 2);
+    const unsigned img_x = (unsigned)(((long long)a.H * a.W - 1) * a.x0.ld + a.Cin) * 2u, img_q = (unsigned)(((long long)a.H * a.W - 1) * a.dy_ld + a.Cout) * 2u;
+    const char* const xb = reinterpret_cast<const char*>(a.x0.p);
+    const char* const qb = reinterpret_cast<const char*>(a.dy);
+    // element j of segment (n, w0, ya) -> slot: rows above / below the image are negative / past-the-end offsets of the per-image resource (read as zero), the columns
+    // left / right of it are tested (hpx), and the elements without a dY row (j < 2) issue their dY instruction out of range, so that every element costs a wave the
+    // same number of vmcnt events
+    auto issue = [&](int n, int w0, int ya, int j, char* slot) {
+        if (wave < 5) {
+            const __amdgpu_buffer_rsrc_t rx = wp_make_rsrc(xb + (size_t)n * a.H * a.W * a.x0.ld * 2, img_x);
+            const unsigned toff = (unsigned)((((ya - 1 + j) * a.W + (w0 - 1)) * a.x0.ld + ci0) * 2);
+            const bool ok = (unsigned)(w0 - 1 + hpx) < (unsigned)a.W;
+            wp_dma16(rx, ok ? (int)(toff + hrel) : WP_OOB, slot + wave * 1024);
+        }
+        const __amdgpu_buffer_rsrc_t rq = wp_make_rsrc(qb + (size_t)n * a.H * a.W * a.dy_ld * 2, img_q);
+        const unsigned qoffs = (unsigned)((((ya + j - 2) * a.W + w0) * a.dy_ld + co0) * 2);
+        wp_dma16(rq, j >= 2 ? (int)(qoffs + qrel) : WP_OOB, slot + WS_HROW + wave * 1024);
+    };
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj) acc[t][fj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = (a.bias_partial != nullptr) && (ci_t == 0);     // block-uniform
+    f32x4 bacc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16x8_t ones8 = __builtin_bit_cast(bf16x8_t, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+
+    // total number of stream elements of this block, and the issue cursor (tile, segment, element) that runs WS_D elements ahead of the steps
+    int total = 0;
+    for (int t = t_begin; t < t_end;) {
+        int n_, w_, y_, R_;
+        segment(t, n_, w_, y_, R_);
+        total += R_ + 2;
+        t += R_ >> 2;
+    }
+    int pt = t_begin, pn, pw0, pya, pR, pj = 0, pslot = 0, issued = 0;
+    segment(pt, pn, pw0, pya, pR);
+    auto issue_next = [&]() {
+        if (issued >= total) __builtin_amdgcn_s_sleep(2);          // (see the note behind the prologue's barrier)
+        if (issued < total) {
+            issue(pn, pw0, pya, pj, smem + pslot * WS_SLOT);
+            ++issued;
+            pslot = pslot == WS_NSLOT - 1 ? 0 : pslot + 1;
+            if (++pj == pR + 2) {
+                pj = 0;
+                pt += pR >> 2;
+                if (pt < t_end) segment(pt, pn, pw0, pya, pR);
+            }
+        }
+    };
+    for (int i = 0; i < WS_D; ++i) issue_next();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // Measured on this kernel (2 x 64 x 64 case, where nothing is issued between this barrier and the first reads): fragment reads that start within a few dozen cycles
+    // of the barrier can still see the OLD contents of bytes whose LDS-DMA another wave has just waited for with vmcnt(0) - the counter runs slightly ahead of the LDS
+    // write becoming visible to other waves.  Every other path of the ping-pong kernels has a DMA issue (30+ instructions) between such a barrier and the first
+    // dependent read; where this kernel has none (here, and the steps at the end of the stream that issue nothing) it sleeps ~128 cycles instead.
+    __builtin_amdgcn_s_sleep(2);
+
+    int slot = 0, e = 0;                               // the element / step about to run
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    bf16x8_t A[3][3];                                  // register rows: input row of element j lives in A[j % 3] for steps j, j + 1, j + 2
+    // one step; PH = j % 3 (compile time), mm = this step carries a k-step (j >= 2)
+    auto step = [&](auto phc, const bool mm) __attribute__((always_inline)) {
+        constexpr int PH = decltype(phc)::value;
+        // ================= R segment =================
+        issue_next();                                  // element e + WS_D -> the slot element e - 1 left (both groups are past its reads)
+        const uint32_t sb = (uint32_t)(uintptr_t)smem + slot * WS_SLOT;
+        bf16x8_t B[4];
+        // the step's 14 transposing reads AND their wait are ONE asm statement: the register rows outlive the step and are written by several copies of this code (warm-up
+        // steps, loop body, tail), so hipcc has to reconcile their registers with copies - and a copy placed between a stand-alone read and its s_waitcnt (which the
+        // compiler cannot see belong together) moves a register the LDS has not written yet (seen: element 1's kw = 0 fragment)
+        {
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            s16x4 r[14];
+            asm volatile(
+                "ds_read_b64_tr_b16 %0, %14\n\tds_read_b64_tr_b16 %1, %15\n\t"
+                "ds_read_b64_tr_b16 %2, %16\n\tds_read_b64_tr_b16 %3, %17\n\t"
+                "ds_read_b64_tr_b16 %4, %18\n\tds_read_b64_tr_b16 %5, %19\n\t"
+                "ds_read_b64_tr_b16 %6, %20\n\tds_read_b64_tr_b16 %7, %21\n\t"
+                "ds_read_b64_tr_b16 %8, %22\n\tds_read_b64_tr_b16 %9, %23\n\t"
+                "ds_read_b64_tr_b16 %10, %24\n\tds_read_b64_tr_b16 %11, %25\n\t"
+                "ds_read_b64_tr_b16 %12, %26\n\tds_read_b64_tr_b16 %13, %27\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]), "=&v"(r[9]), "=&v"(r[10]),
+                  "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13])
+                : "v"(sb + qoff[0]), "v"(sb + qoff[1]), "v"(sb + (qoff[0] ^ 32)), "v"(sb + (qoff[1] ^ 32)), "v"(sb + (qoff[0] ^ 64)), "v"(sb + (qoff[1] ^ 64)), "v"(sb + (qoff[0] ^ 96)),
+                  "v"(sb + (qoff[1] ^ 96)), "v"(sb + poff[0][0]), "v"(sb + poff[1][0]),
+                  "v"(sb + poff[0][1]), "v"(sb + poff[1][1]), "v"(sb + poff[0][2]), "v"(sb + poff[1][2])
+                : "memory");
+            auto mk = [](const s16x4& lo, const s16x4& hi) {
+                const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                return __builtin_bit_cast(bf16x8_t, v);
+            };
+#pragma unroll
+            for (int fj = 0; fj < 4; ++fj) B[fj] = mk(r[2 * fj], r[2 * fj + 1]);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) A[PH][kw] = mk(r[8 + 2 * kw], r[9 + 2 * kw]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // element e + 1 must be in LDS before the next step reads it: everything but the ten youngest elements (this wave: 2 or 1 instructions each); near the end
+        // of the stream fewer are in flight and the wait is for all of them
+        const bool full = e + WS_D < total;            // element e + WS_D was issued in this step
+        if (grp == 1) {
+            if (!full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (wave == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WS_D - 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WS_D - 1) : "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ================= M segment =================
+        if (mm) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int fj = 0; fj < 4; ++fj)
+                        acc[kh * 3 + kw][fj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[(PH + 1 + kh) % 3][kw], B[fj], acc[kh * 3 + kw][fj], 0, 0, 0);
+            if (do_bias) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, wi == 0 ? B[0] : (wi == 1 ? B[1] : (wi == 2 ? B[2] : B[3])), bacc, 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (grp == 0) {
+            if (!full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WS_D - 1)) : "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        slot = slot == WS_NSLOT - 1 ? 0 : slot + 1;
+        ++e;
+    };
+
+#pragma unroll 1
+    for (int t = t_begin; t < t_end;) {
+        int n, w0, ya, R;
+        segment(t, n, w0, ya, R);
+        t += R >> 2;
+        // R + 2 steps, the first two without MFMAs; register rows rotate with period 3
+        step(std::integral_constant<int, 0>{}, false);
+        step(std::integral_constant<int, 1>{}, false);
+        step(std::integral_constant<int, 2>{}, true);
+        int j = 3;
+#pragma unroll 1
+        for (; j + 3 <= R + 2; j += 3) {
+            step(std::integral_constant<int, 0>{}, true);
+            step(std::integral_constant<int, 1>{}, true);
+            step(std::integral_constant<int, 2>{}, true);
+        }
+        if (j < R + 2) step(std::integral_constant<int, 0>{}, true);
+        if (j + 1 < R + 2) step(std::integral_constant<int, 1>{}, true);
+    }
+
+    float* out = a.partial + (size_t)split * a.TT * a.Cin * a.Cout;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj) {
+            const int co = co0 + (wj * 4 + fj) * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = ci0 + wi * 16 + lg * 4 + r;
+                out[((size_t)tap * a.Cin + ci) * a.Cout + co] = acc[tap][fj][r];
+            }
+        }
+    if (do_bias && lg == 0) a.bias_partial[(size_t)split * a.Cout + co0 + (wj * 4 + wi) * 16 + li] = bacc[0];
     if (grp == 0) __builtin_amdgcn_s_barrier();
 }
 
@@ -814,6 +1079,9 @@ static int wp_kind(const MisWgradDesc* d) {
     if (!mis_sw(SW_WGRAD_PP_NOROW) && (fits || mis_sw(SW_WGRAD_PP_ROW))) return base + 3;
     return base;
 }
+
+// the streaming form of kind 3 (wgrad_pp_stream_kernel): 2-D, whole 32 x 4-pixel tiles; MIS_WGRAD_PP_NOSTREAM=1 keeps the tile-staged row kernel
+static bool wp_stream_ok(const MisWgradDesc* d) { return !d->is3d && wp_kind(d) == 3 && d->H % 4 == 0 && d->W % 32 == 0 && !mis_sw(SW_WGRAD_PP_NOSTREAM); }
 
 static bool wp_per_sample(const MisWgradDesc* d) { return d->dw_per_sample != nullptr && wp_kind(d) != 2; }
 
@@ -911,6 +1179,12 @@ int launch_wgrad_pp(const MisWgradDesc* d, float* partial, float* bias_partial, 
     } else if (kind == 1) {
         *tag = is3d ? "k3.3d.pps" : "k3.2d.pps";
         if (const int rc = is3d ? wp_launch_wide<true, true>(a, grid, stream, "wgrad(pps3)") : wp_launch_wide<true, false>(a, grid, stream, "wgrad(pps)")) return rc;
+    } else if (kind == 3 && wp_stream_ok(d)) {
+        *tag = "k3.2d.ppst";
+        static std::atomic<unsigned long long> attr_done{0};
+        const size_t lds = (size_t)WS_NSLOT * WS_SLOT;
+        if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&wgrad_pp_stream_kernel), lds, "wgrad(ppst)")) return rc;
+        hipLaunchKernelGGL(wgrad_pp_stream_kernel, dim3((unsigned)grid), dim3(512), lds, stream, a);
     } else if (kind == 3) {
         *tag = is3d ? "k3.3d.ppwr" : "k3.2d.ppwr";
         if (const int rc = is3d ? wp_launch_row<false, true>(a, grid, stream, "wgrad(ppwr3)") : wp_launch_row<false, false>(a, grid, stream, "wgrad(ppwr)")) return rc;

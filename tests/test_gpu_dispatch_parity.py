@@ -241,9 +241,15 @@ WG_CASES = [
     (BF, 3, 1, 40, 40, 128, 64, "k3.2d.pps", ""),        # two input-channel tiles: only ci tile 0 writes the bias column sums
     (BF, 3, 2, 150, 170, 64, 128, "k3.2d.ppw", ""),      # wide kernel, persistent blocks with the tile loop taken, ragged 8-row tiles
     # row variants (32-pixel-wide tiles, x fragments reused across the k-steps of a tile): the default wherever 32-wide tiles fit the grid
-    (BF, 3, 2, 64, 64, 64, 128, "k3.2d.ppwr", ""),
+    (BF, 3, 2, 64, 64, 64, 128, "k3.2d.ppwr", "MIS_WGRAD_PP_NOSTREAM"),
     (BF, 3, 1, 9, 32, 256, 256, "k3.2d.ppwr", ""),       # ragged 4-row tiles, 8 channel-tile pairs
-    (BF, 3, 1, 32, 32, 1024, 1024, "k3.2d.ppwr", ""),    # 128 pairs x 2 splits
+    (BF, 3, 1, 32, 32, 1024, 1024, "k3.2d.ppwr", "MIS_WGRAD_PP_NOSTREAM"),    # 128 pairs x 2 splits
+    # streaming form of the row kernel (H % 4 == 0, W % 32 == 0): blocks walk down 32-pixel strips through a 12-slot row ring
+    (BF, 3, 2, 64, 64, 64, 128, "k3.2d.ppst", ""),       # 64 tiles over 64 blocks: one 4-row segment each (prefetch deeper than the stream)
+    (BF, 3, 1, 32, 32, 1024, 1024, "k3.2d.ppst", ""),    # 128 pairs x 2 splits: half a strip each
+    (BF, 3, 2, 152, 160, 64, 128, "k3.2d.ppst", ""),     # 380 tiles over 190 blocks: 8-row segments, some across a strip boundary
+    (BF, 3, 3, 64, 96, 128, 256, "k3.2d.ppst", ""),      # 4 pairs x 48 splits of 3 tiles
+    (BF, 3, 2, 128, 64, 256, 128, "k3.2d.ppst", ""),     # 4 pairs x 64 splits: whole 128-row strips (the ring wraps ten times)
     (BF, 3, 2, 20, 36, 64, 128, "k3.2d.ppwr", "MIS_WGRAD_PP_ROW"),     # ragged in W as well (forced)
     (BF, 3, 2, 150, 160, 64, 128, "k3.2d.ppwr", ""),     # 380 tiles over 128 blocks... the tile loop is taken
     (BF, 3, 2, 64, 96, 64, 64, "k3.2d.ppsr", ""),        # 64-column tiles: 32 x 8-pixel tiles, four rows per wave group, two slabs per block
