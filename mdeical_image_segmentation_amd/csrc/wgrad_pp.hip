@@ -881,19 +881,16 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_stream_kernel(const WgArgs a)
     const unsigned img_x = (unsigned)(((long long)a.H * a.W - 1) * a.x0.ld + a.Cin) * 2u, img_q = (unsigned)(((long long)a.H * a.W - 1) * a.dy_ld + a.Cout) * 2u;
     const char* const xb = reinterpret_cast<const char*>(a.x0.p);
     const char* const qb = reinterpret_cast<const char*>(a.dy);
-    // element j of segment (n, w0, ya) -> slot: rows above / below the image are negative / past-the-end offsets of the per-image resource (read as zero), the columns
-    // left / right of it are tested (hpx), and the elements without a dY row (j < 2) issue their dY instruction out of range, so that every element costs a wave the
-    // same number of vmcnt events
-    auto issue = [&](int n, int w0, int ya, int j, char* slot) {
+    // one stream element -> slot.  Rows above / below the image are negative / past-the-end offsets of the per-image resource (read as zero), the columns left / right of
+    // it are tested (hpx), and the elements without a dY row (j < 2) issue their dY instruction out of range, so that every element costs a wave the same number of
+    // vmcnt events.  Everything scalar comes from the issue cursor below (resources per segment, byte offsets advanced by one row per element): the issue sits in the R
+    // segments, where every instruction counts.
+    auto issue = [&](const __amdgpu_buffer_rsrc_t& rx, const __amdgpu_buffer_rsrc_t& rq, unsigned toff, unsigned qoffs, int w0, bool has_q, char* slot) {
         if (wave < 5) {
-            const __amdgpu_buffer_rsrc_t rx = wp_make_rsrc(xb + (size_t)n * a.H * a.W * a.x0.ld * 2, img_x);
-            const unsigned toff = (unsigned)((((ya - 1 + j) * a.W + (w0 - 1)) * a.x0.ld + ci0) * 2);
             const bool ok = (unsigned)(w0 - 1 + hpx) < (unsigned)a.W;
             wp_dma16(rx, ok ? (int)(toff + hrel) : WP_OOB, slot + wave * 1024);
         }
-        const __amdgpu_buffer_rsrc_t rq = wp_make_rsrc(qb + (size_t)n * a.H * a.W * a.dy_ld * 2, img_q);
-        const unsigned qoffs = (unsigned)((((ya + j - 2) * a.W + w0) * a.dy_ld + co0) * 2);
-        wp_dma16(rq, j >= 2 ? (int)(qoffs + qrel) : WP_OOB, slot + WS_HROW + wave * 1024);
+        wp_dma16(rq, has_q ? (int)(qoffs + qrel) : WP_OOB, slot + WS_HROW + wave * 1024);
     };
 
     f32x4 acc[9][4];
@@ -914,17 +911,29 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_stream_kernel(const WgArgs a)
         t += R_ >> 2;
     }
     int pt = t_begin, pn, pw0, pya, pR, pj = 0, pslot = 0, issued = 0;
-    segment(pt, pn, pw0, pya, pR);
+    __amdgpu_buffer_rsrc_t prx, prq;
+    unsigned ptoff, pqoff;                             // byte offsets of element pj's input row / dY row (minus the lane parts) inside image pn
+    const unsigned xrow = (unsigned)(a.W * a.x0.ld * 2), qrow = (unsigned)(a.W * a.dy_ld * 2);
+    auto cursor_segment = [&]() {
+        segment(pt, pn, pw0, pya, pR);
+        prx = wp_make_rsrc(xb + (size_t)pn * a.H * a.W * a.x0.ld * 2, img_x);
+        prq = wp_make_rsrc(qb + (size_t)pn * a.H * a.W * a.dy_ld * 2, img_q);
+        ptoff = (unsigned)((((pya - 1) * a.W + (pw0 - 1)) * a.x0.ld + ci0) * 2);
+        pqoff = (unsigned)((((pya - 2) * a.W + pw0) * a.dy_ld + co0) * 2);
+    };
+    cursor_segment();
     auto issue_next = [&]() {
         if (issued >= total) __builtin_amdgcn_s_sleep(2);          // (see the note behind the prologue's barrier)
         if (issued < total) {
-            issue(pn, pw0, pya, pj, smem + pslot * WS_SLOT);
+            issue(prx, prq, ptoff, pqoff, pw0, pj >= 2, smem + pslot * WS_SLOT);
             ++issued;
             pslot = pslot == WS_NSLOT - 1 ? 0 : pslot + 1;
+            ptoff += xrow;
+            pqoff += qrow;
             if (++pj == pR + 2) {
                 pj = 0;
                 pt += pR >> 2;
-                if (pt < t_end) segment(pt, pn, pw0, pya, pR);
+                if (pt < t_end) cursor_segment();
             }
         }
     };

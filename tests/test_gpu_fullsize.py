@@ -86,7 +86,7 @@ def test_ping_pong_kernels_beyond_4gib_tensors():
     # weight gradient over the whole batch vs the sum over 8-image slices (y doubles as dY)
     dw = torch.empty(Cout, Cin, 3, 3, device=DEV)
     ops.wgrad(x, y, dw, ksize=3, Cin=Cin, Cout=Cout)
-    assert ops.wgrad_last_dispatch()[0] == "k3.2d.ppwr"
+    assert ops.wgrad_last_dispatch()[0] == "k3.2d.ppst"          # (the streaming form of the row kernel: per-image resources, offsets advanced row by row)
     acc = torch.zeros_like(dw)
     part = torch.empty_like(dw)
     for i in range(0, N, 8):
