@@ -212,6 +212,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_kernel(const WgArgs a) {
         wp_static_for<NS>([&](auto sgc) {
             constexpr int sg = decltype(sgc)::value;
             // ================= R segment =================
+            // (a block's last tile issues nothing: keep its first fragment reads ~64 cycles away from the barrier behind the other group's vmcnt(0) - see the note in
+            // wgrad_pp_stream_kernel's prologue)
+            if constexpr (sg == 0) {
+                if (!has_next) __builtin_amdgcn_s_sleep(1);
+            }
             if constexpr (sg < NS - 1) {
                 if (has_next) {
                     wp_static_for<DPS>([&](auto dc) {
@@ -470,6 +475,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_wide_kernel(const WgArgs a) {
         wp_static_for<NS>([&](auto sgc) {
             constexpr int ks = decltype(sgc)::value;
             // ================= R segment =================
+            // (a block's last tile issues nothing: keep its first fragment reads ~64 cycles away from the barrier behind the other group's vmcnt(0) - see the note in
+            // wgrad_pp_stream_kernel's prologue)
+            if constexpr (ks == 0) {
+                if (!has_next) __builtin_amdgcn_s_sleep(1);
+            }
             if constexpr (ks < NS - 1) {
                 if (has_next) {
                     wp_static_for<DPS>([&](auto dc) {
@@ -713,6 +723,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_row_kernel(const WgArgs a) {
         wp_static_for<NS>([&](auto sgc) {
             constexpr int ks = decltype(sgc)::value;
             // ================= R segment =================
+            // (a block's last tile issues nothing: keep its first fragment reads ~64 cycles away from the barrier behind the other group's vmcnt(0) - see the note in
+            // wgrad_pp_stream_kernel's prologue)
+            if constexpr (ks == 0) {
+                if (!has_next) __builtin_amdgcn_s_sleep(1);
+            }
 #ifndef WPT_NO_DMA          // (WPT_NO_*: timing ablations of a diagnostic build, scripts/wgrad_ablate.sh - results are garbage, never shipped)
             if constexpr (ks < NS - 1) {
                 if (has_next) {
