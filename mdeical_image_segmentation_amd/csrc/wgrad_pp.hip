@@ -814,7 +814,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_row_kernel(const WgArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Streaming variant of the row kernel (end of round 3; 2-D, Cout % 128 == 0, H % 4 == 0, W % 32 == 0): the same block / wave tiles, fragments and arithmetic as
+// Streaming variant of the row kernel (end of round 3; H % 4 == 0 [64-column tiles: 8], W % 32 == 0): the same block / wave tiles, fragments and arithmetic as
 // wgrad_pp_row_kernel<false>, but a block walks DOWN a 32-pixel-wide strip of the image and its operands stream through a ring of ROW slots instead of two tile stages.
 // Why: with every prefetch redirected to L2-resident lines (diagnostic build WPT_SAME_TILE) the row kernel's launches of a train step take 8.27 instead of 9.59 ms - a
 // seventh of its time is loaded HBM latency that a prefetch distance of ONE 32 x 4-pixel tile (58 KB, issued over the three segments before the wait) cannot cover, and
@@ -828,29 +828,46 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_row_kernel(const WgArgs a) {
 //     step j + 1 leaves ten elements (130 KB per CU) in flight.
 // Tile order: the split-K plan is the row kernel's (32 x 4-pixel tiles, a.tps per block) with the tiles of an image numbered column-major, so a block's range is a run
 // of whole or partial strips; each run restarts the register rows (two MFMA-free warm-up steps).
+// Template WS<SPLIT>: SPLIT = false is the layout described above (block 64 ci x 128 co, ONE stream for the block, all eight waves issue it).  SPLIT = true serves the layers
+// with 64 output channels per tile the way W4<true> does - a block owns 64 ci x 64 co, the two wave groups accumulate DIFFERENT pixels into their own accumulators and write
+// their own slabs - as two independent streams: group g walks the g-th half of the block's tile range through its own ring of 8 slots (input row + dY row 32 px x 64 co =
+// 9 KiB), issued by its own four waves (wave 0 of the group: 3 instructions per element, the others 2).  The groups only share the barriers; the one whose stream is shorter
+// (a strip boundary more or less) idles through the difference.
+// IS3D: as in the tile-staged kernels - kd joins the block's identity, a "plane" is one depth slice of one sample, the input row comes from plane + kd - 1 (zero outside
+// the volume), the slab row is kd*9 + tap.
 namespace {
 constexpr int WS_HROW = 5 * 1024;                   // input-row image: 34 px x 128 B = 4352 B in 5 DMA instructions (the last a quarter full)
-constexpr int WS_QROW = 8 * 1024;                   // dY-row image: 32 px x 256 B
-constexpr int WS_SLOT = WS_HROW + WS_QROW;
-constexpr int WS_NSLOT = 12;
-constexpr int WS_D = WS_NSLOT - 1;                  // prefetch distance in elements
+template <bool SPLIT> struct WS {
+    static constexpr int QROW = SPLIT ? 4 * 1024 : 8 * 1024;        // dY-row image: 32 px x 128 | 256 B
+    static constexpr int SLOT = WS_HROW + QROW;
+    static constexpr int NSLOT = SPLIT ? 8 : 12;                    // per stream
+    static constexpr int D = NSLOT - 1;                             // prefetch distance in elements
+    static constexpr int LDS = (SPLIT ? 2 : 1) * NSLOT * SLOT;      // 147,456 | 159,744
+};
 }   // namespace
 
+template <bool SPLIT, bool IS3D>
 __global__ __launch_bounds__(512, 2) void wgrad_pp_stream_kernel(const WgArgs a) {
+    using G = WS<SPLIT>;
+    constexpr int WS_SLOT = G::SLOT, WS_NSLOT = G::NSLOT, WS_D = G::D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, wi = wave & 3, wj = wave >> 2;
+    const int grp = wave >> 2, wi = wave & 3, wj = SPLIT ? 0 : (wave >> 2);
     const int li = lane & 15, lg = lane >> 4;
     const int q = li >> 2, pp = li & 3;
+    char* const ring = smem + (SPLIT ? grp * (WS_NSLOT * WS_SLOT) : 0);
 
-    const int npairs = a.nCi * a.nCo;
+    constexpr int KDN = IS3D ? 3 : 1;
+    const int npairs = a.nCi * a.nCo * KDN;
     const int v = xcd_remap(blockIdx.x, gridDim.x);
     const int pair = v % npairs;
     const int split = v / npairs;
-    const int ci_t = pair / a.nCo, co_t = pair - ci_t * a.nCo;
-    const int ci0 = ci_t * 64, co0 = co_t * 128;
+    const int kd = IS3D ? pair % 3 : 0;
+    const int pc = IS3D ? pair / 3 : pair;
+    const int ci_t = pc / a.nCo, co_t = pc - ci_t * a.nCo;
+    const int ci0 = ci_t * 64, co0 = co_t * (SPLIT ? 64 : 128);
     int t_begin = split * a.tps;
     int t_end = t_begin + a.tps;
     if (t_end > a.ntiles) t_end = a.ntiles;
@@ -860,52 +877,94 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_stream_kernel(const WgArgs a)
         t_end = t_begin + a.tps;
         if (t_end > (smp + 1) * a.tpsamp) t_end = (smp + 1) * a.tpsamp;
     }
-    const int tpi = a.tilesH * a.tilesW;
-    // segment starting at tile t (column-major tiles within an image): sample, first column, first row, rows
-    auto segment = [&](int t, int& n, int& w0, int& ya, int& R) {
-        n = t / tpi;
-        const int r = t - n * tpi;
-        const int tw = r / a.tilesH, th = r - tw * a.tilesH;
+    // streams run over 32 x 4-pixel SUB-tiles, column-major within a plane: the plan's tile t (32 x 4, or 32 x 8 for SPLIT) = sub-tile t, or 2t and 2t + 1
+    const int sth = SPLIT ? 2 * a.tilesH : a.tilesH;            // sub-tile rows per plane
+    const int stpi = sth * a.tilesW;
+    const int cnt = t_end - t_begin;                            // SPLIT: sub-tiles per group
+    auto group_range = [&](int g, int& u0, int& u1) {
+        if (SPLIT) {
+            u0 = 2 * t_begin + g * cnt;
+            u1 = u0 + cnt;
+        } else {
+            u0 = t_begin;
+            u1 = t_end;
+        }
+    };
+    // segment starting at sub-tile u of a stream that ends at u_end: plane, first column, first row, rows
+    auto segment = [&](int u, int u_end, int& n, int& w0, int& ya, int& R) {
+        n = u / stpi;
+        const int r = u - n * stpi;
+        const int tw = r / sth, th = r - tw * sth;
         w0 = tw * 32;
         ya = th * 4;
-        int nt = a.tilesH - th;
-        if (nt > t_end - t) nt = t_end - t;
+        int nt = sth - th;
+        if (nt > u_end - u) nt = u_end - u;
         R = nt * 4;
     };
+    auto stream_total = [&](int g) {
+        int u0, u1, tot = 0;
+        group_range(g, u0, u1);
+        for (int u = u0; u < u1;) {
+            int n_, w_, y_, R_;
+            segment(u, u1, n_, w_, y_, R_);
+            tot += R_ + 2;
+            u += R_ >> 2;
+        }
+        return tot;
+    };
+    int u_begin, u_end;
+    group_range(grp, u_begin, u_end);
+    const int total = stream_total(grp);                 // stream elements (= steps) of this wave's stream
+    int steps_all = total;                                // ... and of the longer of the block's streams (the barriers are shared)
+    if (SPLIT) {
+        const int other = stream_total(grp ^ 1);
+        if (other > steps_all) steps_all = other;
+    }
 
-    // fragment offsets inside a slot (wgrad_pp_row_kernel<false>: one row)
+    // fragment offsets inside a slot (wgrad_pp_row_kernel: one row)
     int qoff[2], poff[2][3];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int u = (lg & 1) + 2 * s + 4 * (lg >> 1);
         const int wx = u * 4 + q;
-        qoff[s] = WS_HROW + wx * 256 + (((wj * 8 + (pp >> 1)) ^ ((wx & 7) << 1)) << 4) + (pp & 1) * 8;                       // fragment fj: ^ (fj << 5)
+        if (SPLIT) qoff[s] = WS_HROW + wx * 128 + (((pp >> 1) ^ (wx & 7)) << 4) + (pp & 1) * 8;                       // fragment fj: ^ (fj << 5)
+        else qoff[s] = WS_HROW + wx * 256 + (((wj * 8 + (pp >> 1)) ^ ((wx & 7) << 1)) << 4) + (pp & 1) * 8;
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
             const int px = wx + kw;
             poff[s][kw] = px * 128 + (((wi * 2 + (pp >> 1)) ^ (px & 7)) << 4) + (pp & 1) * 8;
         }
     }
-    // DMA lane parts.  Input row, instruction `wave` (waves 0-4): item = wave*64 + lane -> halo column item >> 3, chunk position item & 7 (XOR column & 7).
-    // dY row, instruction `wave`: column 4*wave + (lane >> 4), chunk position lane & 15 (XOR (column & 7) << 1).
-    const int hitem = wave * 64 + lane;
+    // DMA lane parts.  Input row, instruction i: item = i*64 + lane -> halo column item >> 3, chunk position item & 7 (XOR column & 7).  !SPLIT: instruction `wave` for
+    // waves 0-4; SPLIT: instruction wi, and the quarter-full fifth one (columns 32, 33) by the group's wave 0.
+    // dY row: !SPLIT: instruction `wave`, column 4*wave + (lane >> 4), chunk position lane & 15 (XOR (column & 7) << 1); SPLIT: instruction wi, column 8*wi + (lane >> 3),
+    // chunk position lane & 7 (XOR column & 7).
+    const int hinstr = SPLIT ? wi : wave;
+    const int hitem = hinstr * 64 + lane;
     const int hpx = hitem < 34 * 8 ? (hitem >> 3) : 0x40000000;
     const unsigned hrel = (unsigned)((((hitem >> 3) * a.x0.ld) + (((hitem & 7) ^ ((hitem >> 3) & 7)) << 3)) * 2);
-    const int qcol = 4 * wave + (lane >> 4);
-    const unsigned qrel = (unsigned)((qcol * a.dy_ld + (((lane & 15) ^ ((qcol & 7) << 1)) << 3)) * 2);
+    const int hpx4 = lane < 16 ? 32 + (lane >> 3) : 0x40000000;                    // SPLIT, wave 0 of a group: the fifth instruction
+    const unsigned hrel4 = (unsigned)((((32 + (lane >> 3)) * a.x0.ld) + (((lane & 7) ^ ((32 + (lane >> 3)) & 7)) << 3)) * 2);
+    const int qcol = SPLIT ? 8 * wi + (lane >> 3) : 4 * wave + (lane >> 4);
+    const unsigned qrel = SPLIT ? (unsigned)((qcol * a.dy_ld + (((lane & 7) ^ (qcol & 7)) << 3)) * 2)
+                                : (unsigned)((qcol * a.dy_ld + (((lane & 15) ^ ((qcol & 7) << 1)) << 3)) * 2);
+    const int qinstr = SPLIT ? wi : wave;
     const unsigned img_x = (unsigned)(((long long)a.H * a.W - 1) * a.x0.ld + a.Cin) * 2u, img_q = (unsigned)(((long long)a.H * a.W - 1) * a.dy_ld + a.Cout) * 2u;
     const char* const xb = reinterpret_cast<const char*>(a.x0.p);
     const char* const qb = reinterpret_cast<const char*>(a.dy);
-    // one stream element -> slot.  Rows above / below the image are negative / past-the-end offsets of the per-image resource (read as zero), the columns left / right of
-    // it are tested (hpx), and the elements without a dY row (j < 2) issue their dY instruction out of range, so that every element costs a wave the same number of
-    // vmcnt events.  Everything scalar comes from the issue cursor below (resources per segment, byte offsets advanced by one row per element): the issue sits in the R
-    // segments, where every instruction counts.
-    auto issue = [&](const __amdgpu_buffer_rsrc_t& rx, const __amdgpu_buffer_rsrc_t& rq, unsigned toff, unsigned qoffs, int w0, bool has_q, char* slot) {
-        if (wave < 5) {
-            const bool ok = (unsigned)(w0 - 1 + hpx) < (unsigned)a.W;
-            wp_dma16(rx, ok ? (int)(toff + hrel) : WP_OOB, slot + wave * 1024);
+    // one stream element -> slot.  Rows above / below the image are negative / past-the-end offsets of the per-plane resource (read as zero), the columns left / right of
+    // it are tested (hpx), planes outside the volume (3-D: zok) and the elements without a dY row (j < 2) issue out of range, so that every element costs a wave the same
+    // number of vmcnt events.  Everything scalar comes from the issue cursor below (resources per segment, byte offsets advanced by one row per element).
+    auto issue = [&](const __amdgpu_buffer_rsrc_t& rx, const __amdgpu_buffer_rsrc_t& rq, unsigned toff, unsigned qoffs, int w0, bool zok, bool has_q, char* slot) {
+        if (SPLIT || wave < 5) {
+            const bool ok = zok && (unsigned)(w0 - 1 + hpx) < (unsigned)a.W;
+            wp_dma16(rx, ok ? (int)(toff + hrel) : WP_OOB, slot + hinstr * 1024);
         }
-        wp_dma16(rq, has_q ? (int)(qoffs + qrel) : WP_OOB, slot + WS_HROW + wave * 1024);
+        if (SPLIT && wi == 0) {
+            const bool ok = zok && (unsigned)(w0 - 1 + hpx4) < (unsigned)a.W;
+            wp_dma16(rx, ok ? (int)(toff + hrel4) : WP_OOB, slot + 4 * 1024);
+        }
+        wp_dma16(rq, has_q ? (int)(qoffs + qrel) : WP_OOB, slot + WS_HROW + qinstr * 1024);
     };
 
     f32x4 acc[9][4];
@@ -913,25 +972,25 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_stream_kernel(const WgArgs a)
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int fj = 0; fj < 4; ++fj) acc[t][fj] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = (a.bias_partial != nullptr) && (ci_t == 0);     // block-uniform
+    const bool do_bias = (a.bias_partial != nullptr) && (ci_t == 0) && (!IS3D || kd == 1);     // block-uniform
     f32x4 bacc = f32x4{0.f, 0.f, 0.f, 0.f};
     const bf16x8_t ones8 = __builtin_bit_cast(bf16x8_t, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
 
-    // total number of stream elements of this block, and the issue cursor (tile, segment, element) that runs WS_D elements ahead of the steps
-    int total = 0;
-    for (int t = t_begin; t < t_end;) {
-        int n_, w_, y_, R_;
-        segment(t, n_, w_, y_, R_);
-        total += R_ + 2;
-        t += R_ >> 2;
-    }
-    int pt = t_begin, pn, pw0, pya, pR, pj = 0, pslot = 0, issued = 0;
+    // the issue cursor (sub-tile, segment, element) runs WS_D elements ahead of the steps
+    int pu = u_begin, pn, pw0, pya, pR, pj = 0, pslot = 0, issued = 0;
+    bool pzok = true;
     __amdgpu_buffer_rsrc_t prx, prq;
-    unsigned ptoff, pqoff;                             // byte offsets of element pj's input row / dY row (minus the lane parts) inside image pn
+    unsigned ptoff, pqoff;                             // byte offsets of element pj's input row / dY row (minus the lane parts) inside plane pn
     const unsigned xrow = (unsigned)(a.W * a.x0.ld * 2), qrow = (unsigned)(a.W * a.dy_ld * 2);
     auto cursor_segment = [&]() {
-        segment(pt, pn, pw0, pya, pR);
-        prx = wp_make_rsrc(xb + (size_t)pn * a.H * a.W * a.x0.ld * 2, img_x);
+        segment(pu, u_end, pn, pw0, pya, pR);
+        int xn = pn;
+        if constexpr (IS3D) {
+            const int z = pn % a.D + kd - 1;
+            pzok = (unsigned)z < (unsigned)a.D;
+            xn = pzok ? pn + kd - 1 : pn;
+        }
+        prx = wp_make_rsrc(xb + (size_t)xn * a.H * a.W * a.x0.ld * 2, img_x);
         prq = wp_make_rsrc(qb + (size_t)pn * a.H * a.W * a.dy_ld * 2, img_q);
         ptoff = (unsigned)((((pya - 1) * a.W + (pw0 - 1)) * a.x0.ld + ci0) * 2);
         pqoff = (unsigned)((((pya - 2) * a.W + pw0) * a.dy_ld + co0) * 2);
@@ -940,15 +999,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_stream_kernel(const WgArgs a)
     auto issue_next = [&]() {
         if (issued >= total) __builtin_amdgcn_s_sleep(2);          // (see the note behind the prologue's barrier)
         if (issued < total) {
-            issue(prx, prq, ptoff, pqoff, pw0, pj >= 2, smem + pslot * WS_SLOT);
+            issue(prx, prq, ptoff, pqoff, pw0, pzok, pj >= 2, ring + pslot * WS_SLOT);
             ++issued;
             pslot = pslot == WS_NSLOT - 1 ? 0 : pslot + 1;
             ptoff += xrow;
             pqoff += qrow;
             if (++pj == pR + 2) {
                 pj = 0;
-                pt += pR >> 2;
-                if (pt < t_end) cursor_segment();
+                pu += pR >> 2;
+                if (pu < u_end) cursor_segment();
             }
         }
     };
@@ -970,12 +1029,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_stream_kernel(const WgArgs a)
     auto step = [&](auto phc, const bool mm) __attribute__((always_inline)) {
         constexpr int PH = decltype(phc)::value;
         // ================= R segment =================
-        issue_next();                                  // element e + WS_D -> the slot element e - 1 left (both groups are past its reads)
-        const uint32_t sb = (uint32_t)(uintptr_t)smem + slot * WS_SLOT;
+        issue_next();                                  // element e + WS_D -> the slot element e - 1 left (every reader of this ring is past it)
+        const uint32_t sb = (uint32_t)(uintptr_t)ring + slot * WS_SLOT;
         bf16x8_t B[4];
         // the step's 14 transposing reads AND their wait are ONE asm statement: the register rows outlive the step and are written by several copies of this code (warm-up
         // steps, loop body, tail), so hipcc has to reconcile their registers with copies - and a copy placed between a stand-alone read and its s_waitcnt (which the
-        // compiler cannot see belong together) moves a register the LDS has not written yet (seen: element 1's kw = 0 fragment)
+        // compiler cannot see belong together) would move a register the LDS has not written yet
         {
             typedef __attribute__((ext_vector_type(8))) short s16x8;
             s16x4 r[14];
@@ -1004,14 +1063,20 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_stream_kernel(const WgArgs a)
             for (int kw = 0; kw < 3; ++kw) A[PH][kw] = mk(r[8 + 2 * kw], r[9 + 2 * kw]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        // element e + 1 must be in LDS before the next step reads it: everything but the ten youngest elements (this wave: 2 or 1 instructions each); near the end
-        // of the stream fewer are in flight and the wait is for all of them
+        // element e + 1 must be in LDS before the next step reads it: everything but the WS_D - 1 youngest elements (this wave: 1, 2 or 3 instructions each); near the
+        // end of the stream fewer are in flight and the wait is for all of them
         const bool full = e + WS_D < total;            // element e + WS_D was issued in this step
-        if (grp == 1) {
+        auto wait_stream = [&]() {
             if (!full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (wave == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WS_D - 1)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WS_D - 1) : "memory");
-        }
+            else if (SPLIT) {
+                if (wi == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (WS_D - 1)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WS_D - 1)) : "memory");
+            } else {
+                if (wave < 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WS_D - 1)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WS_D - 1) : "memory");
+            }
+        };
+        if (grp == 1) wait_stream();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -1028,10 +1093,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_stream_kernel(const WgArgs a)
             if (do_bias) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, wi == 0 ? B[0] : (wi == 1 ? B[1] : (wi == 2 ? B[2] : B[3])), bacc, 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         }
-        if (grp == 0) {
-            if (!full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WS_D - 1)) : "memory");
-        }
+        if (grp == 0) wait_stream();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -1040,10 +1102,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_stream_kernel(const WgArgs a)
     };
 
 #pragma unroll 1
-    for (int t = t_begin; t < t_end;) {
+    for (int u = u_begin; u < u_end;) {
         int n, w0, ya, R;
-        segment(t, n, w0, ya, R);
-        t += R >> 2;
+        segment(u, u_end, n, w0, ya, R);
+        u += R >> 2;
         // R + 2 steps, the first two without MFMAs; register rows rotate with period 3
         step(std::integral_constant<int, 0>{}, false);
         step(std::integral_constant<int, 1>{}, false);
@@ -1058,8 +1120,17 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_stream_kernel(const WgArgs a)
         if (j < R + 2) step(std::integral_constant<int, 0>{}, true);
         if (j + 1 < R + 2) step(std::integral_constant<int, 1>{}, true);
     }
+    if constexpr (SPLIT) {
+        // the other group's stream is a few steps longer (a strip boundary more): keep its barriers company
+#pragma unroll 1
+        for (; e < steps_all; ++e) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+        }
+    }
 
-    float* out = a.partial + (size_t)split * a.TT * a.Cin * a.Cout;
+    const int se = SPLIT ? 2 * split + grp : split;            // SPLIT: one slab per wave group
+    float* out = a.partial + (size_t)se * a.TT * a.Cin * a.Cout;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -1068,10 +1139,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_stream_kernel(const WgArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ci = ci0 + wi * 16 + lg * 4 + r;
-                out[((size_t)tap * a.Cin + ci) * a.Cout + co] = acc[tap][fj][r];
+                out[((size_t)(kd * 9 + tap) * a.Cin + ci) * a.Cout + co] = acc[tap][fj][r];
             }
         }
-    if (do_bias && lg == 0) a.bias_partial[(size_t)split * a.Cout + co0 + (wj * 4 + wi) * 16 + li] = bacc[0];
+    if (do_bias && lg == 0) a.bias_partial[(size_t)se * a.Cout + co0 + (wj * 4 + wi) * 16 + li] = bacc[0];
     if (grp == 0) __builtin_amdgcn_s_barrier();
 }
 
@@ -1104,8 +1175,12 @@ static int wp_kind(const MisWgradDesc* d) {
     return base;
 }
 
-// the streaming form of kind 3 (wgrad_pp_stream_kernel): 2-D, whole 32 x 4-pixel tiles; MIS_WGRAD_PP_NOSTREAM=1 keeps the tile-staged row kernel
-static bool wp_stream_ok(const MisWgradDesc* d) { return !d->is3d && wp_kind(d) == 3 && d->H % 4 == 0 && d->W % 32 == 0 && !mis_sw(SW_WGRAD_PP_NOSTREAM); }
+// the streaming forms of kinds 3 / 4 (wgrad_pp_stream_kernel<false / true>): whole 32 x 4 / 32 x 8-pixel tiles; MIS_WGRAD_PP_NOSTREAM=1 keeps the tile-staged row kernels
+static bool wp_stream_ok(const MisWgradDesc* d) {
+    const int kind = wp_kind(d);
+    if (kind != 3 && kind != 4) return false;
+    return d->H % (kind == 4 ? 8 : 4) == 0 && d->W % 32 == 0 && !mis_sw(SW_WGRAD_PP_NOSTREAM);
+}
 
 static bool wp_per_sample(const MisWgradDesc* d) { return d->dw_per_sample != nullptr && wp_kind(d) != 2; }
 
@@ -1203,12 +1278,18 @@ int launch_wgrad_pp(const MisWgradDesc* d, float* partial, float* bias_partial, 
     } else if (kind == 1) {
         *tag = is3d ? "k3.3d.pps" : "k3.2d.pps";
         if (const int rc = is3d ? wp_launch_wide<true, true>(a, grid, stream, "wgrad(pps3)") : wp_launch_wide<true, false>(a, grid, stream, "wgrad(pps)")) return rc;
-    } else if (kind == 3 && wp_stream_ok(d)) {
-        *tag = "k3.2d.ppst";
-        static std::atomic<unsigned long long> attr_done{0};
-        const size_t lds = (size_t)WS_NSLOT * WS_SLOT;
-        if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&wgrad_pp_stream_kernel), lds, "wgrad(ppst)")) return rc;
-        hipLaunchKernelGGL(wgrad_pp_stream_kernel, dim3((unsigned)grid), dim3(512), lds, stream, a);
+    } else if ((kind == 3 || kind == 4) && wp_stream_ok(d)) {
+        *tag = kind == 3 ? (is3d ? "k3.3d.ppst" : "k3.2d.ppst") : (is3d ? "k3.3d.ppss" : "k3.2d.ppss");
+        auto go = [&](auto kernel, size_t lds) -> int {
+            static std::atomic<unsigned long long> attr_done{0};
+            if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(kernel), lds, "wgrad(ppst)")) return rc;
+            hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(512), lds, stream, a);
+            return MIS_OK;
+        };
+        int rc;
+        if (kind == 3) rc = is3d ? go(&wgrad_pp_stream_kernel<false, true>, (size_t)WS<false>::LDS) : go(&wgrad_pp_stream_kernel<false, false>, (size_t)WS<false>::LDS);
+        else rc = is3d ? go(&wgrad_pp_stream_kernel<true, true>, (size_t)WS<true>::LDS) : go(&wgrad_pp_stream_kernel<true, false>, (size_t)WS<true>::LDS);
+        if (rc) return rc;
     } else if (kind == 3) {
         *tag = is3d ? "k3.3d.ppwr" : "k3.2d.ppwr";
         if (const int rc = is3d ? wp_launch_row<false, true>(a, grid, stream, "wgrad(ppwr3)") : wp_launch_row<false, false>(a, grid, stream, "wgrad(ppwr)")) return rc;

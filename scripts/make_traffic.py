@@ -12,7 +12,7 @@ from mdeical_image_segmentation_amd import _lib  # noqa: E402
 
 KEYS = {   # bench key -> kernel symbols (prefix match on the rocprof name) whose launches carry that key at the benchmark shapes
     "conv_igemm/bf16/k3/2d/bn128": ["void conv_ppc_kernel<8, 4,", "void conv_pp_kernel<8>", "void conv_pp_kernel<4>"],
-    "wgrad/bf16/k3/2d": ["wgrad_pp_stream_kernel", "void wgrad_pp_row_kernel<", "void wgrad_pp_wide_kernel<", "wgrad_pp_wide_kernel", "void wgrad_pp_kernel<2>"],
+    "wgrad/bf16/k3/2d": ["void wgrad_pp_stream_kernel<", "wgrad_pp_stream_kernel", "void wgrad_pp_row_kernel<", "void wgrad_pp_wide_kernel<", "wgrad_pp_wide_kernel", "void wgrad_pp_kernel<2>"],
     "conv_igemm/bf16/k3/2d/bn64": ["void conv_ppd_kernel<", "conv64_ws_kernel", "void conv_ppc_kernel<8, 2,"],
     "conv_igemm/bf16/k1/2d/bn128": ["void gemm1_pp_kernel<"],
 }

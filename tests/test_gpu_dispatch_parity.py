@@ -252,7 +252,11 @@ WG_CASES = [
     (BF, 3, 2, 128, 64, 256, 128, "k3.2d.ppst", ""),     # 4 pairs x 64 splits: whole 128-row strips (the ring wraps ten times)
     (BF, 3, 2, 20, 36, 64, 128, "k3.2d.ppwr", "MIS_WGRAD_PP_ROW"),     # ragged in W as well (forced)
     (BF, 3, 2, 150, 160, 64, 128, "k3.2d.ppwr", ""),     # 380 tiles over 128 blocks... the tile loop is taken
-    (BF, 3, 2, 64, 96, 64, 64, "k3.2d.ppsr", ""),        # 64-column tiles: 32 x 8-pixel tiles, four rows per wave group, two slabs per block
+    (BF, 3, 2, 64, 96, 64, 64, "k3.2d.ppsr", "MIS_WGRAD_PP_NOSTREAM"),        # 64-column tiles: 32 x 8-pixel tiles, four rows per wave group, two slabs per block
+    # ... and their streaming form (H % 8 == 0, W % 32 == 0): two row streams per block, one per wave group
+    (BF, 3, 2, 64, 96, 64, 64, "k3.2d.ppss", ""),        # 48 tiles over 48 blocks: one 4-row segment per group
+    (BF, 3, 2, 152, 160, 128, 64, "k3.2d.ppss", ""),     # two input-channel tiles; 190 tiles over 128 blocks: the groups' streams differ in length at strip boundaries
+    (BF, 3, 4, 128, 64, 64, 64, "k3.2d.ppss", ""),       # 128 tiles, one pair: whole and half strips, the ring wraps
     (BF, 3, 2, 20, 36, 64, 64, "k3.2d.ppsr", "MIS_WGRAD_PP_ROW"),
     (BF, 3, 2, 150, 160, 128, 64, "k3.2d.ppsr", ""),
     (BF, 3, 2, 64, 64, 64, 128, "k3.2d.ppw", "MIS_WGRAD_PP_NOROW"),    # the 16-wide tiles stay reachable
@@ -331,7 +335,10 @@ K3D_CASES = [
     (BF, (1, 40, 64, 48), 64, 128, "k3.3d.ppc8", "k3.3d.ppw", {}),                       # 240 tiles... 32-row tiles exact; interior tiles; depth groups of 4
     (BF, (1, 1, 20, 16), 64, 64, "k3.3d.ppc5n2", "k3.3d.pps", {}),                       # exactly one tile, one plane: both neighbour planes are padding
     (BF, (1, 6, 20, 32), 64, 64, "k3.3d.ppc5n2", "k3.3d.ppsr", {}),                      # weight gradient on the row variants (32-wide tiles fit)
-    (BF, (2, 5, 12, 64), 128, 128, "k3.3d.ppc5", "k3.3d.ppwr", {}),
+    (BF, (2, 5, 12, 64), 128, 128, "k3.3d.ppc5", "k3.3d.ppwr", {"MIS_WGRAD_PP_NOSTREAM": 1}),
+    (BF, (2, 5, 12, 64), 128, 128, "k3.3d.ppc5", "k3.3d.ppst", {}),                       # ... and their streaming forms: planes above / below the volume read as zero
+    (BF, (1, 6, 24, 32), 64, 64, "k3.3d.ppc8n2", "k3.3d.ppss", {}),
+    (BF, (2, 3, 16, 64), 192, 64, "k3.3d.ppc5n2", "k3.3d.ppss", {}),                      # three input-channel tiles x three depth slices
     (BF, (1, 3, 10, 18), 192, 64, "k3.3d.ppc5n2", "k3.3d.ppsr", {"MIS_WGRAD_PP_ROW": 1}),        # ... ragged both ways, three input-channel tiles x three depth slices
     (BF, (1, 7, 20, 16), 64, 128, "k3.3d.ppc5", "k3.3d.ppw", {"MIS_CONV3D_COLMAJOR": 1, "MIS_CONV3D_ZG": 3}),
     # the kernels behind them
