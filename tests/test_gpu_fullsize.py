@@ -65,6 +65,36 @@ def test_3d_full_size_determinism_and_sample_independence():
     assert torch.equal(lg0, lg1[:1]) and torch.equal(am0, am1[:1]), "GroupNorm statistics leak across samples"
 
 
+def test_3d_bf16_cfg5_shape_determinism_and_sample_independence():
+    """cfg5's per-GPU shape (2 x 160^3, bf16): the 3-D ping-pong convolutions and the streaming / tile-staged weight gradients (level 0: W = 160 = 5 strips of 32; the
+    deeper levels' W is not a multiple of 32) - a step is bit-reproducible, and sample 0's logits do not depend on sample 1."""
+    from mdeical_image_segmentation_amd import ops
+    from mdeical_image_segmentation_amd.engine3d import UNet3DEngine
+    eng = UNet3DEngine(1, 3, dtype=torch.bfloat16, device=DEV, seed=0)
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(2, 1, 160, 160, 160, device=DEV, generator=gen)
+    t = (torch.rand(2, 3, 160, 160, 160, device=DEV, generator=gen) > 0.5).float()
+
+    def run(xb, tb):
+        loss, logits, am = eng.forward(xb, tb, train=True)
+        eng.backward()
+        torch.cuda.synchronize()
+        return loss.clone(), logits.clone(), am.clone(), eng.flat.g.clone()
+
+    l1, lg1, am1, g1 = run(x, t)
+    l2, lg2, am2, g2 = run(x, t)
+    assert torch.equal(l1, l2) and torch.equal(lg1, lg2) and torch.equal(am1, am2) and torch.equal(g1, g2), "a step is not bit-reproducible"
+    assert torch.isfinite(g1).all() and g1.abs().sum().item() > 0
+    _, lg0, am0, _ = run(x[:1].contiguous(), t[:1].contiguous())
+    assert torch.equal(lg0, lg1[:1]) and torch.equal(am0, am1[:1]), "GroupNorm statistics leak across samples"
+    # the level-0 weight gradients of this shape take the streaming kernels (64 -> 64, 160^3 planes)
+    xs = torch.randn(1, 8, 160, 160, 64, device=DEV, generator=gen).to(torch.bfloat16)
+    dys = torch.randn(1, 8, 160, 160, 64, device=DEV, generator=gen).to(torch.bfloat16)
+    dw = torch.empty(64, 64, 3, 3, 3, device=DEV)
+    ops.wgrad(xs, dys, dw, ksize=3, Cin=64, Cout=64, grid=(1, 8, 160, 160))
+    assert ops.wgrad_last_dispatch()[0] == "k3.3d.ppss"
+
+
 def test_ping_pong_kernels_beyond_4gib_tensors():
     """The ping-pong kernels address their operands through PER-IMAGE buffer resources with 32-bit offsets: tensors far beyond 4 GiB in total (here 72 images of
     512 x 512 x 128 bf16 = 4.8 GB in, 9.7 GB out / dY) must behave exactly like small batches.  Checked by batch independence (the last and the first two images of the big
