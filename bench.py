@@ -133,7 +133,7 @@ SYMBOLS = {
     "k3.2d.pp256": "conv_pp_kernel<8>", "k3.2d.pp128": "conv_pp_kernel<4>",
     "k3.2d.pp64": "conv_pp_kernel<2>", "k3.2d.ws64": "conv64_ws_kernel", "k3.2d.rs64": "conv_pp_rs64_kernel",
     "k3.2d.ppw": "wgrad_pp_wide_kernel<false, false>", "k3.2d.pps": "wgrad_pp_wide_kernel<true, false>", "k3.2d.ppwr": "wgrad_pp_row_kernel<false, false>",
-    "k3.2d.ppsr": "wgrad_pp_row_kernel<true, false>", "k3.2d.ppst": "wgrad_pp_stream_kernel<false, false>", "k3.2d.ppss": "wgrad_pp_stream_kernel<true, false>", "k3.3d.ppst": "wgrad_pp_stream_kernel<false, true>", "k3.3d.ppss": "wgrad_pp_stream_kernel<true, true>", "k3.3d.ppw": "wgrad_pp_wide_kernel<false, true>", "k3.3d.pps": "wgrad_pp_wide_kernel<true, true>",
+    "k3.2d.ppsr": "wgrad_pp_row_kernel<true, false>", "k1.2d.ppg": "wgrad1_pp_kernel", "k3.2d.ppst": "wgrad_pp_stream_kernel<false, false>", "k3.2d.ppss": "wgrad_pp_stream_kernel<true, false>", "k3.3d.ppst": "wgrad_pp_stream_kernel<false, true>", "k3.3d.ppss": "wgrad_pp_stream_kernel<true, true>", "k3.3d.ppw": "wgrad_pp_wide_kernel<false, true>", "k3.3d.pps": "wgrad_pp_wide_kernel<true, true>",
     "k3.3d.ppwr": "wgrad_pp_row_kernel<false, true>", "k3.3d.ppsr": "wgrad_pp_row_kernel<true, true>", "k3.2d.pp": "wgrad_pp_kernel<2>",
 }
 # the column-segment kernels: one instantiation per epilogue mask path (template argument 0 = none, 1 = bf16 mask ".mask", 2 = ReLU bits ".bits")

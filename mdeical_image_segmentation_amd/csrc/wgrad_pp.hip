@@ -1147,7 +1147,182 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_stream_kernel(const WgArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Ping-pong weight gradient of the bf16 1x1 GEMMs (end of round 3):  dW[ci][co] = sum_pixels X[pixel][ci] * dY[pixel][co]  - the weight part of the transposed
+// convolutions' backward (reference model/unet2d/layers.py:165; dY = the pixel-unshuffled gradient, Cout = 4*Cq).  The round-1 kernel (wgrad_kernel, 128 x 128 channel
+// tiles, lock-step waves, register-staged operands) ran these at 0.41-0.48 PFLOP/s.  With one tap there is no fragment reuse across taps: a wave tile of 64 ci x 64 co needs
+// 16 transposing reads per 16 MFMAs, so the kernel lives at the LDS read bandwidth (64 KB per 32-pixel k-step and CU = 512 cycles, exactly the MFMA time) - what can be
+// removed is everything else: operands by LDS-DMA into a three-slot ring two elements ahead (one stream per wave, counted vmcnt), the two wave groups staggered by a barrier.
+// Block = 128 ci x 256 co (for the 128 -> 256 layer the whole dW: each operand byte is fetched once), wave (wi = wave & 1, wj = wave >> 1) owns 64 ci x 64 co; a stream
+// element = 64 consecutive pixels of the flattened (n, y, x) index (a 1x1 GEMM knows no image borders) = two k-steps: X 64 px x 128 ci + dY 64 px x 256 co = 48 KiB as
+// twelve [32 px][64 ch] images with 128-byte pixels, the chunk position XORed with (pixel & 7) (the dY layout of wgrad_pp_wide_kernel<true>).
+namespace {
+constexpr int WK_XB = 16 * 1024, WK_QB = 32 * 1024, WK_SLOT = WK_XB + WK_QB, WK_NSLOT = 3;
+}   // namespace
+
+__global__ __launch_bounds__(512, 2) void wgrad1_pp_kernel(const WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wi = wave & 1, wj = wave >> 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const int q = li >> 2, pp = li & 3;
+
+    const int npairs = a.nCi * a.nCo;                 // 128-ci x 256-co tiles
+    const int v = xcd_remap(blockIdx.x, gridDim.x);
+    const int pair = v % npairs;
+    const int split = v / npairs;
+    const int ci_t = pair / a.nCo, co_t = pair - ci_t * a.nCo;
+    const int ci0 = ci_t * 128, co0 = co_t * 256;
+    int e_begin = split * a.tps;                      // elements of 64 pixels
+    int e_end = e_begin + a.tps;
+    if (e_end > a.ntiles) e_end = a.ntiles;
+    const int total = e_end - e_begin;
+    if (total <= 0) return;                           // block-uniform (never: every split is non-empty)
+
+    // fragment offsets inside a [32 px][64 ch] image; the 16-channel block f of a fragment: ^ (f << 5)
+    int fo[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int u = (lg & 1) + 2 * s + 4 * (lg >> 1);
+        const int wx = u * 4 + q;
+        fo[s] = wx * 128 + (((pp >> 1) ^ (wx & 7)) << 4) + (pp & 1) * 8;
+    }
+    // DMA: one instruction = 8 pixels x 128 bytes of one image: lane -> pixel lane >> 3, chunk position lane & 7 (XOR pixel & 7)
+    const int pl = lane >> 3;
+    const unsigned xrel = (unsigned)((pl * a.x0.ld + (((lane & 7) ^ pl) << 3)) * 2);
+    const unsigned qrel = (unsigned)((pl * a.dy_ld + (((lane & 7) ^ pl) << 3)) * 2);
+    const char* const xb = reinterpret_cast<const char*>(a.x0.p);
+    const char* const qb = reinterpret_cast<const char*>(a.dy);
+    // element el (64 pixels from pixel 64*el) -> slot: X instructions wave, wave + 8 (id = (ks*2 + blk)*4 + pg), dY instructions wave + 8k (id = (ks*4 + blk)*4 + pg);
+    // the image / pixel-group part of the address is the instruction's scalar offset (the lane part is used as it is)
+    auto issue = [&](int el, char* slot) {
+        const size_t p0 = (size_t)el * 64;
+        const __amdgpu_buffer_rsrc_t rx = wp_make_rsrc(xb + p0 * a.x0.ld * 2, (unsigned)(64 * a.x0.ld * 2));
+        const __amdgpu_buffer_rsrc_t rq = wp_make_rsrc(qb + p0 * a.dy_ld * 2, (unsigned)(64 * a.dy_ld * 2));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int id = wave + 8 * k;
+            const int ks = id >> 3, blk = (id >> 2) & 1, pg = id & 3;
+            const int so = ((ks * 32 + pg * 8) * a.x0.ld + ci0 + blk * 64) * 2;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (wp_lds_void_t*)(slot + (ks * 2 + blk) * 4096 + pg * 1024), 16, (int)xrel, so, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int id = wave + 8 * k;
+            const int ks = id >> 4, blk = (id >> 2) & 3, pg = id & 3;
+            const int so = ((ks * 32 + pg * 8) * a.dy_ld + co0 + blk * 64) * 2;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (wp_lds_void_t*)(slot + WK_XB + (ks * 4 + blk) * 4096 + pg * 1024), 16, (int)qrel, so, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj) acc[f][fj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias gradient / column sums of dY: the waves with wi == 0 of the ci_t == 0 blocks, one ones-MFMA per dY fragment and k-step (every row of the result is the sum)
+    const bool do_bias = (a.bias_partial != nullptr) && (ci_t == 0) && (wi == 0);
+    f32x4 bacc[4];
+#pragma unroll
+    for (int fj = 0; fj < 4; ++fj) bacc[fj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16x8_t ones8 = __builtin_bit_cast(bf16x8_t, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+
+    issue(e_begin, smem);
+    if (total > 1) issue(e_begin + 1, smem + WK_SLOT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __builtin_amdgcn_s_sleep(2);                       // (wgrad_pp_stream_kernel: keep the first reads away from the publishing barrier)
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    int slot = 0;
+#pragma unroll 1
+    for (int e = 0; e < total; ++e) {
+        // ================= R segment =================
+        const bool more = e + 2 < total;
+        if (more) issue(e_begin + e + 2, smem + (slot == 0 ? 2 : slot - 1) * WK_SLOT);      // the slot element e - 1 left (both groups are past its reads)
+        else __builtin_amdgcn_s_sleep(1);
+        const uint32_t sa = (uint32_t)(uintptr_t)smem + slot * WK_SLOT + wi * 4096;
+        const uint32_t sq = (uint32_t)(uintptr_t)smem + slot * WK_SLOT + WK_XB + wj * 4096;
+        bf16x8_t A[2][4], B[2][4];
+        wp_static_for<2>([&](auto kc) {
+            constexpr int ks = decltype(kc)::value;
+            wp_static_for<4>([&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                A[ks][f] = wp_frag<ks * 8192>(sa + (fo[0] ^ (f << 5)), sa + (fo[1] ^ (f << 5)));
+                B[ks][f] = wp_frag<ks * 16384>(sq + (fo[0] ^ (f << 5)), sq + (fo[1] ^ (f << 5)));
+            });
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // element e + 1 must have landed before the next step reads it: everything but this step's six instructions
+        if (grp == 1) {
+            if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ================= M segment =================
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int fj = 0; fj < 4; ++fj) acc[f][fj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks][f], B[ks][fj], acc[f][fj], 0, 0, 0);
+        if (do_bias) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int fj = 0; fj < 4; ++fj) bacc[fj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, B[ks][fj], bacc[fj], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (grp == 0) {
+            if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        slot = slot == WK_NSLOT - 1 ? 0 : slot + 1;
+    }
+
+    float* out = a.partial + (size_t)split * a.Cin * a.Cout;       // TT = 1
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj) {
+            const int co = co0 + wj * 64 + fj * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = ci0 + wi * 64 + f * 16 + lg * 4 + r;
+                out[(size_t)ci * a.Cout + co] = acc[f][fj][r];
+            }
+        }
+    if (do_bias && lg == 0) {
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj) a.bias_partial[(size_t)split * a.Cout + co0 + wj * 64 + fj * 16 + li] = bacc[fj][0];
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the 1x1 form (wgrad1_pp_kernel): 2-D, plain single-source operand, 128-ci x 256-co tiles, whole 64-pixel elements
+static bool wgrad1_pp_ok(const MisWgradDesc* d) {
+    if (d->dtype != MIS_BF16 || d->ksize != 1 || d->is3d || d->D != 1 || mis_sw(SW_WGRAD_K1_NOPP)) return false;
+    if (d->x1 != nullptr || d->in_scale != nullptr || d->dw_per_sample != nullptr) return false;
+    if (d->x0_H != d->H || d->x0_W != d->W) return false;
+    if (d->Cin % 128 != 0 || d->Cout % 256 != 0) return false;
+    const long long P = (long long)d->N * d->H * d->W;
+    if (P % 64 != 0 || P / 64 >= (1ll << 30)) return false;
+    if ((long long)64 * d->x0_ld * 2 >= (1ll << 31) || (long long)64 * d->dy_ld * 2 >= (1ll << 31)) return false;
+    return true;
+}
+
 bool wgrad_pp_eligible(const MisWgradDesc* d) {
+    if (d->ksize == 1) return wgrad1_pp_ok(d);
     if (d->dtype != MIS_BF16 || d->ksize != 3) return false;
     if (d->is3d) {
         if (mis_sw(SW_WGRAD3D_NOPP) || d->x0_D != d->D) return false;
@@ -1168,6 +1343,7 @@ bool wgrad_pp_eligible(const MisWgradDesc* d) {
 // 3 / 4 = the row variants of 0 / 1 (32-pixel-wide tiles with x-fragment reuse across k-steps): taken when the 32-wide tiles pad the W axis by at most an eighth
 // (MIS_WGRAD_PP_ROW=1: always, MIS_WGRAD_PP_NOROW=1: never)
 static int wp_kind(const MisWgradDesc* d) {
+    if (d->ksize == 1) return 6;                     // wgrad1_pp_kernel (wgrad_pp_eligible has checked the shape)
     if (!d->is3d && mis_sw(SW_WGRAD_PP_NOWIDE)) return 2;
     const int base = d->Cout % 128 == 0 ? 0 : 1;
     const bool fits = ((d->W + 31) / 32) * 32 * 8 <= d->W * 9;
@@ -1187,6 +1363,21 @@ static bool wp_per_sample(const MisWgradDesc* d) { return d->dw_per_sample != nu
 // spb: splits per sample when the descriptor asks for per-sample weight gradients (the split ranges then never straddle a sample), else 0
 static void wp_plan(const MisWgradDesc* d, int* ntiles, int* tps, int* nsb, int* tilesH, int* tilesW, int* spb = nullptr, int* tpsamp = nullptr) {
     const int kind = wp_kind(d);
+    if (kind == 6) {                                 // "tiles" = stream elements of 64 pixels; one persistent block per CU
+        const long long nt = (long long)d->N * d->H * d->W / 64;
+        const long long npairs = (long long)(d->Cin / 128) * (d->Cout / 256);
+        long long want = 256 / npairs;
+        if (want < 1) want = 1;
+        if (want > nt) want = nt;
+        *ntiles = (int)nt;
+        *tilesH = 1;
+        *tilesW = 1;
+        if (spb != nullptr) *spb = 0;
+        if (tpsamp != nullptr) *tpsamp = (int)nt;
+        *tps = (int)((nt + want - 1) / want);
+        *nsb = (int)((nt + *tps - 1) / *tps);
+        return;
+    }
     const bool wide = kind == 0 || kind == 3;
     const int th = kind == 3 ? 4 : (kind == 0 || kind == 4) ? 8 : 16;
     const int tw = kind >= 3 ? 32 : WP_TW;
@@ -1267,6 +1458,18 @@ int launch_wgrad_pp(const MisWgradDesc* d, float* partial, float* bias_partial, 
     const int kind = wp_kind(d);
     wp_plan(d, &a.ntiles, &a.tps, &nsb, &a.tilesH, &a.tilesW, &a.spb, &a.tpsamp);
     MIS_REQUIRE((long long)d->N * a.D * a.tilesH * a.tilesW < (1ll << 30), MIS_EUNSUPPORTED, "wgrad(pp): too many pixel tiles");
+    if (kind == 6) {
+        a.tilesD = 1; a.nsplit = nsb;
+        a.nCi = d->Cin / 128; a.nCo = d->Cout / 256; a.KDn = 1; a.TT = 1;
+        const long long grid1 = (long long)a.nCi * a.nCo * nsb;
+        *tag = "k1.2d.ppg";
+        static std::atomic<unsigned long long> attr_done{0};
+        const size_t lds = (size_t)WK_NSLOT * WK_SLOT;
+        if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&wgrad1_pp_kernel), lds, "wgrad(k1 pp)")) return rc;
+        hipLaunchKernelGGL(wgrad1_pp_kernel, dim3((unsigned)grid1), dim3(512), lds, stream, a);
+        MIS_LAUNCH_CHECK("wgrad(k1 pp)");
+        return MIS_OK;
+    }
     const bool wide = kind == 0 || kind == 3;
     a.tilesD = a.D; a.nsplit = (kind == 1 || kind == 4) ? 2 * nsb : nsb;
     a.nCi = d->Cin / 64; a.nCo = d->Cout / (wide ? 128 : 64); a.KDn = is3d ? 3 : 1; a.TT = is3d ? 27 : 9;

@@ -15,6 +15,7 @@ KEYS = {   # bench key -> kernel symbols (prefix match on the rocprof name) whos
     "wgrad/bf16/k3/2d": ["void wgrad_pp_stream_kernel<", "wgrad_pp_stream_kernel", "void wgrad_pp_row_kernel<", "void wgrad_pp_wide_kernel<", "wgrad_pp_wide_kernel", "void wgrad_pp_kernel<2>"],
     "conv_igemm/bf16/k3/2d/bn64": ["void conv_ppd_kernel<", "conv64_ws_kernel", "void conv_ppc_kernel<8, 2,"],
     "conv_igemm/bf16/k1/2d/bn128": ["void gemm1_pp_kernel<"],
+    "wgrad/bf16/k1/2d": ["wgrad1_pp_kernel"],
 }
 
 

@@ -266,6 +266,13 @@ WG_CASES = [
     (BF, 1, 2, 10, 18, 256, 512, "k1.2d.wide", ""),   # 128 x 128 channel tiles
     (BF, 1, 1, 9, 17, 2048, 1024, "k1.2d.wide", ""),
     (BF, 1, 2, 10, 18, 64, 256, "k1.2d.tr", ""),      # Cin not a multiple of 128: 64 x 64 tiles
+    # ping-pong 1x1 weight gradient (Cin % 128 == 0, Cout % 256 == 0, N*H*W % 64 == 0): 128 x 256 channel tiles, 64-pixel stream elements
+    (BF, 1, 2, 16, 32, 128, 256, "k1.2d.ppg", ""),    # 16 elements over 16 blocks: one step each
+    (BF, 1, 2, 64, 64, 256, 512, "k1.2d.ppg", ""),    # 4 channel-tile pairs x 64 splits of two elements
+    (BF, 1, 4, 64, 96, 128, 256, "k1.2d.ppg", ""),    # the whole dW in one tile; 384 elements over 192 blocks
+    (BF, 1, 1, 32, 32, 1024, 2048, "k1.2d.ppg", ""),  # 64 pairs x 4 splits of four elements: the ring wraps
+    (BF, 1, 3, 64, 64, 128, 256, "k1.2d.ppg", ""),    # 192 elements over 192 blocks... and (below) the kernel it replaces
+    (BF, 1, 2, 64, 64, 256, 512, "k1.2d.wide", "MIS_WGRAD_K1_NOPP"),
     (F32, 3, 2, 20, 36, 32, 64, "k3.2d", ""),
     (F32, 3, 1, 9, 17, 256, 128, "k3.2d", ""),
     (F32, 1, 2, 10, 18, 128, 256, "k1.2d", ""),
