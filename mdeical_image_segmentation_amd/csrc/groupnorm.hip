@@ -720,6 +720,84 @@ __global__ __launch_bounds__(256) void first3d_fwd_tiled_kernel(const float* __r
     }
 }
 
+// MFMA variant of the tiled kernel (end of round 3): the same 1 x 4 x 64 voxel tile and LDS halo, but the 27 x 32 multiply-adds of a voxel run on the matrix pipe in full
+// fp32 (v_mfma_f32_16x16x4_f32: D[co][voxel] += W[co][tap] * X[tap][voxel], seven k-steps of four taps, tap 27 = a zero weight).  The tiled kernel is bound by its 864
+// vector FMAs per thread (0.84 ms at 2 x 160^3 for 0.5 GB of output); here a wave keeps the whole filter in 14 registers (lane (co, tap group)), reads ONE halo value
+// per lane and k-step and issues 14 MFMAs per 16 voxels.  Arithmetic: exact fp32 products, fp32 accumulation in a different (fixed) order than the fmaf chain.
+template <typename T>
+__global__ __launch_bounds__(256) void first3d_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               int sstride, int N, int D, int H, int W, const float* __restrict__ w /*[32][27]*/, T* y,
+                                                               int y_ld, int Cpad) {
+    constexpr int TH = 4, TW = 64, HH = TH + 2, HW = TW + 2, XS = HW + 2, CO = 32;
+    __shared__ __attribute__((aligned(16))) float xs[3][HH][XS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int tilesW = (W + TW - 1) / TW, tilesH = (H + TH - 1) / TH;
+    long long b = blockIdx.x;
+    const int tw = (int)(b % tilesW);
+    b /= tilesW;
+    const int th = (int)(b % tilesH);
+    b /= tilesH;
+    const int z = (int)(b % D);
+    const int n = (int)(b / D);
+    const int h0 = th * TH, w0 = tw * TW;
+    const float a = scale[n * sstride], sh = shift[n * sstride];
+    const float* xp = x + (long long)n * D * H * W;
+    for (int i = tid; i < 3 * HH * HW; i += 256) {
+        const int px = i % HW, r = i / HW;
+        const int py = r % HH, pz = r / HH;
+        const int sz = z + pz - 1, sy = h0 + py - 1, sx = w0 + px - 1;
+        float v = 0.f;
+        if (sz >= 0 && sz < D && sy >= 0 && sy < H && sx >= 0 && sx < W) v = fmaf(xp[((long long)sz * H + sy) * W + sx], a, sh);
+        xs[pz][py][px] = v;
+    }
+    // A operand (weights): lane (i = li, k = lg) of k-step ks and fragment f holds W[co = f*16 + li][tap = 4*ks + lg] (0 for tap 27)
+    float wa[7][2];
+    int toff[7];           // byte offset of tap 4*ks + lg inside the halo (tap 27 reads tap 26's value: its weight is zero)
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks) {
+        const int t = 4 * ks + lg;
+        const int tt = t < 27 ? t : 26;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) wa[ks][f] = t < 27 ? w[(f * 16 + li) * 27 + t] : 0.f;
+        toff[ks] = (((tt / 9) * HH + (tt / 3) % 3) * XS + tt % 3) * 4;
+    }
+    __syncthreads();
+    const int r = wave;                                   // tile row of this wave; its 64 voxels = four groups of 16 along x
+    const char* const xb = reinterpret_cast<const char*>(&xs[0][0][0]) + (r * XS + li) * 4;
+    const int yy = h0 + r;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        float bv[7];
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) bv[ks] = *reinterpret_cast<const float*>(xb + toff[ks] + g * 64);      // X[tap][voxel g*16 + li]
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ks][f], bv[ks], acc[f], 0, 0, 0);
+        // D: lane (li, lg), register q = output channel f*16 + 4*lg + q of voxel g*16 + li
+        const int xx = w0 + g * 16 + li;
+        if (yy < H && xx < W) {
+            T* dst = y + ((((size_t)n * D + z) * H + yy) * W + xx) * y_ld + 4 * lg;
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                float o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = fmaxf(acc[f][q], 0.f);
+                if constexpr (sizeof(T) == 2) {
+                    const u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                    *reinterpret_cast<u32x2*>(dst + f * 16) = pk;
+                    if (Cpad > CO) *reinterpret_cast<u32x2*>(dst + CO + f * 16) = u32x2{0u, 0u};
+                } else {
+                    *reinterpret_cast<f32x4*>(dst + f * 16) = f32x4{o[0], o[1], o[2], o[3]};
+                    if (Cpad > CO) *reinterpret_cast<f32x4*>(dst + CO + f * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    }
+}
+
 extern "C" int mis_first3d_fwd(int dtype, const float* x, const float* scale, const float* shift, int sstride, int N, int D, int H, int W,
                                const float* w, int Cout, void* y, int y_ld, int Cpad, void* stream) {
     (void)hipGetLastError();
@@ -730,6 +808,14 @@ extern "C" int mis_first3d_fwd(int dtype, const float* x, const float* scale, co
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int tiled = !mis_sw(SW_FIRST3D_UNTILED);
     const long long tiles = (long long)N * D * ((H + 3) / 4) * ((W + 63) / 64);
+    if (tiled && Cout == 32 && tiles < (1ll << 31) && !mis_sw(SW_FIRST3D_NOMFMA)) {
+        if (dtype == MIS_BF16)
+            hipLaunchKernelGGL(first3d_fwd_mfma_kernel<__bf16>, dim3((unsigned)tiles), dim3(256), 0, s, x, scale, shift, sstride, N, D, H, W, w, (__bf16*)y, y_ld, Cpad);
+        else
+            hipLaunchKernelGGL(first3d_fwd_mfma_kernel<float>, dim3((unsigned)tiles), dim3(256), 0, s, x, scale, shift, sstride, N, D, H, W, w, (float*)y, y_ld, Cpad);
+        MIS_LAUNCH_CHECK("first3d_fwd(mfma)");
+        return MIS_OK;
+    }
     if (tiled && Cout == 32 && tiles < (1ll << 31)) {
         if (dtype == MIS_BF16)
             hipLaunchKernelGGL(first3d_fwd_tiled_kernel<__bf16>, dim3((unsigned)tiles), dim3(256), 0, s, x, scale, shift, sstride, N, D, H, W, w, (__bf16*)y,
@@ -940,6 +1026,124 @@ __global__ __launch_bounds__(256) void first3d_wgrad_tiled_kernel(const float* _
     }
 }
 
+// MFMA variant of the tiled kernel (end of round 3; Cout = 32): G[co][tap] = sum_v dY[v][co] * xh[v + tap] and S (the same with the inside-the-volume flags) are GEMMs with
+// K = voxels - D[co][tap] += A[co][voxel] * B[voxel][tap] in full fp32 on the matrix pipe (v_mfma_f32_16x16x4_f32), all 27 taps of a tile at once (two 16-column
+// fragments, columns 27-31 unused).  A persistent block stages a 1 x 4 x 64 voxel tile: the standardised input halo of the three planes z - 1 .. z + 1 and its flags
+// (3 x 6 x 66 each) and dY as fp32 [voxel][32 co] (33-word rows: conflict-free); a wave owns one tile row = 16 k-steps of 4 voxels, per k-step two dY reads, four halo /
+// flag reads and eight MFMAs.  The tiled kernel needs 2 x 216 vector FMAs per voxel and thread group (0.96 ms at 2 x 160^3); same partial layout, same reduction.
+template <typename T>
+__global__ __launch_bounds__(256) void first3d_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 int N, int D, int H, int W, const T* __restrict__ dy, int dy_ld,
+                                                                 float* __restrict__ partial /*[blocks][3][2][9][64]*/) {
+    constexpr int TH = 4, TW = 64, HH = TH + 2, HW = TW + 2, XS = HW + 2, DS = 33;
+    __shared__ __attribute__((aligned(16))) float xs[3][HH][XS], ins[3][HH][XS];
+    __shared__ __attribute__((aligned(16))) float dys[256 * DS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int cg = tid & 3, gq = tid >> 2;
+    const int sr = gq >> 4, wq = (gq & 15) * 4;          // staging: this thread's tile row and first of 4 voxels
+    const int tilesW = (W + TW - 1) / TW, tilesH = (H + TH - 1) / TH;
+    const long long ntiles = (long long)N * D * tilesH * tilesW;
+    // B operand addresses: lane (k = lg, j = li) of tap fragment b reads halo value [kd][row + kh][4*ks + lg + kw] of tap t = b*16 + li (t > 26: tap 26 again, unused)
+    int boff[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int t = b * 16 + li, tt = t < 27 ? t : 26;
+        boff[b] = ((tt / 9) * HH + (tt / 3) % 3 + wave) * XS + tt % 3 + lg;
+    }
+    const int aoff = (wave * 64 + lg) * DS + li;          // A operand: lane (i = li, k = lg) reads dys[voxel wave*64 + 4*ks + lg][f*16 + li]
+    f32x4 accG[2][2], accS[2][2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) accG[f][b] = accS[f][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        long long bb = tile;
+        const int tw = (int)(bb % tilesW);
+        bb /= tilesW;
+        const int th = (int)(bb % tilesH);
+        bb /= tilesH;
+        const int z = (int)(bb % D);
+        const int n = (int)(bb / D);
+        const int h0 = th * TH, w0 = tw * TW;
+        const float a = rstd[n], sh = -mean[n] * rstd[n];
+        const float* xp = x + (long long)n * D * H * W;
+        __syncthreads();                                 // the previous tile's readers are done
+        for (int i = tid; i < 3 * HH * HW; i += 256) {
+            const int px = i % HW, r = i / HW;
+            const int py = r % HH, pz = r / HH;
+            const int sz = z + pz - 1, sy = h0 + py - 1, sx = w0 + px - 1;
+            const bool in = sz >= 0 && sz < D && sy >= 0 && sy < H && sx >= 0 && sx < W;
+            xs[pz][py][px] = in ? fmaf(xp[((long long)sz * H + sy) * W + sx], a, sh) : 0.f;
+            ins[pz][py][px] = in ? 1.f : 0.f;
+        }
+        {
+            const int yy = h0 + sr;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int xx = w0 + wq + v;
+                float g[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] = 0.f;
+                if (yy < H && xx < W) {
+                    const T* src = dy + ((((size_t)n * D + z) * H + yy) * W + xx) * dy_ld + cg * 8;
+                    if constexpr (sizeof(T) == 2) {
+                        unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(src), g);
+                    } else {
+                        unpack_chunk<float>(*reinterpret_cast<const u32x4*>(src), g);
+                        unpack_chunk<float>(*reinterpret_cast<const u32x4*>(src + 4), g + 4);
+                    }
+                }
+                float* dst = &dys[(sr * 64 + wq + v) * DS + cg * 8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dst[j] = g[j];
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+            const float a0 = dys[aoff + ks * 4 * DS], a1 = dys[aoff + ks * 4 * DS + 16];
+            const float* xf = &xs[0][0][0];
+            const float* nf = &ins[0][0][0];
+            const float g0 = xf[boff[0] + 4 * ks], g1 = xf[boff[1] + 4 * ks], s0 = nf[boff[0] + 4 * ks], s1 = nf[boff[1] + 4 * ks];
+            accG[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, g0, accG[0][0], 0, 0, 0);
+            accG[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, g1, accG[0][1], 0, 0, 0);
+            accG[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, g0, accG[1][0], 0, 0, 0);
+            accG[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, g1, accG[1][1], 0, 0, 0);
+            accS[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, s0, accS[0][0], 0, 0, 0);
+            accS[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, s1, accS[0][1], 0, 0, 0);
+            accS[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, s0, accS[1][0], 0, 0, 0);
+            accS[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, s1, accS[1][1], 0, 0, 0);
+        }
+    }
+    // D: lane (li, lg), register q = [co = f*16 + 4*lg + q][tap = b*16 + li].  Per wave -> LDS, summed over the four waves in a fixed order, written in the partial layout
+    __syncthreads();
+    float* red = dys;                                    // [wave][which][tap 27][co 32]
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int t = b * 16 + li;
+            if (t < 27) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    red[((wave * 2 + 0) * 27 + t) * 32 + f * 16 + 4 * lg + q] = accG[f][b][q];
+                    red[((wave * 2 + 1) * 27 + t) * 32 + f * 16 + 4 * lg + q] = accS[f][b][q];
+                }
+            }
+        }
+    __syncthreads();
+    for (int i = tid; i < 3 * 2 * 576; i += 256) {
+        const int co = i & 63, tp = (i >> 6) % 9, which = (i / 576) & 1, kd = i / 1152;
+        float v = 0.f;
+        if (co < 32) {
+            const int t = kd * 9 + tp;
+            for (int wv = 0; wv < 4; ++wv) v += red[((wv * 2 + which) * 27 + t) * 32 + co];
+        }
+        partial[(((size_t)blockIdx.x * 3 + kd) * 2 + which) * 576 + tp * 64 + co] = v;
+    }
+}
+
 // dW = gamma*G + beta*S in the reference layout; G and S totals go to gs[2][3*576] for the finalize kernel
 __global__ void first3d_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, int Cout, const float* __restrict__ gamma,
                                             const float* __restrict__ beta, float* __restrict__ dw, float* __restrict__ gs) {
@@ -1043,7 +1247,14 @@ extern "C" int mis_first3d_bwd(int dtype, const float* x, const float* mean, con
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* gs = workspace + (size_t)F3_BLOCKS * 3 * 2 * 576;
     const int tiled = !mis_sw(SW_FIRST3D_UNTILED);
-    if (tiled && Cout == 32) {
+    if (tiled && Cout == 32 && !mis_sw(SW_FIRST3D_NOMFMA)) {
+        const long long tiles = (long long)N * D * ((H + 3) / 4) * ((W + 63) / 64);
+        blocks = tiles < F3_BLOCKS ? tiles : F3_BLOCKS;
+        if (dtype == MIS_BF16)
+            hipLaunchKernelGGL(first3d_wgrad_mfma_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, x, mean, rstd, N, D, H, W, (const __bf16*)dy, dy_ld, workspace);
+        else
+            hipLaunchKernelGGL(first3d_wgrad_mfma_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, x, mean, rstd, N, D, H, W, (const float*)dy, dy_ld, workspace);
+    } else if (tiled && Cout == 32) {
         const long long tiles = (long long)N * D * ((H + 3) / 4) * ((W + 63) / 64);
         blocks = tiles < F3_BLOCKS ? tiles : F3_BLOCKS;
         if (dtype == MIS_BF16)
