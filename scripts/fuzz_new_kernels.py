@@ -89,6 +89,22 @@ for case in range(ncases):
         g0 = ops.wgrad_last_dispatch()[0]
         ops.dispatch_override("MIS_WGRAD_K1_NOPP", -1)
         note("wgrad1 " + g1, max(rel(dwb, dwa), rel(dbb, dba)), f"{N}x{H}x{W} {C1}->{4 * Cq} vs {g0}")
+# --- 3-D weight gradients: streaming vs tile-staged row kernels (planes above / below the volume, kd in the block identity)
+for case in range(max(ncases // 4, 4)):
+    g = torch.Generator(device=dev).manual_seed(5000 + case)
+    N, D = rng.choice([1, 2]), rng.randint(1, 6)
+    H, W = 8 * rng.randint(1, 5), 32 * rng.randint(1, 3)
+    Cin, Cout = rng.choice([64, 128, 192]), rng.choice([64, 128])
+    x = torch.randn(N, D, H, W, Cin, device=dev, generator=g).to(BF)
+    dy = torch.randn(N, D, H, W, Cout, device=dev, generator=g).to(BF)
+    dw0, dw1 = torch.empty(Cout, Cin, 3, 3, 3, device=dev), torch.empty(Cout, Cin, 3, 3, 3, device=dev)
+    ops.wgrad(x, dy, dw1, ksize=3, Cin=Cin, Cout=Cout, grid=(N, D, H, W))
+    t1 = ops.wgrad_last_dispatch()[0]
+    ops.dispatch_override("MIS_WGRAD_PP_NOSTREAM", 1)
+    ops.wgrad(x, dy, dw0, ksize=3, Cin=Cin, Cout=Cout, grid=(N, D, H, W))
+    t0 = ops.wgrad_last_dispatch()[0]
+    ops.dispatch_override("MIS_WGRAD_PP_NOSTREAM", -1)
+    note("wgrad3 " + t1, rel(dw1, dw0), f"{N}x{D}x{H}x{W} {Cin}->{Cout} vs {t0}")
 torch.cuda.synchronize()
 bad = 0
 for k, (r, d) in sorted(worst.items()):
