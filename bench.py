@@ -211,6 +211,9 @@ def main():
     ap.add_argument("--comm", default="torch", choices=["torch", "native"],
                     help="gradient exchange at N > 1: torch.distributed all_reduce (ProcessGroupNCCL = RCCL) or the RCCL communicator behind the C ABI "
                          "(mis_comm_init / mis_allreduce_bucket, csrc/comm.cpp); same bucket schedule either way")
+    ap.add_argument("--persist-cus", type=int, default=None,
+                    help="grid of the persistent kernels (default 256 = one block per CU).  At N > 1 an RCCL kernel shares the device with the backward kernels: "
+                         "e.g. 248 leaves 8 CUs free for it (MIS_PERSIST_CUS, csrc/dispatch_cfg.hpp) - the A/B switch for the multi-GPU runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary driver-timed legs (2-D fp32, cfg4 3-D fp32) of the default N=1 run")
@@ -256,10 +259,16 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-        assert dist.get_world_size() == args.gpus and dist.get_backend() == backend, (dist.get_world_size(), dist.get_backend())
+        if dist.get_world_size() != args.gpus or dist.get_backend() != backend or (world > 1 and not os.environ.get("MISAMD_BENCH_REHEARSAL") and dist.get_backend() != "nccl"):
+            # (not an assert: python -O must not turn a gloo / wrong-size run into a number)
+            raise SystemExit(f"bench.py: N > 1 needs the RCCL process group of {args.gpus} ranks: got backend {dist.get_backend()!r}, world size {dist.get_world_size()}")
         if args.comm == "native":
             from mdeical_image_segmentation_amd.ddp import native_comm_init
             assert native_comm_init() == args.gpus
+
+    if args.persist_cus is not None:
+        from mdeical_image_segmentation_amd import ops
+        ops.dispatch_override("MIS_PERSIST_CUS", args.persist_cus)
 
     if args.workload == "3d":
         out = run3d(args, rank, world, dev, dist, dtype=args.dtype, batch=args.batch or 2, size=args.size or 128, steps=args.steps,
@@ -300,6 +309,11 @@ def main():
                 o = run3d(args, rank, world, dev, dist, dtype="bf16", batch=2, size=160, steps=5, warmup=2, timing=True, layers=False)
                 ex["unet3d_cfg5_bf16_160_per_gpu_shape"] = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "model_tflops",
                                                                                "roofline", "kernels", "loss_per_step", "config")}
+                del o
+                torch.cuda.empty_cache()
+                o = run_dropin2d(args, dev, batch=32, size=512, steps=5, warmup=2)
+                o["vs_engine_loop_ms"] = round(o["ms_per_step"] / out["ms_per_step"], 4)
+                ex["unet2d_dropin_UNetModel_autograd_torch_adamw"] = o
                 out["extra"] = ex
             print(json.dumps(out), flush=True)
     if DDP_ON:
@@ -367,12 +381,56 @@ def _comm_report(reducer, eng, steps, world, dist, dev):
     ar, exposed = reducer.timing_ms()
     rep["allreduce_ms_per_step"] = round(ar / steps, 3)
     rep["exposed_comm_ms_per_step"] = round(exposed / steps, 3)
+    rep["per_bucket"] = reducer.timing_breakdown()          # issue order (head first, biases last): bytes, all-reduce ms, exposed ms (the part after the backward ran out)
+    from mdeical_image_segmentation_amd import ops
+    rep["persistent_grid_blocks"] = ops.dispatch_switch("MIS_PERSIST_CUS")      # 256 = every CU; fewer leaves CUs to the RCCL kernels (csrc/dispatch_cfg.hpp)
     h = torch.stack([eng.flat.p.double().sum(), eng.flat.p.double().abs().sum(), eng.flat.g.double().sum()])
     hs = [torch.zeros_like(h) for _ in range(world)]
     dist.all_gather(hs, h)
     rep["params_identical_across_ranks"] = bool(all(torch.equal(hs[0][:2], x[:2]) for x in hs))
     rep["grads_identical_across_ranks"] = bool(all(torch.equal(hs[0][2], x[2]) for x in hs))
     return rep
+
+
+def run_dropin2d(args, dev, *, batch, size, steps, warmup):
+    """The drop-in path a user of the reference executes: `UNetModel(UNetConfig(1, 2, "UNet"))` - the nn.Module whose forward / backward are ONE
+    torch.autograd.Function over the fused engine - driven like the HF Trainer step CustomTrainer plugs into (reference trainer/MYtrainer.py:6-11, train.py:147-158):
+    `loss = model(images=..., labels=...).loss; loss.backward(); clip_grad_norm_(1.0); torch AdamW (the Trainer's decay / no-decay split)`, same batch shape, dtype
+    and data as the headline loop, timed the same way.  Reported beside the engine's own loop: the difference is the price of the nn.Module / autograd hand-over."""
+    import mdeical_image_segmentation_amd.dropin as dropin
+    dropin.install()
+    from unet2d import UNetConfig, UNetModel
+    torch.manual_seed(0)
+    m = UNetModel(UNetConfig(in_channels=1, out_channels=2, unet_type="UNet", compute_dtype="bf16")).to(dev).train()
+    decay = [p for n, p in m.named_parameters() if not n.endswith("bias")]
+    nodecay = [p for n, p in m.named_parameters() if n.endswith("bias")]
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 1e-3}, {"params": nodecay, "weight_decay": 0.0}], lr=args.lr, fused=True)
+    g = torch.Generator().manual_seed(1000)
+    images = torch.randn(batch, 1, size, size, generator=g).to(dev)
+    labels = torch.randint(0, 2, (batch, size, size), generator=g).to(dev)
+    losses = torch.zeros(max(steps, 1), dtype=torch.float32, device=dev)
+
+    def step(i):
+        opt.zero_grad(set_to_none=True)
+        out = m(images=images, labels=labels)
+        if i >= 0:
+            losses[i:i + 1].copy_(out.loss.detach().reshape(1), non_blocking=True)
+        out.loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+
+    for _ in range(max(warmup, 1)):
+        step(-1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 2), "unit": "images/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": max(warmup, 1), "dtype": "bf16",
+            "loss_per_step": [round(float(v), 5) for v in losses[:steps].cpu().tolist()],
+            "config": {"workload": f"UNetModel(UNetConfig(1, 2, 'UNet', compute_dtype='bf16')) bs={batch} {size}x{size}: model(images, labels).loss.backward() + "
+                                   f"clip_grad_norm_(1.0) + torch.optim.AdamW(fused, lr {args.lr:g}, wd 1e-3 on weights): the step CustomTrainer / HF Trainer runs per batch"}}
 
 
 def run2d(args, rank, world, dev, dist, *, dtype, batch, size, steps, warmup, timing, layers):

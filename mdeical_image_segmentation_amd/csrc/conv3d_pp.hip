@@ -387,7 +387,7 @@ template <int PF, int NF, int EM> static int pp3_launch_em(const MisConvDesc* d,
     static std::atomic<unsigned long long> attr_done{0};
     if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv3d_ppc_kernel<PF, NF, EM>), lds, "conv_igemm(3d pp)")) return rc;
     const long long total = nsp * a.nCt;
-    hipLaunchKernelGGL((conv3d_ppc_kernel<PF, NF, EM>), dim3((unsigned)(total > 256 ? 256 : total)), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((conv3d_ppc_kernel<PF, NF, EM>), dim3((unsigned)(total > mis_persist_cus() ? mis_persist_cus() : total)), dim3(512), lds, stream, a);
     MIS_LAUNCH_CHECK("conv_igemm(3d pp)");
     return MIS_OK;
 }

@@ -713,7 +713,7 @@ static int launch_ws64(const MisConvDesc* d, hipStream_t stream) {
     const size_t lds = (size_t)WS64::WBYTES + WS64::HBYTES;
     static std::atomic<unsigned long long> attr_done{0};
     if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv64_ws_kernel), lds, "conv_igemm(ws64)")) return rc;
-    hipLaunchKernelGGL(conv64_ws_kernel, dim3((unsigned)(nsp > 256 ? 256 : nsp)), dim3(WS64::NT), lds, stream, a);
+    hipLaunchKernelGGL(conv64_ws_kernel, dim3((unsigned)(nsp > mis_persist_cus() ? mis_persist_cus() : nsp)), dim3(WS64::NT), lds, stream, a);
     MIS_LAUNCH_CHECK("conv_igemm(ws64)");
     return MIS_OK;
 }

@@ -701,7 +701,7 @@ template <int PF, int NF, int EM> static int pp_launch_col_em(const MisConvDesc*
     static std::atomic<unsigned long long> attr_done{0};
     if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv_ppc_kernel<PF, NF, EM>), lds, "conv_igemm(ppc)")) return rc;
     const long long total = nsp * a.nCt;
-    hipLaunchKernelGGL((conv_ppc_kernel<PF, NF, EM>), dim3((unsigned)(total > 256 ? 256 : total)), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((conv_ppc_kernel<PF, NF, EM>), dim3((unsigned)(total > mis_persist_cus() ? mis_persist_cus() : total)), dim3(512), lds, stream, a);
     MIS_LAUNCH_CHECK("conv_igemm(ppc)");
     return MIS_OK;
 }
@@ -869,7 +869,7 @@ static int pp_launch_rs64(const MisConvDesc* d, hipStream_t stream) {
     const size_t lds = 2 * (size_t)PP_HBUF + 256;
     static std::atomic<unsigned long long> attr_done{0};
     if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv_pp_rs64_kernel), lds, "conv_igemm(rs64)")) return rc;
-    hipLaunchKernelGGL(conv_pp_rs64_kernel, dim3((unsigned)(nsp > 256 ? 256 : nsp)), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL(conv_pp_rs64_kernel, dim3((unsigned)(nsp > mis_persist_cus() ? mis_persist_cus() : nsp)), dim3(512), lds, stream, a);
     MIS_LAUNCH_CHECK("conv_igemm(rs64)");
     return MIS_OK;
 }
@@ -909,7 +909,7 @@ template <int NF> static int pp_launch(const MisConvDesc* d, hipStream_t stream)
     static std::atomic<unsigned long long> attr_done{0};
     if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv_pp_kernel<NF>), lds, "conv_igemm(pp)")) return rc;
     const long long total = nsp * a.nCt;
-    hipLaunchKernelGGL((conv_pp_kernel<NF>), dim3((unsigned)(total > 256 ? 256 : total)), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((conv_pp_kernel<NF>), dim3((unsigned)(total > mis_persist_cus() ? mis_persist_cus() : total)), dim3(512), lds, stream, a);
     MIS_LAUNCH_CHECK("conv_igemm(pp)");
     return MIS_OK;
 }

@@ -333,7 +333,7 @@ template <int EM> static int ppd_launch(const MisConvDesc* d, hipStream_t stream
     static std::atomic<unsigned long long> attr_done{0};
     if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv_ppd_kernel<EM>), (size_t)PD_LDS, "conv_igemm(ppd)")) return rc;
     const long long total = nsp * a.nCt;
-    hipLaunchKernelGGL((conv_ppd_kernel<EM>), dim3((unsigned)(total > 256 ? 256 : total)), dim3(512), (size_t)PD_LDS, stream, a);
+    hipLaunchKernelGGL((conv_ppd_kernel<EM>), dim3((unsigned)(total > mis_persist_cus() ? mis_persist_cus() : total)), dim3(512), (size_t)PD_LDS, stream, a);
     MIS_LAUNCH_CHECK("conv_igemm(ppd)");
     return MIS_OK;
 }

@@ -9,9 +9,15 @@ enum MisSwitch {
     SW_CONV_PPC_COLMAJOR, SW_CONV_RS64, SW_CONV_NOPPC, SW_CONV_PPC, SW_CONV_PP_NO256,
     SW_CONV3D_NOPP, SW_CONV3D_PF, SW_CONV3D_ZG, SW_CONV3D_COLMAJOR,
     SW_WGRAD_K1_NARROW, SW_WGRAD_NO_TR, SW_WGRAD_BLOCKS, SW_WGRAD_NOPP, SW_WGRAD_PP_NOWIDE, SW_WGRAD_PP_KSS1, SW_WGRAD3D_NOPP, SW_WGRAD_PP_ROW, SW_WGRAD_PP_NOROW,
-    SW_FIRST2D_UNTILED, SW_FIRST3D_UNTILED, SW_UPCONV_BWD_GENERIC, SW_GEMM1_NOPP, SW_CONV_NOPPD, SW_WGRAD_PP_NOSTREAM, SW_WGRAD_K1_NOPP, SW_FIRST3D_NOMFMA,
+    SW_FIRST2D_UNTILED, SW_FIRST3D_UNTILED, SW_UPCONV_BWD_GENERIC, SW_GEMM1_NOPP, SW_CONV_NOPPD, SW_WGRAD_PP_NOSTREAM, SW_WGRAD_K1_NOPP, SW_FIRST3D_NOMFMA, SW_PERSIST_CUS,
     SW_COUNT
 };
 
 // current value of a switch: the override if one is set, else the environment's value at first use, else the switch's default (0 for the on/off ones)
 int mis_sw(MisSwitch k);
+
+// Grid size of the persistent kernels (one block per CU; conv_pp*.hip, gemm1_pp.hip, wgrad_pp.hip): MIS_PERSIST_CUS (default 256 = every CU of an MI355X), clamped to
+// [8, 256].  Under data parallelism an RCCL all-reduce kernel runs BESIDE the backward kernels and needs CUs of its own: with 256 one-block-per-CU blocks resident, its
+// workgroups wait for a CU to drain, and the last blocks of whichever MFMA kernel shares the device with it finish late.  MIS_PERSIST_CUS=248 (say) leaves 8 CUs free -
+// an A/B switch for the first multi-GPU run; single-GPU runs keep 256.
+int mis_persist_cus();

@@ -260,7 +260,7 @@ template <int EM> static int g1_launch(const MisConvDesc* d, hipStream_t stream)
     static std::atomic<unsigned long long> attr_done{0};
     if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&gemm1_pp_kernel<EM>), lds, "conv_igemm(k1 pp)")) return rc;
     const long long total = nsp * a.nCt;
-    hipLaunchKernelGGL((gemm1_pp_kernel<EM>), dim3((unsigned)(total > 256 ? 256 : total)), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((gemm1_pp_kernel<EM>), dim3((unsigned)(total > mis_persist_cus() ? mis_persist_cus() : total)), dim3(512), lds, stream, a);
     MIS_LAUNCH_CHECK("conv_igemm(k1 pp)");
     return MIS_OK;
 }

@@ -1366,7 +1366,7 @@ static void wp_plan(const MisWgradDesc* d, int* ntiles, int* tps, int* nsb, int*
     if (kind == 6) {                                 // "tiles" = stream elements of 64 pixels; one persistent block per CU
         const long long nt = (long long)d->N * d->H * d->W / 64;
         const long long npairs = (long long)(d->Cin / 128) * (d->Cout / 256);
-        long long want = 256 / npairs;
+        long long want = mis_persist_cus() / npairs;
         if (want < 1) want = 1;
         if (want > nt) want = nt;
         *ntiles = (int)nt;
@@ -1386,7 +1386,8 @@ static void wp_plan(const MisWgradDesc* d, int* ntiles, int* tps, int* nsb, int*
     const long long per = (long long)(d->is3d ? d->D : 1) * *tilesH * *tilesW;      // tiles per sample (3-D: one 2-D tile grid per depth plane)
     const long long nt = (long long)d->N * per;
     const long long npairs = (long long)(d->Cin / 64) * (d->Cout / (wide ? 128 : 64)) * (d->is3d ? 3 : 1);
-    long long want = 256 / npairs;                // one persistent block per CU
+    const int P = mis_persist_cus();              // 256 unless MIS_PERSIST_CUS leaves CUs to a concurrent collective (dispatch_cfg.hpp)
+    long long want = P / npairs;                  // one persistent block per CU
     if (want < 1) want = 1;
     if (want > nt) want = nt;
     *ntiles = (int)nt;
@@ -1399,7 +1400,7 @@ static void wp_plan(const MisWgradDesc* d, int* ntiles, int* tps, int* nsb, int*
         double best = 1e30;
         for (long long c = 1; c <= 4 && c <= per; ++c) {
             const long long blocks = npairs * c * d->N;
-            const double cost = (double)((blocks + 255) / 256) / (double)(c * d->N);
+            const double cost = (double)((blocks + P - 1) / P) / (double)(c * d->N);
             if (cost < best * 0.999) {
                 best = cost;
                 k = c;

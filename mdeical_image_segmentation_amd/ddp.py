@@ -85,6 +85,7 @@ class GradReducer:
         self._slot = 0
         self.buckets_per_step = 0
         self._t_buckets, self._t_join = [], []
+        self._step = 0
 
     def _reduce(self, t):
         if self._skip:
@@ -107,7 +108,7 @@ class GradReducer:
                     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
                 if self.timing:
                     e1.record(self.stream)
-                    self._t_buckets.append((e0, e1))
+                    self._t_buckets.append((e0, e1, self._step, self._slot - 1, t.numel()))
         else:
             self.works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -132,6 +133,7 @@ class GradReducer:
             if self.timing:
                 j1.record(cur)
                 self._t_join.append((j0, j1))
+            self._step += 1
         else:
             self.buckets_per_step = len(self.works)
             for w in self.works:
@@ -140,12 +142,29 @@ class GradReducer:
 
     def reset_timing(self):
         self._t_buckets, self._t_join = [], []
+        self._step = 0
 
     def timing_ms(self):
         """(sum of bucket all-reduce durations, sum of compute-stream waits in finish()) in ms since reset_timing(); synchronises"""
         if not self.timing:
             return 0.0, 0.0
         torch.cuda.synchronize()
-        ar = sum(a.elapsed_time(b) for a, b in self._t_buckets)
+        ar = sum(b[0].elapsed_time(b[1]) for b in self._t_buckets)
         ex = sum(a.elapsed_time(b) for a, b in self._t_join)
         return ar, ex
+
+    def timing_breakdown(self):
+        """per bucket slot (in issue order: head first, biases last), averaged over the steps since reset_timing(): bytes, all-reduce ms, and EXPOSED ms = the part of the
+        bucket's interval on the communication stream that lies after the compute stream arrived at finish()'s join (what the backward could not hide); synchronises"""
+        if not self.timing or not self._t_join:
+            return []
+        torch.cuda.synchronize()
+        nsteps = len(self._t_join)
+        acc = {}
+        for e0, e1, step, slot, numel in self._t_buckets:
+            j0 = self._t_join[step][0]
+            t0, t1 = j0.elapsed_time(e0), j0.elapsed_time(e1)          # bucket start / end relative to the compute stream's arrival at the join (negative: before)
+            a = acc.setdefault(slot, [numel * 4, 0.0, 0.0])
+            a[1] += e0.elapsed_time(e1)
+            a[2] += max(t1, 0.0) - max(t0, 0.0)
+        return [{"bucket": slot, "bytes": v[0], "allreduce_ms": round(v[1] / nsteps, 4), "exposed_ms": round(v[2] / nsteps, 4)} for slot, v in sorted(acc.items())]

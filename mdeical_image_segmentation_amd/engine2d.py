@@ -249,7 +249,9 @@ class UNet2DEngine:
             else:
                 self._conv(self.pooled[l - 1], f"down_conv.{l}.first", self.t1[l], FEATS[l - 1], c, rb=("t1", l))
             self._conv(self.t1[l], f"down_conv.{l}.second", skip, c, c)
-            ops.maxpool2_fwd(skip, self.pooled[l], pbits=self.pb[l] if train else None)
+            # the pool bits are written by EVERY forward: `logits = model(images)` + an external loss + backward() (head_backward) is a supported path, and the
+            # pooling backward reads these bytes instead of the skip tensor (they used to be written only with labels)
+            ops.maxpool2_fwd(skip, self.pooled[l], pbits=self.pb[l])
         self._conv(self.pooled[3], "middle_conv.first", self.m1, 512, 1024, rb="m1")
         self._conv(self.m1, "middle_conv.second", self.m2, 1024, 1024, rb="m2")
         x = self.m2

@@ -84,12 +84,10 @@ class _FusedUNet(torch.autograd.Function):
             eng.head_backward(d.contiguous())
             scale = None
             eng.backward()
-        grads = []
-        for name, p in owner.named_parameters():
-            if not p.requires_grad:
-                grads.append(None)
-            else:
-                grads.append(eng.G[name] * scale if scale is not None else eng.G[name].clone())
+        # the engine's gradients live in ONE flat fp32 buffer: the chain-rule factor (or the copy autograd needs, since the buffer is reused by the next backward) is one
+        # kernel over it, and every parameter's gradient is a view of the result (round 4: this was 46 small multiplies, ~0.5 ms of launches per step)
+        flat = eng.flat.g * scale if scale is not None else eng.flat.g.clone()
+        grads = [eng.flat._view(flat, name) if p.requires_grad else None for name, p in owner.named_parameters()]
         return (None, None, None, None, *grads)
 
 

@@ -134,6 +134,14 @@ def dispatch_override(name, value=1):
     check(load().mis_dispatch_override(None if name is None else name.encode(), int(value)), "mis_dispatch_override")
 
 
+def dispatch_switch(name):
+    """current value of a kernel-selection switch (include/misamd.h: mis_dispatch_switch)"""
+    v = load().mis_dispatch_switch(name.encode())
+    if v < 0:
+        check(v, "mis_dispatch_switch")
+    return v
+
+
 class dispatch_switches:
     """context manager: `with ops.dispatch_switches(MIS_CONV_NOPP=1): ...` - the switches are restored on exit"""
 

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Same-box A/B of the whole 2-D train step between two builds of the library (GPU box): the tree's libmisamd.so against mdeical_image_segmentation_amd/libmisamd_prev.so
-# (built by hand from another commit: `git archive <commit> mdeical_image_segmentation_amd/csrc include | tar -x -C /tmp/old && make -C /tmp/old/.../csrc`, copied next to
+# Same-box A/B of the whole 2-D train step between two builds of the library (GPU box): the tree's libmisamd.so against build_ab/libmisamd_prev.so
+# (built by hand from another commit: `git archive <commit> mdeical_image_segmentation_amd/csrc include | tar -x -C /tmp/old && make -C /tmp/old/.../csrc`, copied to build_ab/, outside the package, not next to
 # the shipped library - *.so files are git-ignored but travel with gpurun), two interleaved rounds, one process per run.  Box-to-box variance is +-2 %: only this kind
 # of comparison decides a kernel change.   bash scripts/ab_prev_lib.sh [ENV=VALUE ...]   (extra environment for the "new" arm, e.g. MISAMD_NO_POOL_BITS=1 as arm "prev")
 cd "$(dirname "$0")/.."
-PREV=$PWD/mdeical_image_segmentation_amd/libmisamd_prev.so
+PREV=$PWD/build_ab/libmisamd_prev.so
 for i in 1 2; do
 for arm in prev new; do
   if [ $arm = prev ]; then

@@ -187,26 +187,7 @@ def g3_unet3d(ns, oracle3):
         d["g_" + k] = v.grad
     save("g3_unet3d_small.npz", **d)
 
-    # default-width net (64..512, 16.3 M params) on 1x1x16^3: stats only
-    torch.manual_seed(0)
-    net = ns.model3d.UNet3D(1, 3)
-    po = oracle3.init_params(1, 3, seed=0)
-    sd = net.state_dict()
-    assert list(sd.keys()) == list(po.keys())
-    for k in sd:
-        assert torch.equal(sd[k], po[k]), k
-    g = torch.Generator().manual_seed(78)
-    x = torch.randn(1, 1, 16, 16, 16, generator=g)
-    t = (torch.rand(1, 3, 16, 16, 16, generator=g) > 0.5).float()
-    logits = net(x)
-    loss = crit(logits, t)
-    loss.backward()
-    d = {"x": x, "t": t, "logits": logits, "loss": loss, "argmax": logits.argmax(1),
-         "names": np.array([k for k, _ in net.named_parameters()]),
-         "param_stats": np.stack([stat(p) for _, p in net.named_parameters()]),
-         "grad_stats": np.stack([stat(p.grad) for _, p in net.named_parameters()]),
-         "g_final_w": net.final_conv.weight.grad, "g_final_b": net.final_conv.bias.grad}
-    save("g3_unet3d_default.npz", **d)
+    g3_unet3d_default(ns, oracle3)
 
     # loss-only vectors (N(0,1) logits / Bernoulli targets)
     g = torch.Generator().manual_seed(3)
@@ -218,9 +199,51 @@ def g3_unet3d(ns, oracle3):
          dice=ns.losses3d.compute_per_channel_dice(torch.sigmoid(lg.detach()), tg))
 
 
+MIN_ARGMAX_GAP = 1e-4
+
+
+def g3_unet3d_default(ns, oracle3):
+    """default-width net (64..512, 16.3 M params) on 1x1x16^3: stats only.
+
+    The arg-max of this golden is a BIT-EXACT bar (north star: "seg masks bit-exact at argmax"), so the input must not hold a voxel whose top-2 logit gap is within
+    reach of fp32 summation-order noise (two correct fp32 evaluations of this net differ by ~2e-5): input seeds are tried from 78 upwards until the smallest gap
+    is >= MIN_ARGMAX_GAP (seed 78, used until round 3, has a 2.4e-5 voxel; seed 79 has 2.3e-4), and the generator asserts it."""
+    crit = ns.losses3d.BCEDiceLoss(1.0, 1.0)
+    torch.manual_seed(0)
+    net = ns.model3d.UNet3D(1, 3)
+    po = oracle3.init_params(1, 3, seed=0)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(po.keys())
+    for k in sd:
+        assert torch.equal(sd[k], po[k]), k
+    for seed in range(78, 178):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(1, 1, 16, 16, 16, generator=g)
+        t = (torch.rand(1, 3, 16, 16, 16, generator=g) > 0.5).float()
+        logits = net(x)
+        top2 = logits.detach().topk(2, dim=1).values
+        gap = float((top2[:, 0] - top2[:, 1]).min())
+        print(f"g3_unet3d_default: input seed {seed}: smallest top-2 logit gap {gap:.3g}")
+        if gap >= MIN_ARGMAX_GAP:
+            break
+    assert gap >= MIN_ARGMAX_GAP, gap
+    loss = crit(logits, t)
+    loss.backward()
+    d = {"x": x, "t": t, "logits": logits, "loss": loss, "argmax": logits.argmax(1),
+         "input_seed": np.int64(seed), "min_top2_gap": np.float64(gap),
+         "names": np.array([k for k, _ in net.named_parameters()]),
+         "param_stats": np.stack([stat(p) for _, p in net.named_parameters()]),
+         "grad_stats": np.stack([stat(p.grad) for _, p in net.named_parameters()]),
+         "g_final_w": net.final_conv.weight.grad, "g_final_b": net.final_conv.bias.grad}
+    save("g3_unet3d_default.npz", **d)
+
+
 def main():
     ns = import_reference()
     from oracle import unet2d_oracle, unet3d_oracle
+    if sys.argv[1:] == ["--only", "unet3d_default"]:        # regenerate that one fixture (round 4: near-tie-free input) without touching the others
+        g3_unet3d_default(ns, unet3d_oracle)
+        return
     g1_blocks(ns)
     g2_unet(ns, 1, 2, 2, 32, 32, "1_2", unet2d_oracle)
     g2_unet(ns, 3, 4, 1, 32, 48, "3_4", unet2d_oracle)

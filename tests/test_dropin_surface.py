@@ -101,6 +101,34 @@ def test_unetmodel_autograd_path_matches_goldens(surface):
 
 
 @pytest.mark.gpu
+def test_forward_without_labels_then_external_loss_backward(surface):
+    """`logits = model(images)` WITHOUT labels, a loss computed by the caller, `.backward()` (a custom compute_loss; reference trainer/MYtrainer.py:6-11 leaves that open):
+    every gradient equals the oracle's.  ADVICE r3 (high): the pooling backward reads the forward's pool bits, which used to be written only when labels were passed.
+    A labelled forward on OTHER images runs first so that stale pool bits / ReLU bits from it would show."""
+    import torch.nn.functional as F
+    from oracle import unet2d_oracle as o2
+    _, unet2d, _ = surface
+    g = load_golden("g2_unet_1_2.npz")
+    torch.manual_seed(0)
+    m = unet2d.UNetModel(unet2d.UNetConfig(1, 2, "UNet")).cuda()
+    images, labels = torch.from_numpy(g["images"]), torch.from_numpy(g["labels"])
+    gen = torch.Generator().manual_seed(123)
+    other = torch.randn(images.shape, generator=gen)
+    m(images=other.cuda(), labels=labels.cuda()).loss.backward()
+    m.zero_grad()
+    out = m(images=images.cuda())
+    assert out.loss is None
+    w = torch.tensor([0.3, 1.7])                          # a loss the built-in head does not offer: class-weighted CE
+    F.cross_entropy(out.logits, labels.cuda(), weight=w.cuda()).backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in o2.init_params(1, 2, seed=0).items()}
+    F.cross_entropy(o2.unet_forward(p, images), labels, weight=w).backward()
+    for n, prm in m.unet.named_parameters():
+        ref = p[n].grad
+        err = (prm.grad.cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
+        assert err < 2e-3, (n, err)
+
+
+@pytest.mark.gpu
 def test_blocks_standalone_match_goldens(surface):
     """DoubleConvolution / UpSample / DownSample used on their own (per-layer HIP path) against the block goldens
     is covered for the supported channel counts by tests/test_gpu_kernels.py; here: DownSample on the golden ties."""

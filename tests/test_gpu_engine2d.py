@@ -141,3 +141,26 @@ def test_larger_batch_vs_oracle_fp32():
         a = eng.G[n].cpu()
         err = (a - gref).abs().max().item()
         assert err <= 2e-3 * gref.abs().max().item() + 1e-7, (n, err, gref.abs().max().item())
+
+
+def test_persistent_grids_leave_cus_free(switches):
+    """MIS_PERSIST_CUS (csrc/dispatch_cfg.hpp): the persistent kernels launch at most that many blocks, so that a concurrent RCCL kernel finds free CUs (the A/B switch of
+    the first multi-GPU run).  A bf16 step at 8 x 128 x 128 (up to 1024 tiles per launch: every persistent grid clips) with 200 instead of 256 blocks:
+    the convolutions walk the same tiles in another order - logits and loss bit-identical; the weight gradients split K differently - equal to fp32 summation order."""
+    gen = torch.Generator().manual_seed(11)
+    images = torch.randn(8, 1, 128, 128, generator=gen).to(DEV)
+    labels = torch.randint(0, 2, (8, 128, 128), generator=gen).to(DEV)
+
+    def run():
+        eng = _engine(1, 2, torch.bfloat16)
+        loss, logits, _ = eng.forward(images, labels, train=True)
+        eng.backward()
+        torch.cuda.synchronize()
+        return loss.clone(), logits.clone(), eng.flat.g.clone()
+
+    l0, lg0, g0 = run()
+    switches("MIS_PERSIST_CUS", 200)
+    l1, lg1, g1 = run()
+    assert torch.equal(lg0, lg1) and torch.equal(l0, l1)
+    rel = ((g0.double() - g1.double()).norm() / g0.double().norm()).item()
+    assert rel < 1e-5, rel

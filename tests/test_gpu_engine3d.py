@@ -38,17 +38,16 @@ def test_fp32_engine3d_matches_reference_golden():
     d = (logits.cpu() - ref).abs().max().item()
     assert d < 1e-4, f"logits max|diff| {d}"
     assert abs(loss.item() - float(g["loss"])) < 1e-4, (loss.item(), float(g["loss"]))
-    # arg-max (count what is excused).  This golden has near-ties: two of its 4096 voxels have a top-2 logit gap below 1e-4, the smallest 2.4e-5,
-    # while two correct fp32 evaluations of this net differ by ~2e-5 (the engine vs the reference's oneDNN path: measured 1.9e-5).  So: (a) the arg-max kernel is
-    # bit-exact on the engine's OWN logits everywhere (first maximum wins, torch's rule); (b) against the golden it is identical on every voxel whose gap exceeds
-    # twice the measured logit error, (c) at most the golden's 2 known near-tie voxels fall under that threshold, and there the engine picks one of the top two.
-    assert torch.equal(am.cpu().long(), logits.cpu().argmax(1))
-    top2 = ref.topk(2, dim=1)
-    near = (top2.values[:, 0] - top2.values[:, 1]) < 2 * d
-    assert int(near.sum()) <= 2, int(near.sum())
-    assert int((am.cpu().long() != T(g["argmax"]).long())[~near].sum()) == 0
-    assert bool(((am.cpu().long() == top2.indices[:, 0]) | (am.cpu().long() == top2.indices[:, 1])).all())
-    print(f"3-D golden arg-max: logits max|diff| {d:.3g}, voxels within 2x of it of a tie: {int(near.sum())} of {near.numel()}, flips elsewhere 0")
+    # arg-max: BIT-EXACT on the golden with NO excused voxel.  The golden's input was chosen so that its smallest top-2 logit gap (2.3e-4,
+    # asserted >= 1e-4 by tests/golden/make_golden.py) is far above what two correct fp32 evaluations of this net differ by (~2e-5), as test_gpu_engine2d.py does.
+    ref_am = T(g["argmax"]).long()
+    top2 = ref.topk(2, dim=1).values
+    near = (top2[:, 0] - top2[:, 1]) < 1e-4
+    assert int(near.sum()) == 0, f"the golden holds {int(near.sum())} near-tie voxels: regenerate it (make_golden.py --only unet3d_default)"
+    assert torch.equal(am.cpu().long(), logits.cpu().argmax(1)), "arg-max kernel vs its own logits"
+    flips = int((am.cpu().long() != ref_am).sum())
+    assert flips == 0, f"{flips} arg-max flips against the reference golden"
+    print(f"3-D golden arg-max: logits max|diff| {d:.3g}, smallest golden top-2 gap {float((top2[:, 0] - top2[:, 1]).min()):.3g}, near-tie voxels 0, flips 0")
     eng.backward()
     torch.cuda.synchronize()
     gs = np.stack([stat(eng.Gr[n]) for n in names])
@@ -124,6 +123,17 @@ def _rel(a, b):
     return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
 
 
+class _RoundKeep(torch.autograd.Function):
+    """round to bf16 values, keep the dtype (fp64 graphs); the gradient passes unrounded"""
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 def test_bf16_engine3d_every_layer_replayed():
     """The bf16 3-D engine, layer by layer.  End-to-end gradients of this net cannot carry a tight bf16 bar: its backward is ill-conditioned at
     random init (every GroupNorm backward subtracts the components of dy along 1 and x - the oracle's own fp32 gradients are 4e-3 away from fp64, seven orders above
@@ -161,8 +171,14 @@ def test_bf16_engine3d_every_layer_replayed():
         ypre = F.conv3d(xn, rw(w), None, padding=1)
         ypre.backward(r["gy"])
         yref = F.relu(ypre.detach()).bfloat16().float()
+        # GroupNorm parameter gradients against an fp64 evaluation of the same layer: dgamma = sum dyn * xhat, dbeta = sum dyn with dyn the EXACT gradient
+        # w.r.t. the normalised operand - the graph in double, bf16 rounding only where the engine stores bf16 (the operand, the weights), no rounding of dyn
+        xc64 = xc.detach().double()
+        gamma64, beta64 = gamma.detach().double().requires_grad_(True), beta.detach().double().requires_grad_(True)
+        xn64 = _RoundKeep.apply(F.group_norm(xc64, s.groups, gamma64, beta64, eps=1e-5))
+        F.conv3d(xn64, w.detach().bfloat16().double(), None, padding=1).backward(r["gy"].double())
         e = {"y": _rel(r["y"], yref), "dW": _rel(eng.Gr[name + ".conv.weight"].cpu(), w.grad), "dxn": _rel(r["dyn"], got_dxn["g"].bfloat16().float()),
-             "dgamma": _rel(eng.Gr[name + ".groupnorm.weight"].cpu(), gamma.grad), "dbeta": _rel(eng.Gr[name + ".groupnorm.bias"].cpu(), beta.grad)}
+             "dgamma": _rel(eng.Gr[name + ".groupnorm.weight"].cpu(), gamma64.grad), "dbeta": _rel(eng.Gr[name + ".groupnorm.bias"].cpu(), beta64.grad)}
         dx0 = x0.grad * (x0.detach() > 0) if r["mask0"] else x0.grad
         e["dx0"] = _rel(r["dx0"], dx0.bfloat16().float())
         if r["x1"] is not None:
@@ -172,10 +188,12 @@ def test_bf16_engine3d_every_layer_replayed():
             worst[k] = max(worst.get(k, ("", 0.0)), (name, v), key=lambda kv: kv[1])
             # relative L2 per tensor.  bf16 outputs: two correct pipelines differ by an occasional 1-ulp flip (2^-8 relative on that element): 2e-3 bounds it with room;
             # fp32 outputs (dW, dgamma, dbeta): summation order only, but over operands that carry those flips
-            # GroupNorm parameter gradients: the engine takes sum dyn * x from the per-sample weight gradients (exact dyn x bf16-rounded operand) where the oracle sums
-            # bf16-rounded dyn x stored input - two roundings of the same quantity, and dgamma = sum rstd * (S2 - mean * S1) amplifies their difference (measured 2.0e-3)
-            bar = 2e-3 if k in ("y", "dxn", "dx0", "dx1") else (5e-3 if k in ("dgamma", "dbeta") else 1e-3)
-            assert v <= bar, (name, k, v)     # measured worst: y 4.4e-4, dW 1.2e-4, dgamma 2.0e-3, the rest < 1e-4
+            # GroupNorm parameter gradients: the engine takes sum dyn * x from the per-sample weight gradients (exact dyn x bf16-rounded operand); the fp64 evaluation
+            # above sums exact dyn x exact xhat - the difference is the rounding of the operand, amplified by dgamma = sum rstd * (S2 - mean * S1)
+            # (each element of the stored operand is off by <= 2^-9 relative, and dgamma = sum dyn * (xn - beta) / gamma is a random-sign sum of terms that carry it): the bar is
+            # ONE bf16 ulp, 2^-8 = 3.9e-3 relative L2, against the fp64 evaluation (measured worst 3.1e-3, decoders.1 SingleConv1; dbeta, which does not touch xn, < 1e-4)
+            bar = 2e-3 if k in ("y", "dxn", "dx0", "dx1") else (2.0 ** -8 if k == "dgamma" else 1e-3)
+            assert v <= bar, (name, k, v)     # measured worst: y 4.4e-4, dW 1.2e-4, dgamma 3.1e-3, the rest < 1e-4
     print("bf16 3-D layer replay, worst rel-L2 per quantity: " + ", ".join(f"{k} {v[1]:.2e} ({v[0].split('.basic_module.')[0]})" for k, v in worst.items()))
 
 
@@ -199,6 +217,7 @@ def test_bf16_engine3d_close():
     rels = {n: _rel(eng.Gr[n].cpu(), g16[n]) for n in g16 if n != "encoders.0.basic_module.SingleConv1.groupnorm.weight"}
     worst = max(rels.items(), key=lambda kv: kv[1])
     print(f"bf16 3-D: gradients vs the bf16-storage oracle, rel-L2: final_conv.weight {rels['final_conv.weight']:.3g}, worst {worst[1]:.3g} ({worst[0]})")
+    print("bf16 3-D: all tensors, worst first: " + ", ".join(f"{k.replace('.basic_module', '')} {v:.3g}" for k, v in sorted(rels.items(), key=lambda kv: -kv[1])))
     assert rels["final_conv.weight"] < 2e-2 and rels["final_conv.bias"] < 2e-2
     # measured on MI355X (round 3): see DESIGN.md §4; the bar sits at ~2x the measurement
     assert worst[1] < BF16_3D_GRAD_BAR, worst
