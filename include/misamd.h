@@ -112,9 +112,20 @@ typedef struct MisWgradDesc {
                               * its backward - which equals sum_{co,tap} W[co][c][tap] * dw_n[co][c][tap] once x is expressed through the normalised operand
                               * (mis_gn_bwd_stats_from_dw): the pass over dyn and x that mis_gn_bwd_stats makes is not needed. */
     float* dbias_per_sample; /* optional [N][Cout]: column sums of dy per sample (with dw_per_sample) */
+    struct MisWgradReduceItem* defer;   /* optional: run the MFMA kernel only and describe the slab reduction that is left in *defer (host memory); the caller then reduces a
+                              * GROUP of layers with one mis_wgrad_reduce_batch call - two launches per group instead of three small kernels per layer.  The workspace must
+                              * stay untouched until that call; not with dw_per_sample / reduce_stream. */
 } MisWgradDesc;
+/* What a deferred mis_wgrad left to do: sum `nsplit` fp32 slabs [TT][Cin][Cout] at `partial` in a fixed order into dw (layout as MisWgradDesc.dw_layout, times alpha) and,
+ * if dbias != NULL, the nsplit rows of column sums at bias_partial into dbias. */
+typedef struct MisWgradReduceItem {
+    float* partial; float* dw; const float* bias_partial; float* dbias;
+    int nsplit, TT, Cin, Cout, dw_layout; float alpha;
+} MisWgradReduceItem;
 size_t mis_wgrad_workspace_bytes(const MisWgradDesc* d);
 int mis_wgrad(const MisWgradDesc* d, void* stream);
+/* Reduce the slabs of n <= 16 deferred weight gradients (host array `items`): same arithmetic and summation order per layer as the undeferred call. */
+int mis_wgrad_reduce_batch(const MisWgradReduceItem* items, int n, void* stream);
 /* Diagnostic twins of mis_conv_last_dispatch for mis_wgrad: configuration name and split-K factor of the calling thread's last call. */
 const char* mis_wgrad_last_dispatch(void);
 int mis_wgrad_last_nsplit(void);

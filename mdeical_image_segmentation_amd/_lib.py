@@ -14,7 +14,7 @@ MIS_F32, MIS_BF16 = 0, 1
 OUT_PLAIN, OUT_SHUFFLE2, OUT_UNSHUFFLE2 = 0, 1, 2
 
 EXPORTS = [
-    "mis_last_error", "mis_version", "mis_conv_igemm", "mis_wgrad_workspace_bytes", "mis_wgrad",
+    "mis_last_error", "mis_version", "mis_conv_igemm", "mis_wgrad_workspace_bytes", "mis_wgrad", "mis_wgrad_reduce_batch",
     "mis_conv_last_dispatch", "mis_wgrad_last_dispatch", "mis_wgrad_last_nsplit", "mis_dispatch_override", "mis_dispatch_switch", "mis_gn_apply",
     "mis_mt19937_words", "mis_legacy_normal", "mis_mt_jump", "mis_mt_generate", "mis_legacy_normal_par_workspace_bytes", "mis_legacy_normal_par",
     "mis_comm_unique_id", "mis_comm_init", "mis_comm_world", "mis_allreduce_bucket", "mis_comm_finalize",
@@ -68,6 +68,14 @@ class WgradDesc(C.Structure):
         ("dbias", C.c_void_p),
         ("reduce_stream", C.c_void_p),
         ("dw_per_sample", C.c_void_p), ("dbias_per_sample", C.c_void_p),
+        ("defer", C.c_void_p),
+    ]
+
+
+class WgradReduceItem(C.Structure):
+    _fields_ = [
+        ("partial", C.c_void_p), ("dw", C.c_void_p), ("bias_partial", C.c_void_p), ("dbias", C.c_void_p),
+        ("nsplit", C.c_int), ("TT", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("dw_layout", C.c_int), ("alpha", C.c_float),
     ]
 
 
@@ -117,6 +125,8 @@ def load():
     lib.mis_dispatch_override.argtypes = [C.c_char_p, C.c_int]
     lib.mis_dispatch_switch.restype = C.c_int
     lib.mis_dispatch_switch.argtypes = [C.c_char_p]
+    lib.mis_wgrad_reduce_batch.restype = C.c_int
+    lib.mis_wgrad_reduce_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.mis_comm_unique_id.argtypes = [C.c_void_p]
     lib.mis_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.mis_comm_world.argtypes = []

@@ -377,15 +377,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 1 : 2)) void wgrad_kernel(co
 // along (ci, tap) for layout 0 / (c, ab) for layout 1, via an LDS transpose.
 // tsplit > 1 (small layers: a 64 -> 64 layer has 2 x 2 tiles, i.e. FOUR blocks walking 9 taps x nsplit slabs one after the other - 40 us of latency for 150 KB): the taps
 // are dealt out over blockIdx.z, one tap group of TT / tsplit taps per block.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int TT, int Cin, int Cout,
-                                                           float* __restrict__ dw, int layout, float alpha, size_t group_stride_partial = 0, size_t group_stride_dw = 0,
-                                                           int tsplit = 1) {
-    __shared__ float tile[32][9][33];     // [ci][tap][co]: both the fill (co fastest) and the drain ((ci,tap) fastest) are conflict free
-    const int zg = blockIdx.z / tsplit, tz = blockIdx.z - zg * tsplit;
-    partial += zg * group_stride_partial;      // zg = slab group (per-sample gradients: one group of slabs and one output per sample)
-    dw += zg * group_stride_dw;
+__device__ __forceinline__ void wg_reduce_body(float (&tile)[32][9][33], const float* __restrict__ partial, int nsplit, int TT, int Cin, int Cout, float* __restrict__ dw,
+                                               int layout, float alpha, int bx, int by, int tz, int tsplit) {
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
+    const int co0 = bx * 32, ci0 = by * 32;
     const size_t slab = (size_t)TT * Cin * Cout;
     const int tper = TT / tsplit;                // (tsplit divides TT)
     const int tbeg = tz * tper, tend = tbeg + tper;
@@ -427,6 +422,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int TT, int Cin, int Cout,
+                                                           float* __restrict__ dw, int layout, float alpha, size_t group_stride_partial = 0, size_t group_stride_dw = 0,
+                                                           int tsplit = 1) {
+    __shared__ float tile[32][9][33];     // [ci][tap][co]: both the fill (co fastest) and the drain ((ci,tap) fastest) are conflict free
+    const int zg = blockIdx.z / tsplit, tz = blockIdx.z - zg * tsplit;
+    partial += zg * group_stride_partial;      // zg = slab group (per-sample gradients: one group of slabs and one output per sample)
+    dw += zg * group_stride_dw;
+    wg_reduce_body(tile, partial, nsplit, TT, Cin, Cout, dw, layout, alpha, blockIdx.x, blockIdx.y, tz, tsplit);
+}
+
 // Stage 0 of the slab reduction when there are many splits: slab z <- sum of slabs {z, z+Z, z+2Z, ...} (in place,
 // element-wise, float4, fixed order), so that the transposing kernel below only has Z <= 16 slabs left to add.
 __global__ __launch_bounds__(256) void wgrad_prereduce_kernel(float* __restrict__ partial, int nsplit, int Z, size_t E4, size_t group_stride = 0) {
@@ -444,12 +449,9 @@ __global__ __launch_bounds__(256) void wgrad_prereduce_kernel(float* __restrict_
 }
 
 // db[c] = alpha * sum over splits (and over the 4 (a,b) column groups for the transposed conv); one wave per output
-__global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ bp, int nsplit, int Cout, int fold, float alpha,
-                                                                float* __restrict__ db, size_t group_stride_bp = 0, size_t group_stride_db = 0) {
-    bp += blockIdx.z * group_stride_bp;
-    db += blockIdx.z * group_stride_db;
+__device__ __forceinline__ void wg_bias_body(const float* __restrict__ bp, int nsplit, int Cout, int fold, float alpha, float* __restrict__ db, int bx) {
     const int cq = Cout / fold;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int c = bx * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (c >= cq) return;
     float s = 0.f;
@@ -459,6 +461,63 @@ __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __r
     }
     s = wave_sum(s);
     if (lane == 0) db[c] = alpha * s;
+}
+
+__global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ bp, int nsplit, int Cout, int fold, float alpha,
+                                                                float* __restrict__ db, size_t group_stride_bp = 0, size_t group_stride_db = 0) {
+    wg_bias_body(bp + blockIdx.z * group_stride_bp, nsplit, Cout, fold, alpha, db + blockIdx.z * group_stride_db, blockIdx.x);
+}
+
+// ---- batched slab reduction (round 4): the three small kernels per layer (prereduce, transposing reduce, bias reduce: 16 + 21 + 5 us each, 59 launches = 0.83 ms of a
+// 2-D step) become TWO launches per group of layers (MisWgradDesc.defer + mis_wgrad_reduce_batch): the blocks of all layers of the group run side by side.  Same
+// arithmetic and summation order per layer as the single-layer kernels.
+constexpr int WRB_MAX = 16;
+struct WgRedIt {
+    float* partial;
+    float* dw;
+    const float* bias_partial;
+    float* dbias;
+    int nsplit, nslab, Z, TT, Cin, Cout, layout, tsplit, fold, nbx, nby;
+    float alpha;
+    unsigned E4, nbE;
+    int pre0, red0, bias0;          // first block of this item in the prereduce launch / in the reduce launch (transposing blocks, then bias blocks)
+};
+struct WgRedBatch {
+    int n;
+    WgRedIt it[WRB_MAX];
+};
+
+__global__ __launch_bounds__(256) void wgrad_prereduce_batch_kernel(const WgRedBatch b) {
+    const int bid = blockIdx.x;
+    int i = 0;
+    while (i + 1 < b.n && bid >= b.it[i + 1].pre0) ++i;          // block-uniform
+    const WgRedIt& t = b.it[i];
+    const unsigned local = (unsigned)(bid - t.pre0);
+    const int z = (int)(local / t.nbE);
+    const size_t e = (size_t)(local - (unsigned)z * t.nbE) * 256 + threadIdx.x;
+    if (e >= t.E4) return;
+    float4* p4 = reinterpret_cast<float4*>(t.partial);
+    float4 s = p4[(size_t)z * t.E4 + e];
+    for (int k = z + t.Z; k < t.nsplit; k += t.Z) {
+        const float4 v = p4[(size_t)k * t.E4 + e];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    p4[(size_t)z * t.E4 + e] = s;
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgRedBatch b) {
+    __shared__ float tile[32][9][33];
+    const int bid = blockIdx.x;
+    int i = 0;
+    while (i + 1 < b.n && bid >= b.it[i + 1].red0) ++i;
+    const WgRedIt& t = b.it[i];
+    if (bid >= t.bias0) {
+        wg_bias_body(t.bias_partial, t.nsplit, t.Cout, t.fold, t.alpha, t.dbias, bid - t.bias0);
+        return;
+    }
+    const int local = bid - t.red0;
+    const int tz = local / (t.nbx * t.nby), r = local - tz * (t.nbx * t.nby);
+    wg_reduce_body(tile, t.partial, t.nslab, t.TT, t.Cin, t.Cout, t.dw, t.layout, t.alpha, r % t.nbx, r / t.nbx, tz, t.tsplit);
 }
 
 // dw = sum over samples of the per-sample gradients (fixed order)
@@ -529,6 +588,15 @@ extern "C" size_t mis_wgrad_workspace_bytes(const MisWgradDesc* d) {
 // Everything after the MFMA kernel: order the reduction stream behind it, sum the split-K slabs in a fixed order, convert to the reference layout,
 // reduce the bias column sums.  Shared by wgrad_kernel and wgrad_pp_kernel.
 static int wg_finish(const MisWgradDesc* d, const WgPlan& p, float* bias_partial, hipStream_t stream) {
+    if (d->defer != nullptr) {          // the caller reduces a group of layers at once (mis_wgrad_reduce_batch): the slabs stay in d->workspace until then
+        MisWgradReduceItem* it = d->defer;
+        it->partial = d->workspace;
+        it->dw = d->dw;
+        it->bias_partial = d->dbias != nullptr ? bias_partial : nullptr;
+        it->dbias = d->dbias;
+        it->nsplit = p.nsplit; it->TT = p.TT; it->Cin = d->Cin; it->Cout = d->Cout; it->dw_layout = d->dw_layout; it->alpha = d->alpha;
+        return MIS_OK;
+    }
     if (d->reduce_stream != nullptr && d->reduce_stream != (void*)stream) {   // reductions go to the side stream, after the MFMA kernel
         // Order the reduction stream behind the MFMA kernel with an event from a process-lifetime ring (per thread; never destroyed while work may reference it).
         // Round 2 replaced the ring by create / record / wait / destroy per call on the strength of an experiment that did not exercise this path;
@@ -597,6 +665,50 @@ static int wg_finish(const MisWgradDesc* d, const WgPlan& p, float* bias_partial
                            (const float*)bias_partial, p.nsplit, d->Cout, fold, d->alpha, d->dbias);
         MIS_LAUNCH_CHECK("wgrad_bias_reduce");
     }
+    return MIS_OK;
+}
+
+extern "C" int mis_wgrad_reduce_batch(const MisWgradReduceItem* items, int n, void* stream_) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(items != nullptr && n > 0 && n <= WRB_MAX, MIS_EINVAL, "wgrad_reduce_batch: 1..%d items", WRB_MAX);
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    WgRedBatch b;
+    b.n = n;
+    long long pre = 0, red = 0;
+    for (int i = 0; i < n; ++i) {
+        const MisWgradReduceItem& m = items[i];
+        MIS_REQUIRE(m.partial != nullptr && m.dw != nullptr && m.nsplit > 0 && m.TT > 0 && m.Cin > 0 && m.Cout > 0 && m.Cin % 32 == 0 && m.Cout % 32 == 0, MIS_EINVAL,
+                    "wgrad_reduce_batch: item %d", i);
+        MIS_REQUIRE(m.dw_layout == 0 || (m.dw_layout == 1 && m.TT == 1 && m.Cout % 4 == 0), MIS_EINVAL, "wgrad_reduce_batch: item %d layout", i);
+        MIS_REQUIRE(m.dbias == nullptr || m.bias_partial != nullptr, MIS_EINVAL, "wgrad_reduce_batch: item %d bias partials", i);
+        WgRedIt& t = b.it[i];
+        t.partial = m.partial; t.dw = m.dw; t.bias_partial = m.bias_partial; t.dbias = m.dbias;
+        t.nsplit = m.nsplit; t.TT = m.TT; t.Cin = m.Cin; t.Cout = m.Cout; t.layout = m.dw_layout; t.alpha = m.alpha;
+        const size_t E = (size_t)m.TT * m.Cin * m.Cout;
+        MIS_REQUIRE(E / 4 < (1ull << 32), MIS_EUNSUPPORTED, "wgrad_reduce_batch: item %d too large", i);
+        t.E4 = (unsigned)(E / 4);
+        t.nbE = (t.E4 + 255) / 256;
+        t.Z = 4;                                               // as wg_finish: more than 4 slabs are first summed down to 4, element-wise
+        t.nslab = m.nsplit > 4 ? 4 : m.nsplit;
+        t.pre0 = (int)pre;
+        if (m.nsplit > 4) pre += (long long)t.nbE * t.Z;
+        t.nbx = (m.Cout + 31) / 32; t.nby = (m.Cin + 31) / 32;
+        const int tiles2 = t.nbx * t.nby;
+        t.tsplit = m.dw_layout != 0 || m.TT == 1 ? 1 : (tiles2 * 4 <= 256 ? m.TT : ((m.TT == 27 && tiles2 * 4 <= 768) ? 3 : 1));
+        t.fold = m.dw_layout == 1 ? 4 : 1;
+        t.red0 = (int)red;
+        red += (long long)tiles2 * t.tsplit;
+        t.bias0 = (int)red;
+        if (m.dbias != nullptr) red += (m.Cout / t.fold + 3) / 4;
+        MIS_REQUIRE(pre < (1ll << 30) && red < (1ll << 30), MIS_EUNSUPPORTED, "wgrad_reduce_batch: grid too large");
+    }
+    // items without a prereduce share the next item's first block index: the scan `bid >= it[i + 1].pre0` then skips them (their range is empty)
+    if (pre > 0) {
+        hipLaunchKernelGGL(wgrad_prereduce_batch_kernel, dim3((unsigned)pre), dim3(256), 0, stream, b);
+        MIS_LAUNCH_CHECK("wgrad_prereduce_batch");
+    }
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)red), dim3(256), 0, stream, b);
+    MIS_LAUNCH_CHECK("wgrad_reduce_batch");
     return MIS_OK;
 }
 
@@ -674,6 +786,7 @@ extern "C" int mis_wgrad(const MisWgradDesc* d, void* stream) {
     MIS_REQUIRE(d->dw_per_sample == nullptr || (p.pp && d->dw_layout == 0 && wgrad_pp_splits_per_sample(d) > 0 && p.nsplit % d->N == 0), MIS_EUNSUPPORTED,
                 "wgrad: per-sample gradients need the bf16 3x3 / 3x3x3 ping-pong path (layout 0)");
     MIS_REQUIRE(d->dbias_per_sample == nullptr || d->dw_per_sample != nullptr, MIS_EINVAL, "wgrad: dbias_per_sample needs dw_per_sample");
+    MIS_REQUIRE(d->defer == nullptr || (d->dw_per_sample == nullptr && d->reduce_stream == nullptr), MIS_EINVAL, "wgrad: defer excludes dw_per_sample / reduce_stream");
     if (p.pp) {
         g_wgrad_last_nsplit = p.nsplit;
         float* bias_partial = (d->dbias != nullptr || d->dbias_per_sample != nullptr) ? d->workspace + (size_t)p.nsplit * p.TT * d->Cin * d->Cout : nullptr;

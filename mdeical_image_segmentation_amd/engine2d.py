@@ -110,6 +110,10 @@ class UNet2DEngine:
         # wgrad's slab reductions can run on a second stream under the following dgrad kernel (MISAMD_SIDE_REDUCE=1).  Off by default since round 2: with
         # one slab per persistent block the reductions are small, and the measured step is the same either way (817.2 vs 817.4 img/s) - one stream less to order.
         self.side_reduce = os.environ.get("MISAMD_SIDE_REDUCE") is not None
+        # round 4: the split-K slab reductions of a whole stage (decoder level / encoder level: 1-3 layers) run as TWO launches (ops.wgrad_reduce_batch) instead of three small
+        # kernels per layer: 59 -> 20 launches, 0.83 -> 0.3 ms per step.  MISAMD_REDUCE_PER_LAYER=1: the per-layer kernels (A/B switch).
+        self.batch_reduce = not self.side_reduce and os.environ.get("MISAMD_REDUCE_PER_LAYER") is None
+        self._red = []
         self.dtype = dtype
         self.device = torch.device(device)
         self.specs = unet2d_param_specs(in_channels, out_channels)
@@ -299,9 +303,12 @@ class UNet2DEngine:
         b = self.rb.get(key)
         return dict(mask=t) if b is None else dict(mask_bits=b)
 
+    def _defer(self, name):
+        return dict(defer=self._red, ws_tag=f"{id(self)}:{name}") if self.batch_reduce else {}
+
     def _bwd_conv(self, x, dy, name, cin, cout, dx=None, mask=None, dx1=None, cout0=None, dx_mode=OUT_PLAIN):
         """grads of y = relu(conv3x3(x) + b) given dy = dL/d(pre-activation); mask: (activation, key of its ReLU bits) of the layer below."""
-        ops.wgrad(x, dy, self.G[name + ".weight"], ksize=3, Cin=cin, Cout=cout, dbias=self.G[name + ".bias"], side=self.side_reduce)
+        ops.wgrad(x, dy, self.G[name + ".weight"], ksize=3, Cin=cin, Cout=cout, dbias=self.G[name + ".bias"], side=self.side_reduce, **self._defer(name))
         if dx is not None:
             ops.conv_igemm(dy, self.wd_[name], dx, ksize=3, Cin=cout, Cout=cin, y0_mode=dx_mode, y1=dx1,
                            Cout0=cout0, **({} if mask is None else self._mask(*mask)))
@@ -311,6 +318,8 @@ class UNet2DEngine:
         stage_cb(module_prefixes) is called as soon as the gradients of those modules have been enqueued
         (used by ddp.GradReducer to start their all-reduce while the rest of backward still runs)."""
         def cb(names):
+            if self._red:
+                ops.wgrad_reduce_batch(self._red)          # the stage's weight gradients: their slabs summed by two launches
             if stage_cb is not None:
                 ops.wgrad_join(self.device)      # the stage's weight gradients are final only after their side-stream reductions
                 stage_cb(names)
@@ -328,7 +337,7 @@ class UNet2DEngine:
                            cout0=c, dx_mode=OUT_UNSHUFFLE2)
             up = f"up_sample.{j}.up"
             ops.wgrad(x_in, self.dys[j], self.G[up + ".weight"], ksize=1, Cin=2 * c, Cout=4 * c, dw_layout=1,
-                      dbias=self.G[up + ".bias"], side=self.side_reduce)
+                      dbias=self.G[up + ".bias"], side=self.side_reduce, **self._defer(up))
             ops.conv_igemm(self.dys[j], self.wd_[up], g_in, ksize=1, Cin=4 * c, Cout=2 * c, **self._mask(x_in, "m2" if j == 0 else ("u2", j - 1)))
             cb([f"up_conv.{j}", f"up_sample.{j}"])
         self._bwd_conv(self.m1, self.g_m2, "middle_conv.second", 1024, 1024, dx=self.g_m1, mask=(self.m1, "m1"))

@@ -7,7 +7,7 @@ import os as _os
 import torch
 
 from . import _lib
-from ._lib import (MIS_BF16, MIS_F32, OUT_PLAIN, OUT_SHUFFLE2, OUT_UNSHUFFLE2, ConvDesc, HeadDesc, MisError, WgradDesc, check,
+from ._lib import (MIS_BF16, MIS_F32, OUT_PLAIN, OUT_SHUFFLE2, OUT_UNSHUFFLE2, ConvDesc, HeadDesc, MisError, WgradDesc, WgradReduceItem, check,
                    dtype_code, load, stream_ptr)
 
 
@@ -214,9 +214,21 @@ def wgrad_join(device=None):
         torch.cuda.current_stream(dev).wait_stream(st["stream"])
 
 
+def wgrad_reduce_batch(items):
+    """reduce the split-K slabs of the weight gradients deferred into `items` (wgrad(..., defer=items)): two launches per 16 layers; empties the list"""
+    lib = load()
+    for i in range(0, len(items), 16):
+        chunk = items[i:i + 16]
+        arr = (WgradReduceItem * len(chunk))(*chunk)
+        check(lib.mis_wgrad_reduce_batch(arr, len(chunk), stream_ptr()), "mis_wgrad_reduce_batch")
+    del items[:]
+
+
 def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alpha=1.0, in_scale=None, in_shift=None, dbias=None, side=False,
-          dw_per_sample=None, dbias_per_sample=None):
-    """side=True: the reduction kernels go to a second stream (see _SideReduce); the caller must call wgrad_join() before using dw."""
+          dw_per_sample=None, dbias_per_sample=None, defer=None, ws_tag=None):
+    """side=True: the reduction kernels go to a second stream (see _SideReduce); the caller must call wgrad_join() before using dw.
+    defer=list: only the MFMA kernel runs; the slab reduction is described by an item appended to the list and done for a group of layers by wgrad_reduce_batch(list)
+    (the slabs live in a workspace of this layer's own, `ws_tag`, until then)."""
     lib = load()
     x0 = _v(x0)
     dy = _v(dy)
@@ -255,6 +267,12 @@ def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alph
         if st["events"][slot] is not None:            # the reduction that last read this workspace must be done
             torch.cuda.current_stream(dy.t.device).wait_event(st["events"][slot])
         d.reduce_stream = st["stream"].cuda_stream
+    elif defer is not None:
+        if ws_tag is None:
+            raise MisError("wgrad(defer=...): ws_tag (a workspace of the layer's own) is required")
+        ws = workspace(need, dy.t.device, "wgrad:" + ws_tag)
+        item = WgradReduceItem()
+        d.defer = C.addressof(item)
     else:
         ws = workspace(need, dy.t.device, "wgrad")
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
@@ -267,6 +285,8 @@ def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alph
         ev = torch.cuda.Event()
         ev.record(st["stream"])
         st["events"][slot] = ev
+    if defer is not None:
+        defer.append(item)
 
 
 def first_conv_fwd(x_nchw, w, bias, y, relu_bits=None):

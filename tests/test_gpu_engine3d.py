@@ -214,16 +214,22 @@ def test_bf16_engine3d_close():
     assert rel < 0.08
     assert abs(loss.item() - float(g["loss"])) < 3e-3
     assert abs(loss.item() - el.item()) < 1e-3
-    rels = {n: _rel(eng.Gr[n].cpu(), g16[n]) for n in g16 if n != "encoders.0.basic_module.SingleConv1.groupnorm.weight"}
-    worst = max(rels.items(), key=lambda kv: kv[1])
-    print(f"bf16 3-D: gradients vs the bf16-storage oracle, rel-L2: final_conv.weight {rels['final_conv.weight']:.3g}, worst {worst[1]:.3g} ({worst[0]})")
-    print("bf16 3-D: all tensors, worst first: " + ", ".join(f"{k.replace('.basic_module', '')} {v:.3g}" for k, v in sorted(rels.items(), key=lambda kv: -kv[1])))
+    # Gradients, per tensor (no blanket bar).  bf16 STORAGE alone moves this net's gradients by 1-50 % (the pinned fp32 oracle against the same oracle
+    # with bf16 rounding at the engine's tensor boundaries: no device code; the error compounds through every GroupNorm backward on the way down, see
+    # test_bf16_engine3d_every_layer_replayed for the tight per-layer statement), so two CORRECT bf16 pipelines differ from each other by about that much: every tensor
+    # of the engine must be within 1.25 x its own storage noise (+ 5e-3) of the bf16-storage oracle.  Measured (round 4): worst error / bar = 0.78 (encoders.1 SingleConv2 groupnorm.weight: 0.375 against a storage noise of 0.382), final_conv.weight 4.3e-3.
+    # The 1-channel GroupNorm weight of the very first layer is excluded by name: its gradient is a difference of nearly equal sums (storage noise 1e3 relative).
+    _, _, g32 = o3.loss_and_grads(p, T(g["x"]), T(g["t"]))
+    skip = "encoders.0.basic_module.SingleConv1.groupnorm.weight"
+    rels = {n: _rel(eng.Gr[n].cpu(), g16[n]) for n in g16 if n != skip}
+    noise = {n: _rel(g16[n], g32[n]) for n in rels}
+    ratio = {n: rels[n] / (1.25 * noise[n] + 5e-3) for n in rels}
+    worst = max(ratio.items(), key=lambda kv: kv[1])
+    print(f"bf16 3-D: gradients vs the bf16-storage oracle, rel-L2: final_conv.weight {rels['final_conv.weight']:.3g}, largest {max(rels.values()):.3g}; "
+          f"worst (error / (1.25 x storage noise + 5e-3)) = {worst[1]:.2f} ({worst[0]}: {rels[worst[0]]:.3g} vs noise {noise[worst[0]]:.3g})")
     assert rels["final_conv.weight"] < 2e-2 and rels["final_conv.bias"] < 2e-2
-    # measured on MI355X (round 3): see DESIGN.md §4; the bar sits at ~2x the measurement
-    assert worst[1] < BF16_3D_GRAD_BAR, worst
-
-
-BF16_3D_GRAD_BAR = 0.6          # measured on MI355X (round 3): worst 0.286 (encoders.0 SingleConv2 groupnorm.bias), final_conv.weight 4.3e-3
+    for n in rels:
+        assert ratio[n] <= 1.0, (n, rels[n], noise[n])
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
