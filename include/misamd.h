@@ -73,6 +73,12 @@ typedef struct MisConvDesc {
      * at 1/16 of its traffic.  Both NULL by default. */
     void* relu_bits;
     const void* mask_bits;
+    /* GroupNorm backward in the epilogue (round 4; bf16 3x3x3 on the ping-pong kernels, single source): with gn_p != NULL the launch is the dgrad of a 'gcr' SingleConv
+     * CONTINUED through the GroupNorm in front of the convolution and the ReLU that produced its input (model/unet3d/buildingblocks.py:87-92):
+     *     out = [gn_relu: (x > 0) *] ( gn_p[n][col] * acc + gn_q[n][col] * x + gn_r[n][col] ),     x = mask[pixel][col]  (`mask` / `mask_ld`: the tensor the GroupNorm read)
+     * with p / q / r the [N][gn_ld] fp32 tables of mis_gn_bwd_finalize - dL/d(normalised operand) is never written and mis_gn_bwd_apply's pass (3 tensors) disappears.
+     * Columns [Cout0, Cout) are DROPPED when y1 == NULL (padding channels of the operand: here Cout0 may be any multiple of 32). */
+    const float* gn_p; const float* gn_q; const float* gn_r; int gn_ld; int gn_relu;
 } MisConvDesc;
 int mis_conv_igemm(const MisConvDesc* d, void* stream);
 /* Name of the kernel configuration the calling thread's last mis_conv_igemm ran, e.g. "k3.2d.bn256.dma" (diagnostic: the parity tests assert
@@ -250,6 +256,12 @@ size_t mis_gn_bwd_stats_from_dw_workspace_bytes(int N, int Cout);
 int mis_gn_bwd_stats_from_dw(int dtype, const void* gy, int gy_ld, int N, int D, int H, int W, int Cout, const float* w, const float* dw_per_sample, int Cw,
                              const float* gy_colsum_per_sample, const float* scale, const float* shift, int sld, const float* mean, int groups, int Cs,
                              float* workspace, float* S1, float* S2, void* stream);
+/* Conditioning guard of mis_gn_bwd_stats_from_dw: flags[l] = 1 when any channel c of GroupNorm layer l has |gamma[c]| < ratio * |beta[c]| (gamma = params + gamma_off[l],
+ * beta = params + beta_off[l], count[l] channels; host arrays, nlayers <= 32).  There the normalised bf16 operand carries too little of x for the route through the weight
+ * gradient (its error grows like |beta / gamma| * 2^-9): the caller sends such a layer through mis_gn_bwd_stats instead.  One launch, device-side flags, no synchronisation. */
+int mis_gn_cond(const float* params, const unsigned long long* gamma_off, const unsigned long long* beta_off, const int* count, int nlayers, float ratio, int* flags,
+                void* stream);
+
 int mis_gn_bwd_finalize(const float* S1, const float* S2, const float* mean, const float* rstd, const float* gamma, int N, int C, int G,
                         double count, float* p, float* q, float* r, float* dgamma, float* dbeta, void* stream);
 /* dx = (p*sum_children(dy) + mult*(q*x + r)) [* (x > 0)] [+ add] for one source */

@@ -23,7 +23,7 @@ EXPORTS = [
     "mis_pack_conv_weight", "mis_pack_convt_weight", "mis_pack_batch", "mis_head_workspace_bytes", "mis_head_loss",
     "mis_adamw_workspace_bytes", "mis_sumsq", "mis_adamw_step", "mis_adamw_step_dev", "mis_sumsq_npartials",
     "mis_chanstats_workspace_bytes", "mis_chanstats", "mis_nchw_to_nhwc", "mis_nhwc_to_nchw", "mis_probe_mfma",
-    "mis_gn_fwd_finalize", "mis_gn_bwd_stats_workspace_bytes", "mis_gn_bwd_stats", "mis_gn_bwd_stats_from_dw_workspace_bytes", "mis_gn_bwd_stats_from_dw", "mis_gn_bwd_finalize", "mis_gn_bwd_apply",
+    "mis_gn_fwd_finalize", "mis_gn_bwd_stats_workspace_bytes", "mis_gn_bwd_stats", "mis_gn_bwd_stats_from_dw_workspace_bytes", "mis_gn_bwd_stats_from_dw", "mis_gn_cond", "mis_gn_bwd_finalize", "mis_gn_bwd_apply",
     "mis_first3d_fwd", "mis_first3d_bwd_workspace_bytes", "mis_first3d_bwd", "mis_relu_mask",
     "mis_convt3_col2im", "mis_convt3_im2col", "mis_seg_metrics_workspace_bytes", "mis_seg_metrics", "mis_iou3d_counts", "mis_se_fc_fwd", "mis_se_apply_fwd", "mis_se_bwd_workspace_bytes", "mis_se_bwd_reduce", "mis_se_fc_bwd", "mis_se_bwd_apply", "mis_patch_gather_reflect", "mis_patch_accumulate", "mis_pred_finalize", "mis_bcedice_workspace_bytes", "mis_bcedice_fwd", "mis_bcedice_bwd", "mis_loss_workspace_bytes", "mis_ce3d_fwd", "mis_ce3d_bwd", "mis_pointloss_fwd", "mis_pointloss_bwd", "mis_maxpoolk_fwd", "mis_maxpoolk_bwd", "mis_bilinear_up_fwd", "mis_bilinear_up_bwd_workspace_bytes", "mis_bilinear_up_bwd", "mis_upconv_gather_fwd_workspace_bytes", "mis_upconv_gather_fwd", "mis_upconv_gather_bwd", "mis_cgm_gate", "mis_scale_sigmoid", "mis_segloss_workspace_bytes", "mis_segloss_fwd", "mis_segloss_bwd", "mis_add_act", "mis_expand1_fwd", "mis_expand1_bwd_workspace_bytes", "mis_expand1_bwd", "mis_bn_fwd_finalize", "mis_bn_bwd_finalize", "mis_affine_act", "mis_bn_bwd_stats_workspace_bytes", "mis_bn_bwd_stats", "mis_bn_bwd_apply",
     "mis_norm_act_fwd", "mis_norm_act_bwd", "mis_mask_scale", "mis_gn_fwd_finalize_ld", "mis_gn_bwd_finalize_ld", "mis_pool3d_fwd", "mis_pool3d_bwd", "mis_gather3d_fwd", "mis_gather3d_bwd",
@@ -50,6 +50,7 @@ class ConvDesc(C.Structure):
         ("y1", C.c_void_p), ("y1_ld", C.c_int), ("y1_mode", C.c_int),
         ("Cout0", C.c_int),
         ("relu_bits", C.c_void_p), ("mask_bits", C.c_void_p),
+        ("gn_p", C.c_void_p), ("gn_q", C.c_void_p), ("gn_r", C.c_void_p), ("gn_ld", C.c_int), ("gn_relu", C.c_int),
     ]
 
 
@@ -125,8 +126,9 @@ def load():
     lib.mis_dispatch_override.argtypes = [C.c_char_p, C.c_int]
     lib.mis_dispatch_switch.restype = C.c_int
     lib.mis_dispatch_switch.argtypes = [C.c_char_p]
-    lib.mis_wgrad_reduce_batch.restype = C.c_int
-    lib.mis_wgrad_reduce_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    if hasattr(lib, "mis_wgrad_reduce_batch"):          # (absent from an older build loaded through MISAMD_LIB for an A/B: scripts/ab_prev_lib.sh sets MISAMD_REDUCE_PER_LAYER=1 for it)
+        lib.mis_wgrad_reduce_batch.restype = C.c_int
+        lib.mis_wgrad_reduce_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.mis_comm_unique_id.argtypes = [C.c_void_p]
     lib.mis_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.mis_comm_world.argtypes = []
@@ -273,6 +275,7 @@ def load():
         "mis_mt_jump": [vp, i, i, i, vp, i, i, i, vp],
         "mis_mt_generate": [vp, i, ll, ll, ll, vp, ll, vp, vp, ll, vp],
         "mis_legacy_normal_par": [vp, ll, vp, vp, ll, dbl, i, dbl, vp, vp, vp],
+        "mis_gn_cond": [vp, vp, vp, vp, i, C.c_float, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

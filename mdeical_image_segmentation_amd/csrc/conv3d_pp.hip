@@ -38,6 +38,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
     char* const hbase = smem;                        // 2 x HBUF
     char* const wbase = smem + 2 * HBUF;             // 2 x WTILE
     char* const bbase = wbase + 2 * WTILE;           // 2 x BN floats
+    char* const pbase = bbase + 2 * BN * 4;          // PP_EM_GN: 2 x [3][BN] floats - p, q, r of the current / the next tile's (sample, column tile)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -151,6 +152,21 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (pp_lds_void_t*)(dst + wave * 256), 4, (col + wave * 64 + l) * 4, 0, 0, 0);
         }
     };
+    // PP_EM_GN: the GroupNorm-backward coefficients of sample n, columns col .. col + BN - 1 (MisConvDesc.gn_p / gn_q / gn_r, [N][gn_ld] floats) -> dst [3][BN]
+    auto issue_pqr = [&](int n, int col, char* dst) {
+        if constexpr (EM == PP_EM_GN) {
+            if (wave < BN / 64) {
+                int l;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+                const unsigned bytes = (unsigned)a.N * (unsigned)a.gn_ld * 4u;
+                const int c = col + wave * 64 + l;
+                const int voff = c < a.gn_ld ? (n * a.gn_ld + c) * 4 : PP_OOB;          // padding columns read as zero (their outputs are dropped anyway)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(pp_make_rsrc(a.gn_p, bytes), (pp_lds_void_t*)(dst + wave * 256), 4, voff, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(pp_make_rsrc(a.gn_q, bytes), (pp_lds_void_t*)(dst + BN * 4 + wave * 256), 4, voff, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(pp_make_rsrc(a.gn_r, bytes), (pp_lds_void_t*)(dst + 2 * BN * 4 + wave * 256), 4, voff, 0, 0, 0);
+            }
+        }
+    };
     // the three tap tiles (kh = 0..2) of depth slice dz, filter column kw, column tile col, channels c0..c0+31: one instruction per tap per wave
     auto issue_weights = [&](int dz, int kw, int col, int c0, char* dst) {
         int soff = (int)((((long long)(dz * 9 + kw) * a.Cout + col) * a.Cin + c0) * 2);
@@ -172,6 +188,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
 #pragma unroll
         for (int pf = 0; pf < PF; ++pf) acc[f][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
     issue_bias(ncol0, bbase);
+    issue_pqr(pl / a.D, ncol0, pbase);
     issue_weights(0, 0, ncol0, 0, wbase);
     if (grp == 1) issue_weights(0, 1, ncol0, 0, wbase + WTILE);       // segment 1 (in the loop group 1 issues two segments ahead)
     pp_static_for<HJ>([&](auto jc) { issue_halo(jc, pl - 1, z >= 1, h0, w0, 0, hbase); });
@@ -319,17 +336,20 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
             // the next tile's bias slice -> the other half of the bias region (last read in the previous tile's first pair); it lands under the rest of this tile's K
             // loop (nvc >= 3) and is read in the next tile's first segment
             if (has_next) issue_bias(ncolN, bbase + (bsel ^ 1) * (BN * 4));
+            if (has_next) issue_pqr(npl / a.D, ncolN, pbase + (bsel ^ 1) * (3 * BN * 4));      // (read by the NEXT tile's epilogue; this tile's sits in the other half)
 #pragma unroll 1
             for (int vc = 1; vc < nvc; ++vc) run_pair(std::false_type{}, vc);
         } else {
 #pragma unroll 1
             for (int vc = 0; vc < nvc; ++vc) run_pair(std::false_type{}, vc);
         }
-        pp_epilogue_plain<NF, PF, EM, false, BINIT>(a, acc, (uint32_t)(uintptr_t)bbase + bsel * (BN * 4), pl, h0, w0, ncol0, wm, wn, u32x4{0u, 0u, 0u, 0u});
+        pp_epilogue_plain<NF, PF, EM, false, BINIT>(a, acc, (uint32_t)(uintptr_t)bbase + bsel * (BN * 4), pl, h0, w0, ncol0, wm, wn, u32x4{0u, 0u, 0u, 0u},
+                                                    (uint32_t)(uintptr_t)pbase + bsel * (3 * BN * 4), BN * 4);
         pl = npl; z = nz; h0 = nh0; w0 = nw0; ncol0 = ncolN;
         bsel ^= 1;
         if constexpr (!BINIT) {
             if (has_next) issue_bias(ncol0, bbase + bsel * (BN * 4));
+            if (has_next) issue_pqr(pl / a.D, ncol0, pbase + bsel * (3 * BN * 4));
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -341,7 +361,11 @@ bool conv3d_pp_eligible(const MisConvDesc* d) {
     if (d->dtype != MIS_BF16 || !d->is3d || d->ksize != 3) return false;
     if (d->x1 != nullptr || d->in_scale != nullptr) return false;
     if (d->x0_D != d->D || d->x0_H != d->H || d->x0_W != d->W) return false;
-    if (d->Cin % 32 != 0 || d->Cout % 64 != 0 || d->Cout0 % 64 != 0) return false;
+    const bool gn = d->gn_p != nullptr;
+    if (d->Cin % 32 != 0 || d->Cout % 64 != 0) return false;
+    // (GroupNorm-backward epilogue: columns past Cout0 may be padding that is dropped - then Cout0 only has to be a multiple of a 64-column block's wave slice)
+    if (gn ? (d->Cout0 % 32 != 0 || (d->Cout0 % 64 != 0 && (d->y1 != nullptr || d->Cout != 64))) : d->Cout0 % 64 != 0) return false;
+    if (gn && (d->gn_q == nullptr || d->gn_r == nullptr || d->mask == nullptr || d->gn_ld <= 0 || d->bias != nullptr || d->relu || (long long)d->N * d->gn_ld * 4 >= (1ll << 31))) return false;
     if (d->y0_mode != MIS_OUT_PLAIN || (d->y1 != nullptr && d->y1_mode != MIS_OUT_PLAIN)) return false;
     // 32-bit buffer offsets, computed in (signed) int: ONE depth plane of the input view and the packed weights must each span less than 2 GiB
     if ((((long long)d->H * d->W - 1) * d->x0_ld + d->Cin) * 2 >= (1ll << 31) - 65536) return false;
@@ -349,13 +373,20 @@ bool conv3d_pp_eligible(const MisConvDesc* d) {
     // pp_epilogue_plain: one depth plane of each destination view / of the mask within 32-bit buffer offsets
     const long long img = (long long)d->H * d->W, lim = (1ll << 32) - 65536;
     if (((img - 1) * d->y0_ld + d->Cout0) * 2 >= lim) return false;
-    if (d->Cout0 < d->Cout && (d->y1 == nullptr || ((img - 1) * d->y1_ld + (d->Cout - d->Cout0)) * 2 >= lim)) return false;
+    if (d->Cout0 < d->Cout && !(gn && d->y1 == nullptr) && (d->y1 == nullptr || ((img - 1) * d->y1_ld + (d->Cout - d->Cout0)) * 2 >= lim)) return false;
     if (d->mask != nullptr && ((img - 1) * d->mask_ld + d->Cout) * 2 >= lim) return false;
     return true;
 }
 
 template <int PF, int NF, int EM> static int pp3_launch_em(const MisConvDesc* d, hipStream_t stream);
-template <int PF, int NF> static int pp3_launch(const MisConvDesc* d, hipStream_t stream) {      // one instantiation per epilogue mask path (3-D: none or the bf16 mask)
+template <int PF, int NF> static int pp3_launch(const MisConvDesc* d, hipStream_t stream) {      // one instantiation per epilogue mask path (3-D: none, the bf16 mask, GroupNorm backward)
+    if (d->gn_p != nullptr) {
+        if constexpr (NF == 6) {
+            MIS_REQUIRE(false, MIS_EUNSUPPORTED, "conv_igemm(3d pp): the GroupNorm-backward epilogue is not built for 192-column blocks");
+        } else {
+            return pp3_launch_em<PF, NF, PP_EM_GN>(d, stream);
+        }
+    }
     if (d->mask != nullptr) return pp3_launch_em<PF, NF, PP_EM_MASK>(d, stream);
     return pp3_launch_em<PF, NF, PP_EM_NONE>(d, stream);
 }
@@ -370,6 +401,7 @@ template <int PF, int NF, int EM> static int pp3_launch_em(const MisConvDesc* d,
     a.w = d->w; a.bias = d->bias; a.relu = d->relu; a.mask = d->mask; a.mask_ld = d->mask_ld; a.relu_bits = nullptr; a.mask_bits = reinterpret_cast<const unsigned char*>(d->mask_bits);
     a.y0 = d->y0; a.y0_ld = d->y0_ld; a.y0_mode = d->y0_mode;
     a.y1 = d->y1; a.y1_ld = d->y1_ld; a.y1_mode = d->y1_mode;
+    a.gn_p = d->gn_p; a.gn_q = d->gn_q; a.gn_r = d->gn_r; a.gn_ld = d->gn_ld; a.gn_relu = d->gn_relu;
     a.tilesD = d->D;
     a.tilesH = (d->H + TH - 1) / TH;
     a.tilesW = (d->W + 15) / 16;
@@ -383,7 +415,7 @@ template <int PF, int NF, int EM> static int pp3_launch_em(const MisConvDesc* d,
     a.zg = zg;
     MIS_REQUIRE(nsp * a.nCt < (1ll << 31), MIS_EUNSUPPORTED, "conv_igemm(3d pp): grid too large");
     a.nSp = (int)nsp;
-    const size_t lds = 2 * (size_t)HINSTR * 1024 + 2 * (size_t)3 * BN * 64 + 2 * (size_t)BN * 4;
+    const size_t lds = 2 * (size_t)HINSTR * 1024 + 2 * (size_t)3 * BN * 64 + 2 * (size_t)BN * 4 + (EM == PP_EM_GN ? 2 * (size_t)3 * BN * 4 : 0);
     static std::atomic<unsigned long long> attr_done{0};
     if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv3d_ppc_kernel<PF, NF, EM>), lds, "conv_igemm(3d pp)")) return rc;
     const long long total = nsp * a.nCt;
@@ -396,7 +428,8 @@ int launch_conv3d_pp(const MisConvDesc* d, hipStream_t stream, const char** tag)
     // column blocks: 128 (Cout % 128 == 0), 192 (Cout % 192 == 0: the 64 -> 192 dgrad of decoders.2 in ONE column tile instead of three 64-column ones), else 64.
     // rows per tile: 20 (PF 5), 32 (PF 8) or - 64-column blocks only, the others have no registers for it - 40 (PF 10): whichever pads the H axis least, ties to the
     // taller tile (fewer fragment reads and barriers per MFMA); MIS_CONV3D_PF forces one.
-    const int nf = d->Cout % 128 == 0 ? 4 : ((d->Cout % 192 == 0 && d->Cout0 % 192 == 0) ? 6 : 2);
+    const bool gn = d->gn_p != nullptr;
+    const int nf = d->Cout % 128 == 0 ? 4 : ((d->Cout % 192 == 0 && d->Cout0 % 192 == 0 && !gn) ? 6 : 2);
     int pf = mis_sw(SW_CONV3D_PF);
     if (!(pf == 5 || (pf == 8 && nf != 6) || (pf == 10 && nf == 2))) {
         const int cand[3] = {5, 8, 10};
@@ -413,10 +446,10 @@ int launch_conv3d_pp(const MisConvDesc* d, hipStream_t stream, const char** tag)
     }
     if (nf == 4) {
         if (pf == 5) {
-            *tag = d->mask != nullptr ? "k3.3d.ppc5.mask" : "k3.3d.ppc5";
+            *tag = gn ? "k3.3d.ppc5.gn" : (d->mask != nullptr ? "k3.3d.ppc5.mask" : "k3.3d.ppc5");
             return pp3_launch<5, 4>(d, stream);
         }
-        *tag = d->mask != nullptr ? "k3.3d.ppc8.mask" : "k3.3d.ppc8";
+        *tag = gn ? "k3.3d.ppc8.gn" : (d->mask != nullptr ? "k3.3d.ppc8.mask" : "k3.3d.ppc8");
         return pp3_launch<8, 4>(d, stream);
     }
     if (nf == 6) {
@@ -424,13 +457,13 @@ int launch_conv3d_pp(const MisConvDesc* d, hipStream_t stream, const char** tag)
         return pp3_launch<5, 6>(d, stream);
     }
     if (pf == 5) {
-        *tag = d->mask != nullptr ? "k3.3d.ppc5n2.mask" : "k3.3d.ppc5n2";
+        *tag = gn ? "k3.3d.ppc5n2.gn" : (d->mask != nullptr ? "k3.3d.ppc5n2.mask" : "k3.3d.ppc5n2");
         return pp3_launch<5, 2>(d, stream);
     }
     if (pf == 8) {
-        *tag = d->mask != nullptr ? "k3.3d.ppc8n2.mask" : "k3.3d.ppc8n2";
+        *tag = gn ? "k3.3d.ppc8n2.gn" : (d->mask != nullptr ? "k3.3d.ppc8n2.mask" : "k3.3d.ppc8n2");
         return pp3_launch<8, 2>(d, stream);
     }
-    *tag = d->mask != nullptr ? "k3.3d.ppc10n2.mask" : "k3.3d.ppc10n2";
+    *tag = gn ? "k3.3d.ppc10n2.gn" : (d->mask != nullptr ? "k3.3d.ppc10n2.mask" : "k3.3d.ppc10n2");
     return pp3_launch<10, 2>(d, stream);
 }

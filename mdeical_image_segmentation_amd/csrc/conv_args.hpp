@@ -25,6 +25,10 @@ struct ConvArgs {
     unsigned char* relu_bits;          // ReLU bits of the output (relu_bits.hpp) or nullptr
     const unsigned char* mask_bits;    // ReLU bits applied to the output instead of `mask`, or nullptr
     int order, zg;     // conv3d_pp.hip: tile order (1 = column-tile major, 2 = spatial major) and depth-group size of the plane walk
+    const float* gn_p;                 // conv3d_pp.hip, PP_EM_GN: GroupNorm backward in the epilogue (MisConvDesc.gn_p ...), x = mask
+    const float* gn_q;
+    const float* gn_r;
+    int gn_ld, gn_relu;
 };
 
 extern thread_local bool g_conv_bits_fused;            // conv_igemm.hip: the launched kernel writes relu_bits itself

@@ -859,8 +859,10 @@ extern "C" int mis_conv_igemm(const MisConvDesc* d, void* stream) {
     MIS_REQUIRE(d->x0 != nullptr && d->w != nullptr && d->y0 != nullptr, MIS_EINVAL, "conv_igemm: null pointer");
     MIS_REQUIRE(d->Cin0 > 0 && d->Cin0 <= d->Cin && (d->Cin0 % CK == 0 || (pp3 && d->Cin0 == d->Cin)), MIS_EINVAL, "conv_igemm: Cin0 %d", d->Cin0);
     MIS_REQUIRE(d->Cin0 == d->Cin || d->x1 != nullptr, MIS_EINVAL, "conv_igemm: x1 missing");
-    MIS_REQUIRE(d->Cout0 > 0 && d->Cout0 <= d->Cout && d->Cout0 % 64 == 0, MIS_EINVAL, "conv_igemm: Cout0 %d", d->Cout0);
-    MIS_REQUIRE(d->Cout0 == d->Cout || d->y1 != nullptr, MIS_EINVAL, "conv_igemm: y1 missing");
+    const bool gnb = d->gn_p != nullptr;          // GroupNorm backward in the epilogue: only the 3-D ping-pong kernels carry it
+    MIS_REQUIRE(!gnb || pp3, MIS_EUNSUPPORTED, "conv_igemm: gn_p needs the bf16 3x3x3 ping-pong path (single source, q / r / mask given, no bias / ReLU)");
+    MIS_REQUIRE(d->Cout0 > 0 && d->Cout0 <= d->Cout && (d->Cout0 % 64 == 0 || (gnb && d->Cout0 % 32 == 0)), MIS_EINVAL, "conv_igemm: Cout0 %d", d->Cout0);
+    MIS_REQUIRE(d->Cout0 == d->Cout || d->y1 != nullptr || gnb, MIS_EINVAL, "conv_igemm: y1 missing");
     MIS_REQUIRE(d->x0_ld % EPC == 0 && d->y0_ld % EPC == 0, MIS_EINVAL, "conv_igemm: ld must keep 16-byte alignment");
     MIS_REQUIRE(d->x1 == nullptr || d->x1_ld % EPC == 0, MIS_EINVAL, "conv_igemm: x1_ld alignment");
     MIS_REQUIRE(d->y1 == nullptr || d->y1_ld % EPC == 0, MIS_EINVAL, "conv_igemm: y1_ld alignment");

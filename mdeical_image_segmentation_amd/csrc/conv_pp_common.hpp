@@ -146,7 +146,9 @@ __device__ __forceinline__ int pp_bits_voff(const ConvArgs& a, int n, int h0, in
 
 // EM (compile time: each kernel instantiation carries ONE mask path - with all of them in one body the 256-VGPR kernels spilled, scalars first):
 //   PP_EM_NONE no mask (the forward form; writes a.relu_bits when asked to), PP_EM_MASK a.mask (bf16 tensor), PP_EM_BITS a.mask_bits (ReLU bits)
-constexpr int PP_EM_NONE = 0, PP_EM_MASK = 1, PP_EM_BITS = 2;
+//   PP_EM_GN (conv3d_pp.hip): out = [a.gn_relu: (x > 0) *] (p * acc + q * x + r) with x = a.mask and p / q / r per (sample, column) staged in LDS at `pqr_lds`
+//   ([3][BN] floats: p, q, r of the tile's sample and column tile) - the GroupNorm backward of a 'gcr' SingleConv continued from its dgrad (MisConvDesc.gn_p)
+constexpr int PP_EM_NONE = 0, PP_EM_MASK = 1, PP_EM_BITS = 2, PP_EM_GN = 3;
 // this lane's ReLU-bits bytes of tile (n, h0, w0, ncol0) (see pp_bits_voff): the kernels issue this a K chunk before the tile's epilogue, which takes the result as `mb`
 template <int NF, int PF>
 __device__ __forceinline__ u32x4 pp_mask_bits_load(const ConvArgs& a, int n, int h0, int w0, int ncol0, int wm, int wn) {
@@ -169,8 +171,21 @@ __device__ __forceinline__ u32x4 pp_mask_bits_load(const ConvArgs& a, int n, int
 // neither adds the bias nor re-arms the accumulators (192 of its ~330 vector instructions per tile and wave).
 template <int NF, int PF, int EM, bool RB = true, bool BINIT = false>
 __device__ __forceinline__ void pp_epilogue_plain(const ConvArgs& a, f32x4 (&acc)[NF][PF], uint32_t bias_lds, int n, int h0, int w0, int ncol0, int wm, int wn,
-                                                  const u32x4& mb_pre) {
+                                                  const u32x4& mb_pre, uint32_t pqr_lds = 0u, int pqr_stride = 0) {
     constexpr int NV = 4 * NF, WAVE_N = NF * 16, NS = NF / 2;          // NS 16-byte stores per pixel
+    constexpr bool gn = EM == PP_EM_GN;
+    if constexpr (gn) {
+        // padding columns of the operand (a.Cout0 < a.Cout without a second destination): nothing to compute or store for this wave (wave-uniform)
+        if (ncol0 + wn * WAVE_N >= a.Cout0 && a.y1 == nullptr) {
+            if constexpr (!BINIT) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+#pragma unroll
+                    for (int pf = 0; pf < PF; ++pf) acc[f][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            return;
+        }
+    }
     constexpr bool BITS = RB && PF == 8 && (NF == 4 || NF == 2);        // ReLU bits: the 2-D instantiations (8-row wave tiles); RB = false: the 3-D kernels
     static_assert(EM != PP_EM_BITS || BITS, "");
     static_assert(NF % 2 == 0, "");
@@ -209,9 +224,10 @@ __device__ __forceinline__ void pp_epilogue_plain(const ConvArgs& a, f32x4 (&acc
     const int x = w0 + li;
     const int xpart = uns ? (x >> 1) * yld + (x & 1) * cview : (shf ? (2 * x + (abq & 1)) * yld : x * yld);
     const int yv = x < a.W ? (xpart + lcols + lg * 8) * 2 : PP_OOB;          // a store past num_records is dropped: the ragged right edge
-    constexpr bool masked = EM == PP_EM_MASK;
+    constexpr bool masked = EM == PP_EM_MASK || gn;          // a row of a.mask is loaded per pixel row (the ReLU mask, or the GroupNorm's input x)
+    const int mcols = (gn && a.y1 == nullptr) ? a.Cout0 : a.Cout;      // channels of the tensor behind a.mask
     const __amdgpu_buffer_rsrc_t rm = pp_make_rsrc(reinterpret_cast<const char*>(masked ? a.mask : a.y0) + (masked ? (size_t)n * img * a.mask_ld * 2 : 0),
-                                                   masked ? (unsigned)(((img - 1) * a.mask_ld + a.Cout) * 2) : 0u);      // (dead unless EM == PP_EM_MASK)
+                                                   masked ? (unsigned)(((img - 1) * a.mask_ld + mcols) * 2) : 0u);      // (dead unless a.mask is read)
     const int mv = x < a.W ? (x * a.mask_ld + colw + lg * 8) * 2 : PP_OOB;
     const unsigned yrow = (unsigned)(uns ? ow : (shf ? 2 * a.W : a.W)) * yld * 2, mrow = (unsigned)a.W * a.mask_ld * 2;
     const unsigned yodd = uns ? (unsigned)cview * 4u : 0u;                    // byte offset of the odd rows' channel blocks
@@ -241,6 +257,28 @@ __device__ __forceinline__ void pp_epilogue_plain(const ConvArgs& a, f32x4 (&acc
                 bias2[f][h] = pp_f32x2{__uint_as_float(u0), __uint_as_float(u1)};
             }
     }
+    // PP_EM_GN: p, q, r of this lane's NV columns (pairs, in the order of the accumulator pairs) out of LDS, once per tile
+    pp_f32x2 gp2[gn ? NF : 1][2], gq2[gn ? NF : 1][2], gr2[gn ? NF : 1][2];
+    if constexpr (gn) {
+        u32x4 praw[3][NF];
+        pp_static_for<NF>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            const uint32_t ad = pqr_lds + (wn * WAVE_N + lg * 8) * 4;
+            praw[0][f] = pp_lds_read128<(f >> 1) * 128 + (f & 1) * 16>(ad);
+            praw[1][f] = pp_lds_read128<(f >> 1) * 128 + (f & 1) * 16>(ad + pqr_stride);
+            praw[2][f] = pp_lds_read128<(f >> 1) * 128 + (f & 1) * 16>(ad + 2 * pqr_stride);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                gp2[f][h] = pp_f32x2{__uint_as_float(praw[0][f][2 * h]), __uint_as_float(praw[0][f][2 * h + 1])};
+                gq2[f][h] = pp_f32x2{__uint_as_float(praw[1][f][2 * h]), __uint_as_float(praw[1][f][2 * h + 1])};
+                gr2[f][h] = pp_f32x2{__uint_as_float(praw[2][f][2 * h]), __uint_as_float(praw[2][f][2 * h + 1])};
+            }
+    }
     constexpr int MG = PF % 4 == 0 ? 2 : (PF % 5 == 0 ? 5 : (PF % 2 == 0 ? 2 : 1));      // pixel rows whose mask loads are in flight together (the 2-D net masks with ReLU bits)
 #pragma unroll
     for (int pg = 0; pg < PF; pg += MG) {
@@ -263,6 +301,12 @@ __device__ __forceinline__ void pp_epilogue_plain(const ConvArgs& a, f32x4 (&acc
                 for (int h = 0; h < 2; ++h) {
                     pp_f32x2 s2 = pp_f32x2{acc[f][pf][2 * h], acc[f][pf][2 * h + 1]};
                     if constexpr (!BINIT) s2 += bias2[f][h];
+                    if constexpr (gn) {
+                        // v = fma(p, acc, fma(q, x, r)): mis_gn_bwd_apply's expression on the fp32 accumulator (that pass reads a bf16-rounded dL/dxn instead)
+                        const uint32_t xw = mk[r][f / 2][(f & 1) * 2 + h];
+                        const pp_f32x2 x2 = pp_f32x2{__uint_as_float(xw << 16), __uint_as_float(xw & 0xffff0000u)};
+                        s2 = __builtin_elementwise_fma(gp2[f][h], s2, __builtin_elementwise_fma(gq2[f][h], x2, gr2[f][h]));
+                    }
                     uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(s2, pp_bf16x2));
                     asm("v_pk_max_i16 %0, %1, %2" : "=v"(pk) : "v"(pk), "s"(lowb));
                     d[f / 2][(f & 1) * 2 + h] = pk;
@@ -271,7 +315,7 @@ __device__ __forceinline__ void pp_epilogue_plain(const ConvArgs& a, f32x4 (&acc
                 if constexpr (!BINIT) acc[f][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
             }
-            if constexpr (masked) {
+            if constexpr (masked) if (!gn || a.gn_relu) {
 #pragma unroll
                 for (int i = 0; i < NS; ++i)
 #pragma unroll

@@ -387,16 +387,31 @@ __device__ __forceinline__ void wg_reduce_body(float (&tile)[32][9][33], const f
     for (int t0 = tbeg; t0 < tend; t0 += 9) {
         const int nt = (tend - t0) < 9 ? (tend - t0) : 9;
         __syncthreads();
-        for (int t = 0; t < nt; ++t)
-            for (int r = ty; r < 32; r += 8) {
-                const int ci = ci0 + r, co = co0 + tx;
-                float s = 0.f;
-                if (ci < Cin && co < Cout) {
-                    const float* src = partial + ((size_t)(t0 + t) * Cin + ci) * Cout + co;
-                    for (int k = 0; k < nsplit; ++k) s += src[(size_t)k * slab];
-                }
-                tile[r][t][tx] = s * alpha;
+        for (int t = 0; t < nt; ++t) {
+            // the four rows of this thread x up to four slabs: every load issued before the first add (round 4: one load in flight per thread made these small kernels
+            // latency-bound, ~20-40 us each); more than four slabs (callers prereduce down to four) continue in the same order
+            float v[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ci = ci0 + ty + 8 * j, co = co0 + tx;
+                const bool ok = ci < Cin && co < Cout;
+                const float* src = partial + ((size_t)(t0 + t) * Cin + ci) * Cout + co;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[j][k] = (ok && k < nsplit) ? src[(size_t)k * slab] : 0.f;
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ci = ci0 + ty + 8 * j, co = co0 + tx;
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s += v[j][k];          // (absent slabs contribute +0.f: the same value as the loop over nsplit)
+                if (nsplit > 4 && ci < Cin && co < Cout) {
+                    const float* src = partial + ((size_t)(t0 + t) * Cin + ci) * Cout + co;
+                    for (int k = 4; k < nsplit; ++k) s += src[(size_t)k * slab];
+                }
+                tile[ty + 8 * j][t][tx] = s * alpha;
+            }
+        }
         __syncthreads();
         if (layout == 0) {
             // dw[co][ci][tap]: for one co, (ci, tap) is contiguous: 32*nt floats per co row of this tile
@@ -441,7 +456,15 @@ __global__ __launch_bounds__(256) void wgrad_prereduce_kernel(float* __restrict_
     if (i >= E4) return;
     float4* p4 = reinterpret_cast<float4*>(partial);
     float4 s = p4[(size_t)z * E4 + i];
-    for (int k = z + Z; k < nsplit; k += Z) {
+    int k = z + Z;
+    for (; k + 7 * Z < nsplit; k += 8 * Z) {          // eight independent loads in flight, added in slab order
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p4[(size_t)(k + u * Z) * E4 + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; k < nsplit; k += Z) {
         const float4 v = p4[(size_t)k * E4 + i];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -497,12 +520,22 @@ __global__ __launch_bounds__(256) void wgrad_prereduce_batch_kernel(const WgRedB
     const size_t e = (size_t)(local - (unsigned)z * t.nbE) * 256 + threadIdx.x;
     if (e >= t.E4) return;
     float4* p4 = reinterpret_cast<float4*>(t.partial);
-    float4 s = p4[(size_t)z * t.E4 + e];
-    for (int k = z + t.Z; k < t.nsplit; k += t.Z) {
-        const float4 v = p4[(size_t)k * t.E4 + e];
+    const size_t E4 = t.E4;
+    const int Z = t.Z, nsplit = t.nsplit;
+    float4 s = p4[(size_t)z * E4 + e];
+    int k = z + Z;
+    for (; k + 7 * Z < nsplit; k += 8 * Z) {          // eight independent loads in flight, added in slab order (as wgrad_prereduce_kernel)
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p4[(size_t)(k + u * Z) * E4 + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; k < nsplit; k += Z) {
+        const float4 v = p4[(size_t)k * E4 + e];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    p4[(size_t)z * t.E4 + e] = s;
+    p4[(size_t)z * E4 + e] = s;
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgRedBatch b) {

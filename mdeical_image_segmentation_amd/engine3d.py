@@ -115,6 +115,10 @@ class UNet3DEngine:
         # ... and with xn at hand the GroupNorm backward statistics (sum dyn, sum dyn * x per sample and channel) follow from the per-sample weight gradients and the
         # border sums of g_y (mis_gn_bwd_stats_from_dw) instead of a pass over dyn and x (2 x 1-3 GB per full-resolution layer).  MISAMD_GN_STATS_KERNEL=1: that pass.
         self.gn_from_dw = self.materialize and os.environ.get("MISAMD_GN_STATS_KERNEL") is None
+        # ... and with the statistics known BEFORE the dgrad runs, the single-source layers (10 of 13) continue their dgrad through the GroupNorm and the ReLU in its
+        # epilogue (MisConvDesc.gn_p, round 4): dx = mask * (p * acc + q * x + r) straight from the fp32 accumulator - dL/d(normalised operand) is never written and
+        # mis_gn_bwd_apply's pass over three tensors disappears.  MISAMD_GN_BWD_UNFUSED=1: the separate pass (A/B switch; the two-source decoder layers always take it).
+        self.fuse_gn_bwd = self.gn_from_dw and os.environ.get("MISAMD_GN_BWD_UNFUSED") is None
         self.levels = len(f_maps)
         self.specs = unet3d_param_specs(in_channels, out_channels, f_maps, upsample)
         self.flat = FlatParams(self.specs, self.device, lambda n: not n.endswith("bias"))
@@ -167,7 +171,20 @@ class UNet3DEngine:
         self.gradnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.loss_buf = torch.zeros(32, dtype=torch.float32, device=self.device)
         self._shape = None
+        # conditioning guard of the statistics-from-dW route (csrc/groupnorm.hip: mis_gn_cond): a layer with a channel whose |gamma| < GN_COND_RATIO * |beta| takes
+        # the direct pass over dyn and x (and the unfused GroupNorm backward) instead.  The flags are computed on the device after every optimizer step and read back
+        # asynchronously (pinned buffer + event): a backward pass uses the newest flags that have ARRIVED - at most a step or two old, which the margin of the ratio covers
+        # (the direct route is exact at any ratio; the route through dW is within ~2^-9 / GN_COND_RATIO of it at the threshold).
+        self._gn_layers = [s for s in self.sc.values() if not s.first]
+        for s in self._gn_layers:
+            s.gn_direct = False
+        if self.gn_from_dw:
+            self._gn_tab = ops.GnCondTable(self.flat.p, [(self.P[s.name + ".groupnorm.weight"], self.P[s.name + ".groupnorm.bias"]) for s in self._gn_layers])
+            self._gn_flags = torch.zeros(len(self._gn_layers), dtype=torch.int32, device=self.device)
+            self._gn_flags_host = torch.zeros(len(self._gn_layers), dtype=torch.int32).pin_memory()
+            self._gn_flags_ev = None
         self.repack()
+        self.refresh_gn_flags(sync=True)
 
     # ---- parameters ------------------------------------------------------------------------------------
     def state_dict(self):
@@ -180,6 +197,28 @@ class UNet3DEngine:
                 raise MisError(f"{n}: shape {tuple(t.shape)} != {s}")
             self.P[n].copy_(t.to(torch.float32))
         self.repack()
+        self.refresh_gn_flags(sync=True)
+
+    GN_COND_RATIO = 2.0 ** -4
+
+    def refresh_gn_flags(self, sync=False):
+        """recompute which layers need the direct GroupNorm-backward statistics (see __init__); sync=True: wait for the result (construction, load_state_dict)"""
+        if not self.gn_from_dw:
+            return
+        ops.gn_cond(self._gn_tab, self.GN_COND_RATIO, self._gn_flags)
+        self._gn_flags_host.copy_(self._gn_flags, non_blocking=True)
+        self._gn_flags_ev = torch.cuda.Event()
+        self._gn_flags_ev.record(torch.cuda.current_stream(self.device))
+        if sync:
+            self._gn_flags_ev.synchronize()
+            self._poll_gn_flags()
+
+    def _poll_gn_flags(self):
+        ev = getattr(self, "_gn_flags_ev", None)
+        if ev is not None and not torch.cuda.is_current_stream_capturing() and ev.query():
+            self._gn_flags_ev = None
+            for s, f in zip(self._gn_layers, self._gn_flags_host.tolist()):
+                s.gn_direct = bool(f)
 
     def repack(self):
         """fp32 master weights -> the packed MFMA operands of every SingleConv in ONE launch (mis_pack_batch: the flat parameter buffer and the operand buffers never
@@ -411,7 +450,7 @@ class UNet3DEngine:
         x0v = View(src0, 0, src0.shape[-1] if src1 is None else c0)
         x1v = None if src1 is None else View(src1, 0, c1)
         dw = self.Gr[s.name + ".conv.weight"] if s.dwpad is None else s.dwpad
-        from_dw = s.xn is not None and getattr(s, "dwn", None) is not None
+        from_dw = s.xn is not None and getattr(s, "dwn", None) is not None and not s.gn_direct
         if s.xn is not None:
             # (per-sample gradients feed this layer's GroupNorm backward right after the dgrad: their reductions stay on the main stream - ~75 MB of slabs per layer -
             #  a side-stream reduction is starved by the persistent dgrad kernel and would be waited for)
@@ -422,9 +461,17 @@ class UNet3DEngine:
                       side=self.side_reduce and s.dwpad is None)
         if s.dwpad is not None:
             self.Gr[s.name + ".conv.weight"].copy_(s.dwpad[:, :s.cin])
+        ctot = c0 + c1
+        if from_dw and self.fuse_gn_bwd and src1 is None and add0 is None:
+            ops.gn_bwd_stats_from_dw(g_y, self.P[s.name + ".conv.weight"] if s.wpad is None else s.wpad, s.dwn, s.gysum, s.scale, s.shift, s.mean, s.groups, ctot,
+                                     s.S1, s.S2)
+            ops.gn_bwd_finalize(s.S1, s.S2, s.mean, s.rstd, self.P[s.name + ".groupnorm.weight"], N, ctot, s.groups, D * H * W,
+                                s.p, s.q, s.r, self.Gr[s.name + ".groupnorm.weight"], self.Gr[s.name + ".groupnorm.bias"])
+            ops.conv_igemm(g_y, s.wd, View(dx0, 0, c0), ksize=3, Cin=s.cout, Cout=s.cin_pad, Cout0=c0, grid=grid, mask=View(src0, 0, c0),
+                           gn_bwd=(s.p, s.q, s.r, mask0))
+            return
         dyn = self.dyn[(self._level(s.name), s.cin_pad)]
         ops.conv_igemm(g_y, s.wd, dyn, ksize=3, Cin=s.cout, Cout=s.cin_pad, grid=grid)
-        ctot = c0 + c1
         if from_dw:
             ops.gn_bwd_stats_from_dw(g_y, self.P[s.name + ".conv.weight"] if s.wpad is None else s.wpad, s.dwn, s.gysum, s.scale, s.shift, s.mean, s.groups, ctot,
                                      s.S1, s.S2)
@@ -451,6 +498,7 @@ class UNet3DEngine:
     def backward(self, stage_cb=None):
         cb = self._stage_cb(stage_cb)
         L = self.levels
+        self._poll_gn_flags()
         cb(["final_conv"])
         for j in range(L - 2, -1, -1):
             l = L - 2 - j
@@ -517,6 +565,7 @@ class UNet3DEngine:
         ops.adamw_step(f.p[:nd], f.g[:nd], f.m[:nd], f.v[:nd], weight_decay=self.wd, gradnorm_out=self.gradnorm, **common)
         ops.adamw_step(f.p[nd:], f.g[nd:], f.m[nd:], f.v[nd:], weight_decay=0.0, **common)
         self.repack()
+        self.refresh_gn_flags()
 
     def train_step(self, x, target, lr=None):
         loss, _, _ = self.forward(x, target, train=True)

@@ -86,9 +86,11 @@ class _Timed:
 
 
 def conv_igemm(x0, w_packed, y0, *, ksize, Cin, Cout, grid=None, x1=None, bias=None, relu=False, mask=None,
-               y0_mode=OUT_PLAIN, y1=None, y1_mode=OUT_PLAIN, Cout0=None, in_scale=None, in_shift=None, relu_bits=None, mask_bits=None):
+               y0_mode=OUT_PLAIN, y1=None, y1_mode=OUT_PLAIN, Cout0=None, in_scale=None, in_shift=None, relu_bits=None, mask_bits=None, gn_bwd=None):
     """grid = (N, D, H, W) of the GEMM rows; defaults to x0's grid.
-    relu_bits (out, uint8 tensor of relu_bits_bytes(N, H, W, Cout) bytes, with relu=True): bit = (output > 0); mask_bits (in): such bits applied instead of `mask`."""
+    relu_bits (out, uint8 tensor of relu_bits_bytes(N, H, W, Cout) bytes, with relu=True): bit = (output > 0); mask_bits (in): such bits applied instead of `mask`.
+    gn_bwd = (p, q, r, relu_mask) with `mask` = the tensor x a GroupNorm in front of this convolution normalised (MisConvDesc.gn_p: bf16 3x3x3 dgrad on the ping-pong
+    kernels): out = [relu_mask: (x > 0) *] (p * acc + q * x + r), p / q / r fp32 [N][ld] tables of gn_bwd_finalize; columns >= Cout0 are dropped when y1 is None."""
     lib = load()
     x0 = _v(x0)
     y0 = _v(y0)
@@ -121,6 +123,10 @@ def conv_igemm(x0, w_packed, y0, *, ksize, Cin, Cout, grid=None, x1=None, bias=N
     if y1 is not None:
         y1 = _v(y1)
         d.y1, d.y1_ld, d.y1_mode = y1.ptr, y1.ld, y1_mode
+    if gn_bwd is not None:
+        gp, gq, gr, grelu = gn_bwd
+        assert gp.dtype == gq.dtype == gr.dtype == torch.float32 and gp.shape == gq.shape == gr.shape and gp.dim() == 2 and gp.is_contiguous() and gq.is_contiguous() and gr.is_contiguous()
+        d.gn_p, d.gn_q, d.gn_r, d.gn_ld, d.gn_relu = gp.data_ptr(), gq.data_ptr(), gr.data_ptr(), gp.shape[1], 1 if grelu else 0
     taps = 1 if ksize == 1 else (27 if d.is3d else 9)
     key = ("conv_igemm", "bf16" if d.dtype == MIS_BF16 else "f32", f"k{ksize}", "3d" if d.is3d else "2d",
            "bn128" if Cout % 128 == 0 else "bn64", f"{d.N}x{d.D}x{d.H}x{d.W} {Cin}->{Cout}")
@@ -529,6 +535,24 @@ def gn_bwd_stats_from_dw(gy, w, dw_per_sample, gy_colsum, scale, shift, mean, gr
     check(lib.mis_gn_bwd_stats_from_dw(dtype_code(gy.dtype), gy.ptr, gy.ld, gy.N, gy.D, gy.H, gy.W, Cout, w.data_ptr(), dw_per_sample.data_ptr(), Cw,
                                        gy_colsum.data_ptr(), scale.data_ptr(), shift.data_ptr(), scale.shape[-1], mean.data_ptr(), groups, Cs, ws.data_ptr(),
                                        S1.data_ptr(), S2.data_ptr(), stream_ptr()), "mis_gn_bwd_stats_from_dw")
+
+
+class GnCondTable:
+    """host-side description of every GroupNorm (gamma, beta) pair inside ONE flat fp32 parameter buffer, for gn_cond"""
+
+    def __init__(self, flat, pairs):
+        n = len(pairs)
+        self.n = n
+        self.flat = flat
+        base = flat.data_ptr()
+        self.goff = (C.c_ulonglong * n)(*[(g.data_ptr() - base) // 4 for g, _ in pairs])
+        self.boff = (C.c_ulonglong * n)(*[(b.data_ptr() - base) // 4 for _, b in pairs])
+        self.cnt = (C.c_int * n)(*[g.numel() for g, _ in pairs])
+
+
+def gn_cond(table, ratio, flags):
+    """flags[l] (int32, device) = 1 when any channel of GroupNorm layer l has |gamma| < ratio * |beta| (include/misamd.h: mis_gn_cond); no synchronisation"""
+    check(load().mis_gn_cond(table.flat.data_ptr(), table.goff, table.boff, table.cnt, table.n, float(ratio), flags.data_ptr(), stream_ptr()), "mis_gn_cond")
 
 
 def gn_bwd_finalize(S1, S2, mean, rstd, gamma, N, Cc, G, count, p, q, r, dgamma, dbeta):

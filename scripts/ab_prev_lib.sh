@@ -8,7 +8,7 @@ PREV=$PWD/build_ab/libmisamd_prev.so
 for i in 1 2; do
 for arm in prev new; do
   if [ $arm = prev ]; then
-    if [ -f "$PREV" ]; then env MISAMD_LIB=$PREV python bench.py --no-cpu-baseline --no-extra > gpurun_out/ab_$arm.json 2>/dev/null
+    if [ -f "$PREV" ]; then env MISAMD_LIB=$PREV MISAMD_REDUCE_PER_LAYER=1 python bench.py --no-cpu-baseline --no-extra > gpurun_out/ab_$arm.json 2>/dev/null
     else env "$@" python bench.py --no-cpu-baseline --no-extra > gpurun_out/ab_$arm.json 2>/dev/null; fi
   else
     python bench.py --no-cpu-baseline --no-extra > gpurun_out/ab_$arm.json 2>/dev/null

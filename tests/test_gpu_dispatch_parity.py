@@ -452,6 +452,50 @@ def test_gn_apply_matches_the_operand_fold(dtype):
     assert torch.equal(ya, yb), (ya.float() - yb.float()).abs().max().item()
 
 
+# GroupNorm backward continued in the dgrad epilogue (MisConvDesc.gn_p, round 4): (grid, Cin = dy channels, Cout = padded operand channels, real channels of x / dx, configuration, switches)
+GN_EPI_CASES = [
+    ((2, 3, 40, 24), 64, 64, 64, "k3.3d.ppc10n2.gn", {}),                      # decoders.2 SingleConv2: 40-row tiles, ragged width, planes of two samples (two p / q / r rows)
+    ((2, 5, 40, 36), 64, 64, 32, "k3.3d.ppc10n2.gn", {}),                      # encoders.0 SingleConv2: 32 real channels, the upper wave slice is dropped (NaN canary)
+    ((1, 4, 22, 36), 128, 64, 64, "k3.3d.ppc5n2.gn", {"MIS_CONV3D_PF": 5}),    # encoders.1 SingleConv2's dgrad (128 -> 64) on ragged 20-row tiles
+    ((3, 3, 24, 20), 64, 64, 64, "k3.3d.ppc8n2.gn", {"MIS_CONV3D_PF": 8}),
+    ((2, 6, 20, 24), 128, 128, 128, "k3.3d.ppc5.gn", {}),                      # decoders.1 SingleConv2
+    ((1, 3, 10, 18), 512, 256, 256, "k3.3d.ppc5.gn", {}),                      # encoders.3 SingleConv2's dgrad: two column tiles, 16 K chunks
+    ((2, 2, 34, 20), 256, 128, 128, "k3.3d.ppc8.gn", {"MIS_CONV3D_PF": 8}),    # the 256-VGPR instantiation (vector bias add, accumulators re-armed by the epilogue)
+    ((2, 30, 40, 48), 64, 64, 64, "k3.3d.ppc5n2.gn", {"MIS_CONV3D_PF": 5}),    # 360 tiles > 256 persistent blocks: the next tile's p / q / r are staged under the K loop
+]
+
+
+@pytest.mark.parametrize("relu_mask", [True, False])
+@pytest.mark.parametrize("case", GN_EPI_CASES, ids=lambda c: f"{'x'.join(map(str, c[0]))}-{c[1]}to{c[2]}r{c[3]}-{c[4]}")
+def test_conv3d_gn_backward_epilogue(case, relu_mask, switches):
+    """out = [x > 0] * (p * dgrad + q * x + r) from the fp32 accumulator of the 3x3x3 dgrad (the 'gcr' SingleConv's backward through GroupNorm + ReLU, reference
+    model/unet3d/buildingblocks.py:87-92) against the same expression in torch on the bf16-rounded operands."""
+    ops = _ops()
+    (N, D, H, W), Cin, Cout, Cr, want, sw = case
+    for k, v in sw.items():
+        switches(k, v)
+    dy = rnd(N, Cin, D, H, W, seed=170)
+    w = rnd(Cin, Cout, 3, 3, 3, seed=171, scale=(27 * Cin) ** -0.5)          # forward weight [co = Cin here][ci = Cout here]: the dgrad contracts over co
+    wd = torch.empty(27, Cout, Cin, dtype=BF, device=DEV)
+    wt = w.flip(2, 3, 4).transpose(0, 1).contiguous()                       # dgrad as a forward convolution with the mirrored, transposed filter
+    ops.pack_conv_weight(wt.to(DEV), wd, None)
+    x = F.relu(rnd(N, Cr, D, H, W, seed=172)) if relu_mask else rnd(N, Cr, D, H, W, seed=172)
+    p_, q_, r_ = 1 + 0.3 * rnd(N, Cr, seed=173), 0.2 * rnd(N, Cr, seed=174), 0.1 * rnd(N, Cr, seed=175)
+    dgrad = F.conv3d(q(dy, BF), q(wt, BF), None, padding=1)[:, :Cr]
+    bc = lambda t_: t_.view(N, Cr, 1, 1, 1)
+    ref = bc(p_) * dgrad + (bc(q_) * q(x, BF) + bc(r_))
+    if relu_mask:
+        ref = ref * (q(x, BF) > 0)
+    out = torch.full((N, D, H, W, Cr + 64), float("nan"), dtype=BF, device=DEV)          # a channel slice of a wider buffer: nothing else may be written
+    xd = to_nhwc(x, BF)
+    ops.conv_igemm(to_nhwc(dy, BF), wd, ops.View(out, 0, Cr), ksize=3, Cin=Cin, Cout=Cout, Cout0=Cr, grid=(N, D, H, W), mask=xd,
+                   gn_bwd=(p_.to(DEV).contiguous(), q_.to(DEV).contiguous(), r_.to(DEV).contiguous(), relu_mask))
+    cfg = ops.conv_last_dispatch()
+    assert cfg == want, f"case meant for {want} ran {cfg}"
+    assert_close(from_nhwc(out[..., :Cr].contiguous()), ref, f"3-D GN-backward epilogue {cfg}", **tol(BF, 27 * Cin))
+    assert torch.isnan(out[..., Cr:].float()).all(), "wrote outside the real channels"
+
+
 @pytest.mark.parametrize("grid", [(1, 5, 20, 20), (2, 3, 40, 24)])
 def test_conv3d_pp_32_channel_slice(grid):
     """encoders.0 SingleConv2 of the bf16 engine: 32 REAL input channels read out of a 64-channel buffer (one 32-channel K chunk per depth slice) - the padding

@@ -164,3 +164,25 @@ def test_persistent_grids_leave_cus_free(switches):
     assert torch.equal(lg0, lg1) and torch.equal(l0, l1)
     rel = ((g0.double() - g1.double()).norm() / g0.double().norm()).item()
     assert rel < 1e-5, rel
+
+
+@pytest.mark.parametrize("dtype,shape", [(torch.bfloat16, (8, 128, 128)), (torch.float32, (2, 48, 64))])
+def test_batched_slab_reduction_is_bit_identical(dtype, shape):
+    """mis_wgrad_reduce_batch (MisWgradDesc.defer: the slab reductions of a stage's layers as two launches) against the three per-layer kernels: the same arithmetic in the
+    same order - every gradient bit-identical (3x3 layers with 2 ... 256 slabs, the transposed convolutions' layout-1 gradients with folded bias sums, both precisions)."""
+    N, H, W = shape
+    gen = torch.Generator().manual_seed(12)
+    images = torch.randn(N, 1, H, W, generator=gen).to(DEV)
+    labels = torch.randint(0, 2, (N, H, W), generator=gen).to(DEV)
+    out = []
+    for batch in (True, False):
+        eng = _engine(1, 2, dtype)
+        assert eng.batch_reduce
+        eng.batch_reduce = batch
+        eng.forward(images, labels, train=True)
+        eng.backward()
+        torch.cuda.synchronize()
+        assert not eng._red
+        out.append(eng.flat.g.clone())
+    assert torch.equal(out[0], out[1])
+    assert float(out[0].abs().sum()) > 0
