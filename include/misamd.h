@@ -213,6 +213,13 @@ typedef struct MisHeadDesc {
 } MisHeadDesc;
 size_t mis_head_workspace_bytes(const MisHeadDesc* d);
 int mis_head_loss(const MisHeadDesc* d, void* stream);
+/* The last 3x3 convolution of the 2-D U-Net (up_conv.3.second: Conv2d(64k, 64, 3, p1) + bias + ReLU, layers.py:122-126) with the head, the loss and their backward in its
+ * EPILOGUE (round 4, csrc/conv_ppd_head.hip): `conv` describes the convolution exactly as for mis_conv_igemm, `head` the head exactly as for mis_head_loss with
+ * head->dy == conv->y0 (and equal ld): the 64-channel feature map is never written - dL/dfeatures takes its place - and mis_head_loss's pass over it disappears.
+ * Eligible: bf16, 2-D, Cin % 64 == 0, Cout == 64, bias + ReLU, grids that fill 32-row tiles, C == 2 with cross entropy or C == 1 with BCE, training form (dy / dw / db
+ * given).  mis_conv3x3_head_fused_eligible returns 1 / 0; the call itself returns MIS_EUNSUPPORTED otherwise (the caller then runs the two entry points separately). */
+int mis_conv3x3_head_fused_eligible(const MisConvDesc* conv, const MisHeadDesc* head);
+int mis_conv3x3_head_fused(const MisConvDesc* conv, const MisHeadDesc* head, void* stream);
 
 /* Global grad-norm clip + AdamW on flat fp32 buffers (HF Trainer: clip_grad_norm_(1.0) then torch.optim.AdamW). */
 size_t mis_adamw_workspace_bytes(long long n);

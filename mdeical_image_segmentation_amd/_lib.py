@@ -20,7 +20,7 @@ EXPORTS = [
     "mis_comm_unique_id", "mis_comm_init", "mis_comm_world", "mis_allreduce_bucket", "mis_comm_finalize",
     "mis_conv3x3_first_fwd", "mis_conv3x3_first_fwd_rb", "mis_relu_bits_bytes", "mis_relu_bits", "mis_conv3x3_first_wgrad_workspace_bytes", "mis_conv3x3_first_wgrad",
     "mis_colsum_workspace_bytes", "mis_colsum", "mis_maxpool2_fwd", "mis_maxpool2_bwd", "mis_maxpool2_fwd_pb", "mis_maxpool2_bwd_pb",
-    "mis_pack_conv_weight", "mis_pack_convt_weight", "mis_pack_batch", "mis_head_workspace_bytes", "mis_head_loss",
+    "mis_pack_conv_weight", "mis_pack_convt_weight", "mis_pack_batch", "mis_head_workspace_bytes", "mis_head_loss", "mis_conv3x3_head_fused_eligible", "mis_conv3x3_head_fused",
     "mis_adamw_workspace_bytes", "mis_sumsq", "mis_adamw_step", "mis_adamw_step_dev", "mis_sumsq_npartials",
     "mis_chanstats_workspace_bytes", "mis_chanstats", "mis_nchw_to_nhwc", "mis_nhwc_to_nchw", "mis_probe_mfma",
     "mis_gn_fwd_finalize", "mis_gn_bwd_stats_workspace_bytes", "mis_gn_bwd_stats", "mis_gn_bwd_stats_from_dw_workspace_bytes", "mis_gn_bwd_stats_from_dw", "mis_gn_cond", "mis_gn_bwd_finalize", "mis_gn_bwd_apply",
@@ -276,6 +276,8 @@ def load():
         "mis_mt_generate": [vp, i, ll, ll, ll, vp, ll, vp, vp, ll, vp],
         "mis_legacy_normal_par": [vp, ll, vp, vp, ll, dbl, i, dbl, vp, vp, vp],
         "mis_gn_cond": [vp, vp, vp, vp, i, C.c_float, vp, vp],
+        "mis_conv3x3_head_fused_eligible": [vp, vp],
+        "mis_conv3x3_head_fused": [vp, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

@@ -265,8 +265,11 @@ class UNet2DEngine:
             ops.conv_igemm(x, self.wf[f"up_sample.{j}.up"], View(self.cat[l], 0, c), ksize=1, Cin=2 * c, Cout=4 * c,
                            bias=P[f"up_sample.{j}.up.bias"], relu=False, y0_mode=OUT_SHUFFLE2)
             self._conv(self.cat[l], f"up_conv.{j}.first", self.u1[j], 2 * c, c, rb=("u1", j))
+            if j == 3 and labels is not None and train and self._fused_head(labels, N, H, W, grad_scale):
+                return self.loss_buf[:1], self.logits, self.argmax
             self._conv(self.u1[j], f"up_conv.{j}.second", self.u2[j], c, c, rb=("u2", j))
             x = self.u2[j]
+        self.features_valid = True
         wh = P["final_conv.weight"].view(self.cout, 64)
         bh = P["final_conv.bias"]
         if labels is None:
@@ -282,6 +285,21 @@ class UNet2DEngine:
                           loss_out=self.loss_buf)
         return self.loss_buf[:1], self.logits, self.argmax
 
+    def _fused_head(self, labels, N, H, W, grad_scale):
+        """up_conv.3.second + final_conv + loss + their backward as ONE kernel (csrc/conv_ppd_head.hip, round 4): the last feature map is never written - dL/dfeatures
+        (g_u2[3]) takes its place - and the head's pass over it disappears (0.58 ms of a 30.6 ms step).  bf16, 1 or 2 classes, training form; everything else (and
+        MISAMD_HEAD_UNFUSED=1 / MIS_HEAD_UNFUSED) runs the convolution and mis_head_loss separately."""
+        if self.dtype != torch.bfloat16 or self.cout > 2 or os.environ.get("MISAMD_HEAD_UNFUSED"):
+            return False
+        self._check_labels(labels, N, H, W)
+        name = "up_conv.3.second"
+        ok = ops.conv3x3_head_fused(self.u1[3], self.wf[name], self.P[name + ".bias"], self.g_u2[3], self.P["final_conv.weight"].view(self.cout, 64),
+                                    self.P["final_conv.bias"], Cin=64, loss=self.loss_kind, labels=labels, logits=self.logits, argmax=self.argmax,
+                                    loss_out=self.loss_buf, dw=self.G["final_conv.weight"], db=self.G["final_conv.bias"], grad_scale=grad_scale)
+        if ok:
+            self.features_valid = False          # u2[3] was not written: head_backward (an external gradient through the logits) regenerates it first
+        return ok
+
     def _check_labels(self, labels, N, H, W):
         if self.loss_kind == ops.LOSS_CE:
             ok = labels.dtype == torch.int64 and tuple(labels.shape) == (N, H, W)
@@ -294,6 +312,9 @@ class UNet2DEngine:
     def head_backward(self, dlogits):
         """backward entry for an EXTERNAL loss: dlogits = dL/dlogits, fp32 (N, C, H, W); then call backward()."""
         wh = self.P["final_conv.weight"].view(self.cout, 64)
+        if not getattr(self, "features_valid", True):          # the forward ran the fused head: the last feature map was never stored
+            self._conv(self.u1[3], "up_conv.3.second", self.u2[3], 64, 64, rb=("u2", 3))
+            self.features_valid = True
         ops.head_loss(self.u2[3], wh, self.P["final_conv.bias"], loss=ops.LOSS_EXTERNAL, labels=dlogits.contiguous(),
                       dy=self.g_u2[3], dw=self.G["final_conv.weight"], db=self.G["final_conv.bias"])
 

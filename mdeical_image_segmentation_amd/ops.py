@@ -67,8 +67,8 @@ def _event():
 
 
 class _Timed:
-    def __init__(self, key, flops):
-        self.key, self.flops = key, flops
+    def __init__(self, key, flops, tag=None):
+        self.key, self.flops, self.tag = key, flops, tag
 
     def __enter__(self):
         if PROFILE is not None:
@@ -80,7 +80,7 @@ class _Timed:
         if PROFILE is not None and exc[0] is None:
             self.e1.record()
             lib = load()            # which kernel configuration this launch ran (names the dominant kernel's symbol in bench.py's roofline)
-            tag = (lib.mis_conv_last_dispatch() if self.key[0] == "conv_igemm" else lib.mis_wgrad_last_dispatch()).decode()
+            tag = self.tag or (lib.mis_conv_last_dispatch() if self.key[0] == "conv_igemm" else lib.mis_wgrad_last_dispatch()).decode()
             PROFILE.append((self.key, self.flops, self.e0, self.e1, tag))
         return False
 
@@ -445,6 +445,44 @@ def head_loss(y, w, b, *, loss, labels=None, logits=None, argmax=None, loss_out=
     ws = workspace(lib.mis_head_workspace_bytes(C.byref(d)), y.t.device, "head")
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     check(lib.mis_head_loss(C.byref(d), stream_ptr()), "mis_head_loss")
+
+
+def conv3x3_head_fused(x, w_packed, bias, dy, wh, bh, *, Cin, loss, labels, logits, argmax, loss_out, dw, db, grad_scale=1.0, dry_run=False):
+    """up_conv.3.second (3x3, Cin -> 64, bias + ReLU) with the 1x1 head, the loss and their backward in its epilogue (include/misamd.h: mis_conv3x3_head_fused):
+    `dy` (N, H, W, 64) receives dL/dfeatures where the features would have been written.  Returns False (nothing launched) when the configuration is not eligible;
+    dry_run=True only asks."""
+    lib = load()
+    x, dy = _v(x), _v(dy)
+    c = ConvDesc()
+    c.dtype, c.ksize = dtype_code(x.dtype), 3
+    c.N, c.D, c.H, c.W, c.is3d = x.N, 1, x.H, x.W, 0
+    c.Cin, c.Cout, c.Cin0, c.Cout0 = Cin, 64, Cin, 64
+    c.x0, c.x0_ld, c.x0_D, c.x0_H, c.x0_W = x.ptr, x.ld, 1, x.H, x.W
+    c.w, c.bias, c.relu = w_packed.data_ptr(), bias.data_ptr(), 1
+    c.y0, c.y0_ld, c.y0_mode = dy.ptr, dy.ld, OUT_PLAIN
+    h = HeadDesc()
+    h.dtype, h.loss = c.dtype, loss
+    h.npix_per_image = x.H * x.W
+    h.N, h.Cfeat, h.C = x.N, 64, wh.shape[0]
+    h.y, h.y_ld = dy.ptr, dy.ld                          # (unused by the fused kernel: the features are never stored)
+    h.w, h.b = wh.data_ptr(), bh.data_ptr()
+    h.labels = labels.data_ptr()
+    h.logits = None if logits is None else logits.data_ptr()
+    h.argmax = None if argmax is None else argmax.data_ptr()
+    h.loss_out = loss_out.data_ptr()
+    h.dy, h.dy_ld = dy.ptr, dy.ld
+    h.dw, h.db = dw.data_ptr(), db.data_ptr()
+    h.grad_scale, h.alpha, h.beta, h.phase = grad_scale, 1.0, 1.0, 0
+    ws = workspace(lib.mis_head_workspace_bytes(C.byref(h)), x.t.device, "head")
+    h.workspace, h.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    if not lib.mis_conv3x3_head_fused_eligible(C.byref(c), C.byref(h)):
+        return False
+    if dry_run:
+        return True
+    key = ("conv_igemm", "bf16", "k3", "2d", "bn64", f"{c.N}x1x{c.H}x{c.W} {Cin}->64+head")
+    with _Timed(key, 2.0 * c.N * c.H * c.W * 9 * Cin * 64, tag="k3.2d.ppd8.head"):
+        check(lib.mis_conv3x3_head_fused(C.byref(c), C.byref(h), stream_ptr()), "mis_conv3x3_head_fused")
+    return True
 
 
 def sumsq(g, partials):

@@ -186,3 +186,57 @@ def test_batched_slab_reduction_is_bit_identical(dtype, shape):
         out.append(eng.flat.g.clone())
     assert torch.equal(out[0], out[1])
     assert float(out[0].abs().sum()) > 0
+
+
+@pytest.mark.parametrize("cout,shape", [(2, (3, 64, 48)), (2, (2, 96, 80)), (1, (2, 64, 64)), (2, (9, 160, 176))])
+def test_fused_head_matches_the_separate_kernels(cout, shape, monkeypatch):
+    """csrc/conv_ppd_head.hip (up_conv.3.second + final_conv + CE / BCE + their backward in ONE kernel; the last feature map is never written) against the separate
+    convolution + mis_head_loss: same loss, logits, arg-max and gradients up to fp32 summation order (the logits come off the matrix pipe with Wh split into bf16 hi + lo
+    parts) and the bf16 rounding flips that follow from it.  Ragged tiles (48 / 80 / 176 columns), 1 and 2 classes, several tiles per persistent block (9 x 5 x 11 = 495)."""
+    from mdeical_image_segmentation_amd import ops
+    N, H, W = shape
+    gen = torch.Generator().manual_seed(31)
+    images = torch.randn(N, 1, H, W, generator=gen).to(DEV)
+    labels = (torch.randint(0, 2, (N, H, W), generator=gen) if cout == 2 else torch.randint(0, 2, (N, 1, H, W), generator=gen).float()).to(DEV)
+    res = []
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("MISAMD_HEAD_UNFUSED", "1")
+        eng = _engine(1, cout, torch.bfloat16)
+        loss, logits, am = eng.forward(images, labels, train=True, grad_scale=0.5)
+        assert eng.features_valid == (not fused), "the case did not take the path it is meant for"
+        eng.backward()
+        torch.cuda.synchronize()
+        res.append((loss.clone(), logits.clone(), am.clone(), eng.flat.g.clone(), {k: eng.G[k].clone() for k in ("final_conv.weight", "final_conv.bias", "up_conv.3.second.weight", "down_conv.0.first.weight")}))
+    (l0, lg0, am0, g0, d0), (l1, lg1, am1, g1, d1) = res
+    assert abs(l0.item() - l1.item()) < 2e-6, (l0.item(), l1.item())
+    assert (lg0 - lg1).abs().max().item() <= 2e-5 * lg1.abs().max().item() + 1e-6
+    top = lg1 if cout == 1 else lg1.topk(2, dim=1).values
+    near = (lg1.abs()[:, 0] < 1e-4) if cout == 1 else ((top[:, 0] - top[:, 1]) < 1e-4)
+    assert torch.equal(am0[~near], am1[~near])
+    for k in d0:
+        r = ((d0[k].double() - d1[k].double()).norm() / (d1[k].double().norm() + 1e-30)).item()
+        assert r < (2e-5 if k.startswith("final_conv") else 3e-3), (k, r)
+    r = ((g0.double() - g1.double()).norm() / g1.double().norm()).item()
+    assert r < 3e-3, r
+
+
+def test_fused_head_then_external_gradient_through_logits():
+    """the rare autograd path after a FUSED forward: a gradient arriving through `logits` needs the last feature map, which the fused kernel never wrote - head_backward
+    regenerates it (one convolution) before the external-gradient head pass"""
+    gen = torch.Generator().manual_seed(32)
+    images = torch.randn(2, 1, 64, 64, generator=gen).to(DEV)
+    labels = torch.randint(0, 2, (2, 64, 64), generator=gen).to(DEV)
+    dlog = torch.randn(2, 2, 64, 64, generator=gen).to(DEV) * 1e-3
+    out = []
+    for fused in (True, False):
+        eng = _engine(1, 2, torch.bfloat16)
+        if not fused:
+            eng._fused_head = lambda *a, **k: False
+        eng.forward(images, labels, train=True)
+        assert eng.features_valid == (not fused)
+        eng.head_backward(dlog)
+        eng.backward()
+        torch.cuda.synchronize()
+        out.append(eng.flat.g.clone())
+    assert torch.equal(out[0], out[1])
