@@ -140,7 +140,7 @@ SYMBOLS = {
 for _t, _k in (("k3.2d.ppc8", "conv_ppc_kernel<8, 4"), ("k3.2d.ppc8n2", "conv_ppc_kernel<8, 2"), ("k3.3d.ppc5", "conv3d_ppc_kernel<5, 4"),
                ("k3.3d.ppc8", "conv3d_ppc_kernel<8, 4"), ("k3.3d.ppc5n6", "conv3d_ppc_kernel<5, 6"), ("k3.3d.ppc5n2", "conv3d_ppc_kernel<5, 2"),
                ("k3.3d.ppc8n2", "conv3d_ppc_kernel<8, 2"), ("k3.3d.ppc10n2", "conv3d_ppc_kernel<10, 2")):
-    for _sfx, _em in (("", 0), (".mask", 1), (".bits", 2)):
+    for _sfx, _em in (("", 0), (".mask", 1), (".bits", 2), (".gn", 3)):          # .gn: GroupNorm backward in the epilogue (3-D dgrads, MisConvDesc.gn_p)
         SYMBOLS[_t + _sfx] = f"{_k}, {_em}>"
 for _sfx, _em in (("", 0), (".mask", 1), (".bits", 2)):
     SYMBOLS["k1.2d.pp" + _sfx] = f"gemm1_pp_kernel<{_em}>"
@@ -207,7 +207,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--lr", type=float, default=1e-5,
                     help="constant learning rate of the timed steps.  The reference's 5e-3 (train.py:98) makes THIS synthetic task (random labels) "
-                         "diverge and collapse to dead ReLUs within ~10 steps (loss = ln 2, activations 0-2 % live): AdamW does the same work at any "
+                         "diverge and collapse to dead ReLUs within ~10 steps (loss = ln 2, activations 0-2 %% live): AdamW does the same work at any "
                          "lr, so the benchmark keeps the network in its initial, live state instead of timing MFMAs on zeros")
     ap.add_argument("--comm", default="torch", choices=["torch", "native"],
                     help="gradient exchange at N > 1: torch.distributed all_reduce (ProcessGroupNCCL = RCCL) or the RCCL communicator behind the C ABI "
