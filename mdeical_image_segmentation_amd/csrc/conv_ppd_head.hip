@@ -165,12 +165,13 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_head_kernel(const ConvArgs a,
 #pragma unroll
         for (int pf = 0; pf < PF; ++pf) acc[f][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
     // per-lane accumulators of the head's parameter gradients and of the loss, over all pixels this lane sees
-    float dwa[C][16], dba[C], lsum = 0.f;
+    pp_f32x2 dwa2[C][8];          // (pairs: the per-row update is one v_pk_fma_f32 per pair and class)
+    float dba[C], lsum = 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         dba[c] = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) dwa[c][k] = 0.f;
+        for (int k = 0; k < 8; ++k) dwa2[c][k] = pp_f32x2{0.f, 0.f};
     }
     issue_bias(bbase);
     if (grp == 0) {
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_head_kernel(const ConvArgs a,
             const int eli = lane_ & 15, elg = lane_ >> 4;
             // Wh of this lane's 16 channels (fp32: dL/dfeatures) and the MFMA operand (bf16 hi / lo of Wh[row & 3][piece*32 + elg*8 .. +7], rows >= C zero)
             const uint32_t wl = (uint32_t)(uintptr_t)whl;
-            float wk[C][16];
+            pp_f32x2 wk2[C][8];
             u32x4 ahi[2], alo[2];
             {
                 u32x4 raw[C][4], araw[2][2];
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_head_kernel(const ConvArgs a,
 #pragma unroll
                 for (int c = 0; c < C; ++c)
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) wk[c][k] = __uint_as_float(raw[c][k >> 2][k & 3]);
+                    for (int k = 0; k < 8; ++k) wk2[c][k] = pp_f32x2{__uint_as_float(raw[c][k >> 1][(k & 1) * 2]), __uint_as_float(raw[c][k >> 1][(k & 1) * 2 + 1])};
                 const bool live = (eli & 3) < C;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -426,17 +427,16 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_head_kernel(const ConvArgs a,
 #pragma unroll
                     for (int jq = 0; jq < 4; ++jq) {
                         const uint32_t dv = d[i][jq];
-                        const float f0 = __uint_as_float(dv << 16), f1 = __uint_as_float(dv & 0xffff0000u);
-                        const int k0 = i * 8 + jq * 2;
-                        float g0 = 0.f, g1 = 0.f;
+                        const pp_f32x2 f2 = pp_f32x2{__uint_as_float(dv << 16), __uint_as_float(dv & 0xffff0000u)};
+                        const int kp = i * 4 + jq;          // pair index: channels 2 kp, 2 kp + 1 of this lane's 16
+                        pp_f32x2 g2 = pp_f32x2{0.f, 0.f};
 #pragma unroll
                         for (int c = 0; c < C; ++c) {
-                            dwa[c][k0] = fmaf(dl[c], f0, dwa[c][k0]);
-                            dwa[c][k0 + 1] = fmaf(dl[c], f1, dwa[c][k0 + 1]);
-                            g0 = fmaf(dl[c], wk[c][k0], g0);
-                            g1 = fmaf(dl[c], wk[c][k0 + 1], g1);
+                            const pp_f32x2 dl2 = pp_f32x2{dl[c], dl[c]};
+                            dwa2[c][kp] = __builtin_elementwise_fma(dl2, f2, dwa2[c][kp]);
+                            g2 = __builtin_elementwise_fma(dl2, wk2[c][kp], g2);
                         }
-                        uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(pp_f32x2{g0, g1}, pp_bf16x2));
+                        uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(g2, pp_bf16x2));
                         uint32_t t = dv;          // per 16-bit half: 1 where the feature is positive (it is >= 0), else 0
                         asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]\n\tv_pk_mul_lo_u16 %0, %0, %2" : "=&v"(t) : "v"(t), "v"(pk));
                         go[i][jq] = t;
@@ -464,12 +464,14 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_head_kernel(const ConvArgs a,
 #pragma unroll
         for (int c = 0; c < C; ++c) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                float v = dwa[c][k];
+            for (int k = 0; k < 8; ++k)
 #pragma unroll
-                for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
-                dwa[c][k] = v;
-            }
+                for (int e = 0; e < 2; ++e) {
+                    float v = dwa2[c][k][e];
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+                    dwa2[c][k][e] = v;
+                }
             float v = dba[c];
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_head_kernel(const ConvArgs a,
 #pragma unroll
             for (int c = 0; c < C; ++c)
 #pragma unroll
-                for (int k = 0; k < 16; ++k) red[wave * 160 + c * 64 + (k >> 3) * 32 + lg * 8 + (k & 7)] = dwa[c][k];
+                for (int k = 0; k < 16; ++k) red[wave * 160 + c * 64 + (k >> 3) * 32 + lg * 8 + (k & 7)] = dwa2[c][k >> 1][k & 1];
             if (lg == 0) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) red[wave * 160 + 128 + c] = dba[c];
