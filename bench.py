@@ -539,8 +539,17 @@ def run3d(args, rank, world, dev, dist, *, dtype, batch, size, steps, warmup, ti
     free = [torch.cuda.Event() for _ in range(2)]
     state = {"n": 0}
 
+    no_aug = bool(os.environ.get("MISAMD_BENCH_NOAUG"))          # diagnostic A/B only (what the on-device augmentation costs the step): the line is then NOT cfg4 / cfg5
+
     def augment_into(k):
         xa, ta = bufs[k]
+        if no_aug:
+            aug_stream.wait_event(free[k])
+            with torch.cuda.stream(aug_stream):
+                xa.copy_(x)
+                ta.copy_(t)
+                ready[k].record(aug_stream)
+            return
         aug_stream.wait_event(free[k])                      # the step that last trained on this pair is past its backward pass
         with torch.cuda.stream(aug_stream):
             for b in range(batch):
@@ -586,7 +595,7 @@ def run3d(args, rank, world, dev, dist, *, dtype, batch, size, steps, warmup, ti
         out = {"metric": f"volumes/sec (3D {size}^3 U-Net train step)", "value": round(value, 3), "unit": "volumes/s", "n_gpus": world,
                "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-               "config": {"workload": f"unet3d 1-ch->3-class bs={batch}/GPU {size}^3, on-device augment (flip+rot90+rotate[order 3 raw / 0 targets]+contrast+"
+               "config": {"workload": ("[DIAGNOSTIC: augmentation replaced by a copy, MISAMD_BENCH_NOAUG] " if no_aug else "") + f"unet3d 1-ch->3-class bs={batch}/GPU {size}^3, on-device augment (flip+rot90+rotate[order 3 raw / 0 targets]+contrast+"
                                       f"Gaussian noise from the reference's own MT19937 stream; one batch ahead on a second HIP stream) + "
                                       f"fwd+BCEDice+bwd+clip+AdamW(lr {args.lr:g}), random-init weights",
                           "global_batch": world * batch, "parallelism": f"dp{world}", "final_loss": loss_list[-1] if loss_list else None},

@@ -325,6 +325,11 @@ int mis_aug_flip_rot90(const void* src, void* dst, long long nvol, int D, int H,
 int mis_aug_crop_reflect(const void* src, void* dst, long long nslices, int H, int W, int y0, int x0, int CH, int CW, int elem_size, void* stream);
 int mis_aug_rotate0(const void* src, void* dst, long long nvol, int D, int H, int W, int a0, int a1, const double* m4 /*host*/,
                     const double* off2 /*host*/, int elem_size, void* stream);
+/* ... with scipy.ndimage's other boundary modes (RandomRotate(mode=...), order 0): mode 0 'reflect' / 'grid-mirror', 1 'constant', 2 'nearest', 3 'mirror', 4 'wrap',
+ * 5 'grid-wrap', 6 'grid-constant'; cval_bits = the bit pattern of the fill value in the element type (low elem_size bytes). */
+int mis_aug_rotate0_mode(const void* src, void* dst, long long nvol, int D, int H, int W, int a0, int a1, const double* m4, const double* off2, int elem_size, int mode,
+                         unsigned long long cval_bits, void* stream);
+
 /* order-3 (cubic spline) variant, fp32 volumes: workspace = nvol*D*H*W doubles (the float64 spline coefficients scipy keeps) */
 size_t mis_aug_rotate3_workspace_bytes(long long nvol, int D, int H, int W);
 int mis_aug_rotate3(const float* src, float* dst, double* workspace, long long nvol, int D, int H, int W, int a0, int a1,

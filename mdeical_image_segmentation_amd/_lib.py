@@ -27,7 +27,7 @@ EXPORTS = [
     "mis_first3d_fwd", "mis_first3d_bwd_workspace_bytes", "mis_first3d_bwd", "mis_relu_mask",
     "mis_convt3_col2im", "mis_convt3_im2col", "mis_seg_metrics_workspace_bytes", "mis_seg_metrics", "mis_iou3d_counts", "mis_se_fc_fwd", "mis_se_apply_fwd", "mis_se_bwd_workspace_bytes", "mis_se_bwd_reduce", "mis_se_fc_bwd", "mis_se_bwd_apply", "mis_patch_gather_reflect", "mis_patch_accumulate", "mis_pred_finalize", "mis_bcedice_workspace_bytes", "mis_bcedice_fwd", "mis_bcedice_bwd", "mis_loss_workspace_bytes", "mis_ce3d_fwd", "mis_ce3d_bwd", "mis_pointloss_fwd", "mis_pointloss_bwd", "mis_maxpoolk_fwd", "mis_maxpoolk_bwd", "mis_bilinear_up_fwd", "mis_bilinear_up_bwd_workspace_bytes", "mis_bilinear_up_bwd", "mis_upconv_gather_fwd_workspace_bytes", "mis_upconv_gather_fwd", "mis_upconv_gather_bwd", "mis_cgm_gate", "mis_scale_sigmoid", "mis_segloss_workspace_bytes", "mis_segloss_fwd", "mis_segloss_bwd", "mis_add_act", "mis_expand1_fwd", "mis_expand1_bwd_workspace_bytes", "mis_expand1_bwd", "mis_bn_fwd_finalize", "mis_bn_bwd_finalize", "mis_affine_act", "mis_bn_bwd_stats_workspace_bytes", "mis_bn_bwd_stats", "mis_bn_bwd_apply",
     "mis_norm_act_fwd", "mis_norm_act_bwd", "mis_mask_scale", "mis_gn_fwd_finalize_ld", "mis_gn_bwd_finalize_ld", "mis_pool3d_fwd", "mis_pool3d_bwd", "mis_gather3d_fwd", "mis_gather3d_bwd",
-    "mis_aug2d_u8", "mis_aug_flip_rot90", "mis_aug_crop_reflect", "mis_aug_rotate0", "mis_aug_rotate3_workspace_bytes", "mis_aug_rotate3", "mis_aug_rotate_spline", "mis_aug_gauss1d", "mis_aug_gauss1d_f32", "mis_aug_map_coordinates", "mis_aug_pointwise", "mis_aug_contrast", "mis_minmax",
+    "mis_aug2d_u8", "mis_aug_flip_rot90", "mis_aug_crop_reflect", "mis_aug_rotate0", "mis_aug_rotate0_mode", "mis_aug_rotate3_workspace_bytes", "mis_aug_rotate3", "mis_aug_rotate_spline", "mis_aug_gauss1d", "mis_aug_gauss1d_f32", "mis_aug_map_coordinates", "mis_aug_pointwise", "mis_aug_contrast", "mis_minmax",
 ]
 
 
@@ -252,6 +252,7 @@ def load():
         "mis_aug_flip_rot90": [vp, vp, ll, i, i, i, i, i, i, vp],
         "mis_aug_crop_reflect": [vp, vp, ll, i, i, i, i, i, i, i, vp],
         "mis_aug_rotate0": [vp, vp, ll, i, i, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double), i, vp],
+        "mis_aug_rotate0_mode": [vp, vp, ll, i, i, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double), i, i, C.c_ulonglong, vp],
         "mis_aug_rotate3": [vp, vp, vp, ll, i, i, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double), vp],
         "mis_aug_rotate_spline": [vp, vp, vp, ll, i, i, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double), i, vp],
         "mis_aug_gauss1d": [vp, vp, ll, i, i, i, i, vp, i, vp],

@@ -98,6 +98,10 @@ class RandomRotate90:
         return _flip_rot90(m, 0, int(k))
 
 
+# scipy.ndimage boundary modes -> the mode codes of mis_aug_rotate0_mode (csrc/augment.hip)
+_ROTATE_MODES = {"reflect": 0, "grid-mirror": 0, "constant": 1, "nearest": 2, "mirror": 3, "wrap": 4, "grid-wrap": 5, "grid-constant": 6}
+
+
 class RandomRotate:
     """transforms.py:83-112: axis = axes[randint(len(axes))]; angle = randint(-spectrum, spectrum);
     scipy.ndimage.rotate(reshape=False, order, mode='reflect', cval=-1)."""
@@ -116,8 +120,9 @@ class RandomRotate:
     def __call__(self, m):
         axis = self.axes[self.random_state.randint(len(self.axes))]
         angle = self.random_state.randint(-self.angle_spectrum, self.angle_spectrum)
-        if self.order not in (0, 1, 2, 3, 4, 5) or self.mode != 'reflect':
-            raise NotImplementedError("on-device RandomRotate: spline orders 0 .. 5 with mode='reflect' (the reference's default and the configs' setting) are built")
+        if self.order not in (0, 1, 2, 3, 4, 5) or self.mode not in _ROTATE_MODES or (self.order >= 1 and _ROTATE_MODES[self.mode] != 0):
+            raise NotImplementedError("on-device RandomRotate: spline orders 0 .. 5 with mode='reflect' (the reference's default and the configs' setting), and every "
+                                      "scipy boundary mode ('constant', 'nearest', 'mirror', 'wrap', 'grid-wrap', 'grid-constant', 'grid-mirror') at order 0, are built")
         m = _dev(m)
         if self.order >= 1 and m.dtype != torch.float32:
             raise MisError(f"RandomRotate(order={self.order}): fp32 volumes only (labels use order 0)")
@@ -142,6 +147,12 @@ class RandomRotate:
             else:
                 check(lib.mis_aug_rotate_spline(m.data_ptr(), out.data_ptr(), ws.data_ptr(), nvol, D, H, W, a0, a1, m4, o2, int(self.order), stream_ptr()),
                       "mis_aug_rotate_spline")
+            return out
+        mode = _ROTATE_MODES[self.mode]
+        if mode != 0:          # scipy.ndimage.rotate(..., mode=self.mode, cval=-1) (transforms.py:110): the fill value in the volume's own dtype
+            cval = torch.tensor([-1], dtype=m.dtype).numpy().view(np.uint32 if m.element_size() == 4 else np.uint64)[0]
+            check(load().mis_aug_rotate0_mode(m.data_ptr(), out.data_ptr(), nvol, D, H, W, a0, a1, m4, o2, m.element_size(), mode, int(cval), stream_ptr()),
+                  "mis_aug_rotate0_mode")
             return out
         check(load().mis_aug_rotate0(m.data_ptr(), out.data_ptr(), nvol, D, H, W, a0, a1, m4, o2, m.element_size(), stream_ptr()),
               "mis_aug_rotate0")

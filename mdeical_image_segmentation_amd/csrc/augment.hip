@@ -93,6 +93,115 @@ __global__ __launch_bounds__(256) void aug_rotate0_kernel(const E* __restrict__ 
     }
 }
 
+// ---- scipy.ndimage's other boundary modes for order 0 (RandomRotate(mode=...), reference augment/unet3d_augment/transforms.py:83-112; round 4) ----
+// mode: 0 'reflect' (= 'grid-mirror'), 1 'constant', 2 'nearest', 3 'mirror', 4 'wrap', 5 'grid-wrap', 6 'grid-constant'.  The double coordinate goes through scipy's
+// map_coordinate (ni_interpolation.c), is rounded (floor(x + 0.5)), and a rounded index that still falls outside the line is mapped with the same extension
+// ('constant' / 'grid-constant': the output is cval); oracle/augment_oracle.py::rotate0_modes restates it in numpy, bit-identical to scipy for every mode.
+__device__ __forceinline__ double map_coord_mode(double x, int n, int mode) {
+    if (mode == 6) return x;
+    if (x < 0) {
+        switch (mode) {
+            case 3:
+                if (n <= 1) return 0.0;
+                {
+                    const int sz2 = 2 * n - 2;
+                    x = sz2 * (double)(long long)(-x / sz2) + x;
+                    return x <= 1 - n ? x + sz2 : -x;
+                }
+            case 0:
+                if (n <= 1) return 0.0;
+                {
+                    const int sz2 = 2 * n;
+                    if (x < -sz2) x = sz2 * (double)(long long)(-x / sz2) + x;
+                    return x < -n ? x + sz2 : ((x > -1e-15 ? 1e-15 : -x) - 1.0);
+                }
+            case 4:
+                if (n <= 1) return 0.0;
+                return x + (double)(n - 1) * ((double)(long long)(-x / (n - 1)) + 1.0);
+            case 5:
+                if (n <= 1) return 0.0;
+                return x + (double)n * ((double)(long long)((-1.0 - x) / n) + 1.0);
+            case 2: return 0.0;
+            default: return -1.0;          // constant
+        }
+    }
+    if (x > n - 1) {
+        switch (mode) {
+            case 3:
+                if (n <= 1) return 0.0;
+                {
+                    const int sz2 = 2 * n - 2;
+                    x -= sz2 * (double)(long long)(x / sz2);
+                    return x >= n ? sz2 - x : x;
+                }
+            case 0:
+                if (n <= 1) return 0.0;
+                {
+                    const int sz2 = 2 * n;
+                    x -= sz2 * (double)(long long)(x / sz2);
+                    return x >= n ? sz2 - x - 1 : x;
+                }
+            case 4:
+                if (n <= 1) return 0.0;
+                return x - (double)(n - 1) * (double)(long long)(x / (n - 1));
+            case 5:
+                if (n <= 1) return 0.0;
+                return x - (double)n * (double)(long long)(x / n);
+            case 2: return (double)(n - 1);
+            default: return -1.0;
+        }
+    }
+    return x;
+}
+// rounded index -> a sample of the line, or `outside` (constant modes)
+__device__ __forceinline__ int idx_mode(long long k, int n, int mode, bool& outside) {
+    if (k >= 0 && k < n) return (int)k;
+    switch (mode) {
+        case 0: return refl_idx(k, n);
+        case 3: {
+            if (n == 1) return 0;
+            const long long p = 2LL * n - 2;
+            long long m = k % p;
+            if (m < 0) m += p;
+            return (int)(m < n ? m : p - m);
+        }
+        case 4:
+        case 5: {
+            long long m = k % n;
+            if (m < 0) m += n;
+            return (int)m;
+        }
+        case 2: return k < 0 ? 0 : n - 1;
+        default: outside = true; return 0;
+    }
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void aug_rotate0_mode_kernel(const E* __restrict__ src, E* __restrict__ dst, long long nvol, int D, int H, int W, int a0,
+                                                               int a1, RotArgs ra, int mode, E cval) {
+    const long long per = (long long)D * H * W, total = nvol * per;
+    const int dims[3] = {D, H, W};
+    const int n0 = dims[a0], n1 = dims[a1];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long v = i / per;
+        long long r = i - v * per;
+        int c[3];
+        c[2] = (int)(r % W);
+        r /= W;
+        c[1] = (int)(r % H);
+        c[0] = (int)(r / H);
+        const double o0 = (double)c[a0], o1 = (double)c[a1];
+        double x0 = __dadd_rn(__dadd_rn(__dadd_rn(0.0, __dmul_rn(o0, ra.m00)), __dmul_rn(o1, ra.m01)), ra.off0);
+        double x1 = __dadd_rn(__dadd_rn(__dadd_rn(0.0, __dmul_rn(o0, ra.m10)), __dmul_rn(o1, ra.m11)), ra.off1);
+        x0 = map_coord_mode(x0, n0, mode);
+        x1 = map_coord_mode(x1, n1, mode);
+        bool outside = mode == 1 && (x0 <= -1.0 || x1 <= -1.0);
+        c[a0] = idx_mode((long long)floor(x0 + 0.5), n0, mode, outside);
+        c[a1] = idx_mode((long long)floor(x1 + 0.5), n1, mode, outside);
+        dst[i] = outside ? cval : src[((v * D + c[0]) * H + c[1]) * W + c[2]];
+    }
+}
+
 static unsigned aug_grid(long long total) {
     long long b = (total + 255) / 256;
     if (b > 8192) b = 8192;
@@ -166,6 +275,26 @@ extern "C" int mis_aug_rotate0(const void* src, void* dst, long long nvol, int D
     else
         hipLaunchKernelGGL(aug_rotate0_kernel<uint64_t>, dim3(g), dim3(256), 0, s, (const uint64_t*)src, (uint64_t*)dst, nvol, D, H, W, a0, a1, ra);
     MIS_LAUNCH_CHECK("aug_rotate0");
+    return MIS_OK;
+}
+
+extern "C" int mis_aug_rotate0_mode(const void* src, void* dst, long long nvol, int D, int H, int W, int a0, int a1, const double* m4, const double* off2,
+                                    int elem_size, int mode, unsigned long long cval_bits, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(src && dst && src != dst && m4 && off2 && nvol > 0 && D > 0 && H > 0 && W > 0, MIS_EINVAL, "aug_rotate0_mode: bad argument");
+    MIS_REQUIRE(a0 >= 0 && a0 < a1 && a1 <= 2, MIS_EINVAL, "aug_rotate0_mode: axes must be sorted and distinct");
+    MIS_REQUIRE(elem_size == 4 || elem_size == 8, MIS_EUNSUPPORTED, "aug_rotate0_mode: element size %d", elem_size);
+    MIS_REQUIRE(mode >= 0 && mode <= 6, MIS_EINVAL, "aug_rotate0_mode: mode %d (0 reflect, 1 constant, 2 nearest, 3 mirror, 4 wrap, 5 grid-wrap, 6 grid-constant)", mode);
+    RotArgs ra{m4[0], m4[1], m4[2], m4[3], off2[0], off2[1]};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned g = aug_grid(nvol * D * H * W);
+    if (elem_size == 4)
+        hipLaunchKernelGGL(aug_rotate0_mode_kernel<uint32_t>, dim3(g), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, nvol, D, H, W, a0, a1, ra, mode,
+                           (uint32_t)cval_bits);
+    else
+        hipLaunchKernelGGL(aug_rotate0_mode_kernel<uint64_t>, dim3(g), dim3(256), 0, s, (const uint64_t*)src, (uint64_t*)dst, nvol, D, H, W, a0, a1, ra, mode,
+                           (uint64_t)cval_bits);
+    MIS_LAUNCH_CHECK("aug_rotate0_mode");
     return MIS_OK;
 }
 

@@ -78,6 +78,86 @@ def rotate0(m, angle, axes):
 _POLE3 = np.sqrt(3.0) - 2.0
 
 
+def _map_coord_mode(x, n, mode):
+    """scipy ni_interpolation.c map_coordinate on a vector of double coordinates (the boundary modes of scipy.ndimage.rotate / affine_transform)"""
+    x = x.copy()
+    if mode == "grid-constant":
+        return x
+    neg, pos = x < 0, x > n - 1
+    if n <= 1 and mode in ("mirror", "reflect", "grid-mirror", "wrap", "grid-wrap"):
+        x[neg | pos] = 0
+        return x
+    if mode == "mirror":
+        sz2 = 2 * n - 2
+        t = sz2 * np.trunc(-x[neg] / sz2) + x[neg]
+        x[neg] = np.where(t <= 1 - n, t + sz2, -t)
+        t = x[pos] - sz2 * np.trunc(x[pos] / sz2)
+        x[pos] = np.where(t >= n, sz2 - t, t)
+    elif mode in ("reflect", "grid-mirror"):
+        sz2 = 2 * n
+        t = x[neg]
+        t = np.where(t < -sz2, sz2 * np.trunc(-t / sz2) + t, t)
+        x[neg] = np.where(t < -n, t + sz2, np.where(t > -1e-15, 1e-15, -t) - 1)
+        t = x[pos] - sz2 * np.trunc(x[pos] / sz2)
+        x[pos] = np.where(t >= n, sz2 - t - 1, t)
+    elif mode == "wrap":
+        sz = n - 1
+        x[neg] = x[neg] + sz * (np.trunc(-x[neg] / sz) + 1)
+        x[pos] = x[pos] - sz * np.trunc(x[pos] / sz)
+    elif mode == "grid-wrap":
+        x[neg] = x[neg] + n * (np.trunc((-1 - x[neg]) / n) + 1)
+        x[pos] = x[pos] - n * np.trunc(x[pos] / n)
+    elif mode == "nearest":
+        x[neg] = 0
+        x[pos] = n - 1
+    elif mode == "constant":
+        x[neg | pos] = -1
+    else:
+        raise ValueError(mode)
+    return x
+
+
+def _idx_mode(i, n, mode):
+    """a rounded support index outside [0, n): the sample scipy reads instead, and whether the output is cval"""
+    inside = np.zeros(i.shape, bool)
+    if mode in ("reflect", "grid-mirror"):
+        m = np.mod(i, 2 * n)
+        return np.where(m < n, m, 2 * n - 1 - m), inside
+    if mode == "mirror":
+        if n == 1:
+            return np.zeros_like(i), inside
+        m = np.mod(i, 2 * n - 2)
+        return np.where(m < n, m, 2 * n - 2 - m), inside
+    if mode in ("wrap", "grid-wrap"):
+        return np.mod(i, n), inside
+    if mode == "nearest":
+        return np.clip(i, 0, n - 1), inside
+    return np.clip(i, 0, n - 1), (i < 0) | (i >= n)          # constant / grid-constant
+
+
+def rotate0_modes(m, angle, axes, mode="reflect", cval=-1):
+    """scipy.ndimage.rotate(m, angle, axes, reshape=False, order=0, mode=mode, cval=cval) for EVERY boundary mode (reference transforms.py:109-111 passes the
+    constructor's mode through): bit-identical to scipy (tests/test_augment.py); mis_aug_rotate0_mode (csrc/augment.hip) is the device form"""
+    a0, a1 = sorted(axes)
+    c, s = special.cosdg(angle), special.sindg(angle)
+    rot = np.array([[c, s], [-s, c]])
+    shp = np.asarray(m.shape)[[a0, a1]]
+    off = (shp - 1) / 2 - rot @ ((shp - 1) / 2)
+    idx = np.indices(m.shape)
+    o0, o1 = idx[a0].astype(np.float64), idx[a1].astype(np.float64)
+    x0 = ((0.0 + o0 * rot[0, 0]) + o1 * rot[0, 1]) + off[0]
+    x1 = ((0.0 + o0 * rot[1, 0]) + o1 * rot[1, 1]) + off[1]
+    n0, n1 = m.shape[a0], m.shape[a1]
+    x0m, x1m = _map_coord_mode(x0.ravel(), n0, mode), _map_coord_mode(x1.ravel(), n1, mode)
+    const = (x0m <= -1.0) | (x1m <= -1.0) if mode == "constant" else np.zeros(x0m.shape, bool)
+    i0, c0 = _idx_mode(np.floor(x0m + 0.5).astype(np.int64), n0, mode)
+    i1, c1 = _idx_mode(np.floor(x1m + 0.5).astype(np.int64), n1, mode)
+    ii = [idx[k].ravel() for k in range(m.ndim)]
+    ii[a0], ii[a1] = i0, i1
+    out = np.where(const | c0 | c1, np.asarray(cval, m.dtype), m[tuple(ii)])
+    return out.reshape(m.shape)
+
+
 def spline_filter3_line(c):
     """scipy ni_splines.c (scipy 1.15, third-party): cubic B-spline prefilter of one line, mode 'reflect' (half-sample symmetric):
     gain (1-z)(1-1/z), exact causal initialisation over the reflected signal, causal and anti-causal recursions.
