@@ -37,8 +37,8 @@ constexpr int PH_HBUF = PH_HINSTR * 1024;
 constexpr int PH_TAPB = PH_BN * 64;
 constexpr int PH_WTILE = 3 * PH_TAPB;
 constexpr int PH_HJ = (PH_HINSTR + 3) / 4;
-// 3 halo + 3 weight buffers + 2 x bias + 8 x 256 B labels + Wh (fp32 [2][64]) + the final block reduction [8][160] floats (reuses the halo ring)
-constexpr int PH_LDS = 3 * PH_HBUF + 3 * PH_WTILE + 2 * PH_BN * 4 + 8 * 256 + 2 * 64 * 4;
+// 3 halo + 3 weight buffers + 2 x bias + 8 x 256 B labels + Wh (fp32 [4][64]) + the final block reduction [8][288] floats (reuses the halo ring)
+constexpr int PH_LDS = 3 * PH_HBUF + 3 * PH_WTILE + 2 * PH_BN * 4 + 8 * 256 + 4 * 64 * 4;
 
 struct HeadFusedArgs {
     const float* wh;        // [C][64]
@@ -51,7 +51,7 @@ struct HeadFusedArgs {
 };
 }   // namespace
 
-// C = 2: cross entropy; C = 1: BCE with logits
+// C = 2 .. 4: cross entropy; C = 1: BCE with logits
 template <int C>
 __global__ __launch_bounds__(512, 2) void conv_ppd_head_kernel(const ConvArgs a, const HeadFusedArgs hd) {
     using T = __bf16;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_head_kernel(const ConvArgs a,
     char* const wbase = smem + 3 * HBUF;
     char* const bbase = wbase + 3 * WTILE;
     char* const lbase = bbase + 2 * BN * 4;                 // 8 x 256 B: the waves' labels of the current tile
-    char* const whl = lbase + 8 * 256;                      // Wh fp32 [2][64]
+    char* const whl = lbase + 8 * 256;                      // Wh fp32 [4][64] (rows >= C zero)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -106,14 +106,19 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_head_kernel(const ConvArgs a,
     const char* const xb = reinterpret_cast<const char*>(a.x0.p);
     const __amdgpu_buffer_rsrc_t rw = pp_make_rsrc(a.w, (unsigned)((long long)9 * a.Cout * a.Cin * 2));
 
-    int hrel[HJ], hpx[HJ];
+    // per-lane halo offsets precomputed where the registers allow it (C <= 3; with four classes the head's 64 gradient accumulators take their place and the offsets
+    // are re-derived at every issue, as conv_ppc_kernel<8, 4> does)
+    constexpr bool HPRE = C <= 3;
+    int hrel[HPRE ? HJ : 1], hpx[HPRE ? HJ : 1];
+    if constexpr (HPRE) {
 #pragma unroll
-    for (int j = 0; j < HJ; ++j) {
-        const int item = (j * 4 + (wave & 3)) * 64 + lane;
-        const int p = item >> 2, pos = item & 3;
-        const int py = p / HW, px = p - py * HW;
-        hrel[j] = ((py * a.W + px) * a.x0.ld + ((pos ^ ((px >> 1) & 3)) << 3)) * 2;
-        hpx[j] = item < PH_HITEMS ? px : 0x40000000;
+        for (int j = 0; j < HJ; ++j) {
+            const int item = (j * 4 + (wave & 3)) * 64 + lane;
+            const int p = item >> 2, pos = item & 3;
+            const int py = p / HW, px = p - py * HW;
+            hrel[j] = ((py * a.W + px) * a.x0.ld + ((pos ^ ((px >> 1) & 3)) << 3)) * 2;
+            hpx[j] = item < PH_HITEMS ? px : 0x40000000;
+        }
     }
     auto issue_halo = [&](auto jc, int n, int h0, int w0, int c0, char* dst) {
         constexpr int j = decltype(jc)::value;
@@ -122,8 +127,19 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_head_kernel(const ConvArgs a,
         const __amdgpu_buffer_rsrc_t rx = pp_make_rsrc(xb + (size_t)n * a.H * a.W * a.x0.ld * 2, img_x);
         unsigned toff = (unsigned)((((h0 - 1) * a.W + (w0 - 1)) * a.x0.ld + c0) * 2);
         asm volatile("" : "+s"(toff));
-        const bool ok = (unsigned)(w0 - 1 + hpx[j]) < (unsigned)a.W;
-        pp_dma16(rx, ok ? (int)(toff + (unsigned)hrel[j]) : PP_OOB, dst + id * 1024);
+        if constexpr (HPRE) {
+            const bool ok = (unsigned)(w0 - 1 + hpx[j]) < (unsigned)a.W;
+            pp_dma16(rx, ok ? (int)(toff + (unsigned)hrel[j]) : PP_OOB, dst + id * 1024);
+        } else {
+            int l_;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
+            const int item = id * 64 + l_;
+            const int p = item >> 2, pos = item & 3;
+            const int py = p / HW, px = p - py * HW;
+            const unsigned rel = (unsigned)(((py * a.W + px) * a.x0.ld + ((pos ^ ((px >> 1) & 3)) << 3)) * 2);
+            const bool ok = item < PH_HITEMS && (unsigned)(w0 - 1 + px) < (unsigned)a.W;
+            pp_dma16(rx, ok ? (int)(toff + rel) : PP_OOB, dst + id * 1024);
+        }
     };
     const __amdgpu_buffer_rsrc_t rb = pp_make_rsrc(a.bias != nullptr ? (const void*)a.bias : a.w, a.bias != nullptr ? (unsigned)a.Cout * 4u : 0u);
     auto issue_bias = [&](char* dst) {
@@ -152,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_head_kernel(const ConvArgs a,
     };
 
     // Wh -> LDS (fp32 [C][64], rows >= C zero), read back per tile in the two operand forms
-    if (tid < 128) reinterpret_cast<float*>(whl)[tid] = (tid >> 6) < C ? hd.wh[tid] : 0.f;
+    if (tid < 256) reinterpret_cast<float*>(whl)[tid] = (tid >> 6) < C ? hd.wh[tid] : 0.f;
     float bh[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) bh[c] = hd.bh[c];
@@ -292,10 +308,10 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_head_kernel(const ConvArgs a,
             const int eli = lane_ & 15, elg = lane_ >> 4;
             // Wh of this lane's 16 channels (fp32: dL/dfeatures) and the MFMA operand (bf16 hi / lo of Wh[row & 3][piece*32 + elg*8 .. +7], rows >= C zero)
             const uint32_t wl = (uint32_t)(uintptr_t)whl;
+            constexpr bool WKR = C <= 3;          // Wh of the lane's channels held in registers for the tile; C = 4: re-read per pixel row (the 64 registers would spill)
             pp_f32x2 wk2[C][8];
-            u32x4 ahi[2], alo[2];
-            {
-                u32x4 raw[C][4], araw[2][2];
+            auto load_wk = [&]() {
+                u32x4 raw[C][4];
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     raw[c][0] = pp_lds_read128<0>(wl + (c * 64 + elg * 8) * 4);
@@ -303,17 +319,24 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_head_kernel(const ConvArgs a,
                     raw[c][2] = pp_lds_read128<128>(wl + (c * 64 + elg * 8) * 4);
                     raw[c][3] = pp_lds_read128<144>(wl + (c * 64 + elg * 8) * 4);
                 }
-                const uint32_t arow = wl + (((eli & 3) & 1) * 64 + elg * 8) * 4;          // (rows 2, 3 of the four-row pattern read row 0 / 1 and are zeroed below)
-                araw[0][0] = pp_lds_read128<0>(arow);
-                araw[0][1] = pp_lds_read128<16>(arow);
-                araw[1][0] = pp_lds_read128<128>(arow);
-                araw[1][1] = pp_lds_read128<144>(arow);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int c = 0; c < C; ++c)
 #pragma unroll
                     for (int k = 0; k < 8; ++k) wk2[c][k] = pp_f32x2{__uint_as_float(raw[c][k >> 1][(k & 1) * 2]), __uint_as_float(raw[c][k >> 1][(k & 1) * 2 + 1])};
+            };
+            if constexpr (WKR) load_wk();
+            u32x4 ahi[2], alo[2];
+            {
+                u32x4 araw[2][2];
+                const uint32_t arow = wl + ((eli & 3) * 64 + elg * 8) * 4;          // row r of the operand = class r & 3 (rows >= C are zero in LDS)
+                araw[0][0] = pp_lds_read128<0>(arow);
+                araw[0][1] = pp_lds_read128<16>(arow);
+                araw[1][0] = pp_lds_read128<128>(arow);
+                araw[1][1] = pp_lds_read128<144>(arow);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
                 const bool live = (eli & 3) < C;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -421,6 +444,7 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_head_kernel(const ConvArgs a,
                     if (hd.argmax != nullptr && elg == 3) hd.argmax[pix] = (unsigned char)am;
                 }
                 // dW += dl x feature; g = (feature > 0) * sum_c dl_c * Wh[c][k]
+                if constexpr (!WKR) load_wk();
                 u32x4 go[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -458,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_head_kernel(const ConvArgs a,
     // ---- block partial: [C*64 dW][C db][1 loss] (+ zeros for the Dice slots), the row layout of head_kernel's partials ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    float* const red = reinterpret_cast<float*>(hbase);    // [8][160]
+    float* const red = reinterpret_cast<float*>(hbase);    // [8][288]: per wave [C*64 dW][C db][loss]
     {
         // sum over the 16 pixel columns (lanes of equal elg) by xor-shuffles within the 16-lane row, then lane eli == 0 of every elg holds the wave's sums
 #pragma unroll
@@ -485,11 +509,11 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_head_kernel(const ConvArgs a,
 #pragma unroll
             for (int c = 0; c < C; ++c)
 #pragma unroll
-                for (int k = 0; k < 16; ++k) red[wave * 160 + c * 64 + (k >> 3) * 32 + lg * 8 + (k & 7)] = dwa2[c][k >> 1][k & 1];
+                for (int k = 0; k < 16; ++k) red[wave * 288 + c * 64 + (k >> 3) * 32 + lg * 8 + (k & 7)] = dwa2[c][k >> 1][k & 1];
             if (lg == 0) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) red[wave * 160 + 128 + c] = dba[c];
-                red[wave * 160 + 128 + 2] = lsum;
+                for (int c = 0; c < C; ++c) red[wave * 288 + 256 + c] = dba[c];
+                red[wave * 288 + 256 + 4] = lsum;
             }
         }
     }
@@ -500,13 +524,13 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_head_kernel(const ConvArgs a,
         float s = 0.f;
         if (i < C * 64) {
 #pragma unroll
-            for (int w = 0; w < 8; ++w) s += red[w * 160 + i];
+            for (int w = 0; w < 8; ++w) s += red[w * 288 + i];
         } else if (i < C * 64 + C) {
 #pragma unroll
-            for (int w = 0; w < 8; ++w) s += red[w * 160 + 128 + (i - C * 64)];
+            for (int w = 0; w < 8; ++w) s += red[w * 288 + 256 + (i - C * 64)];
         } else if (i == C * 64 + C) {
 #pragma unroll
-            for (int w = 0; w < 8; ++w) s += red[w * 160 + 128 + 2];
+            for (int w = 0; w < 8; ++w) s += red[w * 288 + 256 + 4];
         }
         out[i] = s;
     }
@@ -521,7 +545,7 @@ static bool head_fused_ok(const MisConvDesc* d, const MisHeadDesc* h) {
     const long long img = (long long)d->H * d->W;
     if (((img - 1) * d->y0_ld + 64) * 2 >= (1ll << 32) - 65536) return false;
     if (h->dtype != MIS_BF16 || h->Cfeat != 64 || h->N != d->N || h->npix_per_image != img) return false;
-    if (!((h->C == 2 && h->loss == 0) || (h->C == 1 && h->loss == 1))) return false;
+    if (!((h->C >= 2 && h->C <= 4 && h->loss == 0) || (h->C == 1 && h->loss == 1))) return false;
     if (h->dy == nullptr || h->dw == nullptr || h->db == nullptr || h->labels == nullptr || h->loss_out == nullptr || h->workspace == nullptr || h->w == nullptr || h->b == nullptr) return false;
     if (h->dy != d->y0 || h->dy_ld != d->y0_ld) return false;                       // dL/dfeatures goes where the features would have gone
     if (h->phase != 0) return false;
@@ -560,6 +584,14 @@ extern "C" int mis_conv3x3_head_fused(const MisConvDesc* d, const MisHeadDesc* h
         static std::atomic<unsigned long long> attr_done{0};
         if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv_ppd_head_kernel<2>), (size_t)PH_LDS, "conv3x3_head_fused")) return rc;
         hipLaunchKernelGGL((conv_ppd_head_kernel<2>), dim3(grid), dim3(512), (size_t)PH_LDS, stream, a, hd);
+    } else if (h->C == 3) {
+        static std::atomic<unsigned long long> attr_done{0};
+        if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv_ppd_head_kernel<3>), (size_t)PH_LDS, "conv3x3_head_fused")) return rc;
+        hipLaunchKernelGGL((conv_ppd_head_kernel<3>), dim3(grid), dim3(512), (size_t)PH_LDS, stream, a, hd);
+    } else if (h->C == 4) {
+        static std::atomic<unsigned long long> attr_done{0};
+        if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv_ppd_head_kernel<4>), (size_t)PH_LDS, "conv3x3_head_fused")) return rc;
+        hipLaunchKernelGGL((conv_ppd_head_kernel<4>), dim3(grid), dim3(512), (size_t)PH_LDS, stream, a, hd);
     } else {
         static std::atomic<unsigned long long> attr_done{0};
         if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv_ppd_head_kernel<1>), (size_t)PH_LDS, "conv3x3_head_fused")) return rc;

@@ -287,9 +287,9 @@ class UNet2DEngine:
 
     def _fused_head(self, labels, N, H, W, grad_scale):
         """up_conv.3.second + final_conv + loss + their backward as ONE kernel (csrc/conv_ppd_head.hip, round 4): the last feature map is never written - dL/dfeatures
-        (g_u2[3]) takes its place - and the head's pass over it disappears (0.58 ms of a 30.6 ms step).  bf16, 1 or 2 classes, training form; everything else (and
-        MISAMD_HEAD_UNFUSED=1 / MIS_HEAD_UNFUSED) runs the convolution and mis_head_loss separately."""
-        if self.dtype != torch.bfloat16 or self.cout > 2 or os.environ.get("MISAMD_HEAD_UNFUSED"):
+        (g_u2[3]) takes its place - and the head's pass over it disappears (0.58 ms of a 30.6 ms step).  bf16, 1 .. 4 classes (BCE / cross entropy), training form;
+        everything else (and MISAMD_HEAD_UNFUSED=1 / MIS_HEAD_UNFUSED) runs the convolution and mis_head_loss separately."""
+        if self.dtype != torch.bfloat16 or os.environ.get("MISAMD_HEAD_UNFUSED"):
             return False
         self._check_labels(labels, N, H, W)
         name = "up_conv.3.second"

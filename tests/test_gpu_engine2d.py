@@ -188,16 +188,16 @@ def test_batched_slab_reduction_is_bit_identical(dtype, shape):
     assert float(out[0].abs().sum()) > 0
 
 
-@pytest.mark.parametrize("cout,shape", [(2, (3, 64, 48)), (2, (2, 96, 80)), (1, (2, 64, 64)), (2, (9, 160, 176))])
+@pytest.mark.parametrize("cout,shape", [(2, (3, 64, 48)), (2, (2, 96, 80)), (1, (2, 64, 64)), (2, (9, 160, 176)), (4, (2, 64, 80)), (3, (2, 96, 48)), (4, (9, 160, 176))])
 def test_fused_head_matches_the_separate_kernels(cout, shape, monkeypatch):
     """csrc/conv_ppd_head.hip (up_conv.3.second + final_conv + CE / BCE + their backward in ONE kernel; the last feature map is never written) against the separate
     convolution + mis_head_loss: same loss, logits, arg-max and gradients up to fp32 summation order (the logits come off the matrix pipe with Wh split into bf16 hi + lo
-    parts) and the bf16 rounding flips that follow from it.  Ragged tiles (48 / 80 / 176 columns), 1 and 2 classes, several tiles per persistent block (9 x 5 x 11 = 495)."""
+    parts) and the bf16 rounding flips that follow from it.  Ragged tiles (48 / 80 / 176 columns), 1 .. 4 classes, several tiles per persistent block (9 x 5 x 11 = 495)."""
     from mdeical_image_segmentation_amd import ops
     N, H, W = shape
     gen = torch.Generator().manual_seed(31)
     images = torch.randn(N, 1, H, W, generator=gen).to(DEV)
-    labels = (torch.randint(0, 2, (N, H, W), generator=gen) if cout == 2 else torch.randint(0, 2, (N, 1, H, W), generator=gen).float()).to(DEV)
+    labels = (torch.randint(0, cout, (N, H, W), generator=gen) if cout >= 2 else torch.randint(0, 2, (N, 1, H, W), generator=gen).float()).to(DEV)
     res = []
     for fused in (True, False):
         if not fused:
