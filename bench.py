@@ -589,6 +589,8 @@ def run3d(args, rank, world, dev, dist, *, dtype, batch, size, steps, warmup, ti
     dt, prof = _timed_loop(step, steps, warmup - 1, world, dist, dev, timing)
     loss_list = [round(float(v), 5) for v in losses[:steps].cpu().tolist()]
     comm = _comm_report(reducer, eng, steps, world, dist, dev) if reducer is not None else None
+    if comm is not None:
+        comm["exact_dice"] = bool(eng.exact_dice and world > 1)          # the Dice term of the GLOBAL batch (36-byte all-reduce inside the head), as the reference's DataParallel
     out = None
     if rank == 0:
         value = world * batch * steps / dt

@@ -392,8 +392,13 @@ class _PendingState:
 
     def __init__(self, random_state, name, key, pos, res, raw):
         self.rs, self.name, self.key, self.pos, self.res, self.raw = random_state, name, key, pos, res, raw
+        # the kernels that produce res / raw were enqueued on the CURRENT stream: resolve() may run under another one, so it waits for this event, not for
+        # whatever stream happens to be current then
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(res.device))
 
     def resolve(self):
+        self.event.synchronize()
         r = self.res.cpu().numpy()
         if int(r[4]) != 1:
             raise MisError("exact Gaussian noise: the pre-drawn word stream was too short (eight sigma of slack) - the field of the previous call is incomplete; "

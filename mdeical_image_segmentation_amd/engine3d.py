@@ -88,11 +88,12 @@ class UNet3DEngine:
 
     def __init__(self, in_channels=1, out_channels=3, f_maps=(64, 128, 256, 512), num_groups=8, dtype=torch.float32, device="cuda",
                  seed=None, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3, max_grad_norm=1.0, alpha=1.0, beta=1.0,
-                 upsample="default", exact_dice=False, dice_group=None):
+                 upsample="default", exact_dice=None, dice_group=None):
         """exact_dice: under data parallelism (an initialised torch.distributed group) the Dice term is that of the GLOBAL batch - the 3*C per-class sums
         (I_c, P_c, T_c: 36 bytes for C = 3) are all-reduced between the forward and the gradient part of the head, as the reference computes the loss once on the
-        gathered batch (model/unet3d/trainer.py:312-318, nn.DataParallel); default False = the DistributedDataParallel semantics (per-rank loss, averaged gradients)."""
-        self.exact_dice, self.dice_group = exact_dice, dice_group
+        gathered batch (model/unet3d/trainer.py:312-318, nn.DataParallel).  Default (None, round 4 / ADVICE r3): ON whenever a process group with more than one rank
+        exists - the reference's semantics; False = the DistributedDataParallel semantics (per-rank loss, averaged gradients: a different loss and different gradients)."""
+        self.exact_dice, self.dice_group = (True if exact_dice is None else bool(exact_dice)), dice_group
         if upsample not in ("default", "nearest", "deconv"):
             raise MisError(f"UNet3DEngine: upsample must be 'default'/'nearest' or 'deconv', got {upsample!r}")
         self.deconv = upsample == "deconv"
@@ -111,7 +112,10 @@ class UNet3DEngine:
         # bf16: the GroupNorm output is WRITTEN once per SingleConv (mis_gn_apply: same arithmetic and rounding as the operand-staging fold) and feeds both the forward
         # convolution and the weight gradient as a plain single-source tensor - which is what lets them run on the all-DMA ping-pong kernels (conv3d_pp.hip,
         # wgrad_pp.hip); fp32 keeps the fold (its lock-step kernels sit at 0.79 of the f32 MFMA peak).  MISAMD_GN_FOLD=1: the fold in bf16 too (A/B switch).
-        self.materialize = dtype == torch.bfloat16 and os.environ.get("MISAMD_GN_FOLD") is None
+        # (the materialised route lives on the ping-pong kernels - per-sample split-K ranges, 32-channel K chunks: with one of their A/B switches set in the environment the
+        #  engine takes the operand-fold route of the lock-step kernels instead of failing in the middle of a step)
+        pp_off = any(os.environ.get(k) for k in ("MIS_WGRAD_NOPP", "MIS_WGRAD3D_NOPP", "MIS_CONV3D_NOPP", "MIS_WGRAD_NO_TR"))
+        self.materialize = dtype == torch.bfloat16 and os.environ.get("MISAMD_GN_FOLD") is None and not pp_off
         # ... and with xn at hand the GroupNorm backward statistics (sum dyn, sum dyn * x per sample and channel) follow from the per-sample weight gradients and the
         # border sums of g_y (mis_gn_bwd_stats_from_dw) instead of a pass over dyn and x (2 x 1-3 GB per full-resolution layer).  MISAMD_GN_STATS_KERNEL=1: that pass.
         self.gn_from_dw = self.materialize and os.environ.get("MISAMD_GN_STATS_KERNEL") is None
