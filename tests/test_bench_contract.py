@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_keys():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline"):
         assert k in d, k
@@ -31,5 +31,5 @@ def test_traffic_profile_belongs_to_this_tree():
     assert t["source_hash"] == _lib.source_hash(_lib.TRAFFIC_SOURCES), "profiles/traffic.json was measured on other conv / wgrad kernel sources: re-run the PMC passes"
     ent = t["kernels"]["conv_igemm/bf16/k3/2d/bn128"]
     assert ent["hbm_read_bytes_per_launch"] > 0 and ent["hbm_write_bytes_per_launch"] > 0
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
     assert d["roofline"]["traffic"] == ent["hbm_read_bytes_per_launch"] + ent["hbm_write_bytes_per_launch"]
