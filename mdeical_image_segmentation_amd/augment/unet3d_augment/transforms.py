@@ -602,9 +602,7 @@ class PercentileNormalizer:
     the interpolation follows numpy's `_lerp`, the normalisation is one elementwise kernel."""
 
     def __init__(self, pmin=1, pmax=99.6, channelwise=False, eps=1e-10, **kwargs):
-        if channelwise:
-            raise NotImplementedError("PercentileNormalizer(channelwise=True) is not built")
-        self.eps, self.pmin, self.pmax = eps, pmin, pmax
+        self.eps, self.pmin, self.pmax, self.channelwise = eps, pmin, pmax, channelwise
 
     @staticmethod
     def _percentile(flat, q):
@@ -623,6 +621,11 @@ class PercentileNormalizer:
         m = _dev(m)
         if m.dtype != torch.float32:
             raise MisError("PercentileNormalizer: fp32 volumes only")
+        if self.channelwise:          # transforms.py:534-539: percentiles over every axis but the first, i.e. each channel normalised by its own pair (round 4)
+            return torch.stack([self._normalize(m[c].contiguous()) for c in range(m.shape[0])])
+        return self._normalize(m)
+
+    def _normalize(self, m):
         flat = m.reshape(-1)
         pmin, pmax = self._percentile(flat, self.pmin), self._percentile(flat, self.pmax)
         a = np.float32(1.0) / np.float32(pmax - pmin + np.float32(self.eps))

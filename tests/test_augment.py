@@ -72,6 +72,15 @@ def test_device_crop_and_poisson_match_reference_goldens():
     for key, kw in (("pnorm", {}), ("pnorm_5_90", dict(pmin=5, pmax=90))):
         got = tr.PercentileNormalizer(**kw)(g["v"]).cpu().numpy()
         assert np.abs(got - g[key]).max() < 2e-6 * max(1.0, np.abs(g[key]).max()), key
+    # channelwise=True (transforms.py:534-539, round 4): every channel by its own percentile pair - against the reference's own three numpy lines on a 4-D input
+    v4 = np.stack([g["v"], g["v"][::-1].copy() * 2.5 - 0.3, np.sqrt(np.abs(g["v"]))]).astype(np.float32)
+    axes = tuple(range(1, v4.ndim))
+    for kw in ({}, dict(pmin=5, pmax=90)):
+        lo = np.percentile(v4, kw.get("pmin", 1), axis=axes, keepdims=True)
+        hi = np.percentile(v4, kw.get("pmax", 99.6), axis=axes, keepdims=True)
+        want = (v4 - lo) / (hi - lo + 1e-10)
+        got = tr.PercentileNormalizer(channelwise=True, **kw)(v4).cpu().numpy()
+        assert got.shape == want.shape and np.abs(got - want).max() < 2e-6 * max(1.0, np.abs(want).max()), kw
     keep = tr.AdditivePoissonNoise(np.random.RandomState(700), execution_probability=0.0)(g["v"])
     assert np.array_equal(np.asarray(keep if isinstance(keep, np.ndarray) else keep.cpu().numpy()), g["v"])
 
