@@ -181,6 +181,16 @@ typedef struct MisPackItem {
     int rows, cols, taps, kind;
 } MisPackItem;
 int mis_pack_batch(int dtype, const MisPackItem* items_dev, int n, int max_rows, int max_cols, void* stream);
+/* ... with a compact grid: entry i owns blocks [blk0, blk0 + nbx * nby) (blk0 ascending from 0; nbx = ceil(cols / 32), nby = ceil(rows / 32); for kind 0 a block (by, bx)
+ * packs the 32 x 32 tile at (row by * 32, column bx * 32)); total_blocks = the sum. */
+typedef struct MisPackItem2 {
+    const float* w;
+    void* w_fwd;
+    void* w_dgrad;
+    int rows, cols, taps, kind;
+    int blk0, nbx;
+} MisPackItem2;
+int mis_pack_batch2(int dtype, const MisPackItem2* items_dev, int n, int total_blocks, void* stream);
 int mis_pack_conv_weight(int dtype, const float* w, int Cout, int Cin, int taps, void* w_fwd, void* w_dgrad, void* stream);
 /* convT k2s2: w [Cin][Cq][2][2] -> fwd pack [1][4*Cq][Cin] (row = ab*Cq + c) and dgrad pack [1][Cin][4*Cq] */
 int mis_pack_convt_weight(int dtype, const float* w, int Cin, int Cq, void* w_fwd, void* w_dgrad, void* stream);

@@ -20,7 +20,7 @@ EXPORTS = [
     "mis_comm_unique_id", "mis_comm_init", "mis_comm_world", "mis_allreduce_bucket", "mis_comm_finalize",
     "mis_conv3x3_first_fwd", "mis_conv3x3_first_fwd_rb", "mis_relu_bits_bytes", "mis_relu_bits", "mis_conv3x3_first_wgrad_workspace_bytes", "mis_conv3x3_first_wgrad",
     "mis_colsum_workspace_bytes", "mis_colsum", "mis_maxpool2_fwd", "mis_maxpool2_bwd", "mis_maxpool2_fwd_pb", "mis_maxpool2_bwd_pb",
-    "mis_pack_conv_weight", "mis_pack_convt_weight", "mis_pack_batch", "mis_head_workspace_bytes", "mis_head_loss", "mis_conv3x3_head_fused_eligible", "mis_conv3x3_head_fused",
+    "mis_pack_conv_weight", "mis_pack_convt_weight", "mis_pack_batch", "mis_pack_batch2", "mis_head_workspace_bytes", "mis_head_loss", "mis_conv3x3_head_fused_eligible", "mis_conv3x3_head_fused",
     "mis_adamw_workspace_bytes", "mis_sumsq", "mis_adamw_step", "mis_adamw_step_dev", "mis_sumsq_npartials",
     "mis_chanstats_workspace_bytes", "mis_chanstats", "mis_nchw_to_nhwc", "mis_nhwc_to_nchw", "mis_probe_mfma",
     "mis_gn_fwd_finalize", "mis_gn_bwd_stats_workspace_bytes", "mis_gn_bwd_stats", "mis_gn_bwd_stats_from_dw_workspace_bytes", "mis_gn_bwd_stats_from_dw", "mis_gn_cond", "mis_gn_bwd_finalize", "mis_gn_bwd_apply",
@@ -116,7 +116,9 @@ def load():
         C.CDLL(tl, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     lib.mis_last_error.restype = C.c_char_p
+    lib.mis_last_error.argtypes = []
     lib.mis_version.restype = C.c_int
+    lib.mis_version.argtypes = []
     for name in ("mis_conv_last_dispatch", "mis_wgrad_last_dispatch"):
         getattr(lib, name).restype = C.c_char_p
         getattr(lib, name).argtypes = []
@@ -262,6 +264,7 @@ def load():
         "mis_aug_contrast": [vp, vp, ll, f, f, vp],
         "mis_minmax": [vp, ll, vp, vp, vp],
         "mis_pack_batch": [i, vp, i, i, i, vp],
+        "mis_pack_batch2": [i, vp, i, i, vp],
         "mis_norm_act_fwd": [i, vp, i, vp, i, i, ll, i, vp, vp, i, f, vp],
         "mis_mask_scale": [i, vp, i, vp, i, vp, i, ll, i, f, vp],
         "mis_norm_act_bwd": [i, vp, i, vp, i, vp, i, i, ll, i, vp, vp, i, f, vp],

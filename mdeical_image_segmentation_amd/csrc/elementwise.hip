@@ -1139,6 +1139,36 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const MisPackItem* __re
     }
 }
 
+// ... the same with a COMPACT grid (round 4): an entry carries the index of its first block (`blk0`, ascending) and its tile columns, so the launch has exactly the blocks
+// that do work - the (max_cols / 32, max_rows / 32, n) grid above scheduled 21.5 k blocks for the 2-D net, 17 k of which exit at once (pack: 132 us for 250 MB)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_batch2_kernel(const MisPackItem2* __restrict__ items, int n) {
+    __shared__ float tile[9][32][33];
+    const int bid = blockIdx.x;
+    int lo = 0, hi = n - 1;                                   // last entry with blk0 <= bid (block-uniform binary search)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].blk0 <= bid) lo = mid;
+        else hi = mid - 1;
+    }
+    const MisPackItem2 it = items[lo];
+    const int local = bid - it.blk0;
+    const int by = local / it.nbx, bx = local - by * it.nbx;
+    if (it.kind == 0) pack_conv_tile<T>(tile, it.w, it.rows, it.cols, it.taps, (T*)it.w_fwd, (T*)it.w_dgrad, by * 32, bx * 32);
+    else pack_convt_tile<T>(tile, it.w, it.rows, it.cols, (T*)it.w_fwd, (T*)it.w_dgrad, by * 32, bx * 32);
+}
+
+extern "C" int mis_pack_batch2(int dtype, const MisPackItem2* items_dev, int n, int total_blocks, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, MIS_EINVAL, "pack_batch2: bad dtype %d", dtype);
+    MIS_REQUIRE(items_dev && n > 0 && n <= 65535 && total_blocks > 0, MIS_EINVAL, "pack_batch2: bad argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIS_BF16) hipLaunchKernelGGL(pack_batch2_kernel<__bf16>, dim3((unsigned)total_blocks), dim3(256), 0, s, items_dev, n);
+    else hipLaunchKernelGGL(pack_batch2_kernel<float>, dim3((unsigned)total_blocks), dim3(256), 0, s, items_dev, n);
+    MIS_LAUNCH_CHECK("pack_batch2");
+    return MIS_OK;
+}
+
 extern "C" int mis_pack_batch(int dtype, const MisPackItem* items_dev, int n, int max_rows, int max_cols, void* stream) {
     (void)hipGetLastError();
     MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, MIS_EINVAL, "pack_batch: bad dtype %d", dtype);

@@ -386,18 +386,22 @@ class PackTable:
 
     def __init__(self, entries, device):
         import numpy as np
-        dt = np.dtype([("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("taps", "<i4"), ("kind", "<i4")])
-        assert dt.itemsize == 40
+        dt = np.dtype([("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("taps", "<i4"), ("kind", "<i4"), ("blk0", "<i4"), ("nbx", "<i4")])
+        assert dt.itemsize == 48          # MisPackItem2 (include/misamd.h): the compact-grid form
         tab = np.zeros(len(entries), dtype=dt)
         self.keep = []
         dts = set()
+        blk = 0
         for i, (w, wf, wd, kind) in enumerate(entries):
             assert w.dtype == torch.float32 and w.is_contiguous() and wf.is_contiguous() and (wd is None or wd.is_contiguous())
             rows, cols = w.shape[0], w.shape[1]
             taps = w[0, 0].numel() if kind == 0 else 4
-            tab[i] = (w.data_ptr(), wf.data_ptr(), 0 if wd is None else wd.data_ptr(), rows, cols, taps, kind)
+            nbx, nby = (cols + 31) // 32, (rows + 31) // 32
+            tab[i] = (w.data_ptr(), wf.data_ptr(), 0 if wd is None else wd.data_ptr(), rows, cols, taps, kind, blk, nbx)
+            blk += nbx * nby
             dts.add(wf.dtype)
             self.keep.append((w, wf, wd))
+        self.total_blocks = blk
         assert len(dts) == 1
         self.dtype = dts.pop()
         self.n = len(entries)
@@ -409,7 +413,7 @@ class PackTable:
 def pack_batch(table):
     """every weight repack of a network in one launch (mis_pack_batch)"""
     lib = load()
-    check(lib.mis_pack_batch(dtype_code(table.dtype), table.dev.data_ptr(), table.n, table.max_rows, table.max_cols, stream_ptr()), "mis_pack_batch")
+    check(lib.mis_pack_batch2(dtype_code(table.dtype), table.dev.data_ptr(), table.n, table.total_blocks, stream_ptr()), "mis_pack_batch2")
 
 
 def pack_convt_weight(w, w_fwd, w_dgrad):

@@ -31,3 +31,12 @@ def test_argument_validation_needs_no_gpu():
     assert lib.mis_conv_igemm(ctypes.byref(d), None) != 0
     assert b"dtype" in lib.mis_last_error()
     assert lib.mis_wgrad_workspace_bytes(ctypes.byref(_lib.WgradDesc())) == 0
+
+
+def test_every_export_has_a_ctypes_signature():
+    """Without `argtypes` ctypes passes a Python int as a 32-bit C int: a device POINTER handed to such an entry point is silently truncated and the kernel faults on the GPU
+    (round 4: mis_pack_batch2 was added to EXPORTS without its signature - a memory access fault on the box).  Every exported entry point must carry its argument types."""
+    from mdeical_image_segmentation_amd import _lib
+    lib = _lib.load()
+    missing = [n for n in _lib.EXPORTS if getattr(lib, n).argtypes is None]
+    assert not missing, f"no ctypes argtypes for {missing}: add them to _lib.load()"
