@@ -197,6 +197,23 @@ def attach_traffic(roof, batch, size):
 DDP_ON = False
 
 
+class _StdoutToStderr:
+    """RCCL 2.26 prints a version banner ("RCCL version : ...", five lines) on STDOUT when rank 0 creates its first communicator; the contract of this file is ONE JSON line on
+    stdout.  While the process group (and the C-ABI communicator) come up, file descriptor 1 points at stderr."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -256,16 +273,21 @@ def main():
         backend = os.environ.get("MISAMD_BENCH_REHEARSAL", "nccl")
         if backend == "nccl1":
             backend = "nccl"
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        with _StdoutToStderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)                      # (the communicator exists after this call whichever way the backend initialises it)
+            torch.cuda.synchronize()
         if dist.get_world_size() != args.gpus or dist.get_backend() != backend or (world > 1 and not os.environ.get("MISAMD_BENCH_REHEARSAL") and dist.get_backend() != "nccl"):
             # (not an assert: python -O must not turn a gloo / wrong-size run into a number)
             raise SystemExit(f"bench.py: N > 1 needs the RCCL process group of {args.gpus} ranks: got backend {dist.get_backend()!r}, world size {dist.get_world_size()}")
         if args.comm == "native":
             from mdeical_image_segmentation_amd.ddp import native_comm_init
-            assert native_comm_init() == args.gpus
+            with _StdoutToStderr():
+                assert native_comm_init() == args.gpus
 
     if args.persist_cus is not None:
         from mdeical_image_segmentation_amd import ops
