@@ -39,6 +39,14 @@ extern "C" {
 const char* mis_last_error(void);
 int mis_version(void);
 
+/* Layout of the structs of this header AS THE LOADED BUILD SEES THEM (round 5): callers that mirror them by hand in another language (the ctypes / numpy mirrors of
+ * mdeical_image_segmentation_amd/_lib.py and ops.py) compare sizeof, field names, offsets and sizes against this at test time - a field added on one side only is otherwise
+ * a silent wild pointer on the device.  mis_abi_layout fills up to max_fields entries of names / offsets / sizes (any of them may be NULL) and *size = sizeof(struct);
+ * returns the struct's number of fields (in declaration order) or MIS_EINVAL for an unknown name.  mis_abi_struct_name(i), i < mis_abi_struct_count(): the covered structs. */
+int mis_abi_struct_count(void);
+const char* mis_abi_struct_name(int index);
+int mis_abi_layout(const char* struct_name, size_t* size, const char** names, size_t* offsets, size_t* sizes, int max_fields);
+
 /* Implicit-GEMM convolution on MFMA: rows = output pixels, K = taps x Cin, columns = Cout.
  * Replaces nn.Conv2d(k3,p1) fwd and its dgrad (model/unet2d/layers.py:122,125), nn.Conv3d(k3,p1)
  * (model/unet3d/buildingblocks.py:64-66), ConvTranspose2d(k2,s2) fwd/dgrad as a 1x1 GEMM with a

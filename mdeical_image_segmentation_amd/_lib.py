@@ -14,7 +14,7 @@ MIS_F32, MIS_BF16 = 0, 1
 OUT_PLAIN, OUT_SHUFFLE2, OUT_UNSHUFFLE2 = 0, 1, 2
 
 EXPORTS = [
-    "mis_last_error", "mis_version", "mis_conv_igemm", "mis_wgrad_workspace_bytes", "mis_wgrad", "mis_wgrad_reduce_batch",
+    "mis_last_error", "mis_version", "mis_abi_struct_count", "mis_abi_struct_name", "mis_abi_layout", "mis_conv_igemm", "mis_wgrad_workspace_bytes", "mis_wgrad", "mis_wgrad_reduce_batch",
     "mis_conv_last_dispatch", "mis_wgrad_last_dispatch", "mis_wgrad_last_nsplit", "mis_dispatch_override", "mis_dispatch_switch", "mis_gn_apply",
     "mis_mt19937_words", "mis_legacy_normal", "mis_mt_jump", "mis_mt_generate", "mis_legacy_normal_par_workspace_bytes", "mis_legacy_normal_par",
     "mis_comm_unique_id", "mis_comm_init", "mis_comm_world", "mis_allreduce_bucket", "mis_comm_finalize",
@@ -96,6 +96,58 @@ class HeadDesc(C.Structure):
     ]
 
 
+class PackItem(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("w_fwd", C.c_void_p), ("w_dgrad", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("taps", C.c_int), ("kind", C.c_int)]
+
+
+class PackItem2(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("w_fwd", C.c_void_p), ("w_dgrad", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("taps", C.c_int), ("kind", C.c_int),
+                ("blk0", C.c_int), ("nbx", C.c_int)]
+
+
+# C struct (include/misamd.h) -> its Python mirror.  abi_mismatches() compares every mirror with the layout the LOADED library reports (mis_abi_layout); load() refuses
+# a library whose structs differ from these mirrors, and tests/test_cabi_symbols.py shows that a swapped / missing field is caught.
+ABI_MIRRORS = {"MisConvDesc": ConvDesc, "MisWgradDesc": WgradDesc, "MisWgradReduceItem": WgradReduceItem, "MisHeadDesc": HeadDesc, "MisPackItem": PackItem,
+               "MisPackItem2": PackItem2}
+
+
+def pack_item2_dtype():
+    """numpy record dtype of MisPackItem2 (the device-resident table of mis_pack_batch2), derived from the ctypes mirror that abi_mismatches() checks"""
+    import numpy as np
+    code = {C.c_void_p: "<u8", C.c_int: "<i4", C.c_float: "<f4", C.c_longlong: "<i8", C.c_size_t: "<u8"}
+    fields = PackItem2._fields_
+    return np.dtype({"names": [n for n, _ in fields], "formats": [code[t] for _, t in fields], "offsets": [getattr(PackItem2, n).offset for n, _ in fields],
+                     "itemsize": C.sizeof(PackItem2)})
+
+
+def abi_mismatches(lib, mirrors=None):
+    """list of differences between the ctypes mirrors and the structs of the loaded library (empty = they agree): size, field count, and per field name, offset, size"""
+    mirrors = ABI_MIRRORS if mirrors is None else mirrors
+    out = []
+    covered = {lib.mis_abi_struct_name(i).decode() for i in range(lib.mis_abi_struct_count())}
+    for missing in sorted(covered - set(mirrors)):
+        out.append(f"{missing}: the library describes it, no Python mirror is registered")
+    for cname, cls in mirrors.items():
+        size = C.c_size_t(0)
+        cap = 128
+        names, offs, sizes = (C.c_char_p * cap)(), (C.c_size_t * cap)(), (C.c_size_t * cap)()
+        n = lib.mis_abi_layout(cname.encode(), C.byref(size), names, offs, sizes, cap)
+        if n < 0:
+            out.append(f"{cname}: unknown to the library")
+            continue
+        if size.value != C.sizeof(cls):
+            out.append(f"{cname}: sizeof {size.value} in C, {C.sizeof(cls)} in {cls.__name__}")
+        fields = cls._fields_
+        if n != len(fields):
+            out.append(f"{cname}: {n} fields in C, {len(fields)} in {cls.__name__}")
+        for i in range(min(n, len(fields))):
+            fname = fields[i][0]
+            desc = getattr(cls, fname)
+            if names[i].decode() != fname or offs[i] != desc.offset or sizes[i] != desc.size:
+                out.append(f"{cname} field {i}: C has {names[i].decode()} @ {offs[i]} ({sizes[i]} B), {cls.__name__} has {fname} @ {desc.offset} ({desc.size} B)")
+    return out
+
+
 _lib = None
 
 
@@ -119,6 +171,16 @@ def load():
     lib.mis_last_error.argtypes = []
     lib.mis_version.restype = C.c_int
     lib.mis_version.argtypes = []
+    if not os.environ.get("MISAMD_LIB"):                 # (an older build loaded for an A/B has no layout entry points)
+        lib.mis_abi_struct_count.restype = C.c_int
+        lib.mis_abi_struct_count.argtypes = []
+        lib.mis_abi_struct_name.restype = C.c_char_p
+        lib.mis_abi_struct_name.argtypes = [C.c_int]
+        lib.mis_abi_layout.restype = C.c_int
+        lib.mis_abi_layout.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        bad = abi_mismatches(lib)
+        if bad:
+            raise MisError("the ctypes mirrors in _lib.py do not match the structs of " + LIB_PATH + " (rebuild, or update the mirror): " + "; ".join(bad))
     for name in ("mis_conv_last_dispatch", "mis_wgrad_last_dispatch"):
         getattr(lib, name).restype = C.c_char_p
         getattr(lib, name).argtypes = []

@@ -47,3 +47,6 @@ int launch_conv3d_pp(const MisConvDesc* d, hipStream_t stream, const char** tag)
 // gemm1_pp.hip: the ping-pong 1x1 GEMM for the bf16 2-D transposed-convolution GEMMs (plain or pixel-shuffled destination, optional mask / ReLU bits)
 bool gemm1_pp_eligible(const MisConvDesc* d);
 int launch_gemm1_pp(const MisConvDesc* d, hipStream_t stream, const char** tag);
+// conv3d_f32.hip: the fp32 3x3x3 layers of the fused 3-D engine (single plain source: the materialised GroupNorm output), all-DMA / fragment-prefetched
+bool conv3d_f32_eligible(const MisConvDesc* d);
+int launch_conv3d_f32(const MisConvDesc* d, hipStream_t stream, const char** tag);

@@ -809,6 +809,15 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
                 return rc;
             }
         }
+        if constexpr (sizeof(T) == 4) {
+            // fp32, single plain source (the fp32 engine materialises the GroupNorm output since round 5): the all-DMA kernel with prefetched fragments (conv3d_f32.hip)
+            if (!mis_sw(SW_CONV3D_F32_NOPP) && conv3d_f32_eligible(d)) {
+                const char* tag = "";
+                const int rc = launch_conv3d_f32(d, s, &tag);
+                g_conv_last = tag;
+                return rc;
+            }
+        }
         if (wide) RUN("k3.3d.bn128", launch_cfg<T, Geom<4, 4, 8, 3, true>, 2, 4>(d, s));
         // bf16, Cout not a multiple of 128 (the 64- and 192-column layers at full resolution): 8 waves on a 4x8x8 voxel tile, LDS-DMA weight
         // tiles, 3 taps per barrier (+6...11 % over the 4-wave 4x4x8 config; the same tile with 1 tap per barrier or 4 waves was slower)

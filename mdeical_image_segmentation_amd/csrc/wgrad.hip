@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256) void wgrad_sum_samples_kernel(const float* __r
 // ---------------------------------------------------------------------------------------------------------
 struct WgPlan {
     int tilesD, tilesH, tilesW, ntiles, nsplit, tps, nCi, nCo, KDn, TT, CT;
-    bool is3d, wide, pp;
+    bool is3d, wide, pp, f32s;
 };
 
 static int wg_plan(const MisWgradDesc* d, WgPlan* p) {
@@ -609,6 +609,9 @@ static int wg_plan(const MisWgradDesc* d, WgPlan* p) {
     // bf16 3x3 / 3x3x3 layers with a plain single-source operand: the ping-pong kernels (wgrad_pp.hip) with their own split plan (one or two slabs per persistent block)
     p->pp = !mis_sw(SW_WGRAD_NOPP) && wgrad_pp_eligible(d);
     if (p->pp) p->nsplit = wgrad_pp_nsplit(d);
+    // fp32 3x3 / 3x3x3 layers with a plain single-source operand and no bias gradient: the streaming kernel of wgrad_f32.hip (one slab per block)
+    p->f32s = !p->pp && wgrad_f32_eligible(d);
+    if (p->f32s) p->nsplit = wgrad_f32_nsplit(d);
     return MIS_OK;
 }
 
@@ -826,6 +829,12 @@ extern "C" int mis_wgrad(const MisWgradDesc* d, void* stream) {
         rc = launch_wgrad_pp(d, d->workspace, bias_partial, s, &g_wgrad_last);
         if (rc != MIS_OK) return rc;
         return wg_finish(d, p, bias_partial, s);
+    }
+    if (p.f32s) {
+        g_wgrad_last_nsplit = p.nsplit;
+        rc = launch_wgrad_f32(d, d->workspace, s, &g_wgrad_last);
+        if (rc != MIS_OK) return rc;
+        return wg_finish(d, p, nullptr, s);
     }
     const bool use_tr = !mis_sw(SW_WGRAD_NO_TR);
     if (d->dtype == MIS_BF16) return use_tr ? wg_dispatch<__bf16, true>(d, p, s) : wg_dispatch<__bf16, false>(d, p, s);

@@ -28,3 +28,7 @@ bool wgrad_pp_eligible(const MisWgradDesc* d);
 int wgrad_pp_nsplit(const MisWgradDesc* d);
 int wgrad_pp_splits_per_sample(const MisWgradDesc* d);      // > 0 when d asks for per-sample weight gradients: slabs [n * k, (n + 1) * k) belong to sample n, k = this x (slabs per split)
 int launch_wgrad_pp(const MisWgradDesc* d, float* partial, float* bias_partial, hipStream_t stream, const char** tag);
+// wgrad_f32.hip: streaming fp32 weight gradient of the 3x3 / 3x3x3 layers (plain single-source operand, no bias gradient); slabs as wgrad_kernel writes them
+bool wgrad_f32_eligible(const MisWgradDesc* d);
+int wgrad_f32_nsplit(const MisWgradDesc* d);
+int launch_wgrad_f32(const MisWgradDesc* d, float* partial, hipStream_t stream, const char** tag);

@@ -114,11 +114,14 @@ class UNet3DEngine:
         # wgrad_pp.hip); fp32 keeps the fold (its lock-step kernels sit at 0.79 of the f32 MFMA peak).  MISAMD_GN_FOLD=1: the fold in bf16 too (A/B switch).
         # (the materialised route lives on the ping-pong kernels - per-sample split-K ranges, 32-channel K chunks: with one of their A/B switches set in the environment the
         #  engine takes the operand-fold route of the lock-step kernels instead of failing in the middle of a step)
-        pp_off = any(os.environ.get(k) for k in ("MIS_WGRAD_NOPP", "MIS_WGRAD3D_NOPP", "MIS_CONV3D_NOPP", "MIS_WGRAD_NO_TR"))
-        self.materialize = dtype == torch.bfloat16 and os.environ.get("MISAMD_GN_FOLD") is None and not pp_off
+        pp_off = dtype == torch.bfloat16 and any(os.environ.get(k) for k in ("MIS_WGRAD_NOPP", "MIS_WGRAD3D_NOPP", "MIS_CONV3D_NOPP", "MIS_WGRAD_NO_TR"))
+        # round 5: fp32 materialises too - its convolutions and weight gradients now run on all-DMA kernels of their own (conv3d_f32.hip, wgrad_f32.hip), which need a
+        # plain single-source operand exactly like the bf16 ones; the written tensor equals what the operand fold fed the MFMAs bit for bit (fmaf, no rounding step in fp32)
+        self.materialize = os.environ.get("MISAMD_GN_FOLD") is None and not pp_off
         # ... and with xn at hand the GroupNorm backward statistics (sum dyn, sum dyn * x per sample and channel) follow from the per-sample weight gradients and the
         # border sums of g_y (mis_gn_bwd_stats_from_dw) instead of a pass over dyn and x (2 x 1-3 GB per full-resolution layer).  MISAMD_GN_STATS_KERNEL=1: that pass.
-        self.gn_from_dw = self.materialize and os.environ.get("MISAMD_GN_STATS_KERNEL") is None
+        # (bf16 only: the fp32 parity mode keeps the direct statistics pass - exact at any gamma / beta, 2.6 ms of its 180 ms step)
+        self.gn_from_dw = self.materialize and dtype == torch.bfloat16 and os.environ.get("MISAMD_GN_STATS_KERNEL") is None
         # ... and with the statistics known BEFORE the dgrad runs, the single-source layers (10 of 13) continue their dgrad through the GroupNorm and the ReLU in its
         # epilogue (MisConvDesc.gn_p, round 4): dx = mask * (p * acc + q * x + r) straight from the fp32 accumulator - dL/d(normalised operand) is never written and
         # mis_gn_bwd_apply's pass over three tensors disappears.  MISAMD_GN_BWD_UNFUSED=1: the separate pass (A/B switch; the two-source decoder layers always take it).

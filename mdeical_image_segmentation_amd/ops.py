@@ -386,8 +386,8 @@ class PackTable:
 
     def __init__(self, entries, device):
         import numpy as np
-        dt = np.dtype([("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("taps", "<i4"), ("kind", "<i4"), ("blk0", "<i4"), ("nbx", "<i4")])
-        assert dt.itemsize == 48          # MisPackItem2 (include/misamd.h): the compact-grid form
+        from ._lib import pack_item2_dtype
+        dt = pack_item2_dtype()           # MisPackItem2 (include/misamd.h): the compact-grid form; the mirror is checked against the library's own layout at load time
         tab = np.zeros(len(entries), dtype=dt)
         self.keep = []
         dts = set()
@@ -406,7 +406,7 @@ class PackTable:
         self.dtype = dts.pop()
         self.n = len(entries)
         self.max_rows, self.max_cols = int(tab["rows"].max()), int(tab["cols"].max())
-        self.ptrs = tuple(int(v) for v in tab["w"]) + tuple(int(v) for v in tab["wf"])
+        self.ptrs = tuple(int(v) for v in tab["w"]) + tuple(int(v) for v in tab["w_fwd"])
         self.dev = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(device)
 
 
