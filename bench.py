@@ -93,6 +93,15 @@ def cpu_baseline():
             "threads8_s_per_step": round(s_8, 3), "threads8_images256_per_s": round(4.0 / s_8, 4), "logical_cpus": logical}
 
 
+def cpu_baseline3d_entry(size):
+    """the `cpu_baseline` object of a 3-D line: the oracle's train step on ONE volume (B = 1: SURVEY.md §8d), 1 warm-up + 1 timed step on the host's physical cores"""
+    v, sdt, cores = cpu_baseline3d(size)
+    return {"value": round(v, 4), "unit": "volumes/s", "cores": cores, "kind": "port", "s_per_step": round(sdt, 2),
+            "sample": f"oracle (stock PyTorch CPU restatement of the reference: UNet3D(1,3) 'gcr' + BCEDiceLoss, reference model/unet3d/model.py:125-151, losses.py:167-178) fp32 "
+                      f"fwd + loss + bwd + clip + AdamW on one {size}^3 volume (B = 1), 1 warm-up + 1 timed step on {cores} threads = physical cores of the host, "
+                      f"{sdt:.2f} s/step (no augmentation)"}
+
+
 def cpu_baseline3d(size, steps=1, warmup=1):
     """The CPU oracle of the 3-D path (UNet3D(1,3) + BCE-Dice forward/backward + clip + AdamW in stock PyTorch) on ONE volume of the benchmark size."""
     from oracle import unet3d_oracle as o3
@@ -135,6 +144,7 @@ SYMBOLS = {
     "k3.2d.ppw": "wgrad_pp_wide_kernel<false, false>", "k3.2d.pps": "wgrad_pp_wide_kernel<true, false>", "k3.2d.ppwr": "wgrad_pp_row_kernel<false, false>",
     "k3.2d.ppsr": "wgrad_pp_row_kernel<true, false>", "k1.2d.ppg": "wgrad1_pp_kernel", "k3.2d.ppst": "wgrad_pp_stream_kernel<false, false>", "k3.2d.ppss": "wgrad_pp_stream_kernel<true, false>", "k3.3d.ppst": "wgrad_pp_stream_kernel<false, true>", "k3.3d.ppss": "wgrad_pp_stream_kernel<true, true>", "k3.3d.ppw": "wgrad_pp_wide_kernel<false, true>", "k3.3d.pps": "wgrad_pp_wide_kernel<true, true>",
     "k3.3d.ppwr": "wgrad_pp_row_kernel<false, true>", "k3.3d.ppsr": "wgrad_pp_row_kernel<true, true>", "k3.2d.pp": "wgrad_pp_kernel<2>",
+    "k3.3d.f32pp64": "conv3d_f32_kernel<2>", "k3.3d.f32pp128": "conv3d_f32_kernel<4>", "k3.3d.f32s": "wgrad_f32_stream_kernel<true>", "k3.2d.f32s": "wgrad_f32_stream_kernel<false>",
 }
 # the column-segment kernels: one instantiation per epilogue mask path (template argument 0 = none, 1 = bf16 mask ".mask", 2 = ReLU bits ".bits")
 for _t, _k in (("k3.2d.ppc8", "conv_ppc_kernel<8, 4"), ("k3.2d.ppc8n2", "conv_ppc_kernel<8, 2"), ("k3.3d.ppc5", "conv3d_ppc_kernel<5, 4"),
@@ -174,19 +184,20 @@ def kernel_tables(prof, steps, peak):
     return roof, kernels, total, layers, steps
 
 
-def attach_traffic(roof, batch, size):
+def attach_traffic(roof, batch, size, fname="traffic.json", sources=None):
     """HBM bytes per launch of the dominant kernel come from the rocprofv3 PMC passes of THIS command (profiles/README.md), which cannot run
-    inside the process.  The figure is only reported when the committed summary was taken on the same kernel sources (hash match) and shape."""
+    inside the process.  The figure is only reported when the committed summary was taken on the same kernel sources (hash match) and shape.
+    fname / sources: the traffic file and the source list its hash covers (2-D headline: traffic.json / _lib.TRAFFIC_SOURCES; cfg4: traffic_3d_f32.json)."""
     from mdeical_image_segmentation_amd import _lib
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+    path = os.path.join(ROOT, "profiles", fname)
     try:
         tr = json.load(open(path))
     except (OSError, ValueError):
         return
     ent = tr.get("kernels", {}).get(roof["key"])
     roof["traffic_source_hash"] = tr.get("source_hash")
-    if ent is None or tr.get("source_hash") != _lib.source_hash(_lib.TRAFFIC_SOURCES) or tr.get("batch") != batch or tr.get("size") != size:
-        roof["traffic_note"] = "profiles/traffic.json was collected on other kernel sources or another shape: not reported"
+    if ent is None or tr.get("source_hash") != _lib.source_hash(sources or _lib.TRAFFIC_SOURCES) or tr.get("batch") != batch or tr.get("size") != size:
+        roof["traffic_note"] = f"profiles/{fname} was collected on other kernel sources or another shape: not reported"
         return
     roof["traffic"] = ent["hbm_read_bytes_per_launch"] + ent["hbm_write_bytes_per_launch"]
     roof["traffic_unit"] = (f"bytes/launch, FROM THE COMMITTED PROFILE profiles/{tr.get('profile')} of this command on these kernel sources (hash-checked), not measured "
@@ -253,9 +264,12 @@ def main():
         sys.exit(2)
 
     # the CPU baseline runs FIRST (GPU idle), so that the GPU legs form one contiguous busy window at the end of the run
-    cpu = None
+    cpu = cpu3 = None
     if world == 1 and not args.no_cpu_baseline and args.workload == "2d":
         cpu = cpu_baseline()
+        default_shape_ = (args.batch or 32) == 32 and (args.size or 512) == 512 and args.net == "1x2" and args.dtype == "bf16"
+        if default_shape_ and not args.no_extra:
+            cpu3 = cpu_baseline3d_entry(128)          # the 3-D half of the metric (cfg4) gets its CPU figure beside it too (last row): ~35 s
 
     import torch.distributed as dist
     if os.environ.get("MISAMD_BENCH_REHEARSAL"):
@@ -287,7 +301,9 @@ def main():
         if args.comm == "native":
             from mdeical_image_segmentation_amd.ddp import native_comm_init
             with _StdoutToStderr():
-                assert native_comm_init() == args.gpus
+                n_native = native_comm_init()          # (not inside an assert: python -O would strip the CALL)
+            if n_native != args.gpus:
+                raise SystemExit(f"bench.py: the C-ABI communicator came up with {n_native} ranks, {args.gpus} wanted")
 
     if args.persist_cus is not None:
         from mdeical_image_segmentation_amd import ops
@@ -298,10 +314,7 @@ def main():
                     warmup=args.warmup, timing=not args.no_kernel_timing, layers=args.layers)
         if rank == 0:
             if world == 1 and not args.no_cpu_baseline:
-                v, sdt, cores = cpu_baseline3d(args.size or 128)
-                out["cpu_baseline"] = {"value": round(v, 4), "unit": "volumes/s", "cores": cores, "kind": "port",
-                                       "sample": f"oracle (stock PyTorch CPU restatement of the reference) fp32 train step on one {args.size or 128}^3 volume, "
-                                                 f"1 warm-up + 1 timed step on {cores} threads, {sdt:.2f} s/step (no augmentation)"}
+                out["cpu_baseline"] = cpu_baseline3d_entry(args.size or 128)
             print(json.dumps(out), flush=True)
     else:
         out = run2d(args, rank, world, dev, dist, dtype=args.dtype, batch=args.batch or 32, size=args.size or 512, steps=args.steps,
@@ -320,7 +333,9 @@ def main():
                 torch.cuda.empty_cache()
                 o = run3d(args, rank, world, dev, dist, dtype="f32", batch=2, size=128, steps=3, warmup=1, timing=True, layers=False)
                 ex["unet3d_cfg4_f32_128"] = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "model_tflops", "roofline",
-                                                                "loss_per_step", "config")}
+                                                                "kernels", "mfma_kernel_ms_per_step", "loss_per_step", "config")}
+                if cpu3 is not None:
+                    ex["unet3d_cfg4_f32_128"]["cpu_baseline"] = cpu3
                 # the per-GPU shapes of the two 8-GPU configurations (BASELINE configs[2] and configs[4]), so that they are driver-timed at N = 1 as well
                 torch.cuda.empty_cache()
                 a3 = argparse.Namespace(**{**vars(args), "net": "3x4"})
@@ -629,6 +644,9 @@ def run3d(args, rank, world, dev, dist, *, dtype, batch, size, steps, warmup, ti
             peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
             roof, kernels, total, ltab, psteps = kernel_tables(prof, steps, peak)
             roof["steps_with_launch_events"] = psteps
+            if dtype == "f32" and world == 1:
+                from mdeical_image_segmentation_amd import _lib
+                attach_traffic(roof, batch, size, "traffic_3d_f32.json", _lib.TRAFFIC_SOURCES_3D_F32)
             out["roofline"], out["kernels"], out["mfma_kernel_ms_per_step"] = roof, kernels, total
             if layers:
                 for k, v in sorted(ltab.items(), key=lambda kv: -kv[1][1]):

@@ -355,6 +355,8 @@ def load():
 
 # the sources that define the kernels whose HBM traffic profiles/traffic.json records (the 3x3 convolution / weight-gradient kernels of the benchmark)
 TRAFFIC_SOURCES = ("common.hpp", "conv_args.hpp", "conv_pp_common.hpp", "conv_igemm.hip", "conv_pp.hip", "conv_ppd.hip", "gemm1_pp.hip", "wgrad_args.hpp", "wgrad.hip", "wgrad_pp.hip")
+# ... and of cfg4's (3-D fp32) dominant kernels: profiles/traffic_3d_f32.json
+TRAFFIC_SOURCES_3D_F32 = ("common.hpp", "conv_args.hpp", "conv_pp_common.hpp", "conv3d_f32.hip", "wgrad_args.hpp", "wgrad_f32.hip")
 
 
 def source_hash(only=None):

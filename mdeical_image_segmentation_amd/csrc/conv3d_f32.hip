@@ -6,7 +6,7 @@
 // for an LDS read or a global load while it has MFMAs left:
 //   * operands arrive by LDS-DMA only (buffer_load ... lds: no staging registers, zero padding = out-of-range offsets), so the input must be a plain tensor -
 //     the fp32 engine now materialises the GroupNorm output once per SingleConv like the bf16 engines (mis_gn_apply), concat and nearest upsample included;
-//   * output tile = 8 rows x 16 columns of ONE depth plane x BN (64 | 128) channels; K loop = (depth slice dz, 32-channel chunk) groups of nine taps; per group one
+//   * output tile = 8 rows x 16 columns of ONE depth plane x BN (64 | 128) channels; K loop = (32-channel chunk, depth slice dz) groups of nine taps; per group one
 //     halo image of plane z + dz - 1 (10 x 18 px x 128 B, double-buffered, fetched in six pieces per wave under the previous group's taps), per tap one weight
 //     tile [BN x 128 B] (double-buffered, fetched a tap ahead);
 //   * a tap = two half-steps (16 of the chunk's 32 channels each) of NF*PF*4 MFMAs; the fragments of half-step h + 1 are read into the OTHER register set before
@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_f32_kernel(const F3Args a) {
     const unsigned plane_bytes = (unsigned)((((size_t)a.H * a.W - 1) * a.x_ld + 32) * 4);
     const size_t plane_stride = (size_t)a.H * a.W * a.x_ld;
 
-    // group g -> (dz, chunk), chunk fastest.  Per group two scalars: the weight offset of its tap 0 (`ws`) and the buffer resource of its halo plane / chunk (`rx`);
+    // group g -> (chunk, dz), dz fastest: per output element the products are summed in the order of the lock-step kernel this one replaces (chunk, kd, kh, kw, channel) -
+    // bit-identical outputs.  Per group two scalars: the weight offset of its tap 0 (`ws`) and the buffer resource of its halo plane / chunk (`rx`);
     // those of group g + 1 are derived by counters inside group g's first MFMA cluster, so that no address arithmetic stands between a barrier and an MFMA.
     const unsigned tapstride = (unsigned)a.Cout * a.Cin * 4u;
     auto ws_of = [&](int dz, int c0) { return (unsigned)((((unsigned)(dz * 9) * a.Cout + n0) * a.Cin + c0) * 4u); };
@@ -216,13 +217,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_f32_kernel(const F3Args a) {
             mfmas(s0, I0{}, I1{});
             if constexpr (tap == 0) {
                 __builtin_amdgcn_sched_barrier(0);
-                c0 += 32;                        // the next group's scalars (harmless values past the last group)
-                if (c0 == a.Cin) {
-                    c0 = 0;
-                    ++dz;
+                ++dz;                            // the next group's scalars (harmless values past the last group)
+                if (dz > dz_hi) {
+                    dz = dz_lo;
+                    c0 += 32;
                 }
-                ws_next = ws_of(dz, c0);
-                rx_next = rx_of(more ? dz : dz_lo, c0);
+                ws_next = ws_of(dz, more ? c0 : 0);
+                rx_next = rx_of(dz, more ? c0 : 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             mfmas(s0, I1{}, I4{});

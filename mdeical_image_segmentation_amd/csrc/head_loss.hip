@@ -33,12 +33,20 @@ struct HeadArgs {
 
 // Hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each; round 4): the pass was bound by the ~50 instructions per class of the libm expansions, executed
 // by all 8 / 16 lanes of a pixel - 0.97 ms for 1.25 GB at 2 x 160^3.  Absolute error per loss term < 1e-6 (mean loss bars are 1e-4), gradients relative 1e-6.
-__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.f + __expf(-x)); }
+// fp32 = the parity mode (round 5): libm's expf / logf / log1pf (<= 1 ulp) and IEEE division there - the approximations' errors are systematic per term and survive the
+// sums of the head's weight gradient (final_conv.weight against the fp64 oracle: 2.7e-6 of max |g| with them, i.e. 1.9x the reference's own fp32 error, next to the 2.5x bar
+// of tests/test_gpu_engine3d.py); 0.3 ms of a 176 ms step.  bf16 keeps the hardware forms.
+template <bool ACC> __device__ __forceinline__ float h_exp(float x) { return ACC ? expf(x) : __expf(x); }
+template <bool ACC> __device__ __forceinline__ float h_log(float x) { return ACC ? logf(x) : __logf(x); }
+template <bool ACC> __device__ __forceinline__ float h_log1p_exp_neg_abs(float x) { return ACC ? log1pf(expf(-fabsf(x))) : __logf(1.f + __expf(-fabsf(x))); }
+template <bool ACC> __device__ __forceinline__ float h_rcp(float x) { return ACC ? 1.f / x : __frcp_rn(x); }
+template <bool ACC> __device__ __forceinline__ float sigmoidf_(float x) { return ACC ? 1.f / (1.f + expf(-x)) : __frcp_rn(1.f + __expf(-x)); }
 
 // LOSS: 0 CE, 1 BCE, 2 BCE+Dice, -1 none.   PASS: 0 = forward outputs (+ backward for LOSS 0/1 when dy != null), 1 = BCE+Dice gradient pass
 template <typename T, int C, int LOSS, int PASS>
 __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
     constexpr int EPC = Tr<T>::EPC;
+    constexpr bool ACC = sizeof(T) == 4;          // accurate transcendentals in the fp32 parity mode
     constexpr int LPP = 64 / EPC;     // lanes per pixel (8 bf16 / 16 f32)
     constexpr int PPB = 256 / LPP;    // pixels per block iteration
     __shared__ float red[4][HEAD_PSTRIDE];
@@ -135,16 +143,16 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
             float se = 0.f, ex[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                ex[c] = __expf(lg[c] - m);
+                ex[c] = h_exp<ACC>(lg[c] - m);
                 se += ex[c];
             }
-            const float lse = m + __logf(se);
+            const float lse = m + h_log<ACC>(se);
             float xl = 0.f;
 #pragma unroll
             for (int c = 0; c < C; ++c)
                 if (lab == c) xl = lg[c];
             if (sub == 0) lsum += lse - xl;
-            const float inv = __frcp_rn(se);
+            const float inv = h_rcp<ACC>(se);
 #pragma unroll
             for (int c = 0; c < C; ++c) dl[c] = a.grad_scale * inv_total * (ex[c] * inv - (lab == c ? 1.f : 0.f));
         } else if constexpr (LOSS == 3) {
@@ -157,10 +165,10 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
             for (int c = 0; c < C; ++c) {
                 const float t = tg[((size_t)n * C + c) * a.S + sp];
                 const float x = lg[c];
-                const float sg = sigmoidf_(x);
+                const float sg = sigmoidf_<ACC>(x);
                 if constexpr (PASS == 0) {
                     if (sub == 0) {
-                        lsum += fmaxf(x, 0.f) - x * t + __logf(1.f + __expf(-fabsf(x)));
+                        lsum += fmaxf(x, 0.f) - x * t + h_log1p_exp_neg_abs<ACC>(x);
                         if constexpr (LOSS == 2) {
                             dI[c] += sg * t;
                             dP[c] += sg * sg;

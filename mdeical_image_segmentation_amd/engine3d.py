@@ -188,8 +188,7 @@ class UNet3DEngine:
         if self.gn_from_dw:
             self._gn_tab = ops.GnCondTable(self.flat.p, [(self.P[s.name + ".groupnorm.weight"], self.P[s.name + ".groupnorm.bias"]) for s in self._gn_layers])
             self._gn_flags = torch.zeros(len(self._gn_layers), dtype=torch.int32, device=self.device)
-            self._gn_flags_host = torch.zeros(len(self._gn_layers), dtype=torch.int32).pin_memory()
-            self._gn_flags_ev = None
+        self._gn_ring, self._gn_free = [], []
         self.repack()
         self.refresh_gn_flags(sync=True)
 
@@ -209,23 +208,58 @@ class UNet3DEngine:
     GN_COND_RATIO = 2.0 ** -4
 
     def refresh_gn_flags(self, sync=False):
-        """recompute which layers need the direct GroupNorm-backward statistics (see __init__); sync=True: wait for the result (construction, load_state_dict)"""
+        """recompute which layers need the direct GroupNorm-backward statistics (see __init__).  Called by repack(), i.e. at EVERY parameter-change site (optimizer steps incl.
+        the device-side one of the graphed step, load_state_dict, the nn.Module's parameter sync, graph restore).  sync=True: wait for the result (construction,
+        load_state_dict, the module's first parameter copy).  The read-back is asynchronous otherwise: each call queues one (event, pinned buffer) pair in a small ring and
+        _poll_gn_flags applies the NEWEST pair whose event has completed without dropping the pending ones - a free-running loop, where the host stays a step or more ahead
+        of the device, therefore sees flags at most GN_RING - 1 steps old; when the ring is full the oldest pending pair is waited for (a bounded wait on work that is
+        GN_RING steps behind the host).  Under graph capture nothing is queued: the captured step keeps the routes it was captured with, and GraphedTrainStep re-checks the
+        flags between replays (graph.py)."""
         if not self.gn_from_dw:
             return
+        if torch.cuda.is_current_stream_capturing():
+            return
         ops.gn_cond(self._gn_tab, self.GN_COND_RATIO, self._gn_flags)
-        self._gn_flags_host.copy_(self._gn_flags, non_blocking=True)
-        self._gn_flags_ev = torch.cuda.Event()
-        self._gn_flags_ev.record(torch.cuda.current_stream(self.device))
+        ring = self._gn_ring
+        if len(ring) >= self.GN_RING:                        # bounded wait: the pair queued GN_RING refreshes ago
+            ev, buf = ring.pop(0)
+            ev.synchronize()
+            self._apply_gn_flags(buf)
+            self._gn_free.append(buf)
+        buf = self._gn_free.pop() if self._gn_free else torch.zeros(len(self._gn_layers), dtype=torch.int32).pin_memory()
+        buf.copy_(self._gn_flags, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        ring.append((ev, buf))
         if sync:
-            self._gn_flags_ev.synchronize()
+            ev.synchronize()
             self._poll_gn_flags()
 
+    GN_RING = 4
+
+    def _apply_gn_flags(self, buf):
+        for s, f in zip(self._gn_layers, buf.tolist()):
+            s.gn_direct = bool(f)
+
     def _poll_gn_flags(self):
-        ev = getattr(self, "_gn_flags_ev", None)
-        if ev is not None and not torch.cuda.is_current_stream_capturing() and ev.query():
-            self._gn_flags_ev = None
-            for s, f in zip(self._gn_layers, self._gn_flags_host.tolist()):
-                s.gn_direct = bool(f)
+        ring = getattr(self, "_gn_ring", None)
+        if not ring or torch.cuda.is_current_stream_capturing():
+            return
+        done = -1
+        for i, (ev, _) in enumerate(ring):                   # events complete in queue order
+            if ev.query():
+                done = i
+            else:
+                break
+        if done >= 0:
+            self._apply_gn_flags(ring[done][1])
+            for ev, buf in ring[:done + 1]:
+                self._gn_free.append(buf)
+            del ring[:done + 1]
+
+    def gn_routes(self):
+        """the per-layer GroupNorm-backward routes in force (True = direct statistics pass): what a captured graph was recorded with"""
+        return tuple(bool(s.gn_direct) for s in self._gn_layers)
 
     def repack(self):
         """fp32 master weights -> the packed MFMA operands of every SingleConv in ONE launch (mis_pack_batch: the flat parameter buffer and the operand buffers never
@@ -247,6 +281,9 @@ class UNet3DEngine:
         for t in self.ct:       # W [Cin][Cout][27] -> [27*Cout][Cin] (row k*Cout + co), then the two packed GEMM operands
             t.w2d.view(27, t.cout, t.cin).copy_(self.P[t.name].view(t.cin, t.cout, 27).permute(2, 1, 0))
             ops.pack_conv_weight(t.w2d, t.wf, t.wd)
+        # the parameters have (possibly) changed: so may the conditioning of the GroupNorm layers (every parameter-change site goes through here)
+        if getattr(self, "_gn_ring", None) is not None:
+            self.refresh_gn_flags()
 
     # ---- buffers ---------------------------------------------------------------------------------------
     def _alloc(self, N, D, H, W):
@@ -571,8 +608,7 @@ class UNet3DEngine:
                       eps=self.eps, step=self.step_count)
         ops.adamw_step(f.p[:nd], f.g[:nd], f.m[:nd], f.v[:nd], weight_decay=self.wd, gradnorm_out=self.gradnorm, **common)
         ops.adamw_step(f.p[nd:], f.g[nd:], f.m[nd:], f.v[nd:], weight_decay=0.0, **common)
-        self.repack()
-        self.refresh_gn_flags()
+        self.repack()                                        # (refreshes the GroupNorm conditioning flags)
 
     def train_step(self, x, target, lr=None):
         loss, _, _ = self.forward(x, target, train=True)

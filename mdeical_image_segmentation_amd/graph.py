@@ -30,6 +30,11 @@ class GraphedTrainStep:
         cur.wait_stream(s)
         torch.cuda.synchronize(inputs.device)
         self._restore(keep)
+        # the GroupNorm-backward route of every layer (statistics from the weight gradient, or the direct pass: engine3d.refresh_gn_flags) is baked into the captured
+        # launches: settle the flags now, remember the routes, and refuse a replay once the parameters have drifted across the threshold
+        if hasattr(eng, "refresh_gn_flags"):
+            eng.refresh_gn_flags(sync=True)
+        self._routes = eng.gn_routes() if hasattr(eng, "gn_routes") and getattr(eng, "gn_from_dw", False) else None
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._step()
@@ -58,6 +63,13 @@ class GraphedTrainStep:
             self.targets.copy_(targets)
         if lr is not None:
             self.eng.lr_dev.fill_(float(lr))
+        if self._routes is not None:
+            # (outside the capture: one small kernel + an asynchronous read-back per replay; the check uses the newest flags that have arrived)
+            self.eng.refresh_gn_flags()
+            self.eng._poll_gn_flags()
+            if self.eng.gn_routes() != self._routes:
+                raise MisError("GraphedTrainStep: a GroupNorm layer's |gamma| / |beta| ratio crossed the conditioning threshold (engine3d.GN_COND_RATIO): the captured step "
+                               "holds the other backward route for it - capture a new GraphedTrainStep")
         self.graph.replay()
         self.eng.step_count += 1
         return self.eng.loss_buf[:1]

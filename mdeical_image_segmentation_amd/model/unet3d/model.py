@@ -130,6 +130,10 @@ class AbstractUNet(nn.Module):
             for name, p in self.named_parameters():
                 eng.P[name].copy_(p.detach().to(device=x.device, dtype=torch.float32))
                 p.data = eng.P[name]
+            # the engine computed its GroupNorm conditioning flags on its OWN random init: redo them on the module's parameters, and wait (a checkpoint with
+            # |gamma| < |beta| / 16 would otherwise take the statistics-from-dW route on its first steps)
+            eng.repack()
+            eng.refresh_gn_flags(sync=True)
             self._engine = eng
         return self._engine
 

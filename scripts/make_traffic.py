@@ -2,7 +2,8 @@
 HBM bytes per launch of the bench's dominant kernel KEYS, launch-weighted over the kernel symbols that make up a key, stamped with the hash of the
 kernel sources (so bench.py only reports the figure for the build it was measured on).
 
-    python scripts/make_traffic.py profiles/r03_pmc_summary.json [name of the committed summary] > profiles/traffic.json"""
+    python scripts/make_traffic.py profiles/r03_pmc_summary.json [name of the committed summary] > profiles/traffic.json
+    python scripts/make_traffic.py profiles/r05_3d_f32_pmc_summary.json r05_3d_f32_pmc_summary.json 3d_f32 > profiles/traffic_3d_f32.json      (cfg4: bench.py --workload 3d --dtype f32)"""
 import json
 import os
 import sys
@@ -17,13 +18,22 @@ KEYS = {   # bench key -> kernel symbols (prefix match on the rocprof name) whos
     "conv_igemm/bf16/k1/2d/bn128": ["void gemm1_pp_kernel<"],
     "wgrad/bf16/k1/2d": ["wgrad1_pp_kernel"],
 }
+KEYS_3D_F32 = {   # cfg4: UNet3D(1,3), 2 x 128^3 fp32
+    "conv_igemm/f32/k3/3d/bn64": ["void conv3d_f32_kernel<2>"],
+    "conv_igemm/f32/k3/3d/bn128": ["void conv3d_f32_kernel<4>"],
+    "wgrad/f32/k3/3d": ["void wgrad_f32_stream_kernel<true>"],
+}
 
 
-def main(path, profile_name=None):
+def main(path, profile_name=None, preset="2d"):
     summ = json.load(open(path))
-    out = {"source_hash": _lib.source_hash(_lib.TRAFFIC_SOURCES), "hashed_sources": list(_lib.TRAFFIC_SOURCES), "batch": 32, "size": 512,
+    if preset == "3d_f32":
+        keys, sources, batch, size = KEYS_3D_F32, _lib.TRAFFIC_SOURCES_3D_F32, 2, 128
+    else:
+        keys, sources, batch, size = KEYS, _lib.TRAFFIC_SOURCES, 32, 512
+    out = {"source_hash": _lib.source_hash(sources), "hashed_sources": list(sources), "batch": batch, "size": size,
            "profile": profile_name or os.path.basename(path), "kernels": {}}
-    for key, syms in KEYS.items():
+    for key, syms in keys.items():
         rd = wr = n = 0.0
         used = []
         for e in summ:
@@ -40,4 +50,4 @@ def main(path, profile_name=None):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:3])
+    main(*sys.argv[1:4])

@@ -435,6 +435,26 @@ def test_conv3d_every_branch(case, switches):
     assert_close(dw, wq.grad, f"3-D wgrad {wcfg} nsplit={nsplit}", **wt)
 
 
+@pytest.mark.parametrize("shape", [((2, 5, 20, 24), 64, 64), ((1, 3, 9, 17), 192, 64), ((1, 4, 16, 16), 128, 256), ((2, 1, 8, 40), 32, 64)], ids=lambda s: f"{'x'.join(map(str, s[0]))}-{s[1]}to{s[2]}")
+def test_conv3d_f32_kernel_is_bit_identical_to_the_lockstep_kernel(shape):
+    """round 5: conv3d_f32_kernel sums the products of an output element in the order of the lock-step kernel it replaces (chunk, kd, kh, kw, channel; planes outside the
+    volume skipped instead of added as zeros) - the fp32 parity mode's forward bits did not move when the kernel changed"""
+    ops = _ops()
+    (N, D, H, W), Cin, Cout = shape
+    x = to_nhwc(rnd(N, Cin, D, H, W, seed=180), F32)
+    w = rnd(Cout, Cin, 3, 3, 3, seed=181, scale=(27 * Cin) ** -0.5)
+    wf = torch.empty(27, Cout, Cin, dtype=F32, device=DEV)
+    ops.pack_conv_weight(w.to(DEV), wf, None)
+    ya = torch.empty(N, D, H, W, Cout, dtype=F32, device=DEV)
+    yb = torch.empty_like(ya)
+    ops.conv_igemm(x, wf, ya, ksize=3, Cin=Cin, Cout=Cout, grid=(N, D, H, W), relu=True)
+    assert ops.conv_last_dispatch().startswith("k3.3d.f32pp")
+    with ops.dispatch_switches(MIS_CONV3D_F32_NOPP=1):
+        ops.conv_igemm(x, wf, yb, ksize=3, Cin=Cin, Cout=Cout, grid=(N, D, H, W), relu=True)
+        assert ops.conv_last_dispatch().startswith("k3.3d.bn")
+    assert torch.equal(ya, yb), (ya - yb).abs().max().item()
+
+
 @pytest.mark.parametrize("dtype", [BF, F32])
 def test_gn_apply_matches_the_operand_fold(dtype):
     """mis_gn_apply (the normalised tensor the bf16 engines write once per SingleConv) == what mis_conv_igemm computes when it folds the affine into staging:
@@ -457,7 +477,7 @@ def test_gn_apply_matches_the_operand_fold(dtype):
     assert_close(from_nhwc(xn), q(want, dtype), "gn_apply", rtol=1e-2 if dtype == BF else 1e-6, atol=1e-2 if dtype == BF else 1e-6)
     ya = torch.empty(N, D, H, W, Cout, dtype=dtype, device=DEV)
     yb = torch.empty_like(ya)
-    with ops.dispatch_switches(MIS_CONV3D_NOPP=1):          # same kernel for both routes: only the operand path differs
+    with ops.dispatch_switches(MIS_CONV3D_NOPP=1, MIS_CONV3D_F32_NOPP=1):          # the same (lock-step) kernel for both routes: only the operand path differs
         ops.conv_igemm(x0d, wf, ya, ksize=3, Cin=Cin, Cout=Cout, grid=grid, x1=x1d, in_scale=scale, in_shift=shift, relu=True)
         ops.conv_igemm(xn, wf, yb, ksize=3, Cin=Cin, Cout=Cout, grid=grid, relu=True)
     assert torch.equal(ya, yb), (ya.float() - yb.float()).abs().max().item()

@@ -431,3 +431,40 @@ def test_gn_backward_guard_for_small_gamma():
     print(f"dgamma rel-L2 vs fp64 with gamma = 2^-7, beta = 1: guarded {errs[True]:.3g}, unguarded {errs[False]:.3g}")
     assert errs[True] < 2e-2, errs
     assert errs[False] > 5 * errs[True], errs
+
+
+def test_gn_guard_follows_the_parameters_of_the_dropin_module():
+    """the conditioning guard must see the parameters the nn.Module actually trains with.  (1) small-gamma parameters loaded into the module BEFORE its first
+    forward: the engine is built on its own random init, takes the module's parameters, and must recompute the flags on THEM (synchronously); (2) an in-place parameter
+    change (what a torch optimizer does) reaches the flags through the repack of the next forward - asynchronously, within the ring of pending read-backs."""
+    from mdeical_image_segmentation_amd.model.unet3d.model import UNet3D
+    name = "decoders.2.basic_module.SingleConv2"
+    torch.manual_seed(0)
+    m = UNet3D(1, 3, compute_dtype="bf16").to(DEV)
+    sd = m.state_dict()
+    sd[name + ".groupnorm.weight"] = torch.full_like(sd[name + ".groupnorm.weight"], 2.0 ** -7)
+    sd[name + ".groupnorm.bias"] = torch.ones_like(sd[name + ".groupnorm.bias"])
+    m.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(22)
+    x = torch.randn(1, 1, 16, 32, 32, generator=gen).to(DEV)
+    m(x).sum().backward()
+    eng = m._engine
+    assert eng.gn_from_dw and eng.sc[name].gn_direct and sum(s.gn_direct for s in eng._gn_layers) == 1
+    # (2) a second layer drifts below the threshold in place; the first one recovers
+    other = "encoders.1.basic_module.SingleConv2"
+    with torch.no_grad():
+        dict(m.named_parameters())[other + ".groupnorm.weight"].fill_(2.0 ** -8)
+        dict(m.named_parameters())[other + ".groupnorm.bias"].fill_(1.0)
+        dict(m.named_parameters())[name + ".groupnorm.weight"].fill_(1.0)
+    for _ in range(2):                      # the forward's repack queues the read-back; by the next backward (after a sync) it has arrived
+        m.zero_grad(set_to_none=True)
+        m(x).sum().backward()
+        torch.cuda.synchronize()
+    assert eng.sc[other].gn_direct and not eng.sc[name].gn_direct
+    # the ring never drops a pending read-back and stays bounded in a free-running loop
+    for _ in range(3 * eng.GN_RING):
+        eng.refresh_gn_flags()
+    assert len(eng._gn_ring) <= eng.GN_RING
+    torch.cuda.synchronize()
+    eng._poll_gn_flags()
+    assert len(eng._gn_ring) == 0 and eng.sc[other].gn_direct
