@@ -427,7 +427,7 @@ int mis_upconv_gather_bwd(int dtype, const void* dy, int dy_ld, void* dz, int N,
 size_t mis_segloss_workspace_bytes(int N, int H, int W);
 int mis_segloss_fwd(const float* logits, const float* target, int N, int H, int W, float w_f1, float w_msssim, float w_iou, void* workspace,
                     float* out /*[8]*/, void* stream);
-int mis_segloss_bwd(const float* target, int N, int H, int W, void* workspace, const float* out, const float* grad_out, float* dlogits, void* stream);
+int mis_segloss_bwd(const float* target, int N, int H, int W, void* workspace, const float* out, const float* grad_out, float* dlogits, int with_msssim, void* stream);
 
 /* Residual 3-D U-Net pieces (model/unet3d/buildingblocks.py:255-325 ResNetBlock; model.py:197-232): y = [relu](a + b) for the residual join and the
  * decoder's sum-joining; the first block's 1x1x1 conv from ONE input channel on the raw fp32 volume, y[v][c] = w[c]*x[v] + b[c], and its

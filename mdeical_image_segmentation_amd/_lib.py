@@ -305,7 +305,7 @@ def load():
         "mis_upconv_gather_fwd": [i, vp, vp, i, vp, i, i, i, i, i, vp, vp],
         "mis_upconv_gather_bwd": [i, vp, i, vp, i, i, i, i, i, vp],
         "mis_segloss_fwd": [vp, vp, i, i, i, f, f, f, vp, vp, vp],
-        "mis_segloss_bwd": [vp, i, i, i, vp, vp, vp, vp, vp],
+        "mis_segloss_bwd": [vp, i, i, i, vp, vp, vp, vp, i, vp],
         "mis_add_act": [i, vp, i, vp, i, vp, i, ll, i, i, vp],
         "mis_expand1_fwd": [i, vp, vp, vp, vp, i, ll, i, vp],
         "mis_expand1_bwd": [i, vp, vp, i, ll, i, vp, vp, vp, vp],

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void sl_level_fwd_kernel(const float* __restri
 // scalars: out[0] loss, [1] f1 loss, [2] ms-ssim loss, [3] iou loss, [4] c_pt, [5] c_p (dLoss/d(sum p*t), dLoss/d(sum p) of F1 + IoU),
 // state[n][l]: {cs mean, ssim mean, dLoss/d(that mean)} for the backward
 __global__ void sl_finalize_kernel(const double* __restrict__ part_sig, int nb_sig, const double* __restrict__ part_lvl, int nb_lvl, int N, SlDims d,
-                                   float w_f1, float w_ms, float w_iou, float* __restrict__ out, float* __restrict__ state) {
+                                   float w_f1, float w_ms, float w_iou, float* __restrict__ out, float* __restrict__ state, int with_ms) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double eps = 1e-7;
     double spt = 0.0, sp = 0.0, st = 0.0;
@@ -173,8 +173,8 @@ __global__ void sl_finalize_kernel(const double* __restrict__ part_sig, int nb_s
         out[5] = (float)(-((double)w_f1 * df_dp + (double)w_iou * di_dp));
     }
     const float wts[SL_LEVELS] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};
-    float msum = 0.f;
-    for (int n = 0; n < N; ++n) {
+    float msum = with_ms ? 0.f : (float)N;          // (without the MS-SSIM term: lm = 0; the pyramid was not built, F1 / IoU alone take any image size)
+    for (int n = 0; n < (with_ms ? N : 0); ++n) {
         float val = 1.f, term[SL_LEVELS], base[SL_LEVELS];
         for (int l = 0; l < SL_LEVELS; ++l) {
             const long long npx = (long long)(d.H[l] - SL_WIN + 1) * (d.W[l] - SL_WIN + 1);
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void sl_sigmoid_bwd_kernel(const float* __rest
     const float g = gout[0], cpt = out[4], cp = out[5];
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float p = X0[i];
-        dlogits[i] = g * (dX0[i] + cpt * T[i] + cp) * p * (1.f - p);
+        dlogits[i] = g * ((dX0 != nullptr ? dX0[i] : 0.f) + cpt * T[i] + cp) * p * (1.f - p);
     }
 }
 
@@ -293,8 +293,9 @@ extern "C" size_t mis_segloss_workspace_bytes(int N, int H, int W) {
     return sl_ws_floats(N, H, W, d) * sizeof(float) + ((size_t)SL_BLOCKS * 3 + (size_t)SL_LEVELS * N * SL_BLOCKS * 2) * sizeof(double) + 64;
 }
 
-static int sl_check(const char* what, int N, int H, int W) {
-    MIS_REQUIRE(N > 0 && N <= 4096, MIS_EINVAL, "%s: batch %d", what, N);
+static int sl_check(const char* what, int N, int H, int W, bool with_ms) {
+    MIS_REQUIRE(N > 0 && N <= 4096 && H > 0 && W > 0, MIS_EINVAL, "%s: batch %d, image %d x %d", what, N, H, W);
+    if (!with_ms) return MIS_OK;          // F1Loss / IoULoss alone (reference model/unet2d/loss.py:32-56) are global sums: any image size
     const int smaller = H < W ? H : W;
     MIS_REQUIRE(smaller > (SL_WIN - 1) * 16, MIS_EUNSUPPORTED, "%s: image side %d must be larger than %d (4 down-samplings of MS-SSIM)", what, smaller,
                 (SL_WIN - 1) * 16);
@@ -305,7 +306,8 @@ extern "C" int mis_segloss_fwd(const float* logits, const float* target, int N, 
                                float* out /*[8]*/, void* stream) {
     (void)hipGetLastError();
     MIS_REQUIRE(logits && target && workspace && out, MIS_EINVAL, "segloss_fwd: null pointer");
-    if (int rc = sl_check("segloss_fwd", N, H, W)) return rc;
+    const bool ms = w_msssim != 0.f;
+    if (int rc = sl_check("segloss_fwd", N, H, W, ms)) return rc;
     const SlDims d = sl_dims(N, H, W);
     const SlWin g = sl_window();
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -320,28 +322,29 @@ extern "C" int mis_segloss_fwd(const float* logits, const float* target, int N, 
     int nb_sig = (int)sl_grid(n0);
     if (nb_sig > SL_BLOCKS) nb_sig = SL_BLOCKS;
     hipLaunchKernelGGL(sl_sigmoid_kernel, dim3(nb_sig), dim3(256), 0, s, logits, target, n0, X, Y, part_sig);
-    for (int l = 1; l < SL_LEVELS; ++l) {
+    for (int l = 1; ms && l < SL_LEVELS; ++l) {
         hipLaunchKernelGGL(sl_avgpool_kernel, dim3(sl_grid((long long)N * d.H[l] * d.W[l])), dim3(256), 0, s, (const float*)(X + d.off[l - 1]), N, d.H[l - 1],
                            d.W[l - 1], X + d.off[l], d.H[l], d.W[l]);
         hipLaunchKernelGGL(sl_avgpool_kernel, dim3(sl_grid((long long)N * d.H[l] * d.W[l])), dim3(256), 0, s, (const float*)(Y + d.off[l - 1]), N, d.H[l - 1],
                            d.W[l - 1], Y + d.off[l], d.H[l], d.W[l]);
     }
     const int nb_lvl = 64;
-    for (int l = 0; l < SL_LEVELS; ++l)
+    for (int l = 0; ms && l < SL_LEVELS; ++l)
         hipLaunchKernelGGL(sl_level_fwd_kernel, dim3(nb_lvl, N), dim3(256), 0, s, (const float*)(X + d.off[l]), (const float*)(Y + d.off[l]), d.H[l], d.W[l], g,
                            part_lvl + (size_t)l * N * nb_lvl * 2);
     hipLaunchKernelGGL(sl_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)part_sig, nb_sig, (const double*)part_lvl, nb_lvl, N, d, w_f1, w_msssim,
-                       w_iou, out, state);
+                       w_iou, out, state, ms ? 1 : 0);
     MIS_LAUNCH_CHECK("segloss_fwd");
     return MIS_OK;
 }
 
-// after mis_segloss_fwd on the same workspace / out
+// after mis_segloss_fwd on the same workspace / out; with_msssim = (the forward's w_msssim != 0)
 extern "C" int mis_segloss_bwd(const float* target, int N, int H, int W, void* workspace, const float* out, const float* grad_out, float* dlogits,
-                               void* stream) {
+                               int with_msssim, void* stream) {
     (void)hipGetLastError();
     MIS_REQUIRE(target && workspace && out && grad_out && dlogits, MIS_EINVAL, "segloss_bwd: null pointer");
-    if (int rc = sl_check("segloss_bwd", N, H, W)) return rc;
+    const bool ms = with_msssim != 0;
+    if (int rc = sl_check("segloss_bwd", N, H, W, ms)) return rc;
     const SlDims d = sl_dims(N, H, W);
     const SlWin g = sl_window();
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -353,7 +356,7 @@ extern "C" int mis_segloss_bwd(const float* target, int N, int H, int W, void* w
     float* A2 = A1 + (size_t)N * H * W;
     float* M1 = A2 + (size_t)N * H * W;
     const float* state = ws + 3 * d.total + (size_t)3 * N * H * W;
-    for (int l = SL_LEVELS - 1; l >= 0; --l) {
+    for (int l = SL_LEVELS - 1; ms && l >= 0; --l) {
         hipLaunchKernelGGL(sl_level_bwd_maps_kernel, dim3(64, N), dim3(256), 0, s, (const float*)(X + d.off[l]), (const float*)(Y + d.off[l]), d.H[l], d.W[l], g,
                            l, state, A1, A2, M1);
         const bool coarse = l < SL_LEVELS - 1;
@@ -363,7 +366,8 @@ extern "C" int mis_segloss_bwd(const float* target, int N, int H, int W, void* w
                            dX + d.off[l]);
     }
     const long long n0 = (long long)N * H * W;
-    hipLaunchKernelGGL(sl_sigmoid_bwd_kernel, dim3(sl_grid(n0)), dim3(256), 0, s, (const float*)X, target, (const float*)dX, out, grad_out, n0, dlogits);
+    hipLaunchKernelGGL(sl_sigmoid_bwd_kernel, dim3(sl_grid(n0)), dim3(256), 0, s, (const float*)X, target, ms ? (const float*)dX : (const float*)nullptr, out, grad_out, n0,
+                       dlogits);
     MIS_LAUNCH_CHECK("segloss_bwd");
     return MIS_OK;
 }

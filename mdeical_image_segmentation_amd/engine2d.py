@@ -325,7 +325,9 @@ class UNet2DEngine:
         return dict(mask=t) if b is None else dict(mask_bits=b)
 
     def _defer(self, name):
-        return dict(defer=self._red, ws_tag=f"{id(self)}:{name}") if self.batch_reduce else {}
+        # the slabs of a deferred layer live until the stage's mis_wgrad_reduce_batch (same stream, a few launches later): one workspace per POSITION within the stage
+        # (<= 3), shared by every engine on the device - keyed by (engine id, layer) they were 23 grow-only buffers per engine that nothing ever freed
+        return dict(defer=self._red, ws_tag=f"defer:{len(self._red)}") if self.batch_reduce else {}
 
     def _bwd_conv(self, x, dy, name, cin, cout, dx=None, mask=None, dx1=None, cout0=None, dx_mode=OUT_PLAIN):
         """grads of y = relu(conv3x3(x) + b) given dy = dL/d(pre-activation); mask: (activation, key of its ReLU bits) of the layer below."""
@@ -362,8 +364,12 @@ class UNet2DEngine:
             ops.conv_igemm(self.dys[j], self.wd_[up], g_in, ksize=1, Cin=4 * c, Cout=2 * c, **self._mask(x_in, "m2" if j == 0 else ("u2", j - 1)))
             cb([f"up_conv.{j}", f"up_sample.{j}"])
         self._bwd_conv(self.m1, self.g_m2, "middle_conv.second", 1024, 1024, dx=self.g_m1, mask=(self.m1, "m1"))
+        if stage_cb is not None:
+            # data parallel: middle_conv is 56.6 MB of gradients, the largest bucket of the step - hand its 37.7 MB half to the reducer while middle_conv.first's
+            # kernels (and the whole encoder backward) are still to run; without a reducer the stage stays one reduction batch
+            cb(["middle_conv.second"])
         self._bwd_conv(self.pooled[3], self.g_m1, "middle_conv.first", 512, 1024, dx=self.g_pooled[3])
-        cb(["middle_conv"])
+        cb(["middle_conv.first"] if stage_cb is not None else ["middle_conv"])
         for l in range(3, -1, -1):
             c = FEATS[l]
             skip = View(self.cat[l], c, c)

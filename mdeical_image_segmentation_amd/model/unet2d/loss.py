@@ -3,7 +3,7 @@ UNet 3+ models - with forward and backward on the HIP kernels of csrc/segloss.hi
 
 The MS-SSIM term restates pytorch_msssim 1.0.0 `MS_SSIM(data_range=1.0, size_average=True, channel=1)` (third-party, not shipped with the
 reference): 11-tap Gaussian window (sigma 1.5), five scales, weights [0.0448, 0.2856, 0.3001, 0.2363, 0.1333].  Inputs: logits and
-targets of shape (N, 1, H, W) with min(H, W) > 160 (the package's own requirement).  CUDA tensors only."""
+targets of shape (N, 1, H, W) with min(H, W) > 160 (the package's own requirement; F1Loss / IoULoss on their own take any size, as the reference's do).  CUDA tensors only."""
 import torch
 from torch import nn
 
@@ -28,16 +28,16 @@ class _SegLoss(torch.autograd.Function):
                                   stream_ptr()), "mis_segloss_fwd")
         ctx.save_for_backward(t, out)
         ctx.ws = ws                      # the pyramid state of this forward (one loss evaluation in flight at a time)
-        ctx.cfg = (N, H, W, inputs.shape, inputs.dtype)
+        ctx.cfg = (N, H, W, inputs.shape, inputs.dtype, 1 if float(w_ms) != 0.0 else 0)
         return out[0].clone()
 
     @staticmethod
     def backward(ctx, g):
         t, out = ctx.saved_tensors
-        N, H, W, shape, dtype = ctx.cfg
+        N, H, W, shape, dtype, with_ms = ctx.cfg
         dx = torch.empty(N, 1, H, W, dtype=torch.float32, device=t.device)
         gg = g.contiguous().float().reshape(1)
-        check(load().mis_segloss_bwd(t.data_ptr(), N, H, W, ctx.ws.data_ptr(), out.data_ptr(), gg.data_ptr(), dx.data_ptr(), stream_ptr()),
+        check(load().mis_segloss_bwd(t.data_ptr(), N, H, W, ctx.ws.data_ptr(), out.data_ptr(), gg.data_ptr(), dx.data_ptr(), with_ms, stream_ptr()),
               "mis_segloss_bwd")
         return dx.view(shape).to(dtype), None, None, None, None
 

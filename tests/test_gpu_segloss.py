@@ -53,3 +53,21 @@ def test_unet_model_with_unet3plus_trains():
     with pytest.raises(Exception):
         from mdeical_image_segmentation_amd.model.unet2d.loss import SegmentationLoss
         SegmentationLoss()(torch.zeros(1, 1, 64, 64).cuda(), torch.zeros(1, 1, 64, 64).cuda())      # too small for 5 scales: loud
+
+
+def test_f1_and_iou_loss_match_the_reference_classes():
+    """the HIP F1Loss / IoULoss against fixture g19_segloss.npz = values and dL/dlogits of the REAL reference classes (model/unet2d/loss.py:32-56;
+    tests/golden/make_golden_segloss.py), incl. images far smaller than the MS-SSIM term of SegmentationLoss accepts (the two terms alone are global sums)"""
+    from conftest import load_golden
+    from mdeical_image_segmentation_amd.model.unet2d import loss as L
+    g = load_golden("g19_segloss.npz")
+    for i in range(3):
+        t = torch.from_numpy(g[f"t{i}"].astype(np.float32)).cuda()
+        for name, cls in (("f1", L.F1Loss), ("iou", L.IoULoss)):
+            x = torch.from_numpy(g[f"x{i}"]).cuda().requires_grad_(True)
+            loss = cls()(x, t)
+            loss.backward()
+            assert abs(loss.item() - float(g[f"{name}{i}"])) < 2e-6, (name, i, loss.item(), float(g[f"{name}{i}"]))
+            ref = torch.from_numpy(g[f"{name}{i}_grad"])
+            err = (x.grad.cpu() - ref).abs().max().item()
+            assert err <= 2e-5 * ref.abs().max().item() + 1e-12, (name, i, err, ref.abs().max().item())

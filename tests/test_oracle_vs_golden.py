@@ -331,3 +331,19 @@ def test_unet3d_backward_is_ill_conditioned_and_bf16_storage_shows_it():
     assert 1e-4 < rel(g32[n], g64[n]) < 3e-2, rel(g32[n], g64[n])            # fp32 is already four orders above its epsilon here
     assert 0.1 < rel(g16[n], g64[n]) < 0.9, rel(g16[n], g64[n])              # bf16 storage: comparable to the signal
     assert rel(g16["final_conv.weight"], g64["final_conv.weight"]) < 2e-2     # ... while the well-conditioned end of the net stays tight
+
+
+def test_f1_and_iou_loss_oracle_matches_the_reference_classes():
+    """F1Loss / IoULoss are the reference's OWN lines (model/unet2d/loss.py:32-56) - fixture g19_segloss.npz holds values and dL/dlogits of the real classes
+    (tests/golden/make_golden_segloss.py); the MS-SSIM term of SegmentationLoss stays parity-unpinned (pytorch_msssim is third-party and absent)."""
+    from oracle import segloss_oracle as so
+    g = load_golden("g19_segloss.npz")
+    for i in range(3):
+        t = torch.from_numpy(g[f"t{i}"].astype(np.float32))
+        for name, fn in (("f1", so.f1_loss), ("iou", so.iou_loss)):
+            x = torch.from_numpy(g[f"x{i}"]).clone().requires_grad_(True)
+            loss = fn(x, t)
+            loss.backward()
+            assert abs(loss.item() - float(g[f"{name}{i}"])) < 1e-6, (name, i, loss.item(), float(g[f"{name}{i}"]))
+            ref = torch.from_numpy(g[f"{name}{i}_grad"])
+            assert (x.grad - ref).abs().max().item() <= 1e-6 * ref.abs().max().item() + 1e-12, (name, i)
