@@ -331,7 +331,7 @@ def main():
                 ex["unet2d_f32_parity_mode"] = {k: o[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "model_tflops", "roofline", "loss_per_step",
                                                                    "act_nonzero_frac")}
                 torch.cuda.empty_cache()
-                o = run3d(args, rank, world, dev, dist, dtype="f32", batch=2, size=128, steps=3, warmup=1, timing=True, layers=False)
+                o = run3d(args, rank, world, dev, dist, dtype="f32", batch=2, size=128, steps=5, warmup=2, timing=True, layers=False)
                 ex["unet3d_cfg4_f32_128"] = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "model_tflops", "roofline",
                                                                 "kernels", "mfma_kernel_ms_per_step", "loss_per_step", "config")}
                 if cpu3 is not None:

@@ -31,5 +31,12 @@ def test_traffic_profile_belongs_to_this_tree():
     assert t["source_hash"] == _lib.source_hash(_lib.TRAFFIC_SOURCES), "profiles/traffic.json was measured on other conv / wgrad kernel sources: re-run the PMC passes"
     ent = t["kernels"]["conv_igemm/bf16/k3/2d/bn128"]
     assert ent["hbm_read_bytes_per_launch"] > 0 and ent["hbm_write_bytes_per_launch"] > 0
-    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
     assert d["roofline"]["traffic"] == ent["hbm_read_bytes_per_launch"] + ent["hbm_write_bytes_per_launch"]
+    # cfg4 (the 3-D half of the metric): its own traffic file, hashed over the fp32 3-D kernel sources, and the committed line carries it next to its CPU baseline
+    t3 = json.load(open(os.path.join(ROOT, "profiles", "traffic_3d_f32.json")))
+    assert t3["source_hash"] == _lib.source_hash(_lib.TRAFFIC_SOURCES_3D_F32), "profiles/traffic_3d_f32.json was measured on other fp32 3-D kernel sources: re-run scripts/collect_profiles.sh"
+    leg = d["extra"]["unet3d_cfg4_f32_128"]
+    e3 = t3["kernels"][leg["roofline"]["key"]]
+    assert leg["roofline"]["traffic"] == e3["hbm_read_bytes_per_launch"] + e3["hbm_write_bytes_per_launch"]
+    assert leg["cpu_baseline"]["unit"] == "volumes/s" and leg["cpu_baseline"]["value"] > 0 and "kernels" in leg
