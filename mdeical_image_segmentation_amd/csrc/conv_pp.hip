@@ -511,6 +511,9 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
     __syncthreads();
 
     int wsel = 0, hsel = 0, bsel = 0;
+#ifdef MIS_PP_STAMPS          // (diagnostic build: scripts/ppc_stamps.sh; slots as in conv_pp_kernel)
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp_ = __builtin_amdgcn_s_memtime();
+#endif
     if (grp == 1) __builtin_amdgcn_s_barrier();       // the stagger
     __builtin_amdgcn_sched_barrier(0);
 
@@ -559,6 +562,7 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
                     if (hnext) pp_static_for<NH>([&](auto jc) { issue_halo(std::integral_constant<int, (kw == 0 ? 0 : HJ0) + decltype(jc)::value>{}, hn, hh0, hw0, hc0, hbn); });
                 }
 #endif
+                PP_STAMP(5)
                 u32x4 A[3][NF], Brow[PF + 2];
                 f32x4 bq[NF];          // first && kw == 0: the tile's bias, 4 values per fragment (the C operand of the first filter row's MFMAs)
                 if constexpr (first && kw == 0) {
@@ -582,8 +586,10 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
                     constexpr int r = decltype(rc)::value;
                     Brow[r] = pp_lds_read128<r * ROWB>(hb + b_off0[kw]);
                 });
+                PP_STAMP(6)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+                PP_STAMP(7)
                 // how many of this wave's youngest DMAs may stay in flight: the halo instructions of THIS segment (a wave whose last instruction id is past the image
                 // issued one fewer - waiting for one more than necessary is harmless, so the count is the compile-time maximum only when it is exact)
                 constexpr int KEEP = NH;
@@ -598,8 +604,10 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                PP_STAMP(0)
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+                PP_STAMP(1)
                 // ================= M segment: 3 taps x NF x PF MFMAs =================
                 #ifndef PPT_NO_PRIO
                 __builtin_amdgcn_s_setprio(1);
@@ -634,8 +642,10 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                PP_STAMP(2)
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+                PP_STAMP(3)
                 wsel ^= 1;
             });
             hsel ^= 1;
@@ -659,8 +669,14 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
         n = nn; h0 = nh0; w0 = nw0; ncol0 = ncolN;
         bsel ^= 1;
         __builtin_amdgcn_sched_barrier(0);
+        PP_STAMP(4)
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's last barrier
+#ifdef MIS_PP_STAMPS
+    if (lane == 0 && blockIdx.x < 256) {
+        for (int i = 0; i < 8; ++i) g_pp_stamps[(blockIdx.x * 8 + wave) * 8 + i] = st_[i];
+    }
+#endif
 #ifdef PPT_NO_EPI
     {
         f32x4 s4 = acc[0][0];

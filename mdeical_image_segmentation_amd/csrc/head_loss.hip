@@ -33,9 +33,9 @@ struct HeadArgs {
 
 // Hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each; round 4): the pass was bound by the ~50 instructions per class of the libm expansions, executed
 // by all 8 / 16 lanes of a pixel - 0.97 ms for 1.25 GB at 2 x 160^3.  Absolute error per loss term < 1e-6 (mean loss bars are 1e-4), gradients relative 1e-6.
-// fp32 = the parity mode (round 5): libm's expf / logf / log1pf (<= 1 ulp) and IEEE division there - the approximations' errors are systematic per term and survive the
-// sums of the head's weight gradient (final_conv.weight against the fp64 oracle: 2.7e-6 of max |g| with them, i.e. 1.9x the reference's own fp32 error, next to the 2.5x bar
-// of tests/test_gpu_engine3d.py); 0.3 ms of a 176 ms step.  bf16 keeps the hardware forms.
+// (round 5 measured libm's expf / logf / log1pf and IEEE division for the fp32 parity mode: final_conv.weight against the fp64 oracle did not move in any digit - 2.7e-6 of
+// max |g| either way, the error is the forward's, not the transcendentals' - while the pass went from 0.52 + 0.37 to 0.84 + 0.43 ms at 2 x 128^3; ACC is therefore false in
+// both precisions and stays as the switch the measurement was made with)
 template <bool ACC> __device__ __forceinline__ float h_exp(float x) { return ACC ? expf(x) : __expf(x); }
 template <bool ACC> __device__ __forceinline__ float h_log(float x) { return ACC ? logf(x) : __logf(x); }
 template <bool ACC> __device__ __forceinline__ float h_log1p_exp_neg_abs(float x) { return ACC ? log1pf(expf(-fabsf(x))) : __logf(1.f + __expf(-fabsf(x))); }
@@ -46,7 +46,7 @@ template <bool ACC> __device__ __forceinline__ float sigmoidf_(float x) { return
 template <typename T, int C, int LOSS, int PASS>
 __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
     constexpr int EPC = Tr<T>::EPC;
-    constexpr bool ACC = sizeof(T) == 4;          // accurate transcendentals in the fp32 parity mode
+    constexpr bool ACC = false;                   // (see h_exp: libm forms measured, no accuracy gain)
     constexpr int LPP = 64 / EPC;     // lanes per pixel (8 bf16 / 16 f32)
     constexpr int PPB = 256 / LPP;    // pixels per block iteration
     __shared__ float red[4][HEAD_PSTRIDE];

@@ -184,14 +184,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_stream_kernel(const WfArgs a
         if constexpr (kh == 0) B = wf_read32<s * 1024>(qa);
     };
     auto wait_sub = [&](u32x4(&A)[3], uint32_t& B) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(B)::"memory"); };
-    auto mfma_sub = [&](const u32x4(&A)[3], uint32_t B, auto khc) {
-        constexpr int kh = decltype(khc)::value;
+    // the MFMAs of filter columns [K0, K1) of a sub-step (4 per column)
+    auto mfma_cols = [&](const u32x4(&A)[3], uint32_t B, auto khc, auto k0c, auto k1c) {
+        constexpr int kh = decltype(khc)::value, K0 = decltype(k0c)::value, K1 = decltype(k1c)::value;
         const float b = wf_f(B);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
+        for (int kw = K0; kw < K1; ++kw)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[kh * 3 + kw][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf_f(A[kw], r), b, acc[kh * 3 + kw][r], 0, 0, 0);
     };
+    auto mfma_sub = [&](const u32x4(&A)[3], uint32_t B, auto khc) { mfma_cols(A, B, khc, std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}); };
 
     u32x4 A0[3], A1[3];
     uint32_t B0 = 0u, B1 = 0u;                   // B of even / odd k-steps
@@ -224,7 +226,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_stream_kernel(const WfArgs a
                 pp_static_for<11>([&](auto qc) {
                     constexpr int q = decltype(qc)::value;
                     constexpr int s = q / 3, kh = q % 3, s1 = (q + 1) / 3;
-                    // fragments of sub-step q + 1 into the other set (B of k-step s1 into B[s1 & 1]: k-step s still reads B[s & 1])
+                    using K0 = std::integral_constant<int, 0>;
+                    using K1 = std::integral_constant<int, 1>;
+                    using K3 = std::integral_constant<int, 3>;
+                    // the sub-step's first four MFMAs, THEN the fragment reads of sub-step q + 1 into the other set (B of k-step s1 into B[s1 & 1]: k-step s still reads
+                    // B[s & 1]), then its other eight: a sub-step boundary is one s_waitcnt - with the reads at the boundary the pipe ran dry for a few cycles twelve times per row
+                    if constexpr (q % 2 == 0) mfma_cols(A0, s % 2 == 0 ? B0 : B1, std::integral_constant<int, kh>{}, K0{}, K1{});
+                    else mfma_cols(A1, s % 2 == 0 ? B0 : B1, std::integral_constant<int, kh>{}, K0{}, K1{});
+                    __builtin_amdgcn_sched_barrier(0);
                     if constexpr (q % 2 == 0) {
                         if constexpr (s1 % 2 == 0) read_sub(A1, B0, xa, qa, std::integral_constant<int, q + 1>{});
                         else read_sub(A1, B1, xa, qa, std::integral_constant<int, q + 1>{});
@@ -233,8 +242,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_stream_kernel(const WfArgs a
                         else read_sub(A0, B1, xa, qa, std::integral_constant<int, q + 1>{});
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (q % 2 == 0) mfma_sub(A0, s % 2 == 0 ? B0 : B1, std::integral_constant<int, kh>{});
-                    else mfma_sub(A1, s % 2 == 0 ? B0 : B1, std::integral_constant<int, kh>{});
+                    if constexpr (q % 2 == 0) mfma_cols(A0, s % 2 == 0 ? B0 : B1, std::integral_constant<int, kh>{}, K1{}, K3{});
+                    else mfma_cols(A1, s % 2 == 0 ? B0 : B1, std::integral_constant<int, kh>{}, K1{}, K3{});
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (q % 2 == 0) wait_sub(A1, s1 % 2 == 0 ? B0 : B1);
                     else wait_sub(A0, s1 % 2 == 0 ? B0 : B1);
@@ -250,17 +259,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_stream_kernel(const WfArgs a
                 }
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            // sub-step 11 (k-step 3, kh = 2; fragments in A1, B of k-step 3 in B1): its first four MFMAs go out right behind the barrier, the DMA issue of the row three
+            // ahead (cursor bookkeeping: ~50 scalar / vector instructions) and the next element's first fragment reads follow INSIDE the cluster - the first version issued
+            // both between the barrier and the first MFMA, which left the pipe idle for 5 % of every row (PMC: 94.3 % busy)
+            if (comp) {
+                mfma_cols(A1, B1, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (e + 1 < total) {
                 issue_next();
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (comp) {
-                // sub-step 11 (k-step 3, kh = 2; fragments in A1, B of k-step 3 in B1) with the next element's sub-step 0 in flight
+                mfma_cols(A1, B1, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+                __builtin_amdgcn_sched_barrier(0);
                 if (next_comp) {
                     const uint32_t xn[3] = {xa[1], xa[2], a_lane + (uint32_t)(nslot * WF_SLOT)};
                     read_sub(A0, B0, xn, b_lane + (uint32_t)(nslot * WF_SLOT), std::integral_constant<int, 0>{});
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_sub(A1, B1, std::integral_constant<int, 2>{});
+                mfma_cols(A1, B1, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{});
                 __builtin_amdgcn_sched_barrier(0);
                 wait_sub(A0, B0);
             }
@@ -307,18 +326,22 @@ static void wf_plan(const MisWgradDesc* d, int* nsplit, long long* U, long long*
     const long long slab = (long long)(d->is3d ? 27 : 9) * d->Cin * d->Cout * 4;
     while (maxs > 1 && maxs * slab > (512ll << 20)) --maxs;
     if (maxs > 4096) maxs = 4096;
+    // ... and at least `minr` rounds (MIS_WGRAD_F32_ROUNDS, default 1).  Measured at cfg4's decoder layers: 1 / 2 / 4 / 8 rounds = 46.0 / 46.1 / 46.4 / 48.7 ms over the six
+    // launches - there is no tail to shorten, more blocks only add slab traffic and prologues
+    const int minr = mis_sw(SW_WGRAD_F32_ROUNDS) > 0 ? mis_sw(SW_WGRAD_F32_ROUNDS) : 1;
     int best = 1;
     double best_eff = 0.0;
     for (int s = 1; s <= maxs; ++s) {
         const long long grid = (long long)*base * s;
         const long long rounds = (grid + slots - 1) / slots;
         const long long rows = (*U + s - 1) / s;                 // the longest block's rows
-        const double eff = (double)*U / ((double)rounds * slots / *base * rows);      // useful rows per (block slot x rounds) of the longest block
+        double eff = (double)*U / ((double)rounds * slots / *base * rows);      // useful rows per (block slot x rounds) of the longest block
+        if (rounds < minr && s < maxs) eff *= 0.5;
         if (eff > best_eff * 1.02) {
             best_eff = eff;
             best = s;
         }
-        if (grid >= 4ll * slots) break;
+        if (grid >= (long long)(minr + 3) * slots) break;
     }
     *upb = (*U + best - 1) / best;
     *nsplit = (int)((*U + *upb - 1) / *upb);
