@@ -435,6 +435,31 @@ def test_conv3d_every_branch(case, switches):
     assert_close(dw, wq.grad, f"3-D wgrad {wcfg} nsplit={nsplit}", **wt)
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 64, 128, 128), (3, 150, 170, 64, 256), (1, 32, 16, 64, 128), (5, 150, 170, 128, 128)], ids=lambda s: "x".join(map(str, s)))
+def test_conv_pps_experiment_is_bit_identical_to_conv_ppc(shape):
+    """conv_pps_kernel (round-5 experiment, MIS_CONV_PPS=1: one wave per SIMD at 512 registers, both fragment sets resident; measured 12 % SLOWER than conv_ppc_kernel<8, 4> and
+    therefore off by default - EXPERIMENTS.md) sums in conv_ppc_kernel's order: bit-identical outputs in the forward, bf16-mask and ReLU-bits forms, ragged grids included"""
+    ops = _ops()
+    N, H, W, Cin, Cout = shape
+    x = to_nhwc(rnd(N, Cin, H, W, seed=190), BF)
+    w = rnd(Cout, Cin, 3, 3, seed=191, scale=(9 * Cin) ** -0.5)
+    wf = torch.empty(9, Cout, Cin, dtype=BF, device=DEV)
+    ops.pack_conv_weight(w.to(DEV), wf, None)
+    b = rnd(Cout, seed=192).to(DEV)
+    m = to_nhwc(rnd(N, Cout, H, W, seed=193), BF)
+    bits = torch.empty(ops.relu_bits_bytes(N, H, W, Cout), dtype=torch.uint8, device=DEV)
+    ops.relu_bits(m, bits)
+    for form, kw in (("fwd", dict(bias=b, relu=True)), ("mask", dict(mask=m)), ("bits", dict(mask_bits=bits))):
+        outs = []
+        for pps in (0, 1):
+            y = torch.full((N, H, W, Cout), float("nan"), dtype=BF, device=DEV)
+            with ops.dispatch_switches(MIS_CONV_PPS=pps):
+                ops.conv_igemm(x, wf, y, ksize=3, Cin=Cin, Cout=Cout, **kw)
+                assert ops.conv_last_dispatch().startswith("k3.2d.pps" if pps else "k3.2d.ppc8"), ops.conv_last_dispatch()
+            outs.append(y)
+        assert torch.equal(outs[0], outs[1]), (form, (outs[0].float() - outs[1].float()).abs().max().item())
+
+
 @pytest.mark.parametrize("shape", [((2, 5, 20, 24), 64, 64), ((1, 3, 9, 17), 192, 64), ((1, 4, 16, 16), 128, 256), ((2, 1, 8, 40), 32, 64)], ids=lambda s: f"{'x'.join(map(str, s[0]))}-{s[1]}to{s[2]}")
 def test_conv3d_f32_kernel_is_bit_identical_to_the_lockstep_kernel(shape):
     """round 5: conv3d_f32_kernel sums the products of an output element in the order of the lock-step kernel it replaces (chunk, kd, kh, kw, channel; planes outside the
