@@ -23,6 +23,12 @@ constexpr int PP_OOB = (int)0xFFFFFF00u;
 __device__ __forceinline__ void pp_dma16(__amdgpu_buffer_rsrc_t r, int voff, char* lds_dst_wave_uniform) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (pp_lds_void_t*)lds_dst_wave_uniform, 16, voff, 0, 0, 0);
 }
+// ... with a SCALAR offset on top of the per-lane one (round 5): lets a kernel keep its per-lane offsets tile-invariant in registers and move the tile / chunk origin through
+// an SGPR - a DMA issue is then s_add + s_mov m0 + buffer_load instead of ~25 vector instructions.  The range check does not need the scalar part here: lanes that must
+// read zeros carry PP_OOB in voff, valid lanes are in range by construction.  (A __device__ function: a kernel template that names the builtin itself may lose its host stub.)
+__device__ __forceinline__ void pp_dma16s(__amdgpu_buffer_rsrc_t r, int voff, int soff, char* lds_dst_wave_uniform) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (pp_lds_void_t*)lds_dst_wave_uniform, 16, voff, soff, 0, 0);
+}
 // LDS reads as INLINE ASM: hipcc (ROCm 7.2) may put an s_waitcnt vmcnt(N) in front of an LDS read it cannot tell apart from the destination of an LDS-DMA
 // in flight - which then waits for the prefetch that was just issued and serialises the pipeline (seen here as soon as a second kind of LDS-DMA, the 4-byte
 // bias fetch, joined the kernel; in wgrad_pp.hip with the transposing-read builtin).  The asm form is invisible to that analysis; in exchange NOTHING waits for the
