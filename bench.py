@@ -156,6 +156,7 @@ for _sfx, _em in (("", 0), (".mask", 1), (".bits", 2)):
     SYMBOLS["k1.2d.pp" + _sfx] = f"gemm1_pp_kernel<{_em}>"
     SYMBOLS["k3.2d.ppd8" + _sfx] = f"conv_ppd_kernel<{_em}>"
     SYMBOLS["k3.2d.pps" + _sfx] = f"conv_pps_kernel<{_em}>"
+    SYMBOLS["k3.2d.ppc2" + _sfx] = f"conv_ppc2_kernel<{_em}>"
 SYMBOLS["k3.2d.ppd8.head"] = "conv_ppd_head_kernel<C>"          # (C = classes: 2 for the headline net, 4 for cfg3's)
 
 

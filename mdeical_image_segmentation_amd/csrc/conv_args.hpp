@@ -53,3 +53,6 @@ int launch_conv3d_f32(const MisConvDesc* d, hipStream_t stream, const char** tag
 // conv_pps.hip (round-5 experiment, MIS_CONV_PPS=1): the 128-column 3x3 layers with ONE wave per SIMD and both fragment sets in registers
 bool conv_pps_eligible(const MisConvDesc* d);
 int launch_conv_pps(const MisConvDesc* d, hipStream_t stream, const char** tag);
+// conv_ppc2.hip (round 5, MIS_CONV_PPC2): conv_ppc_kernel<8, 4> with register-resident DMA offsets and weight fragments rolling through the M segment
+bool conv_ppc2_eligible(const MisConvDesc* d);
+int launch_conv_ppc2(const MisConvDesc* d, hipStream_t stream, const char** tag);

@@ -10,12 +10,13 @@ from mdeical_image_segmentation_amd import ops  # noqa: E402
 
 BF = torch.bfloat16
 dev = "cuda"
+SW = os.environ.get("CHECK_SWITCH", "MIS_CONV_PPS")          # the kernel under test: MIS_CONV_PPS | MIS_CONV_PPC2
 
 
 def run(x, w, b, form, pps, Cin, Cout, m=None, bits=None):
     y = torch.full((*x.shape[:3], Cout), float("nan"), dtype=BF, device=dev)
     kw = dict(bias=b, relu=True) if form == "fwd" else (dict(mask=m) if form == "mask" else dict(mask_bits=bits))
-    with ops.dispatch_switches(MIS_CONV_PPS=1 if pps else 0):
+    with ops.dispatch_switches(**{SW: 1 if pps else 0}):
         ops.conv_igemm(x, w, y, ksize=3, Cin=Cin, Cout=Cout, **kw)
         tag = ops.conv_last_dispatch()
     return y, tag
@@ -47,7 +48,7 @@ def main():
         y = torch.empty(32, H, H, Cout, dtype=BF, device=dev)
         res = []
         for pps in (0, 1, 0, 1):
-            with ops.dispatch_switches(MIS_CONV_PPS=pps):
+            with ops.dispatch_switches(**{SW: pps}):
                 ops.conv_igemm(x, w, y, ksize=3, Cin=Cin, Cout=Cout, bias=b, relu=True)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()

@@ -22,7 +22,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 lib = ops.load()
 buf = np.zeros(256 * 8 * 8, dtype=np.uint64)
-assert lib.mis_debug_pp_stamps(buf.ctypes.data_as(C.c_void_p)) == 0
+assert getattr(lib, os.environ.get("STAMP_SYMBOL", "mis_debug_pp_stamps"))(buf.ctypes.data_as(C.c_void_p)) == 0
 st = buf.reshape(256, 8, 8).astype(np.float64)
 names = ["R rest/drain", "R barrier", "M work", "M barrier", "epilogue", "R dma issue", "R read issue", "R lgkm wait"]
 print(ops.conv_last_dispatch(), f"{H}^2 {Cin}->{Cout}")

@@ -435,11 +435,14 @@ def test_conv3d_every_branch(case, switches):
     assert_close(dw, wq.grad, f"3-D wgrad {wcfg} nsplit={nsplit}", **wt)
 
 
+@pytest.mark.parametrize("switch", ["MIS_CONV_PPS", "MIS_CONV_PPC2"])
 @pytest.mark.parametrize("shape", [(2, 64, 64, 128, 128), (3, 150, 170, 64, 256), (1, 32, 16, 64, 128), (5, 150, 170, 128, 128)], ids=lambda s: "x".join(map(str, s)))
-def test_conv_pps_experiment_is_bit_identical_to_conv_ppc(shape):
-    """conv_pps_kernel (round-5 experiment, MIS_CONV_PPS=1: one wave per SIMD at 512 registers, both fragment sets resident; measured 12 % SLOWER than conv_ppc_kernel<8, 4> and
-    therefore off by default - EXPERIMENTS.md) sums in conv_ppc_kernel's order: bit-identical outputs in the forward, bf16-mask and ReLU-bits forms, ragged grids included"""
+def test_conv_pps_experiment_is_bit_identical_to_conv_ppc(shape, switch):
+    """the two round-5 experiments on the dominant 2-D kernel - conv_pps_kernel (MIS_CONV_PPS=1: one wave per SIMD at 512 registers, both fragment sets resident; 12 % slower) and
+    conv_ppc2_kernel (MIS_CONV_PPC2=1: halo DMA offsets from an LDS table, weight fragments rolling through the M segment; 0-7 % slower) - are off by default (EXPERIMENTS.md) and
+    sum in conv_ppc_kernel<8, 4>'s order: bit-identical outputs in the forward, bf16-mask and ReLU-bits forms, ragged grids included"""
     ops = _ops()
+    tagp = "k3.2d.pps" if switch == "MIS_CONV_PPS" else "k3.2d.ppc2"
     N, H, W, Cin, Cout = shape
     x = to_nhwc(rnd(N, Cin, H, W, seed=190), BF)
     w = rnd(Cout, Cin, 3, 3, seed=191, scale=(9 * Cin) ** -0.5)
@@ -453,9 +456,9 @@ def test_conv_pps_experiment_is_bit_identical_to_conv_ppc(shape):
         outs = []
         for pps in (0, 1):
             y = torch.full((N, H, W, Cout), float("nan"), dtype=BF, device=DEV)
-            with ops.dispatch_switches(MIS_CONV_PPS=pps):
+            with ops.dispatch_switches(**{switch: pps}):
                 ops.conv_igemm(x, wf, y, ksize=3, Cin=Cin, Cout=Cout, **kw)
-                assert ops.conv_last_dispatch().startswith("k3.2d.pps" if pps else "k3.2d.ppc8"), ops.conv_last_dispatch()
+                assert ops.conv_last_dispatch().startswith(tagp if pps else "k3.2d.ppc8"), ops.conv_last_dispatch()
             outs.append(y)
         assert torch.equal(outs[0], outs[1]), (form, (outs[0].float() - outs[1].float()).abs().max().item())
 
