@@ -457,6 +457,18 @@ int mis_se_fc_bwd(const float* da, const float* a, const float* z1, const float*
 int mis_se_bwd_apply(int dtype, const void* g, int g_ld, const void* e, int e_ld, int N, long long S, int C, const float* a, const float* bgate,
                      const float* dq, const float* w, const float* cross, void* de, int de_ld, void* stream);
 
+/* The three layers of model/unet3d/se.py called ON THEIR OWN (ChannelSELayer3D :18-53, SpatialSELayer3D :56-98, ChannelSpatialSELayer3D :101-116; the reference's
+ * ResNetBlockSE reaches them with se_module 'cse' / 'sse' / 'scse', buildingblocks.py:346-352): the passes above with
+ *   mode 0: y = max(e*a, e*bgate)    1: y = e*a (cSE; w, b0, bgate, dq unused, may be null)    2: y = e*bgate (sSE; a, cross unused, may be null)
+ * and relu_mask = 0: the input is any tensor, not a ReLU output (de is not masked; where e == 0 both products tie and de = g (a + bgate) / 2, torch.max's rule).
+ * Any reduction ratio: the caller zero-pads W1 [C/r][C] and W2 [C][C/r] to C x C (mis_se_fc_fwd / mis_se_fc_bwd are unchanged). */
+int mis_se_layer_fwd(int dtype, const void* e, int e_ld, int N, long long S, int C, const float* a, const float* w, const float* b0, float* bgate, void* y,
+                     int y_ld, int mode, void* stream);
+int mis_se_layer_bwd_reduce(int dtype, const void* g, int g_ld, const void* e, int e_ld, int N, long long S, int C, const float* a, const float* bgate,
+                            float* workspace, float* dq, float* da, float* dw, float* db0, int mode, void* stream);
+int mis_se_layer_bwd_apply(int dtype, const void* g, int g_ld, const void* e, int e_ld, int N, long long S, int C, const float* a, const float* bgate,
+                           const float* dq, const float* w, const float* cross, void* de, int de_ld, int mode, int relu_mask, void* stream);
+
 /* Evaluation metrics of the 2-D trainer (trainer/metrcis.py:61-109,153-168 `compute_metrics`): sigmoid with +1e-6 in the denominator,
  * threshold = global mean probability, per-sample IoU / Dice, mean over samples.  values, labels: fp32 (N, npix); out[3] = {iou, dice, threshold}.
  * values_are_logits = 0 with a given threshold gives compute_iou / compute_dice on ready-made predictions. */

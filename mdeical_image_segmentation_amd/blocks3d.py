@@ -488,6 +488,77 @@ def add_act(a, b, act=None, slope=None):
     return CL(_AddAct.apply(a.t, b.t, code, sl), a.C)
 
 
+# ---- squeeze & excitation layers on their own (se.py:18-116) -----------------------------------------------------------------------------------------------
+def _se_widths_ok(Cp, dtype):
+    """csrc/se3d.hip: a power-of-two group of lanes (at most 64) shares a voxel, 16 bytes per lane and step, up to 4 steps"""
+    nch = Cp // (8 if dtype == torch.bfloat16 else 4)
+    G = min(nch, 64)
+    return (G & (G - 1)) == 0 and nch % G == 0 and nch // G <= 4
+
+
+class _SE(torch.autograd.Function):
+    """y = max(x * cSE gate, x * sSE gate) (mode 0), x * cSE gate (1) or x * sSE gate (2).  fc weights come in their reference shapes ([C/r][C], [C][C/r]) and are
+    zero-padded to the square [Cp][Cp] matrices of the kernels here; their gradients are cut back."""
+
+    @staticmethod
+    def forward(ctx, x, C, mode, fc1_w, fc1_b, fc2_w, fc2_b, conv_w, conv_b):
+        x = x.contiguous()
+        Cp = x.shape[-1]
+        dev = x.device
+        W1 = b1 = W2 = b2 = w = b0 = None
+        if mode != ops.SE_SSE:
+            Cr = fc1_w.shape[0]
+            W1, W2 = torch.zeros(Cp, Cp, device=dev), torch.zeros(Cp, Cp, device=dev)
+            b1, b2 = torch.zeros(Cp, device=dev), torch.zeros(Cp, device=dev)
+            W1[:Cr, :C], W2[:C, :Cr], b1[:Cr], b2[:C] = fc1_w.detach().float(), fc2_w.detach().float(), fc1_b.detach().float(), fc2_b.detach().float()
+            ctx.Cr = Cr
+        if mode != ops.SE_CSE:
+            w = torch.zeros(Cp, device=dev)
+            w[:C] = conv_w.detach().float().reshape(-1)
+            b0 = conv_b.detach().float().reshape(1).contiguous()
+        y = torch.empty_like(x)
+        state = ops.se_layer_fwd(x, y, mode, W1, b1, W2, b2, w, b0)
+        ctx.save_for_backward(x, *[t for t in (W1, W2, w) if t is not None], *[t for t in state if t is not None])
+        ctx.mode, ctx.C, ctx.wshape = mode, C, (None if conv_w is None else tuple(conv_w.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        mode, C = ctx.mode, ctx.C
+        sv = list(ctx.saved_tensors)
+        x = sv.pop(0)
+        W1 = W2 = w = mean = z1 = a = bgate = None
+        if mode != ops.SE_SSE:
+            W1, W2 = sv.pop(0), sv.pop(0)
+        if mode != ops.SE_CSE:
+            w = sv.pop(0)
+        if mode != ops.SE_SSE:
+            mean, z1, a = sv.pop(0), sv.pop(0), sv.pop(0)
+        if mode != ops.SE_CSE:
+            bgate = sv.pop(0)
+        g = g.contiguous()
+        dx = torch.empty_like(g)
+        dW1, db1, dW2, db2, dw, db0 = ops.se_layer_bwd(g, x, dx, mode, (mean, z1, a, bgate), W1, W2, w)
+        if mode != ops.SE_SSE:
+            Cr = ctx.Cr
+            dW1, db1, dW2, db2 = dW1[:Cr, :C].contiguous(), db1[:Cr].contiguous(), dW2[:C, :Cr].contiguous(), db2[:C].contiguous()
+        if mode != ops.SE_CSE:
+            dw, db0 = dw[:C].reshape(ctx.wshape), db0.reshape(1)
+        return dx, None, None, dW1, db1, dW2, db2, dw, db0
+
+
+def se(a, mode, cse=None, sse=None):
+    """a: CL activation; cse: a ChannelSELayer3D (fc1, fc2), sse: a SpatialSELayer3D (conv) - whichever the mode uses"""
+    if not _se_widths_ok(a.t.shape[-1], a.t.dtype):
+        raise MisError(f"squeeze & excitation kernels: {a.C} channels (stored as {a.t.shape[-1]}) - the stored width must be 64 * 2^k or a multiple of "
+                       f"{512 if a.t.dtype == torch.bfloat16 else 256} up to {2048 if a.t.dtype == torch.bfloat16 else 1024}")
+    if mode != ops.SE_SSE and cse.fc1.weight.shape[1] != a.C or mode != ops.SE_CSE and sse.conv.weight.shape[1] != a.C:
+        raise MisError(f"squeeze & excitation layer built for another channel count than the input's {a.C}")
+    f1w, f1b, f2w, f2b = (cse.fc1.weight, cse.fc1.bias, cse.fc2.weight, cse.fc2.bias) if mode != ops.SE_SSE else (None,) * 4
+    cw, cb = (sse.conv.weight, sse.conv.bias) if mode != ops.SE_CSE else (None, None)
+    return CL(_SE.apply(a.t, a.C, mode, f1w, f1b, f2w, f2b, cw, cb), a.C)
+
+
 # ---- ConvTranspose3d(k3, s2, p1, bias=False) + nearest resize to the encoder grid (TransposeConvUpsampling, buildingblocks.py:676-728) -------------------
 class _ConvT2x(torch.autograd.Function):
     """low (N, d, h, w, Cinp) -> (N, 2d, 2h, 2w, Coutp): the (2d-1)^3 transposed-conv output resized (nearest) to exactly twice the input grid - the case

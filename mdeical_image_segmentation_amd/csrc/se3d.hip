@@ -8,6 +8,10 @@
 //   dz2 = da a(1-a), dW2 = dz2 h^T, dh = W2^T dz2, dz1 = dh [z1>0], dW1 = dz1 m^T, cross[n][c] = (W1^T dz1)[c] / S      (mis_se_fc_bwd)
 //   de = [e>0] * ( g (sA a + (1-sA) b) + cross[n][c] + dq[n][v] w[c] )                     (mis_se_bwd_apply; e is a ReLU output: the mask is the
 //        block's own ReLU backward, fused here).  Ties e*a == e*b occur where e == 0, which the mask removes, so torch's half/half rule is moot.
+// Stand-alone layers (round 5: se.py:18-53 ChannelSELayer3D, :56-98 SpatialSELayer3D, :101-116 ChannelSpatialSELayer3D called on their own): the `mis_se_layer_*`
+// entry points run the same three passes with `mode` = 0 max(cSE, sSE) / 1 cSE alone (out = e a) / 2 sSE alone (out = e b) and without the ReLU mask (`relu_mask` 0:
+// the input may be negative; a tie e a == e b at e == 0 then takes torch.max's half / half rule, de = g (a + b) / 2 - the reductions carry the factor e and see nothing).
+// The C x C matrices serve any reduction ratio: the caller pads W1 [C/r][C] / W2 [C][C/r] with zero rows / columns.
 // HBM-bound passes: G = min(C/EPC, 64) lanes share a voxel (one 16-byte chunk per lane and step), channel sums of a voxel by xor-shuffles,
 // per-channel sums over voxels in registers -> per-group partial slabs -> fixed-order second stage (bitwise reproducible).
 #include "common.hpp"
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256) void se_apply_fwd_kernel(const T* __restrict__ e, int e_ld, long long S, int C, SeGeom sg, const float* __restrict__ a,
                                                            const float* __restrict__ w, const float* __restrict__ b0, float* __restrict__ bgate,
-                                                           T* __restrict__ y, int y_ld) {
+                                                           T* __restrict__ y, int y_ld, int mode) {
     constexpr int EPC = Tr<T>::EPC;
     const int n = blockIdx.y;
     const int lg = threadIdx.x % sg.G, grp = threadIdx.x / sg.G;
@@ -146,10 +150,10 @@ __global__ __launch_bounds__(256) void se_apply_fwd_kernel(const T* __restrict__
         if (k < sg.K)
 #pragma unroll
             for (int i = 0; i < EPC; ++i) {
-                av[k][i] = a[(size_t)n * C + (lg + k * sg.G) * EPC + i];
-                wv[k][i] = w[(lg + k * sg.G) * EPC + i];
+                av[k][i] = mode != 2 ? a[(size_t)n * C + (lg + k * sg.G) * EPC + i] : 0.f;
+                wv[k][i] = mode != 1 ? w[(lg + k * sg.G) * EPC + i] : 0.f;
             }
-    const float bias = b0[0];
+    const float bias = mode != 1 ? b0[0] : 0.f;
     const T* eb = e + (size_t)n * S * e_ld;
     T* yb = y + (size_t)n * S * y_ld;
     for (long long v = (long long)blockIdx.x * sg.gpb + grp; v < S; v += (long long)gridDim.x * sg.gpb) {
@@ -164,13 +168,16 @@ __global__ __launch_bounds__(256) void se_apply_fwd_kernel(const T* __restrict__
             }
         q = se_group_sum(q, sg.G) + bias;
         const float bg = se_sigmoid(q);
-        if (lg == 0) bgate[(size_t)n * S + v] = bg;
+        if (lg == 0 && mode != 1) bgate[(size_t)n * S + v] = bg;
 #pragma unroll
         for (int k = 0; k < SE_MAXK; ++k)
             if (k < sg.K) {
                 float o[EPC];
 #pragma unroll
-                for (int i = 0; i < EPC; ++i) o[i] = fmaxf(f[k][i] * av[k][i], f[k][i] * bg);
+                for (int i = 0; i < EPC; ++i) {
+                    const float pa = f[k][i] * av[k][i], pb = f[k][i] * bg;
+                    o[i] = mode == 0 ? fmaxf(pa, pb) : (mode == 1 ? pa : pb);
+                }
                 *reinterpret_cast<u32x4*>(yb + v * y_ld + (size_t)(lg + k * sg.G) * EPC) = pack_chunk<T>(o);
             }
     }
@@ -181,7 +188,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const T* __restrict__ g, int g_ld, const T* __restrict__ e, int e_ld, long long S, int C,
                                                             SeGeom sg, const float* __restrict__ a, const float* __restrict__ bgate,
                                                             float* __restrict__ dq, float* __restrict__ part_da, float* __restrict__ part_dw,
-                                                            float* __restrict__ part_db0, int nslots) {
+                                                            float* __restrict__ part_db0, int nslots, int mode) {
     constexpr int EPC = Tr<T>::EPC;
     const int n = blockIdx.y;
     const int lg = threadIdx.x % sg.G, grp = threadIdx.x / sg.G;
@@ -190,14 +197,14 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const T* __restrict_
     for (int k = 0; k < SE_MAXK; ++k)
 #pragma unroll
         for (int i = 0; i < EPC; ++i) {
-            av[k][i] = k < sg.K ? a[(size_t)n * C + (lg + k * sg.G) * EPC + i] : 0.f;
+            av[k][i] = (k < sg.K && mode != 2) ? a[(size_t)n * C + (lg + k * sg.G) * EPC + i] : 0.f;
             da[k][i] = dw[k][i] = 0.f;
         }
     float db0 = 0.f;
     const T* eb = e + (size_t)n * S * e_ld;
     const T* gb = g + (size_t)n * S * g_ld;
     for (long long v = (long long)blockIdx.x * sg.gpb + grp; v < S; v += (long long)gridDim.x * sg.gpb) {
-        const float bg = bgate[(size_t)n * S + v];
+        const float bg = mode != 1 ? bgate[(size_t)n * S + v] : 0.f;
         float f[SE_MAXK][EPC];
         float dbv = 0.f;
 #pragma unroll
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
                 for (int i = 0; i < EPC; ++i) {
                     const float ge = gg[i] * f[k][i];
-                    const bool sa = f[k][i] * av[k][i] >= f[k][i] * bg;
+                    const bool sa = mode == 0 ? (f[k][i] * av[k][i] >= f[k][i] * bg) : (mode == 1);
                     da[k][i] += sa ? ge : 0.f;
                     dbv += sa ? 0.f : ge;
                 }
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const T* __restrict_
         dbv = se_group_sum(dbv, sg.G);
         const float dqv = dbv * bg * (1.f - bg);
         if (lg == 0) {
-            dq[(size_t)n * S + v] = dqv;
+            if (mode != 1) dq[(size_t)n * S + v] = dqv;
             db0 += dqv;
         }
 #pragma unroll
@@ -282,7 +289,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* g, int g_ld, const T* __restrict__ e, int e_ld, long long S, int C,
                                                            SeGeom sg, const float* __restrict__ a, const float* __restrict__ bgate,
                                                            const float* __restrict__ dq, const float* __restrict__ w, const float* __restrict__ cross,
-                                                           T* de, int de_ld) {
+                                                           T* de, int de_ld, int mode, int relu_mask) {
     constexpr int EPC = Tr<T>::EPC;
     const int n = blockIdx.y;
     const int lg = threadIdx.x % sg.G, grp = threadIdx.x / sg.G;
@@ -293,15 +300,15 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* g, int g_ld,
 #pragma unroll
             for (int i = 0; i < EPC; ++i) {
                 const int c = (lg + k * sg.G) * EPC + i;
-                av[k][i] = a[(size_t)n * C + c];
-                wv[k][i] = w[c];
-                cr[k][i] = cross[(size_t)n * C + c];
+                av[k][i] = mode != 2 ? a[(size_t)n * C + c] : 0.f;
+                wv[k][i] = mode != 1 ? w[c] : 0.f;
+                cr[k][i] = mode != 2 ? cross[(size_t)n * C + c] : 0.f;
             }
     const T* eb = e + (size_t)n * S * e_ld;
     const T* gb = g + (size_t)n * S * g_ld;
     T* ob = de + (size_t)n * S * de_ld;
     for (long long v = (long long)blockIdx.x * sg.gpb + grp; v < S; v += (long long)gridDim.x * sg.gpb) {
-        const float bg = bgate[(size_t)n * S + v], dqv = dq[(size_t)n * S + v];
+        const float bg = mode != 1 ? bgate[(size_t)n * S + v] : 0.f, dqv = mode != 1 ? dq[(size_t)n * S + v] : 0.f;
 #pragma unroll
         for (int k = 0; k < SE_MAXK; ++k)
             if (k < sg.K) {
@@ -310,9 +317,11 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* g, int g_ld,
                 unpack_chunk<T>(*reinterpret_cast<const u32x4*>(gb + v * g_ld + (size_t)(lg + k * sg.G) * EPC), gg);
 #pragma unroll
                 for (int i = 0; i < EPC; ++i) {
-                    const bool sa = f[i] * av[k][i] >= f[i] * bg;
-                    const float d = gg[i] * (sa ? av[k][i] : bg) + cr[k][i] + dqv * wv[k][i];
-                    o[i] = f[i] > 0.f ? d : 0.f;
+                    const bool sa = mode == 0 ? (f[i] * av[k][i] >= f[i] * bg) : (mode == 1);
+                    float gate = sa ? av[k][i] : bg;
+                    if (mode == 0 && !relu_mask && f[i] == 0.f) gate = 0.5f * (av[k][i] + bg);          // torch.max's tie rule (both products are 0)
+                    const float d = gg[i] * gate + cr[k][i] + dqv * wv[k][i];
+                    o[i] = (!relu_mask || f[i] > 0.f) ? d : 0.f;
                 }
                 *reinterpret_cast<u32x4*>(ob + v * de_ld + (size_t)(lg + k * sg.G) * EPC) = pack_chunk<T>(o);
             }
@@ -346,33 +355,44 @@ extern "C" int mis_se_fc_fwd(const float* chan_sum, double count, const float* W
     return MIS_OK;
 }
 
-extern "C" int mis_se_apply_fwd(int dtype, const void* e, int e_ld, int N, long long S, int C, const float* a, const float* w, const float* b0,
-                                float* bgate, void* y, int y_ld, void* stream) {
+static int se_apply_fwd_impl(int dtype, const void* e, int e_ld, int N, long long S, int C, const float* a, const float* w, const float* b0, float* bgate, void* y,
+                             int y_ld, int mode, void* stream) {
     (void)hipGetLastError();
     SeGeom sg;
     if (int rc = se_check("se_apply_fwd", dtype, N, S, C, &sg)) return rc;
-    MIS_REQUIRE(e && a && w && b0 && bgate && y && e != y && e_ld >= C && y_ld >= C, MIS_EINVAL, "se_apply_fwd: pointers / strides");
+    MIS_REQUIRE(mode >= 0 && mode <= 2, MIS_EINVAL, "se_apply_fwd: mode %d (0 scSE, 1 cSE, 2 sSE)", mode);
+    MIS_REQUIRE(e && (a || mode == 2) && ((w && b0 && bgate) || mode == 1) && y && e != y && e_ld >= C && y_ld >= C, MIS_EINVAL, "se_apply_fwd: pointers / strides");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // the forward has no per-slot partials: use a wide grid
     long long b = (S + sg.gpb - 1) / sg.gpb;
     if (b > 8192) b = 8192;
     if (dtype == MIS_BF16)
-        hipLaunchKernelGGL(se_apply_fwd_kernel<__bf16>, dim3((unsigned)b, N), dim3(256), 0, st, (const __bf16*)e, e_ld, S, C, sg, a, w, b0, bgate, (__bf16*)y, y_ld);
+        hipLaunchKernelGGL(se_apply_fwd_kernel<__bf16>, dim3((unsigned)b, N), dim3(256), 0, st, (const __bf16*)e, e_ld, S, C, sg, a, w, b0, bgate, (__bf16*)y, y_ld, mode);
     else
-        hipLaunchKernelGGL(se_apply_fwd_kernel<float>, dim3((unsigned)b, N), dim3(256), 0, st, (const float*)e, e_ld, S, C, sg, a, w, b0, bgate, (float*)y, y_ld);
+        hipLaunchKernelGGL(se_apply_fwd_kernel<float>, dim3((unsigned)b, N), dim3(256), 0, st, (const float*)e, e_ld, S, C, sg, a, w, b0, bgate, (float*)y, y_ld, mode);
     MIS_LAUNCH_CHECK("se_apply_fwd");
     return MIS_OK;
+}
+extern "C" int mis_se_apply_fwd(int dtype, const void* e, int e_ld, int N, long long S, int C, const float* a, const float* w, const float* b0,
+                                float* bgate, void* y, int y_ld, void* stream) {
+    return se_apply_fwd_impl(dtype, e, e_ld, N, S, C, a, w, b0, bgate, y, y_ld, 0, stream);
+}
+extern "C" int mis_se_layer_fwd(int dtype, const void* e, int e_ld, int N, long long S, int C, const float* a, const float* w, const float* b0, float* bgate,
+                                void* y, int y_ld, int mode, void* stream) {
+    return se_apply_fwd_impl(dtype, e, e_ld, N, S, C, a, w, b0, bgate, y, y_ld, mode, stream);
 }
 
 extern "C" size_t mis_se_bwd_workspace_bytes(int N, int C) { return ((size_t)2 * N * SE_PARTS * C + (size_t)N * SE_PARTS + (size_t)N * C) * sizeof(float); }
 
 /* g: dL/d(out), may already carry the [e > 0] mask.  Writes dq (N*S), da (N*C), dw (C), db0 (1). */
-extern "C" int mis_se_bwd_reduce(int dtype, const void* g, int g_ld, const void* e, int e_ld, int N, long long S, int C, const float* a,
-                                 const float* bgate, float* workspace, float* dq, float* da, float* dw, float* db0, void* stream) {
+static int se_bwd_reduce_impl(int dtype, const void* g, int g_ld, const void* e, int e_ld, int N, long long S, int C, const float* a, const float* bgate,
+                              float* workspace, float* dq, float* da, float* dw, float* db0, int mode, void* stream) {
     (void)hipGetLastError();
     SeGeom sg;
     if (int rc = se_check("se_bwd_reduce", dtype, N, S, C, &sg)) return rc;
-    MIS_REQUIRE(g && e && a && bgate && workspace && dq && da && dw && db0 && g_ld >= C && e_ld >= C, MIS_EINVAL, "se_bwd_reduce: pointers / strides");
+    MIS_REQUIRE(mode >= 0 && mode <= 2, MIS_EINVAL, "se_bwd_reduce: mode %d", mode);
+    MIS_REQUIRE(g && e && (a || mode == 2) && ((bgate && dq) || mode == 1) && workspace && da && dw && db0 && g_ld >= C && e_ld >= C, MIS_EINVAL,
+                "se_bwd_reduce: pointers / strides");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const unsigned bx = se_blocks(S, sg);
     const int nslots = (int)bx;
@@ -382,15 +402,23 @@ extern "C" int mis_se_bwd_reduce(int dtype, const void* g, int g_ld, const void*
     float* pb = pw + (size_t)N * SE_PARTS * C;
     if (dtype == MIS_BF16)
         hipLaunchKernelGGL(se_bwd_reduce_kernel<__bf16>, dim3(bx, N), dim3(256), lds, st, (const __bf16*)g, g_ld, (const __bf16*)e, e_ld, S, C, sg, a, bgate, dq,
-                           pa, pw, pb, nslots);
+                           pa, pw, pb, nslots, mode);
     else
         hipLaunchKernelGGL(se_bwd_reduce_kernel<float>, dim3(bx, N), dim3(256), lds, st, (const float*)g, g_ld, (const float*)e, e_ld, S, C, sg, a, bgate, dq, pa,
-                           pw, pb, nslots);
+                           pw, pb, nslots, mode);
     MIS_LAUNCH_CHECK("se_bwd_reduce");
     hipLaunchKernelGGL(se_bwd_finish_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, (const float*)pa, (const float*)pw, (const float*)pb, N, C, nslots,
                        da, dw, db0);
     MIS_LAUNCH_CHECK("se_bwd_finish");
     return MIS_OK;
+}
+extern "C" int mis_se_bwd_reduce(int dtype, const void* g, int g_ld, const void* e, int e_ld, int N, long long S, int C, const float* a,
+                                 const float* bgate, float* workspace, float* dq, float* da, float* dw, float* db0, void* stream) {
+    return se_bwd_reduce_impl(dtype, g, g_ld, e, e_ld, N, S, C, a, bgate, workspace, dq, da, dw, db0, 0, stream);
+}
+extern "C" int mis_se_layer_bwd_reduce(int dtype, const void* g, int g_ld, const void* e, int e_ld, int N, long long S, int C, const float* a, const float* bgate,
+                                       float* workspace, float* dq, float* da, float* dw, float* db0, int mode, void* stream) {
+    return se_bwd_reduce_impl(dtype, g, g_ld, e, e_ld, N, S, C, a, bgate, workspace, dq, da, dw, db0, mode, stream);
 }
 
 extern "C" int mis_se_fc_bwd(const float* da, const float* a, const float* z1, const float* mean, const float* W1, const float* W2, int N, int C,
@@ -407,21 +435,31 @@ extern "C" int mis_se_fc_bwd(const float* da, const float* a, const float* z1, c
     return MIS_OK;
 }
 
-extern "C" int mis_se_bwd_apply(int dtype, const void* g, int g_ld, const void* e, int e_ld, int N, long long S, int C, const float* a,
-                                const float* bgate, const float* dq, const float* w, const float* cross, void* de, int de_ld, void* stream) {
+static int se_bwd_apply_impl(int dtype, const void* g, int g_ld, const void* e, int e_ld, int N, long long S, int C, const float* a, const float* bgate,
+                             const float* dq, const float* w, const float* cross, void* de, int de_ld, int mode, int relu_mask, void* stream) {
     (void)hipGetLastError();
     SeGeom sg;
     if (int rc = se_check("se_bwd_apply", dtype, N, S, C, &sg)) return rc;
-    MIS_REQUIRE(g && e && a && bgate && dq && w && cross && de && g_ld >= C && e_ld >= C && de_ld >= C, MIS_EINVAL, "se_bwd_apply: pointers / strides");
+    MIS_REQUIRE(mode >= 0 && mode <= 2, MIS_EINVAL, "se_bwd_apply: mode %d", mode);
+    MIS_REQUIRE(g && e && ((a && cross) || mode == 2) && ((bgate && dq && w) || mode == 1) && de && g_ld >= C && e_ld >= C && de_ld >= C, MIS_EINVAL,
+                "se_bwd_apply: pointers / strides");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     long long b = (S + sg.gpb - 1) / sg.gpb;
     if (b > 8192) b = 8192;
     if (dtype == MIS_BF16)
         hipLaunchKernelGGL(se_bwd_apply_kernel<__bf16>, dim3((unsigned)b, N), dim3(256), 0, st, (const __bf16*)g, g_ld, (const __bf16*)e, e_ld, S, C, sg, a, bgate,
-                           dq, w, cross, (__bf16*)de, de_ld);
+                           dq, w, cross, (__bf16*)de, de_ld, mode, relu_mask);
     else
         hipLaunchKernelGGL(se_bwd_apply_kernel<float>, dim3((unsigned)b, N), dim3(256), 0, st, (const float*)g, g_ld, (const float*)e, e_ld, S, C, sg, a, bgate, dq,
-                           w, cross, (float*)de, de_ld);
+                           w, cross, (float*)de, de_ld, mode, relu_mask);
     MIS_LAUNCH_CHECK("se_bwd_apply");
     return MIS_OK;
+}
+extern "C" int mis_se_bwd_apply(int dtype, const void* g, int g_ld, const void* e, int e_ld, int N, long long S, int C, const float* a,
+                                const float* bgate, const float* dq, const float* w, const float* cross, void* de, int de_ld, void* stream) {
+    return se_bwd_apply_impl(dtype, g, g_ld, e, e_ld, N, S, C, a, bgate, dq, w, cross, de, de_ld, 0, 1, stream);
+}
+extern "C" int mis_se_layer_bwd_apply(int dtype, const void* g, int g_ld, const void* e, int e_ld, int N, long long S, int C, const float* a, const float* bgate,
+                                      const float* dq, const float* w, const float* cross, void* de, int de_ld, int mode, int relu_mask, void* stream) {
+    return se_bwd_apply_impl(dtype, g, g_ld, e, e_ld, N, S, C, a, bgate, dq, w, cross, de, de_ld, mode, relu_mask, stream);
 }

@@ -9,8 +9,41 @@ from torch import nn
 from transformers import PretrainedConfig, PreTrainedModel
 from transformers.utils import ModelOutput
 
+from ..._lib import MisError, check, load
+from ...ops import stream_ptr
 from .losses import get_loss_criterion
 from .model import UNet3D
+
+
+class _HipSigmoid(torch.autograd.Function):
+    """the wrapper's `nn.Sigmoid()` on the logits (UNet3D.py:50, applied :140-141) as a HIP pass and its backward dL/dx = g * y * (1 - y) as another
+    (mis_scale_sigmoid with a unit gate, csrc/pool_up.hip) - round 4 left this one elementwise op of call stack (D) to ATen"""
+
+    @staticmethod
+    def forward(ctx, x):
+        if x.device.type != "cuda":
+            raise MisError(f"UNet3DForMedicalSegmentation runs on MI355X only: logits on {x.device}")
+        x = x.float().contiguous()
+        one = torch.ones(1, device=x.device)
+        y = torch.empty_like(x)
+        check(load().mis_scale_sigmoid(x.data_ptr(), None, one.data_ptr(), 1, x.numel(), y.data_ptr(), stream_ptr()), "mis_scale_sigmoid")
+        ctx.save_for_backward(x, one)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, one = ctx.saved_tensors
+        g = g.float().contiguous()
+        dx = torch.empty_like(x)
+        check(load().mis_scale_sigmoid(x.data_ptr(), g.data_ptr(), one.data_ptr(), 1, x.numel(), dx.data_ptr(), stream_ptr()), "mis_scale_sigmoid")
+        return dx
+
+
+class Sigmoid(nn.Sigmoid):
+    """nn.Sigmoid in the module tree (no parameters, same repr / state dict), HIP arithmetic"""
+
+    def forward(self, x):
+        return _HipSigmoid.apply(x)
 
 
 class UNet3DForMedicalSegmentationConfig(PretrainedConfig):
@@ -47,7 +80,7 @@ class UNet3DForMedicalSegmentation(PreTrainedModel):
                             is_segmentation=config.is_segmentation, conv_padding=config.conv_padding, conv_upscale=config.conv_upscale,
                             upsample=config.upsample, dropout_prob=config.dropout_prob, compute_dtype=config.compute_dtype)
         if config.is_segmentation and config.final_sigmoid:
-            self.activation = nn.Sigmoid()
+            self.activation = Sigmoid()
         elif config.is_segmentation:
             self.activation = nn.Softmax(dim=1)
         else:

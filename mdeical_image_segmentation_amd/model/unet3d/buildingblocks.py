@@ -12,7 +12,7 @@ import torch
 from torch import nn
 
 from ... import blocks3d as B
-from .se import ChannelSpatialSELayer3D
+from .se import ChannelSELayer3D, ChannelSpatialSELayer3D, SpatialSELayer3D
 
 
 def create_conv(in_channels, out_channels, kernel_size, order, num_groups, padding, dropout_prob, is3d):
@@ -124,19 +124,22 @@ class ResNetBlock(_Block, nn.Module):
 
 
 class ResNetBlockSE(ResNetBlock):
-    """buildingblocks.py:326-362: ResNetBlock followed by a squeeze-and-excitation module.  Only se_module='scse' (the one ResidualUNetSE3D can reach:
-    Encoder / Decoder never pass another) is built: ChannelSpatialSELayer3D with reduction_ratio 1 (csrc/se3d.hip), inside the fused residual engine."""
+    """buildingblocks.py:326-362: ResNetBlock followed by a squeeze-and-excitation module with reduction_ratio 1: 'scse' ChannelSpatialSELayer3D, 'cse'
+    ChannelSELayer3D, 'sse' SpatialSELayer3D (csrc/se3d.hip).  Inside ResidualUNetSE3D ('scse', the only one Encoder / Decoder pass) the fused residual engine
+    runs the block; called on its own it is the stand-alone chain of `_cl` functions."""
 
     def __init__(self, in_channels, out_channels, kernel_size=3, order="cge", num_groups=8, se_module="scse", **kwargs):
         super().__init__(in_channels, out_channels, kernel_size=kernel_size, order=order, num_groups=num_groups, **kwargs)
         assert se_module in ["scse", "cse", "sse"]
-        if se_module != "scse":
-            raise NotImplementedError("ResNetBlockSE on MI355X: se_module='scse'")
-        self.se_module = ChannelSpatialSELayer3D(num_channels=out_channels, reduction_ratio=1)
+        if se_module == "scse":
+            self.se_module = ChannelSpatialSELayer3D(num_channels=out_channels, reduction_ratio=1)
+        elif se_module == "cse":
+            self.se_module = ChannelSELayer3D(num_channels=out_channels, reduction_ratio=1)
+        else:
+            self.se_module = SpatialSELayer3D(num_channels=out_channels)
 
     def _cl(self, a):
-        raise NotImplementedError("ResNetBlockSE runs inside the fused ResidualUNetSE3D engine only (its squeeze-and-excitation kernels are fused with the "
-                                  "block's ReLU): call the whole network")
+        return self.se_module._cl(super()._cl(a))
 
 
 class Encoder(_Block, nn.Module):

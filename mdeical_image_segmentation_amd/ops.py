@@ -748,6 +748,58 @@ def se_bwd(g, e, W1, W2, w, st, dW1, db1, dW2, db2, dw, db0):
                                st.cross.data_ptr(), g.ptr, g.ld, stream_ptr()), "mis_se_bwd_apply")
 
 
+SE_SCSE, SE_CSE, SE_SSE = 0, 1, 2
+
+
+def se_layer_fwd(e, y, mode, W1=None, b1=None, W2=None, b2=None, w=None, b0=None):
+    """one of se.py's three layers on its own (csrc/se3d.hip, mis_se_layer_*): e -> y channels-last, mode SE_SCSE / SE_CSE / SE_SSE.  W1, W2: [C][C] fp32 (the
+    caller zero-pads other reduction ratios), w [C], b0 [1].  Returns the tuple of saved fp32 state for se_layer_bwd: (mean, z1, a, bgate) - None where unused."""
+    lib = load()
+    ev, yv = _v(e), _v(y)
+    S = ev.D * ev.H * ev.W
+    dev = ev.t.device
+    mean = z1 = a = bgate = None
+    if mode != SE_SSE:
+        csum, csq = torch.empty(ev.N, ev.C, device=dev), torch.empty(ev.N, ev.C, device=dev)
+        chanstats(e, csum, csq)
+        mean, z1, a = (torch.empty(ev.N, ev.C, device=dev) for _ in range(3))
+        check(lib.mis_se_fc_fwd(csum.data_ptr(), float(S), W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), ev.N, ev.C, mean.data_ptr(), z1.data_ptr(),
+                                a.data_ptr(), stream_ptr()), "mis_se_fc_fwd")
+    if mode != SE_CSE:
+        bgate = torch.empty(ev.N, S, device=dev)
+    p = lambda t: 0 if t is None else t.data_ptr()       # noqa: E731
+    check(lib.mis_se_layer_fwd(dtype_code(ev.dtype), ev.ptr, ev.ld, ev.N, S, ev.C, p(a), p(w), p(b0), p(bgate), yv.ptr, yv.ld, mode, stream_ptr()), "mis_se_layer_fwd")
+    return mean, z1, a, bgate
+
+
+def se_layer_bwd(g, e, de, mode, state, W1=None, W2=None, w=None):
+    """backward of se_layer_fwd: g = dL/dy -> de = dL/de (may alias g); returns (dW1, db1, dW2, db2, dw, db0) fp32, None where the mode has no such parameter"""
+    lib = load()
+    gv, ev, dv = _v(g), _v(e), _v(de)
+    S = ev.D * ev.H * ev.W
+    dev = ev.t.device
+    mean, z1, a, bgate = state
+    N, C = ev.N, ev.C
+    ws = workspace(lib.mis_se_bwd_workspace_bytes(N, C), dev, "se_bwd")
+    dt = dtype_code(ev.dtype)
+    dq = torch.empty(N, S, device=dev) if mode != SE_CSE else None
+    da, dw, db0 = torch.empty(N, C, device=dev), torch.empty(C, device=dev), torch.empty(1, device=dev)
+    p = lambda t: 0 if t is None else t.data_ptr()       # noqa: E731
+    check(lib.mis_se_layer_bwd_reduce(dt, gv.ptr, gv.ld, ev.ptr, ev.ld, N, S, C, p(a), p(bgate), ws.data_ptr(), p(dq), da.data_ptr(), dw.data_ptr(), db0.data_ptr(),
+                                      mode, stream_ptr()), "mis_se_layer_bwd_reduce")
+    dW1 = db1 = dW2 = db2 = cross = None
+    if mode != SE_SSE:
+        dW1, dW2 = torch.empty(C, C, device=dev), torch.empty(C, C, device=dev)
+        db1, db2, cross = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(N, C, device=dev)
+        check(lib.mis_se_fc_bwd(da.data_ptr(), a.data_ptr(), z1.data_ptr(), mean.data_ptr(), W1.data_ptr(), W2.data_ptr(), N, C, float(S), ws.data_ptr(),
+                                dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(), cross.data_ptr(), stream_ptr()), "mis_se_fc_bwd")
+    check(lib.mis_se_layer_bwd_apply(dt, gv.ptr, gv.ld, ev.ptr, ev.ld, N, S, C, p(a), p(bgate), p(dq), p(w), p(cross), dv.ptr, dv.ld, mode, 0, stream_ptr()),
+          "mis_se_layer_bwd_apply")
+    if mode == SE_CSE:
+        dw = db0 = None
+    return dW1, db1, dW2, db2, dw, db0
+
+
 def upconv_gather_fwd(z, y, scale, C, bias=None):
     """z (N, h, w, 9*C) dense -> y (N, h*s, w*s, C): the 3x3 taps of conv3x3(bilinear_up_s(x)) gathered from the low-resolution tap products"""
     lib = load()

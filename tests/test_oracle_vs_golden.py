@@ -347,3 +347,27 @@ def test_f1_and_iou_loss_oracle_matches_the_reference_classes():
             assert abs(loss.item() - float(g[f"{name}{i}"])) < 1e-6, (name, i, loss.item(), float(g[f"{name}{i}"]))
             ref = torch.from_numpy(g[f"{name}{i}_grad"])
             assert (x.grad - ref).abs().max().item() <= 1e-6 * ref.abs().max().item() + 1e-12, (name, i)
+
+
+def test_se_layer_oracle_matches_the_reference_classes():
+    """the stand-alone squeeze & excitation layers (model/unet3d/se.py): oracle/se_oracle.py against outputs and gradients of the reference's own classes
+    (g20_se_layers.npz, tests/golden/make_golden_se_layers.py) - both signs of the input, a ReLU'd input (exact ties of torch.max at 0), reduction ratios 1 - 8"""
+    from oracle import se_oracle as so
+    g = load_golden("g20_se_layers.npz")
+    for i, case in enumerate(g["cases"]):
+        kind = str(case).split(":")[0]
+        x = torch.from_numpy(g[f"x{i}"]).clone().requires_grad_(True)
+        names = [k[len(f"p{i}."):] for k in g.files if k.startswith(f"p{i}.")]
+        P = {n: torch.from_numpy(g[f"p{i}.{n}"]).clone().requires_grad_(True) for n in names}
+        if kind == "cse":
+            y = so.cse(x, P["fc1.weight"], P["fc1.bias"], P["fc2.weight"], P["fc2.bias"])
+        elif kind == "sse":
+            y = so.sse(x, P["conv.weight"], P["conv.bias"])
+        else:
+            y = so.scse(x, P["cSE.fc1.weight"], P["cSE.fc1.bias"], P["cSE.fc2.weight"], P["cSE.fc2.bias"], P["sSE.conv.weight"], P["sSE.conv.bias"])
+        (y * torch.from_numpy(g[f"r{i}"])).sum().backward()
+        assert (y.detach() - torch.from_numpy(g[f"y{i}"])).abs().max().item() < 1e-6, case
+        assert (x.grad - torch.from_numpy(g[f"dx{i}"])).abs().max().item() < 1e-5, case
+        for n in names:
+            ref = torch.from_numpy(g[f"g{i}.{n}"])
+            assert (P[n].grad - ref).abs().max().item() <= 1e-5 * max(ref.abs().max().item(), 1.0), (case, n)
