@@ -98,6 +98,9 @@ const char* mis_conv_last_dispatch(void);
  * Unknown names: MIS_EINVAL.  This is how the parity tests reach every kernel configuration in one process; the launch path itself never calls getenv. */
 int mis_dispatch_override(const char* name, int value);
 int mis_dispatch_switch(const char* name);
+/* Diagnostic: the eight per-XCD ticket counters of the persistent kernels' tile queue on `stream` (csrc/dispatch_cfg.hpp), after a device synchronisation -
+ * all zero between launches (the kernel that draws a counter's last ticket resets it).  Returns -1 when the stream has no counter block (MIS_TILEQ_OFF=1). */
+int mis_debug_tile_queue(void* stream, unsigned* out8);
 
 /* Weight-gradient GEMM: dW[tap][ci][co] = sum_pixels x[pixel+tap][ci] * dy[pixel][co]   (split-K over pixel tiles,
  * fp32 partial slabs + deterministic reduction).  Replaces the weight part of convolution_backward for

@@ -50,6 +50,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
     const int tstride = (int)gridDim.x;
     int tile = xcd_remap(blockIdx.x, gridDim.x);
     if (tile >= total_tiles) return;                 // block-uniform
+    // dynamic tile queue (conv_pp_common.hpp TileQ; as in conv_ppc_kernel): first tile static, the others drawn by wave 0's lane 0 one tile ahead; wave 0 (group 0) meets a
+    // vmcnt(0) at the end of the kw = 2 segment of every (dz, chunk) pair, so a draw issued at the top of a tile has returned when pair 0 is through
+    // (not in the 256-VGPR instantiations, PF 8 x 128 columns: one more live register there and hipcc spills - into scratch, whose reloads wait on vmcnt)
+    constexpr bool TQ = NF * PF < 32;
+    const TileQ tq = tq_init(TQ ? a.tq : nullptr, total_tiles, tstride, (int)blockIdx.x);
+    const bool dyn = TQ && tq.ctr != nullptr;
+    const bool drawer = dyn && tid == 0;
+    unsigned tk = 1u;
+    if (drawer) tq_draw(tk, tq.ctr);
     const int nchunks = a.Cin >> 5;
     const int nvc = 3 * nchunks;                     // (dz, chunk) pairs per tile
     const int tpi = a.tilesH * a.tilesW;
@@ -193,17 +202,23 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
     if (grp == 1) issue_weights(0, 1, ncol0, 0, wbase + WTILE);       // segment 1 (in the loop group 1 issues two segments ahead)
     pp_static_for<HJ>([&](auto jc) { issue_halo(jc, pl - 1, z >= 1, h0, w0, 0, hbase); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t mailbox = (uint32_t)(uintptr_t)(pbase + (EM == PP_EM_GN ? 2 * 3 * BN * 4 : 0));
+    if (drawer) tq_post(tq, tk, mailbox);
     __syncthreads();
+    int nxt = tile + tstride;
+    if (dyn) nxt = tq_tile(tq, tq_take(mailbox), tstride);
 
     int wsel = 0, hsel = 0, bsel = 0;
     if (grp == 1) __builtin_amdgcn_s_barrier();       // the stagger: group 1 runs one slot behind group 0
     __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll 1
-    for (; tile < total_tiles; tile += tstride) {
-        const bool has_next = tile + tstride < total_tiles;
+    for (;;) {
+        const bool has_next = (unsigned)nxt < (unsigned)total_tiles;
         int npl = pl, nz = z, nh0 = h0, nw0 = w0, ncolN = ncol0;
-        if (has_next) decode(tile + tstride, npl, nz, nh0, nw0, ncolN);
+        if (has_next) decode(nxt, npl, nz, nh0, nw0, ncolN);
+        tk = 1u;
+        if (drawer && has_next) tq_draw(tk, tq.ctr);          // the tile after `nxt`: posted after pair 0, taken at the end of the tile (nvc >= 3 pairs: barriers in between)
         int dz = 0, c0 = 0;
         // The K loop: pair 0 runs a copy of the segment code whose first filter row's MFMAs take the BIAS as their C operand (`first`) - no accumulator zeroing and no
         // bias add by vector instructions anywhere (pp_epilogue_plain<..., BINIT>; the same peeling as conv_ppc_kernel, conv_pp.hip)
@@ -333,6 +348,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
         constexpr bool BINIT = NF * PF < 32;
         if constexpr (BINIT) {
             run_pair(std::true_type{}, 0);
+            if (drawer && has_next) tq_post(tq, tk, mailbox);
             // the next tile's bias slice -> the other half of the bias region (last read in the previous tile's first pair); it lands under the rest of this tile's K
             // loop (nvc >= 3) and is read in the next tile's first segment
             if (has_next) issue_bias(ncolN, bbase + (bsel ^ 1) * (BN * 4));
@@ -352,6 +368,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
             if (has_next) issue_pqr(pl / a.D, ncol0, pbase + bsel * (3 * BN * 4));
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (!has_next) break;
+        tile = nxt;
+        nxt = dyn ? tq_tile(tq, tq_take(mailbox), tstride) : tile + tstride;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's last barrier
 }
@@ -394,6 +413,7 @@ template <int PF, int NF, int EM> static int pp3_launch_em(const MisConvDesc* d,
     constexpr int BN = 2 * NF * 16;
     constexpr int TH = 4 * PF, HINSTR = ((TH + 2) * 18 * 4 + 63) / 64;
     ConvArgs a;
+    a.tq = nullptr;
     a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cin0 = d->Cin; a.Cout0 = d->Cout0;
     a.x0 = SrcView{d->x0, d->x0_ld, d->x0_D, d->x0_H, d->x0_W};
     a.x1 = SrcView{nullptr, 0, 0, 0, 0};
@@ -415,7 +435,8 @@ template <int PF, int NF, int EM> static int pp3_launch_em(const MisConvDesc* d,
     a.zg = zg;
     MIS_REQUIRE(nsp * a.nCt < (1ll << 31), MIS_EUNSUPPORTED, "conv_igemm(3d pp): grid too large");
     a.nSp = (int)nsp;
-    const size_t lds = 2 * (size_t)HINSTR * 1024 + 2 * (size_t)3 * BN * 64 + 2 * (size_t)BN * 4 + (EM == PP_EM_GN ? 2 * (size_t)3 * BN * 4 : 0);
+    const size_t lds = 2 * (size_t)HINSTR * 1024 + 2 * (size_t)3 * BN * 64 + 2 * (size_t)BN * 4 + (EM == PP_EM_GN ? 2 * (size_t)3 * BN * 4 : 0) + 16;      // (+ the tile queue's mailbox)
+    a.tq = mis_tile_queue(stream);
     static std::atomic<unsigned long long> attr_done{0};
     if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv3d_ppc_kernel<PF, NF, EM>), lds, "conv_igemm(3d pp)")) return rc;
     const long long total = nsp * a.nCt;

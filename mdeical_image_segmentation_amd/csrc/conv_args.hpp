@@ -29,6 +29,7 @@ struct ConvArgs {
     const float* gn_q;
     const float* gn_r;
     int gn_ld, gn_relu;
+    unsigned* tq;                      // dynamic tile queue of the persistent kernels (dispatch_cfg.hpp mis_tile_queue) or nullptr = static stride
 };
 
 extern thread_local bool g_conv_bits_fused;            // conv_igemm.hip: the launched kernel writes relu_bits itself

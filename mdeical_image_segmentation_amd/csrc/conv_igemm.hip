@@ -690,6 +690,7 @@ __global__ __launch_bounds__(512, 2) void conv64_ws_kernel(const ConvArgs a) {
 
 static int launch_ws64(const MisConvDesc* d, hipStream_t stream) {
     ConvArgs a;
+    a.tq = nullptr;
     a.N = d->N; a.D = 1; a.H = d->H; a.W = d->W; a.Cin = 64; a.Cout = 64; a.Cin0 = 64; a.Cout0 = 64;
     a.x0 = SrcView{d->x0, d->x0_ld, 1, d->x0_H, d->x0_W};
     a.x1 = SrcView{nullptr, 0, 0, 0, 0};
@@ -723,6 +724,7 @@ template <typename T, typename G, int WN, int NF, int NT = 256, int TPS = 1, int
 static int launch_cfg(const MisConvDesc* d, hipStream_t stream) {
     constexpr int BN = WN * NF * 16;
     ConvArgs a;
+    a.tq = nullptr;
     a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
     a.Cin0 = d->Cin0; a.Cout0 = d->Cout0;
     a.x0 = SrcView{d->x0, d->x0_ld, d->x0_D, d->x0_H, d->x0_W};

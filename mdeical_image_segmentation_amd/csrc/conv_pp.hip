@@ -411,6 +411,12 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
     const int tstride = (int)gridDim.x;
     int tile = xcd_remap(blockIdx.x, gridDim.x);
     if (tile >= total_tiles) return;                 // block-uniform
+    // dynamic tile queue (conv_pp_common.hpp TileQ): this tile is the block's static one; `nxt` = the tile after it, drawn below; wave 0's lane 0 does the drawing
+    const TileQ tq = tq_init(a.tq, total_tiles, tstride, (int)blockIdx.x);
+    const bool dyn = tq.ctr != nullptr;
+    const bool drawer = dyn && tid == 0;
+    unsigned tk = 1u;
+    if (drawer) tq_draw(tk, tq.ctr);                 // (older than every DMA of the prologue: the vmcnt(0) below covers it)
 #ifdef PPT_DESYNC           // diagnostic build: blocks of one XCD start PPT_DESYNC x 64 cycles apart, so that their tile boundaries (store bursts) do not coincide
     for (int i = (int)((blockIdx.x >> 3) & 31); i > 0; --i) __builtin_amdgcn_s_sleep(PPT_DESYNC);
 #endif
@@ -508,7 +514,14 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
     if (grp == 1) issue_weights(1, ncol0, 0, wbase + WTILE);          // segment 1 (in the loop group 1 issues two segments ahead)
     pp_static_for<HJ>([&](auto jc) { issue_halo(jc, n, h0, w0, 0, hbase); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t mailbox = (uint32_t)(uintptr_t)(bbase + 2 * BN * 4);
+    if (drawer) tq_post(tq, tk, mailbox);
     __syncthreads();
+    int nxt = tile + tstride;
+    if (dyn) {
+        const unsigned k0 = tq_take(mailbox);
+        nxt = tq_tile(tq, k0, tstride);
+    }
 
     int wsel = 0, hsel = 0, bsel = 0;
 #ifdef MIS_PP_STAMPS          // (diagnostic build: scripts/ppc_stamps.sh; slots as in conv_pp_kernel)
@@ -518,10 +531,14 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll 1
-    for (; tile < total_tiles; tile += tstride) {
-        const bool has_next = tile + tstride < total_tiles;
+    for (;;) {
+        const bool has_next = (unsigned)nxt < (unsigned)total_tiles;
         int nn = n, nh0 = h0, nw0 = w0, ncolN = ncol0;
-        if (has_next) decode(tile + tstride, nn, nh0, nw0, ncolN);
+        if (has_next) decode(nxt, nn, nh0, nw0, ncolN);
+        // the tile after `nxt`: drawn now (the oldest entry of this wave's vmcnt queue for the whole tile: the kw = 2 wait of chunk 0, vmcnt(0), returns it), posted after
+        // chunk 0, taken by every wave at the end of the tile - at least three segments' barriers later (Cin >= 64: two chunks)
+        tk = 1u;
+        if (drawer && has_next) tq_draw(tk, tq.ctr);
         // EM == PP_EM_BITS: the mask of this tile's epilogue - one 16-byte (8-byte) load per lane, issued here, ahead of the whole K loop (inside the chunk loop the
         // load's destination would be loop-carried and hipcc guards it with an s_waitcnt vmcnt(0) at the loop header, i.e. in front of every chunk's prefetches)
         u32x4 mbits = u32x4{0u, 0u, 0u, 0u};
@@ -651,6 +668,7 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
             hsel ^= 1;
         };
         run_chunk(std::true_type{}, 0);
+        if (drawer && has_next) tq_post(tq, tk, mailbox);
         // the next tile's bias slice -> the other half of the bias region (last read in the previous tile's chunk 0); it lands under the rest of this tile's K loop and is
         // read in the next tile's first segment (nchunks >= 2: at least three segments and their counted waits / barriers in between)
         if (has_next) issue_bias(ncolN, bbase + (bsel ^ 1) * (BN * 4));
@@ -670,6 +688,9 @@ __global__ __launch_bounds__(512, 2) void conv_ppc_kernel(const ConvArgs a) {
         bsel ^= 1;
         __builtin_amdgcn_sched_barrier(0);
         PP_STAMP(4)
+        if (!has_next) break;
+        tile = nxt;
+        nxt = dyn ? tq_tile(tq, tq_take(mailbox), tstride) : tile + tstride;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's last barrier
 #ifdef MIS_PP_STAMPS
@@ -696,6 +717,7 @@ template <int PF, int NF, int EM> static int pp_launch_col_em(const MisConvDesc*
     constexpr int BN = 2 * NF * 16;
     constexpr int TH = 4 * PF, HINSTR = ((TH + 2) * 18 * 4 + 63) / 64;
     ConvArgs a;
+    a.tq = nullptr;
     a.N = d->N; a.D = 1; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cin0 = d->Cin; a.Cout0 = d->Cout0;
     a.x0 = SrcView{d->x0, d->x0_ld, 1, d->x0_H, d->x0_W};
     a.x1 = SrcView{nullptr, 0, 0, 0, 0};
@@ -713,10 +735,11 @@ template <int PF, int NF, int EM> static int pp_launch_col_em(const MisConvDesc*
     a.tilesD = (256 % a.nCt == 0 && !mis_sw(SW_CONV_PPC_COLMAJOR)) ? 2 : 1;
     MIS_REQUIRE(nsp * a.nCt < (1ll << 31), MIS_EUNSUPPORTED, "conv_igemm(ppc): grid too large");
     a.nSp = (int)nsp;
-    const size_t lds = 2 * (size_t)HINSTR * 1024 + 2 * (size_t)3 * BN * 64 + 2 * (size_t)BN * 4;
+    const size_t lds = 2 * (size_t)HINSTR * 1024 + 2 * (size_t)3 * BN * 64 + 2 * (size_t)BN * 4 + 16;          // (+ the tile queue's mailbox)
     static std::atomic<unsigned long long> attr_done{0};
     if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv_ppc_kernel<PF, NF, EM>), lds, "conv_igemm(ppc)")) return rc;
     const long long total = nsp * a.nCt;
+    a.tq = d->Cin >= 64 ? mis_tile_queue(stream) : nullptr;          // (one K chunk: no barrier between the ticket's post and its take)
     hipLaunchKernelGGL((conv_ppc_kernel<PF, NF, EM>), dim3((unsigned)(total > mis_persist_cus() ? mis_persist_cus() : total)), dim3(512), lds, stream, a);
     MIS_LAUNCH_CHECK("conv_igemm(ppc)");
     return MIS_OK;
@@ -868,6 +891,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_rs64_kernel(const ConvArgs a) 
 
 static int pp_launch_rs64(const MisConvDesc* d, hipStream_t stream) {
     ConvArgs a;
+    a.tq = nullptr;
     a.N = d->N; a.D = 1; a.H = d->H; a.W = d->W; a.Cin = 64; a.Cout = 64; a.Cin0 = 64; a.Cout0 = 64;
     a.x0 = SrcView{d->x0, d->x0_ld, 1, d->x0_H, d->x0_W};
     a.x1 = SrcView{nullptr, 0, 0, 0, 0};
@@ -907,6 +931,7 @@ bool conv_pp_eligible(const MisConvDesc* d) {
 template <int NF> static int pp_launch(const MisConvDesc* d, hipStream_t stream) {
     constexpr int BN = 2 * NF * 16;
     ConvArgs a;
+    a.tq = nullptr;
     a.N = d->N; a.D = 1; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cin0 = d->Cin; a.Cout0 = d->Cout0;
     a.x0 = SrcView{d->x0, d->x0_ld, 1, d->x0_H, d->x0_W};
     a.x1 = SrcView{nullptr, 0, 0, 0, 0};

@@ -29,6 +29,53 @@ __device__ __forceinline__ void pp_dma16(__amdgpu_buffer_rsrc_t r, int voff, cha
 __device__ __forceinline__ void pp_dma16s(__amdgpu_buffer_rsrc_t r, int voff, int soff, char* lds_dst_wave_uniform) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (pp_lds_void_t*)lds_dst_wave_uniform, 16, voff, soff, 0, 0);
 }
+// ---- dynamic tile queue (round 5; host side: dispatch_cfg.hpp mis_tile_queue) -------------------------------------------------------------------------------
+// Static schedule: block b runs tiles xcd_remap(b) + r * grid, r = 0, 1, ... - a block whose CU is held by another kernel (an RCCL all-reduce on the side stream) starts
+// when the first blocks END, and the launch takes twice as long (measured with a CU-holding dummy kernel, scripts/hog_probe.sh: +40-63 % with 8 of 256 CUs taken).
+// Dynamic schedule: round 0 stays static; XCD x's rounds r >= 1 (the SAME tiles as before: base_x + j + r * grid, j < q_x - the L2 locality of the tile order is kept) are
+// handed out by a ticket counter per XCD: ticket k -> (r = 1 + k / q_x, j = k % q_x).  Tickets rise, so does the tile index: the first ticket past the end ends the block,
+// and every block draws exactly one such ticket - the counter's last ticket is (tiles of rounds >= 1) + q_x - 1, and whoever draws it stores 0 (nobody draws after it).
+// The draw is ONE lane's global_atomic_add issued a whole tile before its value is needed (the next-but-one tile); it travels through the block's LDS mailbox.
+struct TileQ {
+    unsigned* ctr;      // this XCD's counter (nullptr: static stride)
+    int qx, basex;      // blocks of this XCD, its first tile of round 0
+    unsigned last;      // the last ticket that will ever be drawn from ctr in this launch
+};
+__device__ __forceinline__ TileQ tq_init(unsigned* tq, int total, int grid, int bid) {
+    TileQ q;
+    const int xq = grid >> 3, xr = grid & 7, xcd = bid & 7;
+    q.qx = xq + (xcd < xr ? 1 : 0);
+    q.basex = (xcd < xr) ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+    q.ctr = tq != nullptr ? tq + xcd * 16 : nullptr;
+    const int R = total / grid, rem = total - R * grid;          // (total >= grid: the launchers never over-size the grid)
+    int tail = rem - q.basex;
+    tail = tail < 0 ? 0 : (tail > q.qx ? q.qx : tail);
+    q.last = (unsigned)((R - 1) * q.qx + tail + q.qx - 1);
+    return q;
+}
+__device__ __forceinline__ int tq_tile(const TileQ& q, unsigned k, int grid) {
+    if (k > q.last) return 0x7fffffff;          // (cannot happen with clean counters: a ticket past the launch's last one must never become a tile index)
+    const int r = (int)(k / (unsigned)q.qx);
+    return q.basex + ((int)k - r * q.qx) + (r + 1) * grid;
+}
+// issue only (ONE lane must be active): tk = 1 on entry, the ticket once the wave has waited for vmcnt to drain past this instruction
+__device__ __forceinline__ void tq_draw(unsigned& tk, const unsigned* ctr) {
+    unsigned zero = 0u;
+    // s_nop 4: the counter address may have just been restored from a spill lane (v_readlane writes the SGPR pair) and a VMEM instruction reading an SGPR the VALU wrote
+    // needs five wait states - the hazard recogniser does not look inside an asm block (without it the atomic went out with a stale high dword and faulted)
+    asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %0, %2 sc0" : "+v"(tk) : "v"(zero), "s"(ctr) : "memory");
+}
+// ... the drawn ticket -> the block's mailbox (one LDS word); the last ticket of the launch resets the counter.  Same single lane, after its vmcnt wait.
+__device__ __forceinline__ void tq_post(const TileQ& q, unsigned tk, uint32_t mailbox) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(mailbox), "v"(tk) : "memory");
+    if (tk == q.last) __hip_atomic_store(q.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned tq_take(uint32_t mailbox) {          // every wave, a barrier after tq_post
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(mailbox) : "memory");
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 // LDS reads as INLINE ASM: hipcc (ROCm 7.2) may put an s_waitcnt vmcnt(N) in front of an LDS read it cannot tell apart from the destination of an LDS-DMA
 // in flight - which then waits for the prefetch that was just issued and serialises the pipeline (seen here as soon as a second kind of LDS-DMA, the 4-byte
 // bias fetch, joined the kernel; in wgrad_pp.hip with the transposing-read builtin).  The asm form is invisible to that analysis; in exchange NOTHING waits for the

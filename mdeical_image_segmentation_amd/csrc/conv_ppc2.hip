@@ -408,6 +408,7 @@ template <int EM> static int ppc2_launch_em(const MisConvDesc* d, hipStream_t st
     constexpr int PF = 8, NF = 4, BN = 2 * NF * 16;
     constexpr int TH = 4 * PF, HINSTR = ((TH + 2) * 18 * 4 + 63) / 64;
     ConvArgs a;
+    a.tq = nullptr;
     a.N = d->N; a.D = 1; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cin0 = d->Cin; a.Cout0 = d->Cout0;
     a.x0 = SrcView{d->x0, d->x0_ld, 1, d->x0_H, d->x0_W};
     a.x1 = SrcView{nullptr, 0, 0, 0, 0};

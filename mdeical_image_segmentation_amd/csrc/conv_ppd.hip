@@ -57,6 +57,14 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_kernel(const ConvArgs a) {
     const int tstride = (int)gridDim.x;
     int tile = xcd_remap(blockIdx.x, gridDim.x);
     if (tile >= total_tiles) return;                        // block-uniform
+    // dynamic tile queue (conv_pp_common.hpp TileQ; as in conv_ppc_kernel): the first tile is static, the others are drawn by wave 0's lane 0 one tile ahead.  Wave 0 is a
+    // group-0 wave: its vmcnt queue holds weight DMAs only, every wait from the second segment on is vmcnt(3) or less, so a draw issued at the top of a tile has returned
+    // when chunk 0 is through.
+    const TileQ tq = tq_init(a.tq, total_tiles, tstride, (int)blockIdx.x);
+    const bool dyn = tq.ctr != nullptr;
+    const bool drawer = dyn && tid == 0;
+    unsigned tk = 1u;
+    if (drawer) tq_draw(tk, tq.ctr);
     const int nchunks = a.Cin >> 5;                         // >= 2 (the launcher checks Cin % 64 == 0)
     const int tpi = a.tilesH * a.tilesW;
     auto decode = [&](int t, int& tn, int& th0, int& tw0, int& tcol) {      // tile order: conv_ppc_kernel
@@ -162,17 +170,23 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_kernel(const ConvArgs a) {
     }
     if constexpr (EM == PP_EM_BITS) issue_bits(n, h0, w0, ncol0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t mailbox = (uint32_t)(uintptr_t)(smem + PD_LDS);
+    if (drawer) tq_post(tq, tk, mailbox);
     __syncthreads();
+    int nxt = tile + tstride;
+    if (dyn) nxt = tq_tile(tq, tq_take(mailbox), tstride);
 
     int wsel = 0, hsel = 0, bsel = 0;                      // ring positions of the segment / chunk being computed
     if (grp == 1) __builtin_amdgcn_s_barrier();            // the stagger
     __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll 1
-    for (; tile < total_tiles; tile += tstride) {
-        const bool has_next = tile + tstride < total_tiles;
+    for (;;) {
+        const bool has_next = (unsigned)nxt < (unsigned)total_tiles;
         int nn = n, nh0 = h0, nw0 = w0, ncolN = ncol0;
-        if (has_next) decode(tile + tstride, nn, nh0, nw0, ncolN);
+        if (has_next) decode(nxt, nn, nh0, nw0, ncolN);
+        tk = 1u;
+        if (drawer && has_next) tq_draw(tk, tq.ctr);          // the tile after `nxt`: posted after chunk 0, taken at the end of the tile (nchunks >= 2: barriers in between)
         auto run_chunk = [&](auto firstc, const int chunk) __attribute__((always_inline)) {
             constexpr bool first = decltype(firstc)::value;
             const int c0 = chunk << 5;
@@ -272,6 +286,7 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_kernel(const ConvArgs a) {
             hsel = hsel == 2 ? 0 : hsel + 1;
         };
         run_chunk(std::true_type{}, 0);
+        if (drawer && has_next) tq_post(tq, tk, mailbox);
         if (has_next) issue_bias(ncolN, bbase + (bsel ^ 1) * (BN * 4));          // (last read in the previous tile's chunk 0; lands under the rest of this tile's K loop)
 #pragma unroll 1
         for (int chunk = 1; chunk < nchunks; ++chunk) run_chunk(std::false_type{}, chunk);
@@ -296,6 +311,9 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_kernel(const ConvArgs a) {
             if (has_next) issue_bits(n, h0, w0, ncol0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (!has_next) break;
+        tile = nxt;
+        nxt = dyn ? tq_tile(tq, tq_take(mailbox), tstride) : tile + tstride;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();            // pairs with group 1's last barrier
 #ifdef PPT_NO_EPI
@@ -312,6 +330,7 @@ __global__ __launch_bounds__(512, 2) void conv_ppd_kernel(const ConvArgs a) {
 template <int EM> static int ppd_launch(const MisConvDesc* d, hipStream_t stream) {
     constexpr int BN = PD_BN;
     ConvArgs a;
+    a.tq = nullptr;
     a.N = d->N; a.D = 1; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cin0 = d->Cin; a.Cout0 = d->Cout0;
     a.x0 = SrcView{d->x0, d->x0_ld, 1, d->x0_H, d->x0_W};
     a.x1 = SrcView{nullptr, 0, 0, 0, 0};
@@ -331,9 +350,10 @@ template <int EM> static int ppd_launch(const MisConvDesc* d, hipStream_t stream
     a.nSp = (int)nsp;
     a.order = 0; a.zg = 0;
     static std::atomic<unsigned long long> attr_done{0};
-    if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv_ppd_kernel<EM>), (size_t)PD_LDS, "conv_igemm(ppd)")) return rc;
+    if (const int rc = mis_set_dyn_lds(attr_done, reinterpret_cast<const void*>(&conv_ppd_kernel<EM>), (size_t)PD_LDS + 16, "conv_igemm(ppd)")) return rc;
     const long long total = nsp * a.nCt;
-    hipLaunchKernelGGL((conv_ppd_kernel<EM>), dim3((unsigned)(total > mis_persist_cus() ? mis_persist_cus() : total)), dim3(512), (size_t)PD_LDS, stream, a);
+    a.tq = mis_tile_queue(stream);
+    hipLaunchKernelGGL((conv_ppd_kernel<EM>), dim3((unsigned)(total > mis_persist_cus() ? mis_persist_cus() : total)), dim3(512), (size_t)PD_LDS + 16, stream, a);
     MIS_LAUNCH_CHECK("conv_igemm(ppd)");
     return MIS_OK;
 }

@@ -562,6 +562,7 @@ extern "C" int mis_conv3x3_head_fused(const MisConvDesc* d, const MisHeadDesc* h
     MIS_REQUIRE(h->workspace_bytes >= mis_head_workspace_bytes(h), MIS_EINVAL, "conv3x3_head_fused: head workspace too small");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     ConvArgs a;
+    a.tq = nullptr;
     a.N = d->N; a.D = 1; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cin0 = d->Cin; a.Cout0 = d->Cout0;
     a.x0 = SrcView{d->x0, d->x0_ld, 1, d->x0_H, d->x0_W};
     a.x1 = SrcView{nullptr, 0, 0, 0, 0};

@@ -5,8 +5,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <hip/hip_runtime.h>
+
 #include <atomic>
 #include <mutex>
+#include <unordered_map>
 
 #include "common.hpp"
 
@@ -25,7 +28,7 @@ const SwDef g_defs[SW_COUNT] = {
     {"MIS_WGRAD_K1_NARROW", 0}, {"MIS_WGRAD_NO_TR", 0}, {"MIS_WGRAD_BLOCKS", 1024}, {"MIS_WGRAD_NOPP", 0}, {"MIS_WGRAD_PP_NOWIDE", 0},
     {"MIS_WGRAD_PP_KSS1", 0}, {"MIS_WGRAD3D_NOPP", 0}, {"MIS_WGRAD_PP_ROW", 0}, {"MIS_WGRAD_PP_NOROW", 0},
     {"MIS_FIRST2D_UNTILED", 0}, {"MIS_FIRST3D_UNTILED", 0}, {"MIS_UPCONV_BWD_GENERIC", 0}, {"MIS_GEMM1_NOPP", 0}, {"MIS_CONV_NOPPD", 0}, {"MIS_WGRAD_PP_NOSTREAM", 0}, {"MIS_WGRAD_K1_NOPP", 0}, {"MIS_FIRST3D_NOMFMA", 0}, {"MIS_PERSIST_CUS", 256}, {"MIS_HEAD_UNFUSED", 0},
-    {"MIS_CONV3D_F32_NOPP", 0}, {"MIS_WGRAD_F32_NOPP", 0}, {"MIS_WGRAD_F32_ROUNDS", 1}, {"MIS_CONV_PPS", 0}, {"MIS_CONV_PPC2", 0},
+    {"MIS_CONV3D_F32_NOPP", 0}, {"MIS_WGRAD_F32_NOPP", 0}, {"MIS_WGRAD_F32_ROUNDS", 1}, {"MIS_CONV_PPS", 0}, {"MIS_CONV_PPC2", 0}, {"MIS_TILEQ_OFF", 0},
 };
 std::atomic<int> g_val[SW_COUNT];
 std::once_flag g_once;
@@ -76,4 +79,53 @@ extern "C" int mis_dispatch_switch(const char* name) {
             if (strcmp(name, g_defs[k].name) == 0) return g_val[k].load(std::memory_order_relaxed);
     mis_set_error("mis_dispatch_switch: unknown switch '%s'", name ? name : "(null)");
     return MIS_EINVAL;
+}
+
+// ---- tile-queue counter blocks (dispatch_cfg.hpp) --------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int TQ_SLOTS = 256, TQ_BYTES = 512;
+std::mutex g_tq_mu;
+unsigned char* g_tq_pool = nullptr;
+bool g_tq_failed = false;
+std::unordered_map<unsigned long long, int> g_tq_slot;          // (device << 48 | stream handle) -> slot
+}   // namespace
+
+unsigned* mis_tile_queue(void* stream) {
+    if (mis_sw(SW_TILEQ_OFF)) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_tq_mu);
+    if (g_tq_failed) return nullptr;
+    const unsigned long long key = ((unsigned long long)(unsigned)dev << 48) ^ (unsigned long long)reinterpret_cast<uintptr_t>(stream);
+    auto it = g_tq_slot.find(key);
+    if (it == g_tq_slot.end()) {
+        if ((int)g_tq_slot.size() >= TQ_SLOTS) return nullptr;          // (a process with more than 256 (device, stream) pairs: the further ones run the static stride)
+        if (g_tq_pool == nullptr) {
+            // first use: one allocation for every slot, zeroed once.  A capture in progress on this thread refuses the allocation: leave the pool for a later launch.
+            void* p = nullptr;
+            if (hipMalloc(&p, (size_t)TQ_SLOTS * TQ_BYTES) != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+            if (hipMemset(p, 0, (size_t)TQ_SLOTS * TQ_BYTES) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipFree(p);
+                g_tq_failed = true;
+                return nullptr;
+            }
+            g_tq_pool = static_cast<unsigned char*>(p);
+        }
+        it = g_tq_slot.emplace(key, (int)g_tq_slot.size()).first;
+    }
+    return reinterpret_cast<unsigned*>(g_tq_pool + (size_t)it->second * TQ_BYTES);
+}
+
+// diagnostic / tests: the eight counters of `stream`'s block, read back after a device synchronisation (all zero between launches); -1 if the stream has no block
+extern "C" int mis_debug_tile_queue(void* stream, unsigned* out8) {
+    unsigned* q = mis_tile_queue(stream);
+    if (q == nullptr || out8 == nullptr) return -1;
+    unsigned h[128];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, q, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    for (int x = 0; x < 8; ++x) out8[x] = h[x * 16];
+    return 0;
 }

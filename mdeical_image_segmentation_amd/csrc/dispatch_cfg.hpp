@@ -10,7 +10,7 @@ enum MisSwitch {
     SW_CONV3D_NOPP, SW_CONV3D_PF, SW_CONV3D_ZG, SW_CONV3D_COLMAJOR,
     SW_WGRAD_K1_NARROW, SW_WGRAD_NO_TR, SW_WGRAD_BLOCKS, SW_WGRAD_NOPP, SW_WGRAD_PP_NOWIDE, SW_WGRAD_PP_KSS1, SW_WGRAD3D_NOPP, SW_WGRAD_PP_ROW, SW_WGRAD_PP_NOROW,
     SW_FIRST2D_UNTILED, SW_FIRST3D_UNTILED, SW_UPCONV_BWD_GENERIC, SW_GEMM1_NOPP, SW_CONV_NOPPD, SW_WGRAD_PP_NOSTREAM, SW_WGRAD_K1_NOPP, SW_FIRST3D_NOMFMA, SW_PERSIST_CUS, SW_HEAD_UNFUSED,
-    SW_CONV3D_F32_NOPP, SW_WGRAD_F32_NOPP, SW_WGRAD_F32_ROUNDS, SW_CONV_PPS, SW_CONV_PPC2,
+    SW_CONV3D_F32_NOPP, SW_WGRAD_F32_NOPP, SW_WGRAD_F32_ROUNDS, SW_CONV_PPS, SW_CONV_PPC2, SW_TILEQ_OFF,
     SW_COUNT
 };
 
@@ -22,3 +22,10 @@ int mis_sw(MisSwitch k);
 // workgroups wait for a CU to drain, and the last blocks of whichever MFMA kernel shares the device with it finish late.  MIS_PERSIST_CUS=248 (say) leaves 8 CUs free -
 // an A/B switch for the first multi-GPU run; single-GPU runs keep 256.
 int mis_persist_cus();
+
+// Dynamic tile queue of the persistent kernels (round 5; conv_pp_common.hpp `TileQ`): the first tile of a block is the static one, every further tile is drawn from a
+// per-XCD ticket counter, so that a block that finds its CU taken (by an RCCL kernel of the side stream) no longer owns 1 / 256 of the launch - the blocks that do run share
+// the tiles, and the late block finds the queue empty.  One 512-byte counter block (8 counters, 64 bytes apart) per STREAM: kernels of one stream never overlap, and the
+// block that draws a counter's last ticket stores 0 to it, so the counters are zero again when the kernel ends (graph replays included).  nullptr (pool exhausted, the
+// pool could not be allocated because a capture is running, MIS_TILEQ_OFF=1): the kernel falls back to the static stride.
+unsigned* mis_tile_queue(void* stream);

@@ -240,6 +240,7 @@ bool gemm1_pp_eligible(const MisConvDesc* d) {
 
 template <int EM> static int g1_launch(const MisConvDesc* d, hipStream_t stream) {
     ConvArgs a;
+    a.tq = nullptr;
     a.N = d->N; a.D = 1; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cin0 = d->Cin; a.Cout0 = d->Cout0;
     a.x0 = SrcView{d->x0, d->x0_ld, 1, d->x0_H, d->x0_W};
     a.x1 = SrcView{nullptr, 0, 0, 0, 0};

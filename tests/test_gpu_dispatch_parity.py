@@ -640,3 +640,38 @@ def test_gn_bwd_stats_from_per_sample_dw(grid, C0, C1, Cout):
     k1 = ((K1.cpu().double() - r1).abs() / den).max().item()
     print(f"S1 / S2 vs float64: from dW {e1:.2e} / {e2:.2e}; statistics kernel S1 {k1:.2e}")
     assert k1 < 2e-3
+
+
+TQ_CASES = [("2d", (5, 150, 170), 128, 128, "k3.2d.ppc8"), ("2d", (32, 64, 64), 512, 512, "k3.2d.ppc8"), ("2d", (3, 512, 512), 64, 64, "k3.2d.ppd8"), ("2d", (2, 512, 512), 128, 64, "k3.2d.ppd8"),
+            ("3d", (2, 16, 80, 80), 128, 128, "k3.3d.ppc5"), ("3d", (1, 24, 160, 160), 192, 64, "k3.3d.ppc10n2"), ("3d", (1, 7, 33, 21), 64, 192, "k3.3d.ppc5n6")]
+
+
+@pytest.mark.parametrize("case", TQ_CASES, ids=lambda c: f"{c[0]}-{'x'.join(map(str, c[1]))}-{c[2]}to{c[3]}")
+def test_tile_queue_is_bit_identical_to_the_static_stride_and_leaves_its_counters_at_zero(case):
+    """round 5: the persistent conv kernels draw their tiles (after the first) from per-XCD ticket counters (csrc/conv_pp_common.hpp TileQ; MIS_TILEQ_OFF=1 = the static
+    stride).  Same tiles, same arithmetic per tile: the outputs are bit-identical, with and without the epilogue mask, over several launches in a row - which also shows
+    that the kernel that draws a counter's last ticket has put it back to zero (a dirty counter would skip tiles: NaNs from the fill would remain)"""
+    import ctypes
+    ops = _ops()
+    kind, grid, Cin, Cout, tag = case
+    taps = 9 if kind == "2d" else 27
+    gen = torch.Generator(device=DEV).manual_seed(77)
+    x = torch.randn(*grid, Cin, device=DEV, generator=gen).to(BF)
+    w = (torch.randn(taps, Cout, Cin, device=DEV, generator=gen) * (taps * Cin) ** -0.5).to(BF)
+    m = torch.randn(*grid, Cout, device=DEV, generator=gen).to(BF)
+    lib = ops.load()
+    out8 = (ctypes.c_uint * 8)()
+    for kw in (dict(relu=True), dict(mask=m)):
+        if kind == "3d":
+            kw = dict(kw, grid=grid)
+        ref = torch.full((*grid, Cout), float("nan"), dtype=BF, device=DEV)
+        with ops.dispatch_switches(MIS_TILEQ_OFF=1):
+            ops.conv_igemm(x, w, ref, ksize=3, Cin=Cin, Cout=Cout, **kw)
+            assert ops.conv_last_dispatch().startswith(tag), ops.conv_last_dispatch()
+        assert not torch.isnan(ref.float()).any()
+        for launch in range(3):
+            y = torch.full((*grid, Cout), float("nan"), dtype=BF, device=DEV)
+            ops.conv_igemm(x, w, y, ksize=3, Cin=Cin, Cout=Cout, **kw)
+            assert ops.conv_last_dispatch().startswith(tag)
+            assert torch.equal(y, ref), (launch, int(torch.isnan(y.float()).sum()))
+            assert lib.mis_debug_tile_queue(ops.stream_ptr(), out8) == 0 and list(out8) == [0] * 8, (launch, list(out8))
