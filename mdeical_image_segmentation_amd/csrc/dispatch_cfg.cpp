@@ -83,41 +83,46 @@ extern "C" int mis_dispatch_switch(const char* name) {
 
 // ---- tile-queue counter blocks (dispatch_cfg.hpp) --------------------------------------------------------------------------------------------------------
 namespace {
-constexpr int TQ_SLOTS = 256, TQ_BYTES = 512;
+constexpr int TQ_SLOTS = 256, TQ_BYTES = 512, TQ_MAXDEV = 16;
 std::mutex g_tq_mu;
-unsigned char* g_tq_pool = nullptr;
-bool g_tq_failed = false;
-std::unordered_map<unsigned long long, int> g_tq_slot;          // (device << 48 | stream handle) -> slot
+struct TqDev {
+    unsigned char* pool = nullptr;          // TQ_SLOTS counter blocks in this device's memory, zeroed once
+    bool failed = false;
+    std::unordered_map<uintptr_t, int> slot;          // stream handle -> block
+};
+TqDev g_tq[TQ_MAXDEV];
 }   // namespace
 
 unsigned* mis_tile_queue(void* stream) {
     if (mis_sw(SW_TILEQ_OFF)) return nullptr;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TQ_MAXDEV) return nullptr;
     std::lock_guard<std::mutex> lk(g_tq_mu);
-    if (g_tq_failed) return nullptr;
-    const unsigned long long key = ((unsigned long long)(unsigned)dev << 48) ^ (unsigned long long)reinterpret_cast<uintptr_t>(stream);
-    auto it = g_tq_slot.find(key);
-    if (it == g_tq_slot.end()) {
-        if ((int)g_tq_slot.size() >= TQ_SLOTS) return nullptr;          // (a process with more than 256 (device, stream) pairs: the further ones run the static stride)
-        if (g_tq_pool == nullptr) {
-            // first use: one allocation for every slot, zeroed once.  A capture in progress on this thread refuses the allocation: leave the pool for a later launch.
+    TqDev& t = g_tq[dev];
+    if (t.failed) return nullptr;
+    const uintptr_t key = reinterpret_cast<uintptr_t>(stream);
+    auto it = t.slot.find(key);
+    if (it == t.slot.end()) {
+        if ((int)t.slot.size() >= TQ_SLOTS) return nullptr;          // (more than 256 streams on one device: the further ones run the static stride)
+        if (t.pool == nullptr) {
+            // first use on this device: one allocation for every slot, zeroed once.  A capture in progress on this thread refuses the allocation: the launch runs the
+            // static stride and a later one tries again.
             void* p = nullptr;
             if (hipMalloc(&p, (size_t)TQ_SLOTS * TQ_BYTES) != hipSuccess) {
                 (void)hipGetLastError();
                 return nullptr;
             }
-            if (hipMemset(p, 0, (size_t)TQ_SLOTS * TQ_BYTES) != hipSuccess) {
+            if (hipMemset(p, 0, (size_t)TQ_SLOTS * TQ_BYTES) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
                 (void)hipGetLastError();
                 (void)hipFree(p);
-                g_tq_failed = true;
+                t.failed = true;
                 return nullptr;
             }
-            g_tq_pool = static_cast<unsigned char*>(p);
+            t.pool = static_cast<unsigned char*>(p);
         }
-        it = g_tq_slot.emplace(key, (int)g_tq_slot.size()).first;
+        it = t.slot.emplace(key, (int)t.slot.size()).first;
     }
-    return reinterpret_cast<unsigned*>(g_tq_pool + (size_t)it->second * TQ_BYTES);
+    return reinterpret_cast<unsigned*>(t.pool + (size_t)it->second * TQ_BYTES);
 }
 
 // diagnostic / tests: the eight counters of `stream`'s block, read back after a device synchronisation (all zero between launches); -1 if the stream has no block
