@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_keys():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline"):
         assert k in d, k
