@@ -424,6 +424,7 @@ def _comm_report(reducer, eng, steps, world, dist, dev):
     rep["per_bucket"] = reducer.timing_breakdown()          # issue order (head first, biases last): bytes, all-reduce ms, exposed ms (the part after the backward ran out)
     from mdeical_image_segmentation_amd import ops
     rep["persistent_grid_blocks"] = ops.dispatch_switch("MIS_PERSIST_CUS")      # 256 = every CU; fewer leaves CUs to the RCCL kernels (csrc/dispatch_cfg.hpp)
+    rep["tile_queue"] = not ops.dispatch_switch("MIS_TILEQ_OFF")      # the persistent conv kernels share their tiles dynamically: a collective that holds CUs does not stall a launch
     h = torch.stack([eng.flat.p.double().sum(), eng.flat.p.double().abs().sum(), eng.flat.g.double().sum()])
     hs = [torch.zeros_like(h) for _ in range(world)]
     dist.all_gather(hs, h)
