@@ -101,6 +101,9 @@ int mis_dispatch_switch(const char* name);
 /* Diagnostic: the eight per-XCD ticket counters of the persistent kernels' tile queue on `stream` (csrc/dispatch_cfg.hpp), after a device synchronisation -
  * all zero between launches (the kernel that draws a counter's last ticket resets it).  Returns -1 when the stream has no counter block (MIS_TILEQ_OFF=1). */
 int mis_debug_tile_queue(void* stream, unsigned* out8);
+/* Diagnostic: launches a kernel on `stream` that holds `blocks` (1..128) CUs for `cycles` (<= 4e8) shader cycles - what an all-reduce kernel beside the persistent
+ * kernels looks like to them (tests/test_gpu_dispatch_parity.py: a conv launch beside it must not take the two rounds a static tile stride would). */
+int mis_debug_hold_cus(int blocks, long long cycles, void* stream);
 
 /* Weight-gradient GEMM: dW[tap][ci][co] = sum_pixels x[pixel+tap][ci] * dy[pixel][co]   (split-K over pixel tiles,
  * fp32 partial slabs + deterministic reduction).  Replaces the weight part of convolution_backward for

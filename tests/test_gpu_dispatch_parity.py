@@ -675,3 +675,40 @@ def test_tile_queue_is_bit_identical_to_the_static_stride_and_leaves_its_counter
             assert ops.conv_last_dispatch().startswith(tag)
             assert torch.equal(y, ref), (launch, int(torch.isnan(y.float()).sum()))
             assert lib.mis_debug_tile_queue(ops.stream_ptr(), out8) == 0 and list(out8) == [0] * 8, (launch, list(out8))
+
+
+def test_tile_queue_keeps_a_conv_launch_from_doubling_beside_a_kernel_that_holds_cus():
+    """what the queue is for: an RCCL kernel on the side stream takes CUs and keeps them (nothing of ours fits beside another workgroup).  With the static stride the 8 blocks
+    that find no CU start when the first ones END (+40-63 % measured, scripts/hog_probe.sh); with the queue the running blocks share the tiles (+0-17 %).  Timing test with a
+    wide margin: beside a holder of 8 CUs the queue's launch stays under 1.35 x its time alone."""
+    ops = _ops()
+    lib = ops.load()
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    N, H, W, Cin, Cout = 32, 64, 64, 512, 512
+    x = torch.randn(N, H, W, Cin, device=DEV, generator=gen).to(BF)
+    w = (torch.randn(9, Cout, Cin, device=DEV, generator=gen) * (9 * Cin) ** -0.5).to(BF)
+    y = torch.empty(N, H, W, Cout, dtype=BF, device=DEV)
+    side = torch.cuda.Stream()
+
+    def timed(hold):
+        for _ in range(2):
+            ops.conv_igemm(x, w, y, ksize=3, Cin=Cin, Cout=Cout, relu=True)
+        torch.cuda.synchronize()
+        if hold:
+            assert lib.mis_debug_hold_cus(hold, 30_000_000, side.cuda_stream) == 0          # ~15 ms at 2 GHz: longer than the six launches below
+            torch.cuda._sleep(2_000_000)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(6):
+            ops.conv_igemm(x, w, y, ksize=3, Cin=Cin, Cout=Cout, relu=True)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 6
+
+    alone = min(timed(0) for _ in range(2))
+    beside = min(timed(8) for _ in range(2))
+    assert ops.conv_last_dispatch().startswith("k3.2d.ppc8")
+    with ops.dispatch_switches(MIS_TILEQ_OFF=1):
+        static_beside = timed(8)
+    print(f"conv 512->512 at 64^2: alone {alone:.3f} ms, beside a holder of 8 CUs {beside:.3f} ms (static stride: {static_beside:.3f} ms)")
+    assert beside < 1.35 * alone, (alone, beside, static_beside)
