@@ -149,7 +149,7 @@ SYMBOLS = {
 # the column-segment kernels: one instantiation per epilogue mask path (template argument 0 = none, 1 = bf16 mask ".mask", 2 = ReLU bits ".bits")
 for _t, _k in (("k3.2d.ppc8", "conv_ppc_kernel<8, 4"), ("k3.2d.ppc8n2", "conv_ppc_kernel<8, 2"), ("k3.3d.ppc5", "conv3d_ppc_kernel<5, 4"),
                ("k3.3d.ppc8", "conv3d_ppc_kernel<8, 4"), ("k3.3d.ppc5n6", "conv3d_ppc_kernel<5, 6"), ("k3.3d.ppc5n2", "conv3d_ppc_kernel<5, 2"),
-               ("k3.3d.ppc8n2", "conv3d_ppc_kernel<8, 2"), ("k3.3d.ppc10n2", "conv3d_ppc_kernel<10, 2")):
+               ("k3.3d.ppc8n2", "conv3d_ppc_kernel<8, 2"), ("k3.3d.ppc10n2", "conv3d_ppc_kernel<10, 2"), ("k3.3d.ppc10", "conv3d_ppc_kernel<10, 4")):
     for _sfx, _em in (("", 0), (".mask", 1), (".bits", 2), (".gn", 3)):          # .gn: GroupNorm backward in the epilogue (3-D dgrads, MisConvDesc.gn_p)
         SYMBOLS[_t + _sfx] = f"{_k}, {_em}>"
 for _sfx, _em in (("", 0), (".mask", 1), (".bits", 2)):

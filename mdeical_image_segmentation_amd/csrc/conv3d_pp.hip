@@ -54,6 +54,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
     // vmcnt(0) at the end of the kw = 2 segment of every (dz, chunk) pair, so a draw issued at the top of a tile has returned when pair 0 is through
     // (not in the 256-VGPR instantiations, PF 8 x 128 columns: one more live register there and hipcc spills - into scratch, whose reloads wait on vmcnt)
     constexpr bool TQ = NF * PF < 32;
+    constexpr bool STREAM = NF * PF >= 40;          // PF 10 x 128 columns: pixel-row fragments streamed through the M segment (below)
     const TileQ tq = tq_init(TQ ? a.tq : nullptr, total_tiles, tstride, (int)blockIdx.x);
     const bool dyn = TQ && tq.ctr != nullptr;
     const bool drawer = dyn && tid == 0;
@@ -145,8 +146,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
             return;
         }
         asm volatile("" : "+s"(toff));
-        int item = id * 64 + lane;
-        asm volatile("" : "+v"(item));
+        int item;
+        if constexpr (STREAM) {          // (256 VGPRs: id * 64 + lane per instruction, kept across the tile loop, was SPILLED - the lane index is re-derived instead, as in conv_ppc_kernel)
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(item));
+            item += id * 64;
+        } else {
+            item = id * 64 + lane;
+            asm volatile("" : "+v"(item));
+        }
         const int p = item >> 2, pos = item & 3;
         const int py = p / HW, px = p - py * HW;
         const unsigned rel = (unsigned)(((py * a.W + px) * a.x0.ld + ((pos ^ ((px >> 1) & 3)) << 3)) * 2);
@@ -224,6 +231,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
         // bias add by vector instructions anywhere (pp_epilogue_plain<..., BINIT>; the same peeling as conv_ppc_kernel, conv_pp.hip)
         auto run_pair = [&](auto firstc, const int vc) __attribute__((always_inline)) {
             constexpr bool first = decltype(firstc)::value;
+            // STREAM (256 VGPRs): hipcc kept `grp == 0` as a VECTOR boolean across the loops and spilled it to scratch - reloaded, with an s_waitcnt vmcnt(0), at the head of
+            // every pair.  Laundered through an asm, the comparison is redone from the scalar register here.
+            int grp_s = grp;
+            if constexpr (STREAM) asm volatile("" : "+s"(grp_s));
+#define GRP_ (STREAM ? grp_s : grp)
             // the (dz, chunk) pair after this one within the tile
             int ndz = dz, nc0 = c0 + 32;
             if (nc0 == a.Cin) {
@@ -256,13 +268,13 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
                 const int w2c0 = (kw < 1) ? c0 : hc0;
                 const int w2dz = (kw < 1) ? dz : hdz;
                 // ================= R segment =================
-                if (grp == 0 && wnext) issue_weights(wdz, wkw, wcol, wc0, wbn);
+                if (GRP_ == 0 && wnext) issue_weights(wdz, wkw, wcol, wc0, wbn);
                 constexpr int NH = kw == 0 ? HJ0 : (kw == 1 ? HJ1 : 0);          // halo instructions issued in this segment (per wave; the last may be past the image)
                 if constexpr (NH > 0) {
                     if (hnext)
                         pp_static_for<NH>([&](auto jc) { issue_halo(std::integral_constant<int, (kw == 0 ? 0 : HJ0) + decltype(jc)::value>{}, hpl, hval, hh0, hw0, hc0, hbn); });
                 }
-                u32x4 A[3][NF], Brow[PF + 2];
+                u32x4 A[3][NF], Brow[STREAM ? 3 : PF + 2];
                 f32x4 bq[NF];          // first && kw == 0: the tile's bias, 4 values per fragment (the C operand of the first filter row's MFMAs)
                 if constexpr (first && kw == 0) {
                     int l_;
@@ -288,7 +300,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
                     const int px = (l_ & 15) + kw;
                     ba_rows = hb + (wm * PF * HW + px) * 64 + (((l_ >> 4) ^ ((px >> 1) & 3)) << 4);
                 }
-                pp_static_for<PF + 2>([&](auto rc) {
+                // STREAM (PF 10 x 128 columns: 160 accumulator + 48 weight-fragment registers leave no room for twelve pixel rows): R reads rows 0 and 1 only, the M segment
+                // streams the others through a three-slot rotation, each row read two rows ahead of its use
+                pp_static_for<(STREAM ? 2 : PF + 2)>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
                     Brow[r] = pp_lds_read128<r * ROWB>(ba_rows);
                 });
@@ -296,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 // how many of this wave's youngest DMAs may stay in flight: the halo instructions of THIS segment
                 constexpr int KEEP = NH;
-                if (grp == 1) {                                  // group 1: its weight DMAs for the next segment (issued one slot pair ago, in its M) must have landed
+                if (GRP_ == 1) {                                  // group 1: its weight DMAs for the next segment (issued one slot pair ago, in its M) must have landed
                     if (hnext && KEEP > 0) {
                         const int last_id = ((kw == 0 ? 0 : HJ0) + KEEP - 1) * 8 + wave;      // wave-uniform: did this wave really issue KEEP halo instructions?
                         if (last_id < HINSTR) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
@@ -310,23 +324,53 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 // ================= M segment: 3 taps x NF x PF MFMAs =================
                 __builtin_amdgcn_s_setprio(1);
+                if constexpr (STREAM) {
+                    // by INPUT row r = 0 .. PF + 1: row r feeds tap kh of output row r - kh.  Every accumulator still receives its three taps in the order kh = 0, 1, 2 (rows
+                    // pf, pf + 1, pf + 2), i.e. the sums are those of the row-major loop below, bit for bit.  Row r + 2 is read IN PLACE into the slot row r - 1 has just left
+                    // ("+v": the tie is the write-after-read dependency and keeps hipcc from giving the late rows fresh registers); before row r is used, everything but the
+                    // one read issued after it must have returned (LDS returns in order).
+                    pp_static_for<PF + 2>([&](auto rc) {
+                        constexpr int r = decltype(rc)::value;
+                        if constexpr (r >= 2) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(Brow[r % 3]) : "n"(r + 1 <= PF + 1 ? 1 : 0) : "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if constexpr (r + 2 <= PF + 1) {          // row r + 2 -> the slot row r - 1 left in the previous iteration (row 2: the third, so far unused slot)
+                            __builtin_amdgcn_sched_barrier(0);
+                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(Brow[(r + 2) % 3]) : "v"(ba_rows), "n"((r + 2) * ROWB));
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        pp_static_for<3>([&](auto hc) {
+                            constexpr int kh = decltype(hc)::value, pf = r - kh;
+                            if constexpr (pf >= 0 && pf < PF) {
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                    for (int f = 0; f < NF; ++f) {
-#pragma unroll
-                        for (int pf = 0; pf < PF; ++pf) {
-                            if constexpr (first && kw == 0) {
-                                if (kh == 0) acc[f][pf] = bq[f];          // (becomes the MFMA's C operand)
+                                for (int f = 0; f < NF; ++f) mma_b128<T>(acc[f][pf], A[kh][f], Brow[r % 3]);
                             }
-                            mma_b128<T>(acc[f][pf], A[kh][f], Brow[pf + kh]);
+                        });
+                        if constexpr (r == 0) {
+                            if (GRP_ == 1 && w2next) issue_weights(w2dz, w2kw, w2col, w2c0, wb_self);
                         }
-                        if (kh == 0 && f == 0) {
-                            if (grp == 1 && w2next) issue_weights(w2dz, w2kw, w2col, w2c0, wb_self);
+                    });
+                } else {
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) {
+#pragma unroll
+                            for (int pf = 0; pf < PF; ++pf) {
+                                if constexpr (first && kw == 0) {
+                                    if (kh == 0) acc[f][pf] = bq[f];          // (becomes the MFMA's C operand)
+                                }
+                                mma_b128<T>(acc[f][pf], A[kh][f], Brow[pf + kh]);
+                            }
+                            if (kh == 0 && f == 0) {
+                                if (GRP_ == 1 && w2next) issue_weights(w2dz, w2kw, w2col, w2c0, wb_self);
+                            }
                         }
-                    }
+                }
                 __builtin_amdgcn_s_setprio(0);
-                if (grp == 0) {                                  // group 0: the weight DMAs it issued in this segment's R
+                if (GRP_ == 0) {                                  // group 0: the weight DMAs it issued in this segment's R
                     if (hnext && KEEP > 0) {
                         const int last_id = ((kw == 0 ? 0 : HJ0) + KEEP - 1) * 8 + wave;
                         if (last_id < HINSTR) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
@@ -344,6 +388,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_ppc_kernel(const ConvArgs a) {
             dz = ndz;
             c0 = nc0;
         };
+#undef GRP_
         // (the 256-VGPR instantiations, PF 8 x 128 columns, keep the vector-instruction bias add: with the bias quads live through the peeled pair they spill)
         constexpr bool BINIT = NF * PF < 32;
         if constexpr (BINIT) {
@@ -399,15 +444,20 @@ bool conv3d_pp_eligible(const MisConvDesc* d) {
 
 template <int PF, int NF, int EM> static int pp3_launch_em(const MisConvDesc* d, hipStream_t stream);
 template <int PF, int NF> static int pp3_launch(const MisConvDesc* d, hipStream_t stream) {      // one instantiation per epilogue mask path (3-D: none, the bf16 mask, GroupNorm backward)
-    if (d->gn_p != nullptr) {
-        if constexpr (NF == 6) {
-            MIS_REQUIRE(false, MIS_EUNSUPPORTED, "conv_igemm(3d pp): the GroupNorm-backward epilogue is not built for 192-column blocks");
-        } else {
-            return pp3_launch_em<PF, NF, PP_EM_GN>(d, stream);
+    if constexpr (PF == 10 && NF == 4) {      // the streamed 40-row tile: plain epilogue only (with a mask operand one more register is live and hipcc spills the weight DMA offset)
+        MIS_REQUIRE(d->gn_p == nullptr && d->mask == nullptr, MIS_EUNSUPPORTED, "conv_igemm(3d pp): the 40-row 128-column tile has no masked epilogue");
+        return pp3_launch_em<PF, NF, PP_EM_NONE>(d, stream);
+    } else {
+        if (d->gn_p != nullptr) {
+            if constexpr (NF == 6) {
+                MIS_REQUIRE(false, MIS_EUNSUPPORTED, "conv_igemm(3d pp): the GroupNorm-backward epilogue is not built for 192-column blocks");
+            } else {
+                return pp3_launch_em<PF, NF, PP_EM_GN>(d, stream);
+            }
         }
+        if (d->mask != nullptr) return pp3_launch_em<PF, NF, PP_EM_MASK>(d, stream);
+        return pp3_launch_em<PF, NF, PP_EM_NONE>(d, stream);
     }
-    if (d->mask != nullptr) return pp3_launch_em<PF, NF, PP_EM_MASK>(d, stream);
-    return pp3_launch_em<PF, NF, PP_EM_NONE>(d, stream);
 }
 template <int PF, int NF, int EM> static int pp3_launch_em(const MisConvDesc* d, hipStream_t stream) {
     constexpr int BN = 2 * NF * 16;
@@ -452,12 +502,13 @@ int launch_conv3d_pp(const MisConvDesc* d, hipStream_t stream, const char** tag)
     const bool gn = d->gn_p != nullptr;
     const int nf = d->Cout % 128 == 0 ? 4 : ((d->Cout % 192 == 0 && d->Cout0 % 192 == 0 && !gn) ? 6 : 2);
     int pf = mis_sw(SW_CONV3D_PF);
-    if (!(pf == 5 || (pf == 8 && nf != 6) || (pf == 10 && nf == 2))) {
+    if (!(pf == 5 || (pf == 8 && nf != 6) || (pf == 10 && (nf == 2 || (nf == 4 && !gn && d->mask == nullptr))))) {
         const int cand[3] = {5, 8, 10};
         int best = 1 << 30;
         pf = 5;
         for (int i = 0; i < 3; ++i) {
-            if ((cand[i] == 10 && nf != 2) || (cand[i] == 8 && nf == 6)) continue;
+            if ((cand[i] == 10 && nf == 6) || (cand[i] == 8 && nf == 6)) continue;
+            if (cand[i] == 10 && nf == 4 && (gn || d->mask != nullptr || mis_sw(SW_CONV3D_NOPF10N4))) continue;      // the streamed 40-row 128-column tile of round 5: plain epilogue only; MIS_CONV3D_NOPF10N4=1: A/B switch
             const int th = 4 * cand[i], pad = (d->H + th - 1) / th * th;
             if (pad <= best) {
                 best = pad;
@@ -469,6 +520,10 @@ int launch_conv3d_pp(const MisConvDesc* d, hipStream_t stream, const char** tag)
         if (pf == 5) {
             *tag = gn ? "k3.3d.ppc5.gn" : (d->mask != nullptr ? "k3.3d.ppc5.mask" : "k3.3d.ppc5");
             return pp3_launch<5, 4>(d, stream);
+        }
+        if (pf == 10) {
+            *tag = gn ? "k3.3d.ppc10.gn" : (d->mask != nullptr ? "k3.3d.ppc10.mask" : "k3.3d.ppc10");
+            return pp3_launch<10, 4>(d, stream);
         }
         *tag = gn ? "k3.3d.ppc8.gn" : (d->mask != nullptr ? "k3.3d.ppc8.mask" : "k3.3d.ppc8");
         return pp3_launch<8, 4>(d, stream);

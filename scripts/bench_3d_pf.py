@@ -11,7 +11,7 @@ from mdeical_image_segmentation_amd import ops  # noqa: E402
 
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 ops.load()
-for Cin, Cout, pfs in ((128, 128, (5, 8)), (384, 128, (5, 8)), (64, 64, (5, 8, 10)), (192, 64, (5, 8, 10))):
+for Cin, Cout, pfs in ((128, 128, (5, 8, 10)), (384, 128, (5, 8, 10)), (256, 256, (5, 8, 10)), (64, 64, (5, 8, 10)), (192, 64, (5, 8, 10))):
     g = torch.Generator(device="cuda").manual_seed(1)
     grid = (1, D, 160, 160)
     x = torch.randn(*grid, Cin, device="cuda", generator=g).to(torch.bfloat16)

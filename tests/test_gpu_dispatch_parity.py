@@ -643,7 +643,7 @@ def test_gn_bwd_stats_from_per_sample_dw(grid, C0, C1, Cout):
 
 
 TQ_CASES = [("2d", (5, 150, 170), 128, 128, "k3.2d.ppc8"), ("2d", (32, 64, 64), 512, 512, "k3.2d.ppc8"), ("2d", (3, 512, 512), 64, 64, "k3.2d.ppd8"), ("2d", (2, 512, 512), 128, 64, "k3.2d.ppd8"),
-            ("3d", (2, 16, 80, 80), 128, 128, "k3.3d.ppc5"), ("3d", (1, 24, 160, 160), 192, 64, "k3.3d.ppc10n2"), ("3d", (1, 7, 33, 21), 64, 192, "k3.3d.ppc5n6")]
+            ("3d", (2, 16, 60, 80), 128, 128, "k3.3d.ppc5"), ("3d", (1, 24, 160, 160), 192, 64, "k3.3d.ppc10n2"), ("3d", (1, 7, 33, 21), 64, 192, "k3.3d.ppc5n6")]
 
 
 @pytest.mark.parametrize("case", TQ_CASES, ids=lambda c: f"{c[0]}-{'x'.join(map(str, c[1]))}-{c[2]}to{c[3]}")
@@ -712,3 +712,28 @@ def test_tile_queue_keeps_a_conv_launch_from_doubling_beside_a_kernel_that_holds
         static_beside = timed(8)
     print(f"conv 512->512 at 64^2: alone {alone:.3f} ms, beside a holder of 8 CUs {beside:.3f} ms (static stride: {static_beside:.3f} ms)")
     assert beside < 1.35 * alone, (alone, beside, static_beside)
+
+
+@pytest.mark.parametrize("case", [((2, 6, 40, 48), 128, 128), ((1, 5, 80, 36), 384, 128), ((3, 3, 33, 21), 64, 256), ((1, 2, 40, 16), 256, 512)],
+                         ids=lambda c: f"{'x'.join(map(str, c[0]))}-{c[1]}to{c[2]}")
+def test_conv3d_streamed_40_row_tile_is_bit_identical_to_the_20_row_tile(case):
+    """round 5: conv3d_ppc_kernel<10, 4> (40 x 16-pixel tiles x 128 columns, the pixel-row fragments streamed through a three-slot rotation inside the M segment; plain
+    epilogue only) adds the taps of every accumulator in the order of the 20-row tile: bit-identical, ragged grids and several column tiles included; a masked launch of the
+    same layer falls back to the 20- / 32-row tiles"""
+    ops = _ops()
+    grid, Cin, Cout = case
+    gen = torch.Generator(device=DEV).manual_seed(91)
+    x = torch.randn(*grid, Cin, device=DEV, generator=gen).to(BF)
+    w = (torch.randn(27, Cout, Cin, device=DEV, generator=gen) * (27 * Cin) ** -0.5).to(BF)
+    outs = []
+    for pf, tag in ((5, "k3.3d.ppc5"), (10, "k3.3d.ppc10")):
+        y = torch.full((*grid, Cout), float("nan"), dtype=BF, device=DEV)
+        with ops.dispatch_switches(MIS_CONV3D_PF=pf):
+            ops.conv_igemm(x, w, y, ksize=3, Cin=Cin, Cout=Cout, grid=grid, relu=True)
+            assert ops.conv_last_dispatch() == tag, ops.conv_last_dispatch()
+        outs.append(y)
+    assert not torch.isnan(outs[0].float()).any() and torch.equal(outs[0], outs[1])
+    m = torch.randn(*grid, Cout, device=DEV, generator=gen).to(BF)
+    with ops.dispatch_switches(MIS_CONV3D_PF=10):
+        ops.conv_igemm(x, w, outs[1], ksize=3, Cin=Cin, Cout=Cout, grid=grid, mask=m)
+        assert ops.conv_last_dispatch() in ("k3.3d.ppc5.mask", "k3.3d.ppc8.mask"), ops.conv_last_dispatch()
