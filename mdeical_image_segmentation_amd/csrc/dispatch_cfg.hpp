@@ -28,4 +28,6 @@ int mis_persist_cus();
 // the tiles, and the late block finds the queue empty.  One 512-byte counter block (8 counters, 64 bytes apart) per STREAM: kernels of one stream never overlap, and the
 // block that draws a counter's last ticket stores 0 to it, so the counters are zero again when the kernel ends (graph replays included).  nullptr (pool exhausted, the
 // pool could not be allocated because a capture is running, MIS_TILEQ_OFF=1): the kernel falls back to the static stride.
+// (A captured launch carries the counter block of the stream it was CAPTURED on: graphs captured on one stream must not be replayed concurrently on two streams - replays on one
+// stream, the normal case, are ordered like eager launches.)
 unsigned* mis_tile_queue(void* stream);
