@@ -313,7 +313,10 @@ int launch_conv3d_f32(const MisConvDesc* d, hipStream_t stream, const char** tag
     a.tilesH = (d->H + F3_TH - 1) / F3_TH;
     a.tilesW = (d->W + F3_TW - 1) / F3_TW;
     a.relu = d->relu;
-    const bool wide = d->Cout % 128 == 0;
+    // 128-column tiles unless they leave the chip underfilled (two 256-thread blocks per CU = 512 slots): the 16^3 level of cfg4 has 64 spatial tiles - 128 / 256 blocks of
+    // 128 columns ran at 72 TFLOP/s; 64-column tiles double the blocks (same summation order per output element: bit-identical)
+    const long long sp = (long long)d->N * d->D * a.tilesH * a.tilesW;
+    const bool wide = d->Cout % 128 == 0 && (sp * (d->Cout / 128) >= 384 || mis_sw(SW_CONV3D_F32_WIDE));          // (MIS_CONV3D_F32_WIDE=1: 128 columns whatever the grid - tests)
     a.nCt = d->Cout / (wide ? 128 : 64);
     const long long grid = (long long)d->N * d->D * a.tilesH * a.tilesW * a.nCt;
     MIS_REQUIRE(grid < (1ll << 31), MIS_EUNSUPPORTED, "conv3d_f32: grid too large");

@@ -67,7 +67,7 @@ __device__ __forceinline__ void tq_draw(unsigned& tk, const unsigned* ctr) {
 }
 // ... the drawn ticket -> the block's mailbox (one LDS word); the last ticket of the launch resets the counter.  Same single lane, after its vmcnt wait.
 __device__ __forceinline__ void tq_post(const TileQ& q, unsigned tk, uint32_t mailbox) {
-    asm volatile("ds_write_b32 %0, %1" ::"v"(mailbox), "v"(tk) : "memory");
+    asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(mailbox), "v"(tk) : "memory");          // (written before this wave's next barrier, whatever the compiler waits for)
     if (tk == q.last) __hip_atomic_store(q.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ unsigned tq_take(uint32_t mailbox) {          // every wave, a barrier after tq_post

@@ -28,7 +28,7 @@ const SwDef g_defs[SW_COUNT] = {
     {"MIS_WGRAD_K1_NARROW", 0}, {"MIS_WGRAD_NO_TR", 0}, {"MIS_WGRAD_BLOCKS", 1024}, {"MIS_WGRAD_NOPP", 0}, {"MIS_WGRAD_PP_NOWIDE", 0},
     {"MIS_WGRAD_PP_KSS1", 0}, {"MIS_WGRAD3D_NOPP", 0}, {"MIS_WGRAD_PP_ROW", 0}, {"MIS_WGRAD_PP_NOROW", 0},
     {"MIS_FIRST2D_UNTILED", 0}, {"MIS_FIRST3D_UNTILED", 0}, {"MIS_UPCONV_BWD_GENERIC", 0}, {"MIS_GEMM1_NOPP", 0}, {"MIS_CONV_NOPPD", 0}, {"MIS_WGRAD_PP_NOSTREAM", 0}, {"MIS_WGRAD_K1_NOPP", 0}, {"MIS_FIRST3D_NOMFMA", 0}, {"MIS_PERSIST_CUS", 256}, {"MIS_HEAD_UNFUSED", 0},
-    {"MIS_CONV3D_F32_NOPP", 0}, {"MIS_WGRAD_F32_NOPP", 0}, {"MIS_WGRAD_F32_ROUNDS", 1}, {"MIS_CONV_PPS", 0}, {"MIS_CONV_PPC2", 0}, {"MIS_TILEQ_OFF", 0}, {"MIS_CONV3D_NOPF10N4", 0},
+    {"MIS_CONV3D_F32_NOPP", 0}, {"MIS_WGRAD_F32_NOPP", 0}, {"MIS_WGRAD_F32_ROUNDS", 1}, {"MIS_CONV_PPS", 0}, {"MIS_CONV_PPC2", 0}, {"MIS_TILEQ_OFF", 0}, {"MIS_CONV3D_NOPF10N4", 0}, {"MIS_CONV3D_F32_WIDE", 0},
 };
 std::atomic<int> g_val[SW_COUNT];
 std::once_flag g_once;

@@ -10,7 +10,7 @@ enum MisSwitch {
     SW_CONV3D_NOPP, SW_CONV3D_PF, SW_CONV3D_ZG, SW_CONV3D_COLMAJOR,
     SW_WGRAD_K1_NARROW, SW_WGRAD_NO_TR, SW_WGRAD_BLOCKS, SW_WGRAD_NOPP, SW_WGRAD_PP_NOWIDE, SW_WGRAD_PP_KSS1, SW_WGRAD3D_NOPP, SW_WGRAD_PP_ROW, SW_WGRAD_PP_NOROW,
     SW_FIRST2D_UNTILED, SW_FIRST3D_UNTILED, SW_UPCONV_BWD_GENERIC, SW_GEMM1_NOPP, SW_CONV_NOPPD, SW_WGRAD_PP_NOSTREAM, SW_WGRAD_K1_NOPP, SW_FIRST3D_NOMFMA, SW_PERSIST_CUS, SW_HEAD_UNFUSED,
-    SW_CONV3D_F32_NOPP, SW_WGRAD_F32_NOPP, SW_WGRAD_F32_ROUNDS, SW_CONV_PPS, SW_CONV_PPC2, SW_TILEQ_OFF, SW_CONV3D_NOPF10N4,
+    SW_CONV3D_F32_NOPP, SW_WGRAD_F32_NOPP, SW_WGRAD_F32_ROUNDS, SW_CONV_PPS, SW_CONV_PPC2, SW_TILEQ_OFF, SW_CONV3D_NOPF10N4, SW_CONV3D_F32_WIDE,
     SW_COUNT
 };
 

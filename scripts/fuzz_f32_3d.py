@@ -39,7 +39,7 @@ for case in range(ncases):
     outs = []
     for old in (0, 1):
         ybuf = torch.full((*grid, Cout + yoff), float("nan"), device=dev)
-        with ops.dispatch_switches(MIS_CONV3D_F32_NOPP=old):
+        with ops.dispatch_switches(MIS_CONV3D_F32_NOPP=old, MIS_CONV3D_F32_WIDE=case & 1):          # (odd cases: 128-column tiles even on grids that do not fill the chip)
             ops.conv_igemm(x, wf, ops.View(ybuf, yoff, Cout), ksize=3, Cin=Cin, Cout=Cout, grid=grid, **kw)
             tag = ops.conv_last_dispatch()
         if not old:

@@ -362,15 +362,16 @@ K3D_CASES = [
     (F32, (1, 5, 20, 20), 64, 64, "k3.3d.bn64", "k3.3d", {"MIS_CONV3D_F32_NOPP": 1, "MIS_WGRAD_F32_NOPP": 1}),
     # round 5: the fp32 all-DMA kernels (conv3d_f32.hip: 8 x 16-pixel plane tiles x 64 | 128 columns; wgrad_f32.hip: 16-pixel strips streamed row by row) - the channel
     # plans of UNet3D's layers on ragged grids, single planes (both neighbour planes padding), planes of two samples, several split-K ranges per (ci, co, kd) tile
-    (F32, (1, 2, 9, 17), 256, 512, "k3.3d.f32pp128", "k3.3d.f32s", {}),                    # enc3.conv2: four column tiles, eight K chunks, ragged both ways
+    (F32, (1, 2, 9, 17), 256, 512, "k3.3d.f32pp128", "k3.3d.f32s", {"MIS_CONV3D_F32_WIDE": 1}),                    # enc3.conv2: four column tiles, eight K chunks, ragged both ways
     (F32, (1, 5, 20, 20), 64, 64, "k3.3d.f32pp64", "k3.3d.f32s", {}),
     (F32, (2, 4, 16, 32), 32, 64, "k3.3d.f32pp64", "k3.3d", {}),                           # enc0.conv2's forward over its 32 real channels: ONE K chunk per depth slice
     (F32, (2, 6, 24, 40), 192, 64, "k3.3d.f32pp64", "k3.3d.f32s", {}),                     # dec2.conv1: six chunks; weight gradient: three ci tiles x three depth slices
     (F32, (1, 3, 12, 20), 64, 192, "k3.3d.f32pp64", "k3.3d.f32s", {}),                     # its dgrad: three 64-column tiles
-    (F32, (2, 3, 8, 16), 768, 256, "k3.3d.f32pp128", "k3.3d.f32s", {}),                    # dec0.conv1: 24 chunks, one tile per plane
+    (F32, (2, 3, 8, 16), 768, 256, "k3.3d.f32pp128", "k3.3d.f32s", {"MIS_CONV3D_F32_WIDE": 1}),                    # dec0.conv1: 24 chunks, one tile per plane
     (F32, (1, 1, 20, 16), 64, 64, "k3.3d.f32pp64", "k3.3d.f32s", {}),                      # one plane: only the centre depth slice contributes
-    (F32, (2, 8, 40, 48), 64, 128, "k3.3d.f32pp128", "k3.3d.f32s", {}),                    # 240 tiles; strips of three 16-pixel columns, rows split over many blocks
-    (F32, (3, 2, 7, 5), 128, 128, "k3.3d.f32pp128", "k3.3d.f32s", {}),                     # grid smaller than one tile / one strip
+    (F32, (2, 8, 40, 48), 64, 128, "k3.3d.f32pp128", "k3.3d.f32s", {"MIS_CONV3D_F32_WIDE": 1}),                    # 240 tiles; strips of three 16-pixel columns, rows split over many blocks
+    (F32, (3, 2, 7, 5), 128, 128, "k3.3d.f32pp128", "k3.3d.f32s", {"MIS_CONV3D_F32_WIDE": 1}),
+    (F32, (2, 16, 16, 16), 256, 256, "k3.3d.f32pp64", "k3.3d.f32s", {}),                   # cfg4's 16^3 level: 64 spatial tiles - 64-column tiles are chosen to fill the chip                     # grid smaller than one tile / one strip
 ]
 
 
