@@ -165,6 +165,8 @@ def kernel_tables(prof, steps, peak):
     agg, layers, tags = {}, {}, {}
     for key, flops, e0, e1, tag in prof:
         ms = e0.elapsed_time(e1) * 1e-3
+        if tag.startswith("k3.3d.f32pp"):          # the fp32 3-D launcher picks the tile width by grid size too (64 columns on underfilled grids): key by what ran
+            key = key[:4] + ("bn" + tag[len("k3.3d.f32pp"):],) + key[5:]
         for table, k in ((layers, key), (agg, key[:5])):
             a = table.setdefault(k, [0.0, 0.0, 0])
             a[0] += flops
