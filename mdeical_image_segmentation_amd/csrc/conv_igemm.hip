@@ -866,13 +866,15 @@ extern "C" int mis_conv_igemm(const MisConvDesc* d, void* stream) {
     // (the 3-D ping-pong kernel walks 32-channel K chunks in bf16: encoders.0 SingleConv2 of UNet3D reads its 32 real input channels out of a 64-channel buffer)
     const bool pp3 = d->dtype == MIS_BF16 && d->is3d && d->ksize == 3 && !mis_sw(SW_CONV3D_NOPP) && conv3d_pp_eligible(d);
     MIS_REQUIRE(d->Cin > 0 && (d->Cin % CK == 0 || (pp3 && d->Cin % 32 == 0)), MIS_EUNSUPPORTED, "conv_igemm: Cin %d must be a multiple of %d", d->Cin, CK);
-    MIS_REQUIRE(d->Cout > 0 && d->Cout % 64 == 0, MIS_EUNSUPPORTED, "conv_igemm: Cout %d must be a multiple of 64", d->Cout);
+    // (round 6: the fp32 3x3x3 all-DMA kernel has a 32-column tile - the dgrad of encoders.0 SingleConv2 writes the layer's 32 real input channels)
+    const bool f3 = d->dtype == MIS_F32 && d->is3d && d->ksize == 3 && !mis_sw(SW_CONV3D_F32_NOPP) && conv3d_f32_eligible(d);
+    MIS_REQUIRE(d->Cout > 0 && (d->Cout % 64 == 0 || (f3 && d->Cout % 32 == 0)), MIS_EUNSUPPORTED, "conv_igemm: Cout %d must be a multiple of 64", d->Cout);
     MIS_REQUIRE(d->x0 != nullptr && d->w != nullptr && d->y0 != nullptr, MIS_EINVAL, "conv_igemm: null pointer");
     MIS_REQUIRE(d->Cin0 > 0 && d->Cin0 <= d->Cin && (d->Cin0 % CK == 0 || (pp3 && d->Cin0 == d->Cin)), MIS_EINVAL, "conv_igemm: Cin0 %d", d->Cin0);
     MIS_REQUIRE(d->Cin0 == d->Cin || d->x1 != nullptr, MIS_EINVAL, "conv_igemm: x1 missing");
     const bool gnb = d->gn_p != nullptr;          // GroupNorm backward in the epilogue: only the 3-D ping-pong kernels carry it
     MIS_REQUIRE(!gnb || pp3, MIS_EUNSUPPORTED, "conv_igemm: gn_p needs the bf16 3x3x3 ping-pong path (single source, q / r / mask given, no bias / ReLU)");
-    MIS_REQUIRE(d->Cout0 > 0 && d->Cout0 <= d->Cout && (d->Cout0 % 64 == 0 || (gnb && d->Cout0 % 32 == 0)), MIS_EINVAL, "conv_igemm: Cout0 %d", d->Cout0);
+    MIS_REQUIRE(d->Cout0 > 0 && d->Cout0 <= d->Cout && (d->Cout0 % 64 == 0 || ((gnb || f3) && d->Cout0 % 32 == 0)), MIS_EINVAL, "conv_igemm: Cout0 %d", d->Cout0);
     MIS_REQUIRE(d->Cout0 == d->Cout || d->y1 != nullptr || gnb, MIS_EINVAL, "conv_igemm: y1 missing");
     MIS_REQUIRE(d->x0_ld % EPC == 0 && d->y0_ld % EPC == 0, MIS_EINVAL, "conv_igemm: ld must keep 16-byte alignment");
     MIS_REQUIRE(d->x1 == nullptr || d->x1_ld % EPC == 0, MIS_EINVAL, "conv_igemm: x1_ld alignment");

@@ -35,14 +35,27 @@ struct WfArgs {
 
 namespace {
 constexpr int WF_TW = 16;
-constexpr int WF_XROW = 5 * 1024;                // X row image: 18 px x 256 B = 4608 B in five DMA instructions (the last half full)
 constexpr int WF_QROW = 4 * 1024;                // dY row image: 16 px x 256 B
-constexpr int WF_SLOT = WF_XROW + WF_QROW;
 constexpr int WF_R = 5;                          // ring slots
 constexpr int WF_D = 3;                          // prefetch distance in rows
-constexpr int WF_LDS = WF_R * WF_SLOT;           // 46,080
+// X row image.  64 input channels per block: 18 px x 256 B = 4608 B in five DMA instructions (the last half full).  C32 (round 6: 32 input channels per block - the
+// weight gradient of encoders.0 SingleConv2, whose operand has 32 real channels, reference buildingblocks.py:202-211): 18 px x 128 B = 2304 B; instruction q = wave q covers
+// pixels 8q .. 8q + 7, so wave 2 lands pixels 16, 17 and zeros, wave 3 zeros only - every wave issues two instructions per element and the counted waits are uniform
+template <bool C32> struct WfGeom {
+    static constexpr int XPB = C32 ? 128 : 256;              // bytes of a pixel in the X row image
+    static constexpr int XROW = C32 ? 4 * 1024 : 5 * 1024;
+    static constexpr int SLOT = XROW + WF_QROW;
+    static constexpr int LDS = WF_R * SLOT;                  // 46,080 / 40,960
+    static constexpr int CIB = C32 ? 32 : 64;                // input channels per block
+    static constexpr int NR = C32 ? 2 : 4;                   // row tiles (MFMAs) per fragment read
+};
 
 
+template <int OFF> __device__ __forceinline__ u32x2 wf_read64(uint32_t addr) {
+    u32x2 r;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
 template <int OFF> __device__ __forceinline__ uint32_t wf_read32(uint32_t addr) {
     uint32_t r;
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
@@ -53,10 +66,17 @@ __device__ __forceinline__ float wf_f(const u32x4& v, int t) {
     const uint32_t u = v[t];
     return __uint_as_float(u);
 }
+__device__ __forceinline__ float wf_f(const u32x2& v, int t) {
+    const uint32_t u = v[t];
+    return __uint_as_float(u);
+}
 }   // namespace
 
-template <bool IS3D>
+template <bool IS3D, bool C32>
 __global__ __launch_bounds__(256, 2) void wgrad_f32_stream_kernel(const WfArgs a) {
+    using GEO = WfGeom<C32>;
+    constexpr int WF_XROW = GEO::XROW, WF_SLOT = GEO::SLOT, XPB = GEO::XPB, NR = GEO::NR;
+    using AFrag = std::conditional_t<C32, u32x2, u32x4>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
     const int tid = threadIdx.x;
@@ -70,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_stream_kernel(const WfArgs a
     const int kd = IS3D ? pair % 3 : 0;
     const int pc = IS3D ? pair / 3 : pair;
     const int ci_t = pc / a.nCo, co_t = pc - ci_t * a.nCo;
-    const int ci0 = ci_t * 64, co0 = co_t * 64;
+    const int ci0 = ci_t * GEO::CIB, co0 = co_t * 64;
     const long long u_begin = (long long)split * a.upb;
     long long u_end = u_begin + a.upb;
     if (u_end > a.U) u_end = a.U;
@@ -95,13 +115,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_stream_kernel(const WfArgs a
 
     // ---- DMA lane parts: X instruction q covers slots q*64 .. q*64 + 63 of the row image (slot = pixel * 16 + 16-byte chunk), waves 0-3: q = wave, wave 0 also q = 4 ----
     const int xs = wave * 64 + lane;
-    const int xpx = xs >> 4;                                                             // 0 .. 15
-    const unsigned xrel = (unsigned)((xpx * a.x_ld + ((xs & 15) << 2)) * 4);
+    const int xpx = C32 ? ((xs >> 3) < 18 ? (xs >> 3) : 0x40000000) : xs >> 4;            // 0 .. 15 (C32: 0 .. 17, the rest out of range)
+    const unsigned xrel = C32 ? (unsigned)(((xs >> 3) * a.x_ld + ((xs & 7) << 2)) * 4) : (unsigned)((xpx * a.x_ld + ((xs & 15) << 2)) * 4);
     const int xpx4 = lane < 32 ? 16 + (lane >> 4) : 0x40000000;                           // wave 0's fifth instruction: pixels 16, 17
     const unsigned xrel4 = (unsigned)(((16 + (lane >> 4)) * a.x_ld + ((lane & 15) << 2)) * 4);
-    const int qpx = xpx;
+    const int qpx = xs >> 4;
     const unsigned qrel = (unsigned)((qpx * a.dy_ld + ((xs & 15) << 2)) * 4);
-    const unsigned img_x = (unsigned)((((size_t)a.H * a.W - 1) * a.x_ld + a.Cin) * 4), img_q = (unsigned)((((size_t)a.H * a.W - 1) * a.dy_ld + a.Cout) * 4);
+    const unsigned img_x = (unsigned)((((size_t)a.H * a.W - 1) * a.x_ld + ci0 + GEO::CIB) * 4), img_q = (unsigned)((((size_t)a.H * a.W - 1) * a.dy_ld + a.Cout) * 4);
     const unsigned xrow = (unsigned)(a.W * a.x_ld * 4), qrow = (unsigned)(a.W * a.dy_ld * 4);
 
     // ---- the issue cursor runs WF_D elements ahead of the steps ----
@@ -132,9 +152,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_stream_kernel(const WfArgs a
                 const bool ok = pzok && (unsigned)(pw0 - 1 + xpx) < (unsigned)a.W;
                 pp_dma16(prx, ok ? (int)(ptoff + xrel) : PP_OOB, slot + wave * 1024);
             }
-            if (wave == 0) {
-                const bool ok = pzok && (unsigned)(pw0 - 1 + xpx4) < (unsigned)a.W;
-                pp_dma16(prx, ok ? (int)(ptoff + xrel4) : PP_OOB, slot + 4 * 1024);
+            if constexpr (!C32) {
+                if (wave == 0) {
+                    const bool ok = pzok && (unsigned)(pw0 - 1 + xpx4) < (unsigned)a.W;
+                    pp_dma16(prx, ok ? (int)(ptoff + xrel4) : PP_OOB, slot + 4 * 1024);
+                }
             }
             {
                 const bool ok = pj >= 2 && pw0 + qpx < a.W;
@@ -152,20 +174,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_stream_kernel(const WfArgs a
         }
     };
 
-    f32x4 acc[9][4];
+    f32x4 acc[9][NR];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < NR; ++r) acc[t][r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // fragment lane parts: A = pixel lg (+ k-step / tap shift as immediate), 16-byte chunk li; B = pixel lg, channel 16 * wave + li
-    const uint32_t a_lane = lds0 + (uint32_t)(lg * 256 + li * 16);
+    const uint32_t a_lane = lds0 + (uint32_t)(lg * XPB + li * (C32 ? 8 : 16));      // (C32: 8 bytes per lane = channels 2 li, 2 li + 1: 256 contiguous bytes per half-wave)
     const uint32_t b_lane = lds0 + (uint32_t)(WF_XROW + lg * 256 + (wave * 16 + li) * 4);
 
     for (int i = 0; i < WF_D; ++i) issue_next();
     // element 0 must have landed; WF_D - 1 younger ones may stay in flight (wave 0 issues three instructions per element, the others two)
     if (total >= WF_D) {
-        if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (WF_D - 1)) : "memory");
+        if (!C32 && wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (WF_D - 1)) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WF_D - 1)) : "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -175,27 +197,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_stream_kernel(const WfArgs a
     __builtin_amdgcn_s_sleep(2);                 // (see wgrad_pp.hip: keep the first reads away from the publishing barrier)
 
     // reads of sub-step q = s * 3 + kh of the element whose X rows (kh = 0, 1, 2) are at xa[0..2] and whose dY row is at qa; B of k-step s joins sub-step s * 3
-    auto read_sub = [&](u32x4(&A)[3], uint32_t& B, const uint32_t (&xa)[3], uint32_t qa, auto qc) {
+    auto read_sub = [&](AFrag(&A)[3], uint32_t& B, const uint32_t (&xa)[3], uint32_t qa, auto qc) {
         constexpr int q = decltype(qc)::value, s = q / 3, kh = q % 3;
         pp_static_for<3>([&](auto kwc) {
             constexpr int kw = decltype(kwc)::value;
-            A[kw] = pp_lds_read128<(4 * s + kw) * 256>(xa[kh]);
+            if constexpr (C32) A[kw] = wf_read64<(4 * s + kw) * XPB>(xa[kh]);
+            else A[kw] = pp_lds_read128<(4 * s + kw) * XPB>(xa[kh]);
         });
         if constexpr (kh == 0) B = wf_read32<s * 1024>(qa);
     };
-    auto wait_sub = [&](u32x4(&A)[3], uint32_t& B) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(B)::"memory"); };
+    auto wait_sub = [&](AFrag(&A)[3], uint32_t& B) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(B)::"memory"); };
     // the MFMAs of filter columns [K0, K1) of a sub-step (4 per column)
-    auto mfma_cols = [&](const u32x4(&A)[3], uint32_t B, auto khc, auto k0c, auto k1c) {
+    auto mfma_cols = [&](const AFrag(&A)[3], uint32_t B, auto khc, auto k0c, auto k1c) {
         constexpr int kh = decltype(khc)::value, K0 = decltype(k0c)::value, K1 = decltype(k1c)::value;
         const float b = wf_f(B);
 #pragma unroll
         for (int kw = K0; kw < K1; ++kw)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[kh * 3 + kw][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf_f(A[kw], r), b, acc[kh * 3 + kw][r], 0, 0, 0);
+            for (int r = 0; r < NR; ++r) acc[kh * 3 + kw][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf_f(A[kw], r), b, acc[kh * 3 + kw][r], 0, 0, 0);
     };
-    auto mfma_sub = [&](const u32x4(&A)[3], uint32_t B, auto khc) { mfma_cols(A, B, khc, std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}); };
+    auto mfma_sub = [&](const AFrag(&A)[3], uint32_t B, auto khc) { mfma_cols(A, B, khc, std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}); };
 
-    u32x4 A0[3], A1[3];
+    AFrag A0[3], A1[3];
     uint32_t B0 = 0u, B1 = 0u;                   // B of even / odd k-steps
     uint32_t xa[3] = {a_lane, a_lane, a_lane};   // X rows of elements e - 2, e - 1, e
     bool pref = false;                           // sub-step 0 of the current element was read during the previous element's last sub-step
@@ -252,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_stream_kernel(const WfArgs a
             // ---- the next element becomes visible; the slot of element e - 2 is handed to element e + WF_D ----
             if (e + 1 < total) {
                 if (e + WF_D < total) {          // the issue cursor is still running: WF_D - 2 younger elements stay in flight
-                    if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (WF_D - 2)) : "memory");
+                    if (!C32 && wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (WF_D - 2)) : "memory");
                     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WF_D - 2)) : "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -288,15 +311,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_stream_kernel(const WfArgs a
         }
     }
 
-    // ---- this block's slab: partial[split][kd * 9 + tap][ci][co]; lane (li, lg) holds ci = 16 lg + 4 i + r, co = 16 wave + li of row tile r ----
+    // ---- this block's slab: partial[split][kd * 9 + tap][ci][co]; lane (li, lg) holds ci = 16 lg + 4 i + r (C32: 8 lg + 2 i + r), co = 16 wave + li of row tile r ----
     float* out = a.partial + (size_t)split * (IS3D ? 27 : 9) * a.Cin * a.Cout;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < NR; ++r)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int ci = ci0 + 16 * lg + 4 * i + r, co = co0 + 16 * wave + li;
+                const int ci = ci0 + (C32 ? 8 * lg + 2 * i + r : 16 * lg + 4 * i + r), co = co0 + 16 * wave + li;
                 out[((size_t)(kd * 9 + tap) * a.Cin + ci) * a.Cout + co] = acc[tap][r][i];
             }
 }
@@ -306,7 +329,7 @@ bool wgrad_f32_eligible(const MisWgradDesc* d) {
     if (mis_sw(SW_WGRAD_F32_NOPP)) return false;
     if (d->dtype != MIS_F32 || d->ksize != 3) return false;
     if (d->x1 != nullptr || d->in_scale != nullptr || d->dbias != nullptr || d->dw_per_sample != nullptr || d->dbias_per_sample != nullptr || d->dw_layout != 0) return false;
-    if (d->Cin0 != d->Cin || d->Cin % 64 != 0 || d->Cout % 64 != 0 || d->x0_ld % 4 != 0 || d->dy_ld % 4 != 0) return false;
+    if (d->Cin0 != d->Cin || d->Cin % 32 != 0 || d->Cout % 64 != 0 || d->x0_ld % 4 != 0 || d->dy_ld % 4 != 0) return false;
     if (d->x0_D != d->D || d->x0_H != d->H || d->x0_W != d->W) return false;
     if (!d->is3d && d->D != 1) return false;
     const size_t ld = d->x0_ld > d->dy_ld ? d->x0_ld : d->dy_ld;
@@ -317,7 +340,7 @@ bool wgrad_f32_eligible(const MisWgradDesc* d) {
 static void wf_plan(const MisWgradDesc* d, int* nsplit, long long* U, long long* upb, int* base, int* nstrips) {
     const int KD = d->is3d ? 3 : 1;
     *nstrips = (d->W + WF_TW - 1) / WF_TW;
-    *base = (d->Cin / 64) * (d->Cout / 64) * KD;
+    *base = (d->Cin / (d->Cin % 64 != 0 ? 32 : 64)) * (d->Cout / 64) * KD;           // (Cin = 32 mod 64: 32-channel blocks)
     *U = (long long)d->N * d->D * *nstrips * d->H;
     // two blocks per CU: grids that fill whole rounds of 512 block slots; among equally full ones the coarsest split (fewest slabs), but at least eight rows per block
     const int slots = 2 * mis_persist_cus();
@@ -367,12 +390,20 @@ int launch_wgrad_f32(const MisWgradDesc* d, float* partial, hipStream_t stream, 
     a.KD = d->is3d ? 3 : 1;
     const long long grid = (long long)a.base * ns;
     MIS_REQUIRE(grid < (1ll << 31), MIS_EUNSUPPORTED, "wgrad_f32: grid too large");
-    if (d->is3d) {
+    if (d->Cin % 64 != 0) {
+        if (d->is3d) {
+            *tag = "k3.3d.f32s32";
+            hipLaunchKernelGGL((wgrad_f32_stream_kernel<true, true>), dim3((unsigned)grid), dim3(256), WfGeom<true>::LDS, stream, a);
+        } else {
+            *tag = "k3.2d.f32s32";
+            hipLaunchKernelGGL((wgrad_f32_stream_kernel<false, true>), dim3((unsigned)grid), dim3(256), WfGeom<true>::LDS, stream, a);
+        }
+    } else if (d->is3d) {
         *tag = "k3.3d.f32s";
-        hipLaunchKernelGGL(wgrad_f32_stream_kernel<true>, dim3((unsigned)grid), dim3(256), WF_LDS, stream, a);
+        hipLaunchKernelGGL((wgrad_f32_stream_kernel<true, false>), dim3((unsigned)grid), dim3(256), WfGeom<false>::LDS, stream, a);
     } else {
         *tag = "k3.2d.f32s";
-        hipLaunchKernelGGL(wgrad_f32_stream_kernel<false>, dim3((unsigned)grid), dim3(256), WF_LDS, stream, a);
+        hipLaunchKernelGGL((wgrad_f32_stream_kernel<false, false>), dim3((unsigned)grid), dim3(256), WfGeom<false>::LDS, stream, a);
     }
     MIS_LAUNCH_CHECK("wgrad_f32");
     return MIS_OK;

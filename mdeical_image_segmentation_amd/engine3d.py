@@ -156,13 +156,18 @@ class UNet3DEngine:
                 t.dw2d = torch.empty(27 * t.cout, t.cin, device=self.device)
                 self.ct.append(t)
         self.sc = {}
+        # round 6: the fp32 all-DMA kernels have 32-column (dgrad) and 32-input-channel (weight gradient) tiles, so encoders.0 SingleConv2 (32 -> 64,
+        # buildingblocks.py:202-211) keeps its 32 real channels everywhere - operand, dgrad output and weight gradient are not padded to 64 (half of that layer's backward
+        # was multiplications by zero: 928 GFLOP of cfg4's step).  With the lock-step kernels selected (MIS_CONV3D_F32_NOPP / MIS_WGRAD_F32_NOPP) the padded plan stays.
+        self.narrow32 = (dtype == torch.float32 and self.materialize and not ops.dispatch_switch("MIS_CONV3D_F32_NOPP")
+                         and not ops.dispatch_switch("MIS_WGRAD_F32_NOPP") and os.environ.get("MISAMD_F32_PAD64") is None)
         for grp, plan in (("encoders", enc), ("decoders", dec)):
             for i, convs in enumerate(plan):
                 for j, (ci, co) in enumerate(convs):
                     s = _SC()
                     s.name = f"{grp}.{i}.basic_module.SingleConv{j + 1}"
                     s.cin, s.cout = ci, co
-                    s.cin_pad = (ci + 63) // 64 * 64 if ci > 1 else 1
+                    s.cin_pad = ci if (self.narrow32 and ci % 32 == 0) else ((ci + 63) // 64 * 64 if ci > 1 else 1)
                     s.groups = 1 if ci < num_groups else num_groups
                     s.first = (grp == "encoders" and i == 0 and j == 0)
                     if not s.first:

@@ -364,14 +364,19 @@ K3D_CASES = [
     # plans of UNet3D's layers on ragged grids, single planes (both neighbour planes padding), planes of two samples, several split-K ranges per (ci, co, kd) tile
     (F32, (1, 2, 9, 17), 256, 512, "k3.3d.f32pp128", "k3.3d.f32s", {"MIS_CONV3D_F32_WIDE": 1}),                    # enc3.conv2: four column tiles, eight K chunks, ragged both ways
     (F32, (1, 5, 20, 20), 64, 64, "k3.3d.f32pp64", "k3.3d.f32s", {}),
-    (F32, (2, 4, 16, 32), 32, 64, "k3.3d.f32pp64", "k3.3d", {}),                           # enc0.conv2's forward over its 32 real channels: ONE K chunk per depth slice
+    (F32, (2, 4, 16, 32), 32, 64, "k3.3d.f32pp64", "k3.3d.f32s32", {}),                    # enc0.conv2's forward over its 32 real channels: ONE K chunk per depth slice; round 6: its weight gradient on 32-channel blocks
+    (F32, (2, 5, 24, 40), 64, 32, "k3.3d.f32pp32", None, {}),                              # round 6: enc0.conv2's dgrad on 32-column tiles (planes of two samples, ragged width)
+    (F32, (1, 3, 9, 17), 64, 96, "k3.3d.f32pp32", None, {}),                               # three 32-column tiles, ragged both ways
+    (F32, (1, 3, 9, 17), 96, 64, "k3.3d.f32pp64", "k3.3d.f32s32", {}),                     # three 32-channel ci tiles x three depth slices, ragged strips
+    (F32, (2, 8, 40, 48), 32, 128, "k3.3d.f32pp128", "k3.3d.f32s32", {"MIS_CONV3D_F32_WIDE": 1}),          # two co tiles; rows split over many blocks (segments across strip / plane boundaries)
+    (F32, (1, 1, 20, 16), 32, 64, "k3.3d.f32pp64", "k3.3d.f32s32", {}),                    # one plane: kd = 0 / 2 blocks see only padding
     (F32, (2, 6, 24, 40), 192, 64, "k3.3d.f32pp64", "k3.3d.f32s", {}),                     # dec2.conv1: six chunks; weight gradient: three ci tiles x three depth slices
     (F32, (1, 3, 12, 20), 64, 192, "k3.3d.f32pp64", "k3.3d.f32s", {}),                     # its dgrad: three 64-column tiles
     (F32, (2, 3, 8, 16), 768, 256, "k3.3d.f32pp128", "k3.3d.f32s", {"MIS_CONV3D_F32_WIDE": 1}),                    # dec0.conv1: 24 chunks, one tile per plane
     (F32, (1, 1, 20, 16), 64, 64, "k3.3d.f32pp64", "k3.3d.f32s", {}),                      # one plane: only the centre depth slice contributes
     (F32, (2, 8, 40, 48), 64, 128, "k3.3d.f32pp128", "k3.3d.f32s", {"MIS_CONV3D_F32_WIDE": 1}),                    # 240 tiles; strips of three 16-pixel columns, rows split over many blocks
     (F32, (3, 2, 7, 5), 128, 128, "k3.3d.f32pp128", "k3.3d.f32s", {"MIS_CONV3D_F32_WIDE": 1}),
-    (F32, (2, 16, 16, 16), 256, 256, "k3.3d.f32pp64", "k3.3d.f32s", {}),                   # cfg4's 16^3 level: 64 spatial tiles - 64-column tiles are chosen to fill the chip                     # grid smaller than one tile / one strip
+    (F32, (2, 16, 16, 16), 256, 256, "k3.3d.f32pp64", "k3.3d.f32s", {}),                   # cfg4's 16^3 level: 64 spatial tiles - 64-column tiles are chosen to fill the chip
 ]
 
 
@@ -427,6 +432,8 @@ def test_conv3d_every_branch(case, switches):
     assert _same_kernel(ops.conv_last_dispatch(), cfg)
     assert_close(from_nhwc(y2), ref * (q(m, dtype) > 0), f"3-D mask {cfg}", **t)
     # (c) weight gradient of the same operand
+    if want_wg is None:         # (a 32-column case: the weight gradients need Cout % 64 == 0)
+        return
     dw = torch.full((Cout, Cin, 3, 3, 3), float("nan"), device=DEV)
     ops.wgrad(xd, to_nhwc(dy, dtype), dw, ksize=3, Cin=Cin, Cout=Cout, grid=grid, **kw)
     wcfg, nsplit = ops.wgrad_last_dispatch()
@@ -482,6 +489,37 @@ def test_conv3d_f32_kernel_is_bit_identical_to_the_lockstep_kernel(shape):
         ops.conv_igemm(x, wf, yb, ksize=3, Cin=Cin, Cout=Cout, grid=(N, D, H, W), relu=True)
         assert ops.conv_last_dispatch().startswith("k3.3d.bn")
     assert torch.equal(ya, yb), (ya - yb).abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [((2, 5, 24, 40), 64, 32), ((1, 3, 9, 17), 128, 96)], ids=lambda s: f"{'x'.join(map(str, s[0]))}-{s[1]}to{s[2]}")
+def test_conv3d_f32_32_column_tiles_are_bit_identical_to_the_padded_64_column_launch(shape):
+    """round 6: conv3d_f32_kernel<1> (32-column tiles: the dgrad of encoders.0 SingleConv2, reference buildingblocks.py:202-211) against what the engine ran until round 5 -
+    the same weights zero-padded to the next multiple of 64 columns on conv3d_f32_kernel<2>, and against the lock-step kernel on the padded weights: the real columns are
+    bit-identical (an output element's products are summed in the same order whatever the column tile)"""
+    ops = _ops()
+    (N, D, H, W), Cin, Cout = shape
+    Cp = (Cout + 63) // 64 * 64
+    x = to_nhwc(rnd(N, Cin, D, H, W, seed=182), F32)
+    w = rnd(Cout, Cin, 3, 3, 3, seed=183, scale=(27 * Cin) ** -0.5)
+    wp = torch.zeros(Cp, Cin, 3, 3, 3)
+    wp[:Cout] = w
+    wf = torch.empty(27, Cout, Cin, dtype=F32, device=DEV)
+    wfp = torch.empty(27, Cp, Cin, dtype=F32, device=DEV)
+    ops.pack_conv_weight(w.to(DEV), wf, None)
+    ops.pack_conv_weight(wp.to(DEV), wfp, None)
+    m = to_nhwc(rnd(N, Cout, D, H, W, seed=184), F32)
+    ya = torch.full((N, D, H, W, Cout), float("nan"), dtype=F32, device=DEV)
+    ops.conv_igemm(x, wf, ya, ksize=3, Cin=Cin, Cout=Cout, grid=(N, D, H, W), mask=m)
+    assert ops.conv_last_dispatch() == "k3.3d.f32pp32"
+    mp = torch.ones(N, D, H, W, Cp, dtype=F32, device=DEV)
+    mp[..., :Cout] = m
+    for sw, tag in ((dict(), "k3.3d.f32pp64"), (dict(MIS_CONV3D_F32_NOPP=1), "k3.3d.bn128" if Cp % 128 == 0 else "k3.3d.bn64")):
+        yb = torch.full((N, D, H, W, Cp), float("nan"), dtype=F32, device=DEV)
+        with ops.dispatch_switches(**sw):
+            ops.conv_igemm(x, wfp, yb, ksize=3, Cin=Cin, Cout=Cp, grid=(N, D, H, W), mask=mp)
+            assert ops.conv_last_dispatch().startswith(tag), ops.conv_last_dispatch()
+        assert torch.equal(ya, yb[..., :Cout]), (tag, (ya - yb[..., :Cout]).abs().max().item())
+        assert (yb[..., Cout:] == 0).all()
 
 
 @pytest.mark.parametrize("dtype", [BF, F32])
