@@ -144,7 +144,9 @@ SYMBOLS = {
     "k3.2d.ppw": "wgrad_pp_wide_kernel<false, false>", "k3.2d.pps": "wgrad_pp_wide_kernel<true, false>", "k3.2d.ppwr": "wgrad_pp_row_kernel<false, false>",
     "k3.2d.ppsr": "wgrad_pp_row_kernel<true, false>", "k1.2d.ppg": "wgrad1_pp_kernel", "k3.2d.ppst": "wgrad_pp_stream_kernel<false, false>", "k3.2d.ppss": "wgrad_pp_stream_kernel<true, false>", "k3.3d.ppst": "wgrad_pp_stream_kernel<false, true>", "k3.3d.ppss": "wgrad_pp_stream_kernel<true, true>", "k3.3d.ppw": "wgrad_pp_wide_kernel<false, true>", "k3.3d.pps": "wgrad_pp_wide_kernel<true, true>",
     "k3.3d.ppwr": "wgrad_pp_row_kernel<false, true>", "k3.3d.ppsr": "wgrad_pp_row_kernel<true, true>", "k3.2d.pp": "wgrad_pp_kernel<2>",
-    "k3.3d.f32pp64": "conv3d_f32_kernel<2>", "k3.3d.f32pp128": "conv3d_f32_kernel<4>", "k3.3d.f32s": "wgrad_f32_stream_kernel<true>", "k3.2d.f32s": "wgrad_f32_stream_kernel<false>",
+    "k3.3d.f32pp64": "conv3d_f32_kernel<2>", "k3.3d.f32pp128": "conv3d_f32_kernel<4>", "k3.3d.f32pp32": "conv3d_f32_kernel<1>",
+    "k3.3d.f32s": "wgrad_f32_stream_kernel<true, false>", "k3.2d.f32s": "wgrad_f32_stream_kernel<false, false>", "k3.3d.f32s32": "wgrad_f32_stream_kernel<true, true>",
+    "k3.2d.f32s32": "wgrad_f32_stream_kernel<false, true>",
 }
 # the column-segment kernels: one instantiation per epilogue mask path (template argument 0 = none, 1 = bf16 mask ".mask", 2 = ReLU bits ".bits")
 for _t, _k in (("k3.2d.ppc8", "conv_ppc_kernel<8, 4"), ("k3.2d.ppc8n2", "conv_ppc_kernel<8, 2"), ("k3.3d.ppc5", "conv3d_ppc_kernel<5, 4"),
@@ -163,26 +165,29 @@ SYMBOLS["k3.2d.ppd8.head"] = "conv_ppd_head_kernel<C>"          # (C = classes: 
 def kernel_tables(prof, steps, peak):
     prof, steps = prof          # (events, number of steps whose launches were bracketed)
     agg, layers, tags = {}, {}, {}
-    for key, flops, e0, e1, tag in prof:
+    # flops = ALGORITHMIC work of the launch (the layer's real channel counts); xflops = what the kernel executed (more where an operand is zero-padded to the tile width:
+    # the bf16 3-D engine's encoders.0 SingleConv2 dgrad / weight gradient) - achieved / frac / tflops are priced on the first, the second is reported beside it
+    for key, flops, e0, e1, tag, xflops in prof:
         ms = e0.elapsed_time(e1) * 1e-3
         if tag.startswith("k3.3d.f32pp"):          # the fp32 3-D launcher picks the tile width by grid size too (64 columns on underfilled grids): key by what ran
             key = key[:4] + ("bn" + tag[len("k3.3d.f32pp"):],) + key[5:]
         for table, k in ((layers, key), (agg, key[:5])):
-            a = table.setdefault(k, [0.0, 0.0, 0])
+            a = table.setdefault(k, [0.0, 0.0, 0, 0.0])
             a[0] += flops
             a[1] += ms
             a[2] += 1
+            a[3] += xflops
         t = tags.setdefault(key[:5], {})
         t[tag] = t.get(tag, 0) + 1
-    key, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
+    key, (fl, sec, cnt, xfl) = max(agg.items(), key=lambda kv: kv[1][1])
     ach = fl / sec / 1e12
     # the dominant key's launches by kernel symbol (conv_igemm.hip's template kernels print as conv_igemm_kernel<...> in rocprofv3: the configuration tag stands for them)
     syms = {SYMBOLS.get(t, f"conv_igemm_kernel<{t}>" if key[0] == "conv_igemm" else f"wgrad_kernel<{t}>"): c for t, c in sorted(tags[key].items(), key=lambda kv: -kv[1])}
     roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
             "kernel": " + ".join(syms), "kernel_launches_by_symbol": syms, "key": "/".join(k for k in key if k), "launches": cnt,
-            "avg_launch_ms": round(sec / cnt * 1e3, 4), "alg_gflop_per_launch": round(fl / cnt / 1e9, 2)}
+            "avg_launch_ms": round(sec / cnt * 1e3, 4), "alg_gflop_per_launch": round(fl / cnt / 1e9, 2), "executed_gflop_per_launch": round(xfl / cnt / 1e9, 2)}
     kernels = {"/".join(k for k in key if k): {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / steps * 1e3, 3),
-                                              "launches_per_step": v[2] // steps}
+                                              "launches_per_step": v[2] // steps, **({"tflops_executed": round(v[3] / v[1] / 1e12, 1)} if v[3] != v[0] else {})}
                for key, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
     total = round(sum(v[1] for v in agg.values()) / steps * 1e3, 3)
     return roof, kernels, total, layers, steps
@@ -403,6 +408,7 @@ def _timed_loop(step, steps, warmup, world, dist, dev, timing):
         host.append(time.perf_counter())
     fence()
     dt = time.perf_counter() - t0
+    ops.tile_queue_check()          # (outside the timed region) a persistent launch that lost tiles to dirty queue counters would make the figure meaningless: fail loudly
     global LAST_STEP_TRACE
     LAST_STEP_TRACE = {"gpu_ms_each": [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(steps)],
                        "host_enqueue_ms_each": [round((host[i] - (host[i - 1] if i else t0)) * 1e3, 2) for i in range(steps)]}

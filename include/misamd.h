@@ -87,8 +87,24 @@ typedef struct MisConvDesc {
      * with p / q / r the [N][gn_ld] fp32 tables of mis_gn_bwd_finalize - dL/d(normalised operand) is never written and mis_gn_bwd_apply's pass (3 tensors) disappears.
      * Columns [Cout0, Cout) are DROPPED when y1 == NULL (padding channels of the operand: here Cout0 may be any multiple of 32). */
     const float* gn_p; const float* gn_q; const float* gn_r; int gn_ld; int gn_relu;
+    /* Per-channel sums of the output in the epilogue (round 6; fp32 3x3x3 on conv3d_f32.hip - mis_conv_stats_rows(d) > 0 says whether the launch this descriptor would
+     * take carries them): st_mode 1 = the two reductions of the GroupNorm backward behind a dgrad (model/unet3d/buildingblocks.py:87-92), S1 = sum out, S2 = sum out * x with
+     * x the tensor that GroupNorm read - columns [0, st_c0) from st_x0, [st_c0, Cout) from st_x1 (st_up: on the half grid, read at >> 1; st_x1 NULL: all from st_x0) -
+     * instead of mis_gn_bwd_stats' pass over both tensors; st_mode 2 = S1 = sum out, S2 = sum out^2 of the stored (post-ReLU) output, the statistics the NEXT GroupNorm needs
+     * (mis_chanstats' pass).  The kernel writes one partial row per (spatial tile, row half): st_part[n][row][S1 columns | S2 columns] with
+     * mis_conv_stats_rows(d) rows per sample and 2 * Cout floats per row; the caller reduces the rows with mis_conv_stats_reduce (double precision, fixed order). 0: off. */
+    int st_mode;
+    const void* st_x0; int st_x0_ld;
+    const void* st_x1; int st_x1_ld;
+    int st_c0; int st_up;
+    float* st_part;
 } MisConvDesc;
 int mis_conv_igemm(const MisConvDesc* d, void* stream);
+/* rows per sample of MisConvDesc.st_part for this descriptor, or 0 when the kernel it dispatches to has no statistics epilogue (st_mode is then refused) */
+long long mis_conv_stats_rows(const MisConvDesc* d);
+/* st_part (N x rows x 2 * Cout floats, as the launch left it) -> S1, S2 [N][Cout]: rows added in double precision, fixed order */
+size_t mis_conv_stats_reduce_workspace_bytes(int N, int Cout);
+int mis_conv_stats_reduce(const float* part, int N, long long rows, int Cout, void* workspace, float* S1, float* S2, void* stream);
 /* Name of the kernel configuration the calling thread's last mis_conv_igemm ran, e.g. "k3.2d.bn256.dma" (diagnostic: the parity tests assert
  * that each case reaches the dispatch branch it is written for). */
 const char* mis_conv_last_dispatch(void);
@@ -101,6 +117,18 @@ int mis_dispatch_switch(const char* name);
 /* Diagnostic: the eight per-XCD ticket counters of the persistent kernels' tile queue on `stream` (csrc/dispatch_cfg.hpp), after a device synchronisation -
  * all zero between launches (the kernel that draws a counter's last ticket resets it).  Returns -1 when the stream has no counter block (MIS_TILEQ_OFF=1). */
 int mis_debug_tile_queue(void* stream, unsigned* out8);
+/* Diagnostic: plant `value` in counter `xcd` (0..7) of `stream`'s block - the state an unfinished launch would leave (tests: the next launch must report it). -1: no block. */
+int mis_debug_tile_queue_poke(void* stream, int xcd, unsigned value);
+/* Tile queue housekeeping (round 6).  mis_tile_queue_init: allocate and zero the current device's counter pool now (library load time) instead of inside the first
+ * launch - nothing on the launch path allocates or synchronises, and a launch captured before any eager one still finds the pool.  mis_tile_queue_reset: zero the counters
+ * of `stream` (or of the capture running on it: a memset node) - the engines call it at the start of every train step.  mis_tile_queue_errors: device-synchronising check -
+ * the number of counters that handed out a ticket past their launch's last one since the previous call (such a launch left output tiles unwritten; cannot happen on
+ * clean counters), 0 = clean; the message is in mis_last_error(). */
+int mis_tile_queue_init(void);
+int mis_tile_queue_reset(void* stream);
+int mis_tile_queue_errors(void);
+/* 1 when the library was built with `make EXPERIMENTS=1` (csrc/experiments: kernel variants that lost their A/B, selectable through MIS_CONV_PPS / MIS_CONV_PPC2) */
+int mis_build_has_experiments(void);
 /* Diagnostic: launches a kernel on `stream` that holds `blocks` (1..128) CUs for `cycles` (<= 4e8) shader cycles - what an all-reduce kernel beside the persistent
  * kernels looks like to them (tests/test_gpu_dispatch_parity.py: a conv launch beside it must not take the two rounds a static tile stride would). */
 int mis_debug_hold_cus(int blocks, long long cycles, void* stream);

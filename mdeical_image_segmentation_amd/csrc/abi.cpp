@@ -25,7 +25,8 @@ const AbiField conv_fields[] = {
     F(MisConvDesc, x1_D), F(MisConvDesc, x1_H), F(MisConvDesc, x1_W), F(MisConvDesc, Cin0), F(MisConvDesc, in_scale), F(MisConvDesc, in_shift), F(MisConvDesc, w),
     F(MisConvDesc, bias), F(MisConvDesc, relu), F(MisConvDesc, mask), F(MisConvDesc, mask_ld), F(MisConvDesc, y0), F(MisConvDesc, y0_ld), F(MisConvDesc, y0_mode),
     F(MisConvDesc, y1), F(MisConvDesc, y1_ld), F(MisConvDesc, y1_mode), F(MisConvDesc, Cout0), F(MisConvDesc, relu_bits), F(MisConvDesc, mask_bits), F(MisConvDesc, gn_p),
-    F(MisConvDesc, gn_q), F(MisConvDesc, gn_r), F(MisConvDesc, gn_ld), F(MisConvDesc, gn_relu),
+    F(MisConvDesc, gn_q), F(MisConvDesc, gn_r), F(MisConvDesc, gn_ld), F(MisConvDesc, gn_relu), F(MisConvDesc, st_mode), F(MisConvDesc, st_x0), F(MisConvDesc, st_x0_ld),
+    F(MisConvDesc, st_x1), F(MisConvDesc, st_x1_ld), F(MisConvDesc, st_c0), F(MisConvDesc, st_up), F(MisConvDesc, st_part),
 };
 const AbiField wgrad_fields[] = {
     F(MisWgradDesc, dtype), F(MisWgradDesc, ksize), F(MisWgradDesc, N), F(MisWgradDesc, D), F(MisWgradDesc, H), F(MisWgradDesc, W), F(MisWgradDesc, is3d), F(MisWgradDesc, Cin),

@@ -32,6 +32,14 @@ struct F3Args {
     int N, D, H, W, Cin, Cout;
     int tilesH, tilesW, nCt;
     int relu;
+    // per-channel sums of the tile in the epilogue (round 6; MisConvDesc.st_mode): 1 = sum out, sum out * x (the two reductions of the GroupNorm backward, x = the tensor the
+    // GroupNorm read: columns [0, sc0) from sx0, the rest from sx1 - on the half grid when sup), 2 = sum out, sum out^2 (the statistics of the next GroupNorm);
+    // spart[spatial tile][row half wm][S1 | S2][Cout]
+    int smode;
+    const float* sx0;
+    const float* sx1;
+    int sx0_ld, sx1_ld, sc0, sup;
+    float* spart;
 };
 
 namespace {
@@ -58,6 +66,17 @@ template <int N> __device__ __forceinline__ void f3_wait_lgkm(u32x4 (&r)[N]) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])::"memory");
 }
 
+// sum over the 16 lanes of a DPP row (every lane ends up with the total; fixed order)
+template <int CTRL> __device__ __forceinline__ float f3_dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float f3_row16_sum(float v) {
+    v = f3_dpp_add<0xB1>(v);          // quad_perm [1, 0, 3, 2]
+    v = f3_dpp_add<0x4E>(v);          // quad_perm [2, 3, 0, 1]
+    v = f3_dpp_add<0x141>(v);         // row_half_mirror
+    return f3_dpp_add<0x140>(v);      // row_mirror
+}
 __device__ __forceinline__ float f3_f(const u32x4& v, int t) {
     const uint32_t u = v[t];
     return __uint_as_float(u);
@@ -265,12 +284,26 @@ __global__ __launch_bounds__(256, 2) void conv3d_f32_kernel(const F3Args a) {
     // ---- epilogue: lane (li, lg) holds, per pixel row pf, NV consecutive channels of pixel (y0 + wm*4 + pf, x0 + li) ----
     const int x = x0 + li;
     const int col = n0 + wn * WAVE_N + lg * NV;
+    float st1[NV], st2[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) st1[i] = st2[i] = 0.f;
+    // the x source of this wave's columns (wave-uniform: sc0 is a multiple of 64 >= WAVE_N)
+    const bool sfrom1 = a.smode == 1 && a.sx1 != nullptr && n0 + wn * WAVE_N >= a.sc0;
+    const float* const sxp = sfrom1 ? a.sx1 + (col - a.sc0) : a.sx0 + col;
+    const int sxld = sfrom1 ? a.sx1_ld : a.sx0_ld;
+    const bool shalf = sfrom1 && a.sup;
 #pragma unroll
     for (int pf = 0; pf < PF; ++pf) {
         const int y = y0 + wm * PF + pf;
         if (y < a.H && x < a.W) {
             const size_t pix = ((size_t)pz * a.H + y) * a.W + x;
             float* dst = a.y + pix * a.y_ld + col;
+            f32x4 sxv[NF];
+            if (a.smode == 1) {
+                const size_t spix = shalf ? ((size_t)((pz / a.D) * (a.D >> 1) + (z >> 1)) * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1) : pix;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) sxv[f] = *reinterpret_cast<const f32x4*>(sxp + spix * sxld + f * 4);
+            }
             f32x4 mk[NF];
             if (a.mask != nullptr) {
 #pragma unroll
@@ -288,6 +321,30 @@ __global__ __launch_bounds__(256, 2) void conv3d_f32_kernel(const F3Args a) {
                     for (int i = 0; i < 4; ++i) o[i] = mk[f][i] > 0.f ? o[i] : 0.f;
                 }
                 *reinterpret_cast<f32x4*>(dst + f * 4) = o;
+                if (a.smode != 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        st1[f * 4 + i] += o[i];
+                        st2[f * 4 + i] = fmaf(o[i], a.smode == 1 ? sxv[f][i] : o[i], st2[f * 4 + i]);
+                    }
+                }
+            }
+        }
+    }
+    if (a.smode != 0) {
+        // sum over the 16 pixel columns (lanes li of one lg: butterfly inside 16-lane groups), fixed order; lane li == 0 stores the wave's NV channels of both sums
+        // (DPP adds: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror - one VALU instruction per step and value instead of a trip through the LDS crossbar)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            st1[i] = f3_row16_sum(st1[i]);
+            st2[i] = f3_row16_sum(st2[i]);
+        }
+        if (li == 0) {
+            float* const row = a.spart + ((size_t)(v / a.nCt) * 2 + wm) * 2 * a.Cout + col;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                *reinterpret_cast<f32x4*>(row + f * 4) = f32x4{st1[f * 4], st1[f * 4 + 1], st1[f * 4 + 2], st1[f * 4 + 3]};
+                *reinterpret_cast<f32x4*>(row + a.Cout + f * 4) = f32x4{st2[f * 4], st2[f * 4 + 1], st2[f * 4 + 2], st2[f * 4 + 3]};
             }
         }
     }
@@ -304,6 +361,63 @@ bool conv3d_f32_eligible(const MisConvDesc* d) {
     return true;
 }
 
+// The partial rows of the statistics epilogue -> S1 / S2 [N][Cout], in DOUBLE (the GroupNorm backward subtracts nearly equal sums: an fp32 reduction over 32 k rows cost the
+// deconv golden 1e-3 on the gradients behind it) and in a fixed order.  Stage 1: block (16 columns, sample, row slice z of CSR_Z) x 16 row lanes, four independent loads in
+// flight per thread; stage 2: one thread per (sample, column) adds the CSR_Z slice sums.
+constexpr int CSR_Z = 64;
+__global__ __launch_bounds__(256) void conv_stats_reduce1_kernel(const float* __restrict__ part, long long rows, int C2, double* __restrict__ ws /*[N][CSR_Z][C2]*/) {
+    __shared__ double red[16][17];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl, n = blockIdx.y, z = blockIdx.z;
+    const long long per = (rows + CSR_Z - 1) / CSR_Z;
+    const long long r0 = (long long)z * per, r1 = r0 + per < rows ? r0 + per : rows;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (c < C2) {
+        const float* p = part + (size_t)n * rows * C2 + c;
+        long long r = r0 + g;
+        for (; r + 48 < r1; r += 64) {
+            const float v0 = p[(size_t)r * C2], v1 = p[(size_t)(r + 16) * C2], v2 = p[(size_t)(r + 32) * C2], v3 = p[(size_t)(r + 48) * C2];
+            a0 += (double)v0; a1 += (double)v1; a2 += (double)v2; a3 += (double)v3;
+        }
+        for (; r < r1; r += 16) a0 += (double)p[(size_t)r * C2];
+    }
+    red[g][cl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (g == 0 && c < C2) {
+        double t = red[0][cl];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k][cl];
+        ws[((size_t)n * CSR_Z + z) * C2 + c] = t;
+    }
+}
+__global__ __launch_bounds__(256) void conv_stats_reduce2_kernel(const double* __restrict__ ws, int N, int C2, int Cout, float* __restrict__ S1, float* __restrict__ S2) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N * C2) return;
+    const int n = idx / C2, c = idx - n * C2;
+    double t = 0.0;
+#pragma unroll 8
+    for (int z = 0; z < CSR_Z; ++z) t += ws[((size_t)n * CSR_Z + z) * C2 + c];
+    if (c < Cout) S1[(size_t)n * Cout + c] = (float)t;
+    else S2[(size_t)n * Cout + (c - Cout)] = (float)t;
+}
+
+extern "C" size_t mis_conv_stats_reduce_workspace_bytes(int N, int Cout) { return (size_t)N * CSR_Z * 2 * Cout * sizeof(double); }
+
+extern "C" int mis_conv_stats_reduce(const float* part, int N, long long rows, int Cout, void* workspace, float* S1, float* S2, void* stream) {
+    (void)hipGetLastError();
+    MIS_REQUIRE(part && workspace && S1 && S2 && N > 0 && N <= 65535 && rows > 0 && Cout > 0 && Cout % 16 == 0, MIS_EINVAL, "conv_stats_reduce: bad argument");
+    MIS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, MIS_EINVAL, "conv_stats_reduce: workspace alignment");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(conv_stats_reduce1_kernel, dim3((unsigned)(2 * Cout / 16), (unsigned)N, CSR_Z), dim3(256), 0, s, part, rows, 2 * Cout, reinterpret_cast<double*>(workspace));
+    MIS_LAUNCH_CHECK("conv_stats_reduce1");
+    hipLaunchKernelGGL(conv_stats_reduce2_kernel, dim3((unsigned)((N * 2 * Cout + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const double*>(workspace), N, 2 * Cout, Cout, S1, S2);
+    MIS_LAUNCH_CHECK("conv_stats_reduce2");
+    return MIS_OK;
+}
+
+// rows per sample of the statistics partials (MisConvDesc.st_part): one per (spatial tile, row half of the tile)
+long long conv3d_f32_stats_rows(const MisConvDesc* d) { return (long long)d->D * ((d->H + F3_TH - 1) / F3_TH) * ((d->W + F3_TW - 1) / F3_TW) * 2; }
+
 int launch_conv3d_f32(const MisConvDesc* d, hipStream_t stream, const char** tag) {
     F3Args a;
     a.x = reinterpret_cast<const float*>(d->x0);
@@ -315,6 +429,18 @@ int launch_conv3d_f32(const MisConvDesc* d, hipStream_t stream, const char** tag
     a.tilesH = (d->H + F3_TH - 1) / F3_TH;
     a.tilesW = (d->W + F3_TW - 1) / F3_TW;
     a.relu = d->relu;
+    a.smode = d->st_mode;
+    a.sx0 = reinterpret_cast<const float*>(d->st_x0); a.sx1 = reinterpret_cast<const float*>(d->st_x1);
+    a.sx0_ld = d->st_x0_ld; a.sx1_ld = d->st_x1_ld; a.sc0 = d->st_x1 != nullptr ? d->st_c0 : d->Cout; a.sup = d->st_up;
+    a.spart = d->st_part;
+    if (d->st_mode != 0) {
+        MIS_REQUIRE((d->st_mode == 1 || d->st_mode == 2) && d->st_part != nullptr, MIS_EINVAL, "conv3d_f32: st_mode %d / st_part", d->st_mode);
+        if (d->st_mode == 1) {
+            MIS_REQUIRE(d->st_x0 != nullptr && d->st_x0_ld % 4 == 0, MIS_EINVAL, "conv3d_f32: st_x0");
+            MIS_REQUIRE(d->st_x1 == nullptr || (d->st_x1_ld % 4 == 0 && d->st_c0 > 0 && d->st_c0 < d->Cout && d->st_c0 % 64 == 0), MIS_EINVAL, "conv3d_f32: st_x1 / st_c0");
+            MIS_REQUIRE(d->st_x1 == nullptr || !d->st_up || (d->D % 2 == 0 && d->H % 2 == 0 && d->W % 2 == 0), MIS_EUNSUPPORTED, "conv3d_f32: st_up needs an even grid");
+        }
+    }
     // 128-column tiles unless they leave the chip underfilled (two 256-thread blocks per CU = 512 slots): the 16^3 level of cfg4 has 64 spatial tiles - 128 / 256 blocks of
     // 128 columns ran at 72 TFLOP/s; 64-column tiles double the blocks (same summation order per output element: bit-identical)
     const long long sp = (long long)d->N * d->D * a.tilesH * a.tilesW;

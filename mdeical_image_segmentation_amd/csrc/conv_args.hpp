@@ -51,6 +51,7 @@ int launch_gemm1_pp(const MisConvDesc* d, hipStream_t stream, const char** tag);
 // conv3d_f32.hip: the fp32 3x3x3 layers of the fused 3-D engine (single plain source: the materialised GroupNorm output), all-DMA / fragment-prefetched
 bool conv3d_f32_eligible(const MisConvDesc* d);
 int launch_conv3d_f32(const MisConvDesc* d, hipStream_t stream, const char** tag);
+long long conv3d_f32_stats_rows(const MisConvDesc* d);
 // conv_pps.hip (round-5 experiment, MIS_CONV_PPS=1): the 128-column 3x3 layers with ONE wave per SIMD and both fragment sets in registers
 bool conv_pps_eligible(const MisConvDesc* d);
 int launch_conv_pps(const MisConvDesc* d, hipStream_t stream, const char** tag);

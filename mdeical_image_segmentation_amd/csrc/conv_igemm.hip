@@ -854,6 +854,11 @@ template <typename T> static int dispatch(const MisConvDesc* d, hipStream_t s) {
     RUN("k1.3d.bn64", launch_cfg<T, Geom<4, 4, 8, 1, true>, 2, 2>(d, s));
 }
 
+extern "C" long long mis_conv_stats_rows(const MisConvDesc* d) {
+    if (d == nullptr || d->dtype != MIS_F32 || !d->is3d || d->ksize != 3 || mis_sw(SW_CONV3D_F32_NOPP) || !conv3d_f32_eligible(d)) return 0;
+    return conv3d_f32_stats_rows(d);
+}
+
 extern "C" int mis_conv_igemm(const MisConvDesc* d, void* stream) {
     (void)hipGetLastError();   // drop any stale (already handled) error of this thread
     MIS_REQUIRE(d != nullptr, MIS_EINVAL, "conv_igemm: null descriptor");
@@ -872,6 +877,7 @@ extern "C" int mis_conv_igemm(const MisConvDesc* d, void* stream) {
     MIS_REQUIRE(d->x0 != nullptr && d->w != nullptr && d->y0 != nullptr, MIS_EINVAL, "conv_igemm: null pointer");
     MIS_REQUIRE(d->Cin0 > 0 && d->Cin0 <= d->Cin && (d->Cin0 % CK == 0 || (pp3 && d->Cin0 == d->Cin)), MIS_EINVAL, "conv_igemm: Cin0 %d", d->Cin0);
     MIS_REQUIRE(d->Cin0 == d->Cin || d->x1 != nullptr, MIS_EINVAL, "conv_igemm: x1 missing");
+    MIS_REQUIRE(d->st_mode == 0 || f3, MIS_EUNSUPPORTED, "conv_igemm: st_mode needs the fp32 3x3x3 all-DMA path (mis_conv_stats_rows(d) == 0 for this descriptor)");
     const bool gnb = d->gn_p != nullptr;          // GroupNorm backward in the epilogue: only the 3-D ping-pong kernels carry it
     MIS_REQUIRE(!gnb || pp3, MIS_EUNSUPPORTED, "conv_igemm: gn_p needs the bf16 3x3x3 ping-pong path (single source, q / r / mask given, no bias / ReLU)");
     MIS_REQUIRE(d->Cout0 > 0 && d->Cout0 <= d->Cout && (d->Cout0 % 64 == 0 || ((gnb || f3) && d->Cout0 % 32 == 0)), MIS_EINVAL, "conv_igemm: Cout0 %d", d->Cout0);

@@ -995,8 +995,10 @@ int conv_ppc_choice(const MisConvDesc* d) {
 int launch_conv_pp(const MisConvDesc* d, hipStream_t stream, const char** tag) {
     const int ppc = conv_ppc_choice(d);
     // (the tag names the instantiation: one per epilogue mask path, ".mask" = bf16 mask tensor, ".bits" = ReLU bits)
+#ifdef MIS_EXPERIMENTS          // (make EXPERIMENTS=1: the two round-5 experiments on this kernel, csrc/experiments/ - slower, kept as evidence, not part of the shipped library)
     if (ppc == 4 && conv_pps_eligible(d)) return launch_conv_pps(d, stream, tag);
     if (ppc == 4 && conv_ppc2_eligible(d)) return launch_conv_ppc2(d, stream, tag);
+#endif
     if (ppc == 4) {
         *tag = d->mask_bits != nullptr ? "k3.2d.ppc8.bits" : (d->mask != nullptr ? "k3.2d.ppc8.mask" : "k3.2d.ppc8");
         return pp_launch_col<8, 4>(d, stream);

@@ -54,7 +54,13 @@ __device__ __forceinline__ TileQ tq_init(unsigned* tq, int total, int grid, int 
     return q;
 }
 __device__ __forceinline__ int tq_tile(const TileQ& q, unsigned k, int grid) {
-    if (k > q.last) return 0x7fffffff;          // (cannot happen with clean counters: a ticket past the launch's last one must never become a tile index)
+    // a ticket past the launch's last one must never become a tile index.  It cannot be drawn from clean counters; a counter that did NOT start at zero (a launch that
+    // never finished, two replays of one captured graph running concurrently) means tiles of this launch go unwritten - that is made LOUD: the word next to
+    // the counter takes the ticket, mis_tile_queue_errors() (ops.tile_queue_check: tests, bench.py, smoke, every graph replay check) reports it and raises
+    if (k > q.last) {
+        __hip_atomic_store(q.ctr + 1, k | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0x7fffffff;
+    }
     const int r = (int)(k / (unsigned)q.qx);
     return q.basex + ((int)k - r * q.qx) + (r + 1) * grid;
 }

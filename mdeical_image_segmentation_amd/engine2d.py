@@ -106,6 +106,8 @@ class UNet2DEngine:
         if not (1 <= out_channels <= 4):
             raise MisError("out_channels must be 1..4")
         ops.load()
+        with torch.cuda.device(torch.device(device)):
+            ops.tile_queue_init()          # the tile queue's counter pool exists before the first launch (and before any graph capture)
         self.cin, self.cout = in_channels, out_channels
         # wgrad's slab reductions can run on a second stream under the following dgrad kernel (MISAMD_SIDE_REDUCE=1).  Off by default since round 2: with
         # one slab per persistent block the reductions are small, and the measured step is the same either way (817.2 vs 817.4 img/s) - one stream less to order.
@@ -245,6 +247,7 @@ class UNet2DEngine:
             raise MisError(f"expected {self.cin} input channels, got {Cin}")
         self._alloc(N, H, W)
         self._images = images
+        ops.tile_queue_reset()          # a step never inherits tile-queue counters from an earlier launch (captured as a memset node)
         P = self.P
         for l, c in enumerate(FEATS):
             skip = View(self.cat[l], c, c)

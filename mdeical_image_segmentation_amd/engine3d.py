@@ -85,6 +85,8 @@ class _SC:
 
 class UNet3DEngine:
     exact_dice, dice_group = False, None          # class defaults (the residual engines do not take the options)
+    narrow32 = epi_stats = False
+    _ystats = {}                                  # (never written while epi_stats is off)
 
     def __init__(self, in_channels=1, out_channels=3, f_maps=(64, 128, 256, 512), num_groups=8, dtype=torch.float32, device="cuda",
                  seed=None, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3, max_grad_norm=1.0, alpha=1.0, beta=1.0,
@@ -105,6 +107,8 @@ class UNet3DEngine:
         if f_maps[0] != 64 or any(f % 64 for f in f_maps):
             raise MisError("UNet3DEngine: f_maps must start at 64 and be multiples of 64")
         ops.load()
+        with torch.cuda.device(torch.device(device)):
+            ops.tile_queue_init()          # the tile queue's counter pool exists before the first launch (and before any graph capture)
         self.cin, self.cout, self.f_maps, self.G = in_channels, out_channels, f_maps, num_groups
         self.dtype, self.device = dtype, torch.device(device)
         # split-K slab reductions of the weight-gradient kernels run on a second stream under the next MFMA kernel (joined per DDP stage / at the end)
@@ -161,6 +165,11 @@ class UNet3DEngine:
         # was multiplications by zero: 928 GFLOP of cfg4's step).  With the lock-step kernels selected (MIS_CONV3D_F32_NOPP / MIS_WGRAD_F32_NOPP) the padded plan stays.
         self.narrow32 = (dtype == torch.float32 and self.materialize and not ops.dispatch_switch("MIS_CONV3D_F32_NOPP")
                          and not ops.dispatch_switch("MIS_WGRAD_F32_NOPP") and os.environ.get("MISAMD_F32_PAD64") is None)
+        # ... and a statistics epilogue (MisConvDesc.st_mode): the dgrad leaves the two reductions of the GroupNorm backward (sum dyn, sum dyn * x: mis_gn_bwd_stats' pass over
+        # both tensors, 2.6 ms of cfg4's step) and the forward convolution the sums the NEXT GroupNorm needs (mis_chanstats' pass, 0.9 ms) as per-tile partial rows, reduced in
+        # a fixed order.  MISAMD_NO_EPI_STATS=1: the separate passes (A/B switch).
+        self.epi_stats = self.narrow32 and os.environ.get("MISAMD_NO_EPI_STATS") is None
+        self._ystats, self._epi_ok = {}, {}
         for grp, plan in (("encoders", enc), ("decoders", dec)):
             for i, convs in enumerate(plan):
                 for j, (ci, co) in enumerate(convs):
@@ -294,6 +303,8 @@ class UNet3DEngine:
     def _alloc(self, N, D, H, W):
         if self._shape == (N, D, H, W):
             return
+        if self.epi_stats:
+            self._ystats = {}                     # keyed by buffer address: the buffers are about to be replaced
         div = 1 << (self.levels - 1)
         if D % div or H % div or W % div:
             raise MisError(f"the fused 3-D engine needs D, H, W divisible by {div}; got {D}x{H}x{W}")
@@ -366,14 +377,33 @@ class UNet3DEngine:
         return i if grp == "encoders" else self.levels - 2 - i
 
     # ---- forward ---------------------------------------------------------------------------------------
+    def _epi(self, x, y, cin, cout, grid):
+        """does the convolution x -> y of this shape run on a kernel with the statistics epilogue?  (asked once per shape)"""
+        if not self.epi_stats:
+            return False
+        key = (x.shape[-1], y.shape[-1], cin, cout, grid)
+        ok = self._epi_ok.get(key)
+        if ok is None:
+            ok = self._epi_ok[key] = bool(ops.conv_stats_supported(x, y, Cin=cin, Cout=cout, grid=grid))
+        return ok
+
+    def _src_stats(self, src, c, own_sum, own_sq):
+        """per-(sample, channel) sum / sum of squares of a GroupNorm input: left behind by the convolution that produced it (statistics epilogue), or one pass over it"""
+        st = self._ystats.get(src.data_ptr())
+        if st is not None and st[2] == (tuple(src.shape), c):
+            return st[0], st[1]
+        ops.chanstats(View(src, 0, c), own_sum, own_sq)
+        return own_sum, own_sq
+
     def _gn_fwd(self, s, src0, c0, src1=None, c1=0):
         N = src0.shape[0]
         count = src0.shape[1] * src0.shape[2] * src0.shape[3]
-        ops.chanstats(View(src0, 0, c0), s.sum0, s.sq0)
+        sum0, sq0 = self._src_stats(src0, c0, s.sum0, s.sq0)
+        sum1 = sq1 = None
         if src1 is not None:
-            ops.chanstats(View(src1, 0, c1), s.sum1, s.sq1)
+            sum1, sq1 = self._src_stats(src1, c1, s.sum1, s.sq1)
         mult1 = 8.0 if (src1 is not None and src1.shape[1] != src0.shape[1]) else 1.0     # nearest-upsampled source: 8 children per voxel
-        ops.gn_fwd_finalize(s.sum0, s.sq0, c0, 1.0, s.sum1 if src1 is not None else None, s.sq1 if src1 is not None else None, c1, mult1,
+        ops.gn_fwd_finalize(sum0, sq0, c0, 1.0, sum1, sq1, c1, mult1,
                             N, s.groups, count, self.P[s.name + ".groupnorm.weight"], self.P[s.name + ".groupnorm.bias"], s.cin_pad,
                             s.scale, s.shift, s.mean, s.rstd)
 
@@ -390,7 +420,14 @@ class UNet3DEngine:
             if getattr(s, "wf_real", None) is not None:
                 ops.conv_igemm(View(s.xn, 0, s.cin), s.wf_real, y, ksize=3, Cin=s.cin, Cout=s.cout, grid=grid, relu=getattr(s, "relu", True))
             else:
-                ops.conv_igemm(s.xn, s.wf, y, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid, relu=getattr(s, "relu", True))
+                st = None
+                if y.shape[-1] == s.cout and self._epi(s.xn, y, s.cin_pad, s.cout, grid):      # the output's statistics for the GroupNorm that reads it next
+                    ent = self._ystats.get(y.data_ptr())
+                    if ent is None or ent[2] != (tuple(y.shape), s.cout):
+                        ent = self._ystats[y.data_ptr()] = (torch.zeros(grid[0], s.cout, device=self.device), torch.zeros(grid[0], s.cout, device=self.device),
+                                                            (tuple(y.shape), s.cout))
+                    st = dict(mode=2, S1=ent[0], S2=ent[1])
+                ops.conv_igemm(s.xn, s.wf, y, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid, relu=getattr(s, "relu", True), stats=st, real=(s.cin, s.cout))
             return
         ops.conv_igemm(View(src0, 0, src0.shape[-1] if src1 is None else c0), s.wf, y, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid,
                        x1=None if src1 is None else View(src1, 0, c1), relu=getattr(s, "relu", True), in_scale=s.scale, in_shift=s.shift)
@@ -424,6 +461,7 @@ class UNet3DEngine:
         N, _, D, H, W = x.shape
         self._alloc(N, D, H, W)
         self._x = x
+        ops.tile_queue_reset()          # a step never inherits tile-queue counters from an earlier launch (captured as a memset node)
         P, L = self.P, self.levels
         npix = D * H * W
         # first SingleConv: GroupNorm(1 group over the single channel) + direct conv
@@ -504,7 +542,7 @@ class UNet3DEngine:
             # (per-sample gradients feed this layer's GroupNorm backward right after the dgrad: their reductions stay on the main stream - ~75 MB of slabs per layer -
             #  a side-stream reduction is starved by the persistent dgrad kernel and would be waited for)
             ops.wgrad(s.xn, g_y, dw, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid, side=self.side_reduce and s.dwpad is None and not from_dw,
-                      dw_per_sample=s.dwn if from_dw else None, dbias_per_sample=s.gysum if from_dw else None)
+                      dw_per_sample=s.dwn if from_dw else None, dbias_per_sample=s.gysum if from_dw else None, real=(s.cin, s.cout))
         else:
             ops.wgrad(x0v, g_y, dw, ksize=3, Cin=s.cin_pad, Cout=s.cout, grid=grid, x1=x1v, in_scale=s.scale, in_shift=s.shift,
                       side=self.side_reduce and s.dwpad is None)
@@ -517,11 +555,15 @@ class UNet3DEngine:
             ops.gn_bwd_finalize(s.S1, s.S2, s.mean, s.rstd, self.P[s.name + ".groupnorm.weight"], N, ctot, s.groups, D * H * W,
                                 s.p, s.q, s.r, self.Gr[s.name + ".groupnorm.weight"], self.Gr[s.name + ".groupnorm.bias"])
             ops.conv_igemm(g_y, s.wd, View(dx0, 0, c0), ksize=3, Cin=s.cout, Cout=s.cin_pad, Cout0=c0, grid=grid, mask=View(src0, 0, c0),
-                           gn_bwd=(s.p, s.q, s.r, mask0))
+                           gn_bwd=(s.p, s.q, s.r, mask0), real=(s.cout, s.cin))
             return
         dyn = self.dyn[(self._level(s.name), s.cin_pad)]
-        ops.conv_igemm(g_y, s.wd, dyn, ksize=3, Cin=s.cout, Cout=s.cin_pad, grid=grid)
-        if from_dw:
+        epi = not from_dw and s.cin_pad == ctot and self._epi(g_y, dyn, s.cout, s.cin_pad, grid)
+        ops.conv_igemm(g_y, s.wd, dyn, ksize=3, Cin=s.cout, Cout=s.cin_pad, grid=grid, real=(s.cout, s.cin),
+                       stats=dict(mode=1, x0=View(src0, 0, c0), x1=x1v, up=up1, S1=s.S1, S2=s.S2) if epi else None)
+        if epi:
+            pass
+        elif from_dw:
             ops.gn_bwd_stats_from_dw(g_y, self.P[s.name + ".conv.weight"] if s.wpad is None else s.wpad, s.dwn, s.gysum, s.scale, s.shift, s.mean, s.groups, ctot,
                                      s.S1, s.S2)
         else:

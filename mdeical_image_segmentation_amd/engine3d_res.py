@@ -85,6 +85,8 @@ class ResidualUNet3DEngine(UNet3DEngine):
         if f_maps[0] != 64 or any(f % 64 for f in f_maps):
             raise MisError("ResidualUNet3DEngine: f_maps must start at 64 and be multiples of 64")
         ops.load()
+        with torch.cuda.device(torch.device(device)):
+            ops.tile_queue_init()          # the tile queue's counter pool exists before the first launch (and before any graph capture)
         self.deconv = True
         self.cin, self.cout, self.f_maps, self.G = in_channels, out_channels, f_maps, num_groups
         self.dtype, self.device = dtype, torch.device(device)

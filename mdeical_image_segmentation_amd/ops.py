@@ -67,8 +67,12 @@ def _event():
 
 
 class _Timed:
-    def __init__(self, key, flops, tag=None):
+    """flops = ALGORITHMIC work of the launch (the layer's real channel counts); exec_flops = what the kernel executed (>= flops where an operand is zero-padded
+    to the tile width; None: the same) - bench.py prices roofline.achieved on the first and reports the second beside it"""
+
+    def __init__(self, key, flops, tag=None, exec_flops=None):
         self.key, self.flops, self.tag = key, flops, tag
+        self.exec_flops = flops if exec_flops is None else exec_flops
 
     def __enter__(self):
         if PROFILE is not None:
@@ -81,16 +85,20 @@ class _Timed:
             self.e1.record()
             lib = load()            # which kernel configuration this launch ran (names the dominant kernel's symbol in bench.py's roofline)
             tag = self.tag or (lib.mis_conv_last_dispatch() if self.key[0] == "conv_igemm" else lib.mis_wgrad_last_dispatch()).decode()
-            PROFILE.append((self.key, self.flops, self.e0, self.e1, tag))
+            PROFILE.append((self.key, self.flops, self.e0, self.e1, tag, self.exec_flops))
         return False
 
 
 def conv_igemm(x0, w_packed, y0, *, ksize, Cin, Cout, grid=None, x1=None, bias=None, relu=False, mask=None,
-               y0_mode=OUT_PLAIN, y1=None, y1_mode=OUT_PLAIN, Cout0=None, in_scale=None, in_shift=None, relu_bits=None, mask_bits=None, gn_bwd=None):
+               y0_mode=OUT_PLAIN, y1=None, y1_mode=OUT_PLAIN, Cout0=None, in_scale=None, in_shift=None, relu_bits=None, mask_bits=None, gn_bwd=None, stats=None,
+               real=None):
     """grid = (N, D, H, W) of the GEMM rows; defaults to x0's grid.
     relu_bits (out, uint8 tensor of relu_bits_bytes(N, H, W, Cout) bytes, with relu=True): bit = (output > 0); mask_bits (in): such bits applied instead of `mask`.
     gn_bwd = (p, q, r, relu_mask) with `mask` = the tensor x a GroupNorm in front of this convolution normalised (MisConvDesc.gn_p: bf16 3x3x3 dgrad on the ping-pong
-    kernels): out = [relu_mask: (x > 0) *] (p * acc + q * x + r), p / q / r fp32 [N][ld] tables of gn_bwd_finalize; columns >= Cout0 are dropped when y1 is None."""
+    kernels): out = [relu_mask: (x > 0) *] (p * acc + q * x + r), p / q / r fp32 [N][ld] tables of gn_bwd_finalize; columns >= Cout0 are dropped when y1 is None.
+    stats (MisConvDesc.st_mode; fp32 3x3x3 all-DMA kernels, check conv_stats_supported first) = dict(mode=1, x0=View, x1=View | None, up=bool, S1=, S2=): the GroupNorm-backward
+    reductions S1 = sum out, S2 = sum out * x per (sample, column) from the epilogue, or dict(mode=2, S1=, S2=): sum out / sum out^2 of the stored output; S1 / S2 fp32 [N][Cout].
+    real = (Cin, Cout) of the layer when the launch runs on zero-padded operands: the timing brackets then carry the algorithmic FLOPs (executed ones beside them)."""
     lib = load()
     x0 = _v(x0)
     y0 = _v(y0)
@@ -130,8 +138,42 @@ def conv_igemm(x0, w_packed, y0, *, ksize, Cin, Cout, grid=None, x1=None, bias=N
     taps = 1 if ksize == 1 else (27 if d.is3d else 9)
     key = ("conv_igemm", "bf16" if d.dtype == MIS_BF16 else "f32", f"k{ksize}", "3d" if d.is3d else "2d",
            "bn128" if Cout % 128 == 0 else "bn64", f"{d.N}x{d.D}x{d.H}x{d.W} {Cin}->{Cout}")
-    with _Timed(key, 2.0 * d.N * d.D * d.H * d.W * taps * Cin * Cout):
+    if stats is not None:
+        rows = lib.mis_conv_stats_rows(C.byref(d))
+        if rows <= 0:
+            raise MisError("conv_igemm(stats=...): this launch has no statistics epilogue (fp32 3x3x3 all-DMA path only)")
+        part = workspace(d.N * rows * 2 * Cout * 4, y0.t.device, "convstats")[:d.N * rows * 2 * Cout].view(d.N, 1, 1, rows, 2 * Cout)
+        d.st_mode, d.st_part = int(stats["mode"]), part.data_ptr()
+        if d.st_mode == 1:
+            sx0 = _v(stats["x0"])
+            d.st_x0, d.st_x0_ld = sx0.ptr, sx0.ld
+            if stats.get("x1") is not None:
+                sx1 = _v(stats["x1"])
+                assert sx0.C + sx1.C == Cout
+                d.st_x1, d.st_x1_ld, d.st_c0, d.st_up = sx1.ptr, sx1.ld, sx0.C, 1 if stats.get("up") else 0
+    rc_, rco_ = (Cin, Cout) if real is None else real
+    with _Timed(key, 2.0 * d.N * d.D * d.H * d.W * taps * rc_ * rco_, exec_flops=2.0 * d.N * d.D * d.H * d.W * taps * Cin * Cout):
         check(lib.mis_conv_igemm(C.byref(d), stream_ptr()), "mis_conv_igemm")
+    if stats is not None:
+        # the partial rows -> [N][Cout] sums, added in double precision in a fixed order
+        S1, S2 = stats["S1"], stats["S2"]
+        assert S1.dtype == S2.dtype == torch.float32 and S1.is_contiguous() and S2.is_contiguous() and tuple(S1.shape) == tuple(S2.shape) == (d.N, Cout)
+        ws2 = workspace(lib.mis_conv_stats_reduce_workspace_bytes(d.N, Cout), y0.t.device, "convstats.red")
+        check(lib.mis_conv_stats_reduce(part.data_ptr(), d.N, rows, Cout, ws2.data_ptr(), S1.data_ptr(), S2.data_ptr(), stream_ptr()), "mis_conv_stats_reduce")
+
+
+def conv_stats_supported(x0, y0, *, Cin, Cout, grid=None):
+    """whether a plain single-source fp32 3x3x3 conv_igemm(x0 -> y0) would run on a kernel with the statistics epilogue (conv_igemm(stats=...))"""
+    lib = load()
+    x0, y0 = _v(x0), _v(y0)
+    d = ConvDesc()
+    d.dtype, d.ksize, d.is3d = dtype_code(x0.dtype), 3, 1 if x0.t.dim() == 5 else 0
+    d.N, d.D, d.H, d.W = grid if grid is not None else (x0.N, x0.D, x0.H, x0.W)
+    d.Cin = d.Cin0 = Cin
+    d.Cout = d.Cout0 = Cout
+    d.x0, d.x0_ld, d.x0_D, d.x0_H, d.x0_W = x0.ptr, x0.ld, x0.D, x0.H, x0.W
+    d.y0, d.y0_ld = y0.ptr, y0.ld
+    return lib.mis_conv_stats_rows(C.byref(d)) > 0
 
 
 def dispatch_override(name, value=1):
@@ -163,6 +205,30 @@ class dispatch_switches:
         for k in self.kw:
             dispatch_override(k, -1)
         return False
+
+
+def tile_queue_init():
+    """allocate and zero the current device's tile-queue counter pool NOW (engine construction) rather than inside the first launch (include/misamd.h)"""
+    check(load().mis_tile_queue_init(), "mis_tile_queue_init")
+
+
+def tile_queue_reset():
+    """zero the tile-queue counters of the current stream / of the capture running on it (a memset node): the engines call it at the start of every train step"""
+    check(load().mis_tile_queue_reset(stream_ptr()), "mis_tile_queue_reset")
+
+
+def tile_queue_check():
+    """device-synchronising: raises MisError when a persistent kernel drew a ticket past its launch's last one since the previous check (that launch left output tiles
+    unwritten - csrc/conv_pp_common.hpp tq_tile); tests, bench.py, smoke() and GraphedTrainStep call it"""
+    lib = load()
+    n = lib.mis_tile_queue_errors()
+    if n != 0:
+        raise MisError(lib.mis_last_error().decode("utf-8", "replace"))
+
+
+def build_has_experiments():
+    """True when libmisamd.so was built with `make EXPERIMENTS=1` (csrc/experiments: MIS_CONV_PPS / MIS_CONV_PPC2)"""
+    return bool(load().mis_build_has_experiments())
 
 
 def conv_last_dispatch():
@@ -231,7 +297,7 @@ def wgrad_reduce_batch(items):
 
 
 def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alpha=1.0, in_scale=None, in_shift=None, dbias=None, side=False,
-          dw_per_sample=None, dbias_per_sample=None, defer=None, ws_tag=None):
+          dw_per_sample=None, dbias_per_sample=None, defer=None, ws_tag=None, real=None):
     """side=True: the reduction kernels go to a second stream (see _SideReduce); the caller must call wgrad_join() before using dw.
     defer=list: only the MFMA kernel runs; the slab reduction is described by an item appended to the list and done for a group of layers by wgrad_reduce_batch(list)
     (the slabs live in a workspace of this layer's own, `ws_tag`, until then)."""
@@ -285,7 +351,8 @@ def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alph
     taps = 1 if ksize == 1 else (27 if d.is3d else 9)
     key = ("wgrad", "bf16" if d.dtype == MIS_BF16 else "f32", f"k{ksize}", "3d" if d.is3d else "2d", "",
            f"{d.N}x{d.D}x{d.H}x{d.W} {Cin}->{Cout}")
-    with _Timed(key, 2.0 * d.N * d.D * d.H * d.W * taps * Cin * Cout):
+    rc_, rco_ = (Cin, Cout) if real is None else real
+    with _Timed(key, 2.0 * d.N * d.D * d.H * d.W * taps * rc_ * rco_, exec_flops=2.0 * d.N * d.D * d.H * d.W * taps * Cin * Cout):
         check(lib.mis_wgrad(C.byref(d), stream_ptr()), "mis_wgrad")
     if st is not None:
         ev = torch.cuda.Event()

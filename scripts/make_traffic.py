@@ -21,7 +21,8 @@ KEYS = {   # bench key -> kernel symbols (prefix match on the rocprof name) whos
 KEYS_3D_F32 = {   # cfg4: UNet3D(1,3), 2 x 128^3 fp32
     "conv_igemm/f32/k3/3d/bn64": ["void conv3d_f32_kernel<2>"],
     "conv_igemm/f32/k3/3d/bn128": ["void conv3d_f32_kernel<4>"],
-    "wgrad/f32/k3/3d": ["void wgrad_f32_stream_kernel<true>"],
+    "conv_igemm/f32/k3/3d/bn32": ["void conv3d_f32_kernel<1>"],
+    "wgrad/f32/k3/3d": ["void wgrad_f32_stream_kernel<true"],
 }
 
 

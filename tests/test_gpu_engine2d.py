@@ -85,23 +85,28 @@ def test_fp32_engine_matches_reference_goldens(tag, cin, cout):
     assert np.allclose(st[:, :3], ref[:, :3], rtol=5e-3, atol=1e-4), "parameters after 3 steps"
 
 
-@pytest.mark.parametrize("net", [(1, 2, "g2_unet_1_2.npz"), (3, 4, "g2_unet_3_4.npz")], ids=["1x2", "3x4"])
+# (net, fixture, input, FIXED bar against the bf16-storage oracle).  Round 6: no data-derived bars.  The 3 -> 4 net runs on the reference golden's OWN
+# input again (one 32 x 48 image: 24 pixels at the deepest level, where one ReLU flip moves down_conv.3.first.weight / middle_conv.first.weight by several percent - measured
+# worst 0.071 / 0.062 on two builds, hence 0.10) AND on a batch of the 1 -> 2 fixture's shape from the pinned oracle (0.08); the tight statement for the four-class fused
+# head is test_fused_head_kernel_against_fp64_on_the_same_bf16_operands below.
+BF16_E2E_CASES = [(1, 2, "g2_unet_1_2.npz", "golden", 6e-2), (3, 4, "g2_unet_3_4.npz", "golden", 1e-1), (3, 4, "g2_unet_3_4.npz", "oracle-2x64x64", 8e-2)]
+
+
+@pytest.mark.parametrize("net", BF16_E2E_CASES, ids=["1x2", "3x4-golden-input", "3x4-oracle-batch"])
 def test_bf16_engine_close_to_oracle(net):
-    """bf16 storage / fp32 accumulate.  (round 5: also UNet(3, 4), cfg3's net - its four-class head runs conv_ppd_head_kernel<4>, which until now met the oracle only
-    through its unfused twin.)  Two bars: (a) TIGHT, per gradient tensor, against the oracle with bf16 storage emulated at the same tensor
-    boundaries (oracle.unet2d_oracle.loss_and_grads_bf16_storage) - this is the parity statement for the bf16 kernels end to end; (b) against the fp32
-    reference, where bf16 storage itself costs 3-12 % relative L2 on this net (the emulation shows it without any device code)."""
+    """bf16 storage / fp32 accumulate.  (round 5: also UNet(3, 4), cfg3's net - its four-class head runs conv_ppd_head_kernel<4>.)  Two bars: (a) per gradient tensor,
+    against the oracle with bf16 storage emulated at the same tensor boundaries (oracle.unet2d_oracle.loss_and_grads_bf16_storage) - the parity statement for the bf16
+    kernels end to end, a FIXED number per case; (b) against the fp32 reference, where bf16 storage itself costs 3-12 % relative L2 on this net (the emulation shows it
+    without any device code)."""
     from oracle import unet2d_oracle as o2
-    cin, cout, fixture = net
+    cin, cout, fixture, which, bar_emu = net
     g = load_golden(fixture)
     eng = _engine(cin, cout, torch.bfloat16)
     p = o2.init_params(cin, cout, seed=0)
-    if cin == 1:
+    if which == "golden":
         im_c, lb_c = T(g["images"]), T(g["labels"])
         ref_logits, ref_loss = T(g["logits"]), float(g["loss"])
     else:
-        # the 3 -> 4 fixture is ONE 32 x 48 image (24 pixels at the deepest level: a single ReLU flip there moves a gradient tensor by several percent): the same batch
-        # shape as the 1 -> 2 fixture, from the pinned oracle (tests/test_oracle_vs_golden.py holds it to that fixture)
         gen = torch.Generator().manual_seed(34)
         im_c, lb_c = torch.randn(2, 3, 64, 64, generator=gen), torch.randint(0, 4, (2, 64, 64), generator=gen)
         rl_, ref_logits, _ = o2.loss_and_grads(p, im_c, lb_c)
@@ -120,10 +125,6 @@ def test_bf16_engine_close_to_oracle(net):
     assert (logits.cpu() - elogits).abs().max().item() < 2e-5 + 2e-3 * elogits.abs().max().item()
     assert abs(loss.item() - el.item()) < 1e-4
     worst_emu, worst_f32, storage = ("", 0.0), ("", 0.0), 0.0
-    # what bf16 STORAGE alone costs on this input (oracle against oracle, no device code): the bar of (a) is half of it, and never below the 6e-2 that the 1 -> 2 fixture
-    # has been held to since round 2 (its storage noise is 0.12; the 3 -> 4 input's is 0.13)
-    storage_all = max(((g16[n].flatten().double() - g32[n].flatten().double()).norm() / (g32[n].flatten().double().norm() + 1e-30)).item() for n in g32)
-    bar_emu = max(6e-2, 0.5 * storage_all)
     for n in g32:          # all 46 tensors
         a, b, c = eng.G[n].cpu().flatten().double(), g16[n].flatten().double(), g32[n].flatten().double()
         r_emu = ((a - b).norm() / (b.norm() + 1e-30)).item()
@@ -133,10 +134,11 @@ def test_bf16_engine_close_to_oracle(net):
         worst_f32 = max(worst_f32, (n, r_f32), key=lambda t: t[1])
         # measured worst 2.6e-2 ... 4.3e-2 depending on the build's summation order: every differently rounded activation perturbs the ReLU masks downstream,
         # so two correct bf16-storage pipelines agree to a few percent here while bf16 storage itself costs up to 12 %; a wrong tap / slice would be O(1)
-        assert r_emu <= bar_emu, (n, "vs bf16-storage oracle", r_emu, bar_emu)
-        assert r_f32 <= 0.16, (n, "vs fp32 oracle", r_f32)
-    print(f"bf16: worst gradient rel-L2 vs the bf16-storage oracle {worst_emu[1]:.3g} ({worst_emu[0]}), vs the fp32 oracle {worst_f32[1]:.3g} "
-          f"({worst_f32[0]}); bf16-storage oracle vs fp32 oracle (no device code) up to {storage:.3g}")
+    # (the worst tensors are printed before anything is asserted: a failure names its tensor AND shows the rest)
+    print(f"bf16 {cin}->{cout} ({which}): worst gradient rel-L2 vs the bf16-storage oracle {worst_emu[1]:.3g} ({worst_emu[0]}; fixed bar {bar_emu}), vs the fp32 oracle "
+          f"{worst_f32[1]:.3g} ({worst_f32[0]}); bf16-storage oracle vs fp32 oracle (no device code) up to {storage:.3g}")
+    assert worst_emu[1] <= bar_emu, (worst_emu, "vs bf16-storage oracle", bar_emu)
+    assert worst_f32[1] <= 0.16, (worst_f32, "vs fp32 oracle")
 
 
 def test_larger_batch_vs_oracle_fp32():
@@ -236,6 +238,63 @@ def test_fused_head_matches_the_separate_kernels(cout, shape, monkeypatch):
         assert r < (2e-5 if k.startswith("final_conv") else 3e-3), (k, r)
     r = ((g0.double() - g1.double()).norm() / g1.double().norm()).item()
     assert r < 3e-3, r
+
+
+@pytest.mark.parametrize("C", [1, 2, 3, 4])
+@pytest.mark.parametrize("shape", [(2, 64, 80, 64), (3, 96, 48, 128)], ids=lambda s: "x".join(map(str, s)))
+def test_fused_head_kernel_against_fp64_on_the_same_bf16_operands(C, shape):
+    """conv_ppd_head_kernel<C> on its own: bf16 input features / bf16-rounded weights / labels in, through mis_conv3x3_head_fused, against an fp64 evaluation
+    of THE SAME operands - Conv2d(Cin, 64, 3, p1) + bias + ReLU (reference layers.py:122-126), the features rounded to bf16 as the unfused pipeline stores them, final_conv
+    (unet.py:89), cross entropy / BCE-with-logits (unet.py:1184-1188), arg-max, dL/dfeatures, head dW / db.  Fixed numeric bars: logits / loss / dW / db <= 2e-3 relative L2
+    (measured ~1e-5: Wh travels through the matrix pipe as bf16 hi + lo parts), dL/dfeatures <= 2e-3 (stored in bf16: its rounding is ~1e-3), arg-max exact away from
+    1e-4 ties."""
+    import torch.nn.functional as F
+    from mdeical_image_segmentation_amd import ops
+    N, H, W, Cin = shape
+    gen = torch.Generator().manual_seed(40 + C)
+    bf = torch.bfloat16
+    x = (torch.randn(N, Cin, H, W, generator=gen).clamp_min(0)).to(bf)                     # a ReLU output, as up_conv.3.first leaves it
+    w = (torch.randn(64, Cin, 3, 3, generator=gen) * (9 * Cin) ** -0.5)
+    b = torch.randn(64, generator=gen) * 0.1
+    wh = torch.randn(C, 64, generator=gen) * 0.2
+    bh = torch.randn(C, generator=gen) * 0.1
+    labels = torch.randint(0, C, (N, H, W), generator=gen) if C > 1 else torch.randint(0, 2, (N, 1, H, W), generator=gen).float()
+    gs = 0.37
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wf = torch.empty(9, 64, Cin, dtype=bf, device=DEV)
+    ops.pack_conv_weight(w.to(DEV), wf, None)
+    dy = torch.full((N, H, W, 64), float("nan"), dtype=bf, device=DEV)
+    logits = torch.full((N, C, H, W), float("nan"), device=DEV)
+    am = torch.full((N, H, W), 255, dtype=torch.uint8, device=DEV)
+    loss_out = torch.zeros(16, device=DEV)
+    dw = torch.full((C, 64), float("nan"), device=DEV)
+    db = torch.full((C,), float("nan"), device=DEV)
+    ok = ops.conv3x3_head_fused(xd, wf, b.to(DEV), dy, wh.to(DEV), bh.to(DEV), Cin=Cin, loss=ops.LOSS_CE if C > 1 else ops.LOSS_BCE, labels=labels.to(DEV), logits=logits,
+                                argmax=am, loss_out=loss_out, dw=dw, db=db, grad_scale=gs)
+    assert ok, "the fused head refused an eligible configuration"
+    torch.cuda.synchronize()
+    # ---- fp64 on the same operands ----
+    pre = F.conv2d(x.double(), w.to(bf).double(), b.double(), padding=1)
+    f = pre.clamp_min(0).float().to(bf).double().requires_grad_(True)                      # the feature map as bf16 storage holds it
+    whd, bhd = wh.double().requires_grad_(True), bh.double().requires_grad_(True)
+    lg = torch.einsum("nkhw,ck->nchw", f, whd) + bhd.view(1, C, 1, 1)
+    ref_loss = F.cross_entropy(lg, labels) if C > 1 else F.binary_cross_entropy_with_logits(lg, labels.double())
+    (ref_loss * gs).backward()
+    rel = lambda a, r: ((a.double().cpu() - r).norm() / (r.norm() + 1e-300)).item()
+    r_lg, r_dw, r_db = rel(logits, lg.detach()), rel(dw, whd.grad), rel(db, bhd.grad)
+    r_df = rel(dy.permute(0, 3, 1, 2), f.grad * (f.detach() > 0))
+    print(f"fused head C={C}: logits {r_lg:.2e}, loss {abs(loss_out[0].item() - ref_loss.item()):.2e}, dfeatures {r_df:.2e}, dW {r_dw:.2e}, db {r_db:.2e}")
+    assert r_lg <= 2e-3 and r_dw <= 2e-3 and r_db <= 2e-3 and r_df <= 2e-3, (r_lg, r_df, r_dw, r_db)
+    assert abs(loss_out[0].item() - ref_loss.item()) <= 1e-4 * max(1.0, abs(ref_loss.item()))
+    if C > 1:
+        top = lg.detach().topk(2, dim=1).values
+        near = (top[:, 0] - top[:, 1]) < 1e-4
+        want = lg.detach().argmax(1)
+    else:
+        near = lg.detach()[:, 0].abs() < 1e-4
+        want = (lg.detach()[:, 0] > 0).long()
+    assert torch.equal(am.cpu().long()[~near], want[~near])
+    assert int((~near).sum()) > 0.99 * near.numel()
 
 
 def test_fused_head_then_external_gradient_through_logits():
