@@ -186,8 +186,11 @@ def kernel_tables(prof, steps, peak):
     roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
             "kernel": " + ".join(syms), "kernel_launches_by_symbol": syms, "key": "/".join(k for k in key if k), "launches": cnt,
             "avg_launch_ms": round(sec / cnt * 1e3, 4), "alg_gflop_per_launch": round(fl / cnt / 1e9, 2), "executed_gflop_per_launch": round(xfl / cnt / 1e9, 2)}
+    def _syms(k):          # the key's launches (bracketed steps) by kernel symbol - tests/test_profiles_consistency.py holds them against the rocprofv3 CSV of the same run
+        return {SYMBOLS.get(t, f"conv_igemm_kernel<{t}>" if k[0] == "conv_igemm" else f"wgrad_kernel<{t}>"): c for t, c in sorted(tags[k].items(), key=lambda kv: -kv[1])}
     kernels = {"/".join(k for k in key if k): {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / steps * 1e3, 3),
-                                              "launches_per_step": v[2] // steps, **({"tflops_executed": round(v[3] / v[1] / 1e12, 1)} if v[3] != v[0] else {})}
+                                              "launches_per_step": v[2] // steps, **({"tflops_executed": round(v[3] / v[1] / 1e12, 1)} if v[3] != v[0] else {}),
+                                              "launches_by_symbol": _syms(key)}
                for key, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
     total = round(sum(v[1] for v in agg.values()) / steps * 1e3, 3)
     return roof, kernels, total, layers, steps
@@ -338,11 +341,11 @@ def main():
                 torch.cuda.empty_cache()
                 o = run2d(args, rank, world, dev, dist, dtype="f32", batch=32, size=512, steps=3, warmup=1, timing=True, layers=False)
                 ex["unet2d_f32_parity_mode"] = {k: o[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "model_tflops", "roofline", "loss_per_step",
-                                                                   "act_nonzero_frac")}
+                                                                   "act_nonzero_frac", "clock")}
                 torch.cuda.empty_cache()
                 o = run3d(args, rank, world, dev, dist, dtype="f32", batch=2, size=128, steps=5, warmup=2, timing=True, layers=False)
                 ex["unet3d_cfg4_f32_128"] = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "model_tflops", "roofline",
-                                                                "kernels", "mfma_kernel_ms_per_step", "loss_per_step", "config")}
+                                                                "kernels", "mfma_kernel_ms_per_step", "loss_per_step", "config", "clock")}
                 if cpu3 is not None:
                     ex["unet3d_cfg4_f32_128"]["cpu_baseline"] = cpu3
                 # the per-GPU shapes of the two 8-GPU configurations (BASELINE configs[2] and configs[4]), so that they are driver-timed at N = 1 as well
@@ -350,12 +353,12 @@ def main():
                 a3 = argparse.Namespace(**{**vars(args), "net": "3x4"})
                 o = run2d(a3, rank, world, dev, dist, dtype="bf16", batch=32, size=512, steps=5, warmup=2, timing=True, layers=False)
                 ex["unet2d_cfg3_3x4_bf16_per_gpu_shape"] = {k: o[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "model_tflops", "roofline",
-                                                                               "loss_per_step", "act_nonzero_frac", "config")}
+                                                                               "loss_per_step", "act_nonzero_frac", "config", "clock")}
                 del o
                 torch.cuda.empty_cache()
                 o = run3d(args, rank, world, dev, dist, dtype="bf16", batch=2, size=160, steps=5, warmup=2, timing=True, layers=False)
                 ex["unet3d_cfg5_bf16_160_per_gpu_shape"] = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "model_tflops",
-                                                                               "roofline", "kernels", "loss_per_step", "config")}
+                                                                               "roofline", "kernels", "loss_per_step", "config", "clock")}
                 del o
                 torch.cuda.empty_cache()
                 o = run_dropin2d(args, dev, batch=32, size=512, steps=5, warmup=2)
@@ -373,6 +376,77 @@ def main():
 
 # ------------------------------------------------------------------------------------------------------------------
 LAST_STEP_TRACE = None
+LAST_CLOCK = None
+
+
+class ClockSampler:
+    """Shader clock and socket power of the device WHILE the timed steps run ("settle the clock"): a host thread reads the amdgpu hwmon files of the card
+    (freq1_input = sclk in Hz, power1_input = socket power in uW; plain sysfs reads, no GPU runtime call, nothing inside any kernel) every `period` seconds.  The dense
+    MFMA peaks of MI355X_MICROARCH.md are quoted at the 2.4 GHz boost clock; under the bf16 MFMA load of this benchmark the part holds less (PMC: GRBM_GUI_ACTIVE / duration =
+    1.93 GHz in round 5) - the line reports what it held and the peak at THAT clock beside the nominal one.  Never fails the benchmark: no readable hwmon -> no `clock`."""
+
+    def __init__(self, dev, period=0.02):
+        import glob
+        import threading
+        self.period, self.samples, self._stop, self._thr = period, [], threading.Event(), None
+        cands = []
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")):
+            h = os.path.dirname(f)
+            if os.access(f, os.R_OK) and os.access(os.path.join(h, "power1_input"), os.R_OK):
+                cands.append((os.path.basename(os.path.realpath(os.path.join(h, "..", ".."))), h))          # (PCI address of the card, hwmon directory)
+        self.hwmon = None
+        if cands:
+            want = None
+            try:
+                p = torch.cuda.get_device_properties(dev)
+                want = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+            except Exception:
+                pass
+            match = [h for a, h in cands if a == want]
+            self.hwmon = match[0] if match else (cands[0][1] if len(cands) == 1 else None)
+        self.cap_w = None
+        if self.hwmon:
+            try:
+                self.cap_w = int(open(os.path.join(self.hwmon, "power1_cap")).read()) / 1e6
+            except (OSError, ValueError):
+                pass
+
+    def _run(self):
+        fq, pw = os.path.join(self.hwmon, "freq1_input"), os.path.join(self.hwmon, "power1_input")
+        while not self._stop.is_set():
+            try:
+                self.samples.append((time.perf_counter(), int(open(fq).read()) / 1e6, int(open(pw).read()) / 1e6))
+            except (OSError, ValueError):
+                pass
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self.hwmon:
+            import threading
+            self._thr = threading.Thread(target=self._run, daemon=True)
+            self._thr.start()
+
+    def stop(self):
+        if self._thr is None:
+            return None
+        self._stop.set()
+        self._thr.join()
+        s = self.samples[1:] if len(self.samples) > 3 else self.samples          # (the first sample may predate the first kernel)
+        if not s:
+            return None
+        mhz, w = [v[1] for v in s], [v[2] for v in s]
+        return {"sclk_mhz_mean": round(sum(mhz) / len(mhz), 1), "sclk_mhz_min": round(min(mhz), 1), "sclk_mhz_max": round(max(mhz), 1),
+                "socket_power_w_mean": round(sum(w) / len(w), 1), "socket_power_w_max": round(max(w), 1), "power_cap_w": self.cap_w, "samples": len(s),
+                "source": f"amdgpu hwmon freq1_input / power1_input every {int(self.period * 1e3)} ms during the timed steps (host thread, sysfs reads only)"}
+
+
+def attach_clock(roof, nominal_mhz=2400.0):
+    """roofline.peak is the dense peak at the 2.4 GHz boost clock; next to it: the peak at the clock the part HELD during these timed steps, and the fraction of that"""
+    if LAST_CLOCK and roof is not None and LAST_CLOCK.get("sclk_mhz_mean"):
+        held = roof["peak"] * LAST_CLOCK["sclk_mhz_mean"] / nominal_mhz
+        roof["peak_at_held_clock"] = round(held, 1)
+        roof["frac_of_held_clock_peak"] = round(roof["achieved"] / held, 4)
+        roof["held_sclk_mhz"] = LAST_CLOCK["sclk_mhz_mean"]
 
 
 def _timed_loop(step, steps, warmup, world, dist, dev, timing):
@@ -397,6 +471,9 @@ def _timed_loop(step, steps, warmup, world, dist, dev, timing):
     fence()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]       # one event per step boundary: shows a ramp (clocks, host) if there is one
     host = []
+    sampler = ClockSampler(dev) if not os.environ.get("MISAMD_BENCH_NO_CLOCK") else None
+    if sampler is not None:
+        sampler.start()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(steps):
@@ -408,6 +485,8 @@ def _timed_loop(step, steps, warmup, world, dist, dev, timing):
         host.append(time.perf_counter())
     fence()
     dt = time.perf_counter() - t0
+    global LAST_CLOCK
+    LAST_CLOCK = sampler.stop() if sampler is not None else None
     ops.tile_queue_check()          # (outside the timed region) a persistent launch that lost tiles to dirty queue counters would make the figure meaningless: fail loudly
     global LAST_STEP_TRACE
     LAST_STEP_TRACE = {"gpu_ms_each": [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(steps)],
@@ -529,7 +608,7 @@ def run2d(args, rank, world, dev, dist, *, dtype, batch, size, steps, warmup, ti
             "config": {"workload": f"unet2d {cin}-ch->{ncls}-class, bs={batch}/GPU {size}x{size}, "
                                    f"fwd+CE loss+bwd+clip_grad_norm(1.0)+AdamW(lr {args.lr:g} constant, wd 1e-3 on weights), PyTorch-default init (seed 0), N(0,1) images",
                        "global_batch": world * batch, "parallelism": f"dp{world}", "final_loss": loss_list[-1] if loss_list else None},
-            "loss_per_step": loss_list, "step_trace": LAST_STEP_TRACE,
+            "loss_per_step": loss_list, "step_trace": LAST_STEP_TRACE, "clock": LAST_CLOCK,
             "act_nonzero_frac": {"before_timed_steps": live0, "after_timed_steps": live1},
         }
         out["model_tflops"] = round(value * (FLOP_PER_IMAGE_512 if args.net == "1x2" else FLOP_PER_IMAGE_512_3X4) * (size / 512.0) ** 2 / 1e12, 1)
@@ -539,6 +618,7 @@ def run2d(args, rank, world, dev, dist, *, dtype, batch, size, steps, warmup, ti
             roof["steps_with_launch_events"] = psteps
             if dtype == "bf16":
                 attach_traffic(roof, batch, size)
+            attach_clock(roof)
             out["roofline"], out["kernels"], out["mfma_kernel_ms_per_step"] = roof, kernels, total
             if layers:
                 for key, v in sorted(ltab.items(), key=lambda kv: -kv[1][1]):
@@ -649,7 +729,7 @@ def run3d(args, rank, world, dev, dist, *, dtype, batch, size, steps, warmup, ti
                                       f"Gaussian noise from the reference's own MT19937 stream; one batch ahead on a second HIP stream) + "
                                       f"fwd+BCEDice+bwd+clip+AdamW(lr {args.lr:g}), random-init weights",
                           "global_batch": world * batch, "parallelism": f"dp{world}", "final_loss": loss_list[-1] if loss_list else None},
-               "loss_per_step": loss_list, "step_trace": LAST_STEP_TRACE}
+               "loss_per_step": loss_list, "step_trace": LAST_STEP_TRACE, "clock": LAST_CLOCK}
         out["model_tflops"] = round(value * FLOP_PER_VOLUME_128 * (size / 128.0) ** 3 / 1e12, 1)
         if prof:
             peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
@@ -658,6 +738,7 @@ def run3d(args, rank, world, dev, dist, *, dtype, batch, size, steps, warmup, ti
             if dtype == "f32" and world == 1:
                 from mdeical_image_segmentation_amd import _lib
                 attach_traffic(roof, batch, size, "traffic_3d_f32.json", _lib.TRAFFIC_SOURCES_3D_F32)
+            attach_clock(roof, 2400.0)
             out["roofline"], out["kernels"], out["mfma_kernel_ms_per_step"] = roof, kernels, total
             if layers:
                 for k, v in sorted(ltab.items(), key=lambda kv: -kv[1][1]):
