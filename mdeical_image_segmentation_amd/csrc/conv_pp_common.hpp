@@ -338,7 +338,15 @@ __device__ __forceinline__ void pp_epilogue_plain(const ConvArgs& a, f32x4 (&acc
                 gr2[f][h] = pp_f32x2{__uint_as_float(praw[2][f][2 * h]), __uint_as_float(praw[2][f][2 * h + 1])};
             }
     }
-    constexpr int MG = PF % 4 == 0 ? 2 : (PF % 5 == 0 ? 5 : (PF % 2 == 0 ? 2 : 1));      // pixel rows whose mask loads are in flight together (the 2-D net masks with ReLU bits)
+    // pixel rows whose mask loads are in flight together (the 2-D net masks with ReLU bits).  Round 6, PP_EM_GN below 256 VGPRs: ALL rows of the wave tile at once (the
+    // 64-column 3-D dgrads: 10 or 8 loads, 32-40 registers that the dead fragments leave free) - the epilogue then waits out ONE memory latency per tile instead of
+    // PF / MG of them (PMC r05: conv3d_ppc_kernel<10, 2, 3> 48 % pipe busy, 47.7 % of its wave cycles waiting, against 58.9 % for the same kernel without the x rows)
+    constexpr int MG0 = PF % 4 == 0 ? 2 : (PF % 5 == 0 ? 5 : (PF % 2 == 0 ? 2 : 1));
+#ifdef PP_GN_MG0          // (A/B build: the round-5 grouping)
+    constexpr int MG = MG0;
+#else
+    constexpr int MG = (gn && PF * NS <= 10 && NF * PF < 32) ? PF : MG0;
+#endif
 #pragma unroll
     for (int pg = 0; pg < PF; pg += MG) {
         u32x4 mk[masked ? MG : 1][NS];

@@ -243,15 +243,27 @@ def wgrad_last_dispatch():
 
 
 _ws_cache = {}
+_ws_captured = set()          # keys whose buffer a stream capture has baked into a graph
+_ws_retired = []              # ... such buffers after they were outgrown: a graph may still replay into them - they are never handed back to the allocator
+
+
+def _ws_key(tag, device):
+    return (tag, str(device))
 
 
 def workspace(nbytes, device, tag="default"):
-    """Grow-only scratch buffers (caller-owned workspaces of the C ABI)."""
-    key = (tag, str(device))
+    """Grow-only scratch buffers (caller-owned workspaces of the C ABI), one per (tag, device).  A buffer that a stream capture has used stays alive when a larger request
+    replaces it (a second engine with a larger shape used to release the buffer a captured GraphedTrainStep of the first still wrote its slabs into)."""
+    key = _ws_key(tag, device)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
+        if buf is not None and key in _ws_captured:
+            _ws_retired.append(buf)
+            _ws_captured.discard(key)
         buf = torch.empty((max(nbytes, 1) + 3) // 4, dtype=torch.float32, device=device)
         _ws_cache[key] = buf
+    if key not in _ws_captured and buf.is_cuda and torch.cuda.is_current_stream_capturing():
+        _ws_captured.add(key)
     return buf
 
 
@@ -332,7 +344,7 @@ def wgrad(x0, dy, dw, *, ksize, Cin, Cout, grid=None, x1=None, dw_layout=0, alph
         st = _side.state(dy.t.device)
         slot = st["n"] & 1
         st["n"] += 1
-        cur = _ws_cache.get((f"wgrad{slot}", str(dy.t.device)))
+        cur = _ws_cache.get(_ws_key(f"wgrad{slot}", dy.t.device))
         if cur is None or cur.numel() * 4 < need:     # growing = freeing the old buffer: no side-stream reduction may still be reading it
             st["stream"].synchronize()
         ws = workspace(need, dy.t.device, f"wgrad{slot}")

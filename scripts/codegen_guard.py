@@ -65,6 +65,31 @@ def check_object(obj):
     return drawn
 
 
+# The all-DMA fp32 kernels (conv3d_f32.hip, wgrad_f32.hip): a ds_read that starts within a few dozen cycles of the barrier that published ANOTHER wave's LDS-DMA can still see the
+# old bytes (wgrad_pp.hip).  Those kernels rely on distance, not on a documented wait: behind every s_barrier either an s_sleep or at least four f32 MFMAs (4 x 32
+# cycles) come before the first LDS read.  ADVICE r5: a different schedule (another NF, a compiler upgrade) could close that gap silently - this check pins it.
+MARGIN_KERNELS = {"conv3d_f32.o": "conv3d_f32_kernel", "wgrad_f32.o": "wgrad_f32_stream_kernel"}
+
+
+def check_margins(obj):
+    kernels = {k: v for k, v in disasm(obj).items() if MARGIN_KERNELS[obj] in k}
+    assert kernels, f"no {MARGIN_KERNELS[obj]} in {obj}"
+    n = 0
+    for name, ins in kernels.items():
+        for i, t in enumerate(ins):
+            if not t.startswith("s_barrier"):
+                continue
+            mfma = sleep = 0
+            for u in ins[i + 1:]:
+                if u.startswith("ds_read"):
+                    break
+                mfma += u.startswith("v_mfma")
+                sleep += u.startswith("s_sleep")
+            assert sleep >= 1 or mfma >= 4, f"{name}: only {mfma} MFMAs and no s_sleep between a barrier (instruction {i}) and the next LDS read"
+            n += 1
+    return n
+
+
 def main():
     if not os.path.exists(OBJDUMP):
         print(f"codegen guard: {OBJDUMP} is missing - the guard cannot run, and the build must not pass without it", file=sys.stderr)
@@ -78,6 +103,16 @@ def main():
         try:
             n = check_object(obj)
             print(f"codegen guard: {obj}: {n} ticket draws, no scratch - ok")
+        except AssertionError as e:
+            print(f"codegen guard FAILED: {obj}: {e}", file=sys.stderr)
+            rc = 1
+    for obj in sorted(MARGIN_KERNELS):
+        if not os.path.exists(os.path.join(CSRC, obj)):
+            print(f"codegen guard: {obj} has not been built", file=sys.stderr)
+            rc = 2
+            continue
+        try:
+            print(f"codegen guard: {obj}: {check_margins(obj)} barriers, each followed by an s_sleep or >= 4 MFMAs before the next LDS read - ok")
         except AssertionError as e:
             print(f"codegen guard FAILED: {obj}: {e}", file=sys.stderr)
             rc = 1

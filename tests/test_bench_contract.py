@@ -7,8 +7,16 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _newest_bench_line():
+    """the newest round's full default line (scripts/collect_profiles.sh prints it after the traffic files of the same collection are in place)"""
+    import glob
+    import re
+    rounds = [int(m.group(1)) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")) for m in [re.match(r"r(\d+)_bench\.json$", os.path.basename(f))] if m]
+    return json.load(open(os.path.join(ROOT, "profiles", f"r{max(rounds):02d}_bench.json")))
+
+
 def test_committed_bench_line_has_the_contract_keys():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
+    d = _newest_bench_line()
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline"):
         assert k in d, k
@@ -31,7 +39,7 @@ def test_traffic_profile_belongs_to_this_tree():
     assert t["source_hash"] == _lib.source_hash(_lib.TRAFFIC_SOURCES), "profiles/traffic.json was measured on other conv / wgrad kernel sources: re-run the PMC passes"
     ent = t["kernels"]["conv_igemm/bf16/k3/2d/bn128"]
     assert ent["hbm_read_bytes_per_launch"] > 0 and ent["hbm_write_bytes_per_launch"] > 0
-    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
+    d = _newest_bench_line()
     assert d["roofline"]["traffic"] == ent["hbm_read_bytes_per_launch"] + ent["hbm_write_bytes_per_launch"]
     # cfg4 (the 3-D half of the metric): its own traffic file, hashed over the fp32 3-D kernel sources, and the committed line carries it next to its CPU baseline
     t3 = json.load(open(os.path.join(ROOT, "profiles", "traffic_3d_f32.json")))

@@ -16,7 +16,7 @@ _spec.loader.exec_module(guard)
 @pytest.fixture(scope="module")
 def built():
     assert os.path.exists(guard.OBJDUMP), f"{guard.OBJDUMP} is missing: the code-generation guards cannot run"
-    if not all(os.path.exists(os.path.join(guard.CSRC, o)) for o in guard.QUEUE_KERNELS):
+    if not all(os.path.exists(os.path.join(guard.CSRC, o)) for o in list(guard.QUEUE_KERNELS) + list(guard.MARGIN_KERNELS)):
         subprocess.run(["make", "-C", guard.CSRC, "-j", "8", "GUARD=0"], check=True, capture_output=True)
     return True
 
@@ -24,6 +24,11 @@ def built():
 @pytest.mark.parametrize("obj", sorted(guard.QUEUE_KERNELS))
 def test_tile_queue_kernels_keep_the_ticket_register_and_use_no_scratch(obj, built):
     assert guard.check_object(obj) >= 2
+
+
+@pytest.mark.parametrize("obj", sorted(guard.MARGIN_KERNELS))
+def test_fp32_all_dma_kernels_keep_their_distance_between_a_barrier_and_the_next_lds_read(obj, built):
+    assert guard.check_margins(obj) >= 2
 
 
 def test_guard_script_exit_code(built):
