@@ -129,9 +129,6 @@ int mis_tile_queue_reset(void* stream);
 int mis_tile_queue_errors(void);
 /* 1 when the library was built with `make EXPERIMENTS=1` (csrc/experiments: kernel variants that lost their A/B, selectable through MIS_CONV_PPS / MIS_CONV_PPC2) */
 int mis_build_has_experiments(void);
-/* Diagnostic: launches a kernel on `stream` that holds `blocks` (1..128) CUs for `cycles` (<= 4e8) shader cycles - what an all-reduce kernel beside the persistent
- * kernels looks like to them (tests/test_gpu_dispatch_parity.py: a conv launch beside it must not take the two rounds a static tile stride would). */
-int mis_debug_hold_cus(int blocks, long long cycles, void* stream);
 
 /* Weight-gradient GEMM: dW[tap][ci][co] = sum_pixels x[pixel+tap][ci] * dy[pixel][co]   (split-K over pixel tiles,
  * fp32 partial slabs + deterministic reduction).  Replaces the weight part of convolution_backward for

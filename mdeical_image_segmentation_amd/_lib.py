@@ -25,7 +25,7 @@ EXPORTS = [
     "mis_chanstats_workspace_bytes", "mis_chanstats", "mis_nchw_to_nhwc", "mis_nhwc_to_nchw", "mis_probe_mfma",
     "mis_gn_fwd_finalize", "mis_gn_bwd_stats_workspace_bytes", "mis_gn_bwd_stats", "mis_gn_bwd_stats_from_dw_workspace_bytes", "mis_gn_bwd_stats_from_dw", "mis_gn_cond", "mis_gn_bwd_finalize", "mis_gn_bwd_apply",
     "mis_first3d_fwd", "mis_first3d_bwd_workspace_bytes", "mis_first3d_bwd", "mis_relu_mask",
-    "mis_convt3_col2im", "mis_convt3_im2col", "mis_seg_metrics_workspace_bytes", "mis_seg_metrics", "mis_iou3d_counts", "mis_se_fc_fwd", "mis_se_apply_fwd", "mis_se_bwd_workspace_bytes", "mis_se_bwd_reduce", "mis_se_fc_bwd", "mis_se_bwd_apply", "mis_debug_tile_queue", "mis_debug_tile_queue_poke", "mis_tile_queue_init", "mis_tile_queue_reset", "mis_tile_queue_errors", "mis_build_has_experiments", "mis_debug_hold_cus", "mis_se_layer_fwd", "mis_se_layer_bwd_reduce", "mis_se_layer_bwd_apply", "mis_patch_gather_reflect", "mis_patch_accumulate", "mis_pred_finalize", "mis_bcedice_workspace_bytes", "mis_bcedice_fwd", "mis_bcedice_bwd", "mis_loss_workspace_bytes", "mis_ce3d_fwd", "mis_ce3d_bwd", "mis_pointloss_fwd", "mis_pointloss_bwd", "mis_maxpoolk_fwd", "mis_maxpoolk_bwd", "mis_bilinear_up_fwd", "mis_bilinear_up_bwd_workspace_bytes", "mis_bilinear_up_bwd", "mis_upconv_gather_fwd_workspace_bytes", "mis_upconv_gather_fwd", "mis_upconv_gather_bwd", "mis_cgm_gate", "mis_scale_sigmoid", "mis_segloss_workspace_bytes", "mis_segloss_fwd", "mis_segloss_bwd", "mis_add_act", "mis_expand1_fwd", "mis_expand1_bwd_workspace_bytes", "mis_expand1_bwd", "mis_bn_fwd_finalize", "mis_bn_bwd_finalize", "mis_affine_act", "mis_bn_bwd_stats_workspace_bytes", "mis_bn_bwd_stats", "mis_bn_bwd_apply",
+    "mis_convt3_col2im", "mis_convt3_im2col", "mis_seg_metrics_workspace_bytes", "mis_seg_metrics", "mis_iou3d_counts", "mis_se_fc_fwd", "mis_se_apply_fwd", "mis_se_bwd_workspace_bytes", "mis_se_bwd_reduce", "mis_se_fc_bwd", "mis_se_bwd_apply", "mis_debug_tile_queue", "mis_debug_tile_queue_poke", "mis_tile_queue_init", "mis_tile_queue_reset", "mis_tile_queue_errors", "mis_build_has_experiments", "mis_se_layer_fwd", "mis_se_layer_bwd_reduce", "mis_se_layer_bwd_apply", "mis_patch_gather_reflect", "mis_patch_accumulate", "mis_pred_finalize", "mis_bcedice_workspace_bytes", "mis_bcedice_fwd", "mis_bcedice_bwd", "mis_loss_workspace_bytes", "mis_ce3d_fwd", "mis_ce3d_bwd", "mis_pointloss_fwd", "mis_pointloss_bwd", "mis_maxpoolk_fwd", "mis_maxpoolk_bwd", "mis_bilinear_up_fwd", "mis_bilinear_up_bwd_workspace_bytes", "mis_bilinear_up_bwd", "mis_upconv_gather_fwd_workspace_bytes", "mis_upconv_gather_fwd", "mis_upconv_gather_bwd", "mis_cgm_gate", "mis_scale_sigmoid", "mis_segloss_workspace_bytes", "mis_segloss_fwd", "mis_segloss_bwd", "mis_add_act", "mis_expand1_fwd", "mis_expand1_bwd_workspace_bytes", "mis_expand1_bwd", "mis_bn_fwd_finalize", "mis_bn_bwd_finalize", "mis_affine_act", "mis_bn_bwd_stats_workspace_bytes", "mis_bn_bwd_stats", "mis_bn_bwd_apply",
     "mis_norm_act_fwd", "mis_norm_act_bwd", "mis_mask_scale", "mis_gn_fwd_finalize_ld", "mis_gn_bwd_finalize_ld", "mis_pool3d_fwd", "mis_pool3d_bwd", "mis_gather3d_fwd", "mis_gather3d_bwd",
     "mis_aug2d_u8", "mis_aug_flip_rot90", "mis_aug_crop_reflect", "mis_aug_rotate0", "mis_aug_rotate0_mode", "mis_aug_rotate3_workspace_bytes", "mis_aug_rotate3", "mis_aug_rotate_spline", "mis_aug_gauss1d", "mis_aug_gauss1d_f32", "mis_aug_map_coordinates", "mis_aug_pointwise", "mis_aug_contrast", "mis_minmax",
 ]
@@ -298,7 +298,6 @@ def load():
         "mis_tile_queue_reset": [vp],
         "mis_tile_queue_errors": [],
         "mis_build_has_experiments": [],
-        "mis_debug_hold_cus": [i, ll, vp],
         "mis_se_layer_fwd": [i, vp, i, i, ll, i, vp, vp, vp, vp, vp, i, i, vp],
         "mis_se_layer_bwd_reduce": [i, vp, i, vp, i, i, ll, i, vp, vp, vp, vp, vp, vp, vp, i, vp],
         "mis_se_layer_bwd_apply": [i, vp, i, vp, i, i, ll, i, vp, vp, vp, vp, vp, vp, i, i, i, vp],

@@ -212,24 +212,3 @@ extern "C" int mis_debug_tile_queue_poke(void* stream, int xcd, unsigned value) 
     return 0;
 }
 
-// diagnostic / tests: a kernel that HOLDS `blocks` CUs for `cycles` shader cycles on `stream` - the stand-in for a collective's kernel beside the persistent MFMA kernels
-// (1024 threads and 64 KiB of LDS per block: no block of theirs fits on the same CU).  Every wave reaches the bound: the grid always drains.
-__global__ __launch_bounds__(1024) void mis_hold_cus_kernel(long long cycles, unsigned* sink) {
-    __shared__ unsigned pad[16384];
-    pad[threadIdx.x] = threadIdx.x;
-    __syncthreads();
-    const long long t0 = (long long)__builtin_readcyclecounter();
-    unsigned v = pad[(threadIdx.x * 7) & 16383];
-    while ((long long)__builtin_readcyclecounter() - t0 < cycles) {
-        v = v * 1664525u + 1013904223u;
-        __builtin_amdgcn_s_sleep(8);
-    }
-    if (v == 0x12345u && sink != nullptr) sink[0] = v;
-}
-extern "C" int mis_debug_hold_cus(int blocks, long long cycles, void* stream) {
-    (void)hipGetLastError();
-    MIS_REQUIRE(blocks > 0 && blocks <= 128 && cycles > 0 && cycles <= 400000000ll, MIS_EINVAL, "debug_hold_cus: blocks %d (1..128), cycles %lld (at most 4e8)", blocks, cycles);
-    hipLaunchKernelGGL(mis_hold_cus_kernel, dim3(blocks), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), cycles, (unsigned*)nullptr);
-    MIS_LAUNCH_CHECK("debug_hold_cus");
-    return MIS_OK;
-}
