@@ -236,6 +236,24 @@ def test_conv3x3_wgrad(case, dtype, no_tr):
     assert_close(dbf, q(dy, dtype).sum((0, 2, 3)), "bias grad fused in wgrad", rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("case", [(2, 20, 36, 64, 64, "k3.2d.f32s"), (3, 9, 17, 32, 64, "k3.2d.f32s32"), (1, 33, 40, 96, 128, "k3.2d.f32s32"), (2, 64, 48, 128, 64, "k3.2d.f32s")])
+def test_conv3x3_wgrad_f32_streaming_kernels_2d(case):
+    """the 2-D instantiations of wgrad_f32_stream_kernel (no bias gradient: the 3-D engines' form of the call, here on images): 64-channel blocks and, round 6, the
+    32-channel blocks (Cin = 32 mod 64) - against torch autograd on CPU, ragged strips, several split-K ranges"""
+    ops = _ops()
+    N, H, W, Cin, Cout, want = case
+    x = rnd(N, Cin, H, W, seed=44)
+    dy = rnd(N, Cout, H, W, seed=45)
+    wq = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    F.conv2d(x, wq, None, padding=1).backward(dy)
+    dw = torch.full((Cout, Cin, 3, 3), float("nan"), device=DEV)
+    ops.wgrad(to_nhwc(x, torch.float32), to_nhwc(dy, torch.float32), dw, ksize=3, Cin=Cin, Cout=Cout)
+    tag, nsplit = ops.wgrad_last_dispatch()
+    assert tag == want, (tag, want)
+    k = N * H * W
+    assert_close(dw, wq.grad, f"2-D f32 streaming wgrad {case} nsplit={nsplit}", rtol=1e-4, atol=1e-4 * k ** 0.5)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cin", [1, 3])
 def test_first_layer(cin, dtype):
