@@ -440,8 +440,20 @@ class ClockSampler:
                 "source": f"amdgpu hwmon freq1_input / power1_input every {int(self.period * 1e3)} ms during the timed steps (host thread, sysfs reads only)"}
 
 
+# What the matrix pipe of an MI355X of this pool DELIVERS on a pure MFMA stream with operands that toggle like real data (scripts/mfma_peak.hip -> profiles/r06_mfma_peak.txt:
+# register operands only, eight different pseudo-random pairs, 256 blocks): the part's power management holds 2.17-2.19 GHz at ~1.25 kW on v_mfma_f32_16x16x32_bf16
+# (2102-2108 TFLOP/s = 0.84 of the nominal dense peak; constant operands: 2362-2425 at 2.39 GHz / 0.83 kW) and 2.39 GHz on v_mfma_f32_16x16x4_f32 (154.1-154.7 TFLOP/s = 0.98).
+# Reported beside `peak` (the nominal figure of MI355X_MICROARCH.md, which `frac` is priced on); never replaces it.
+MEASURED_MFMA_PEAK = {2500.0: 2105.0, 157.3: 154.7}
+
+
 def attach_clock(roof, nominal_mhz=2400.0):
-    """roofline.peak is the dense peak at the 2.4 GHz boost clock; next to it: the peak at the clock the part HELD during these timed steps, and the fraction of that"""
+    """roofline.peak is the dense peak at the 2.4 GHz boost clock; next to it: the peak at the clock the part HELD during these timed steps and the fraction of that, and the
+    rate a pure MFMA stream with toggling operands was MEASURED to deliver on this pool (MEASURED_MFMA_PEAK) and the fraction of that"""
+    if roof is not None and roof.get("peak") in MEASURED_MFMA_PEAK:
+        roof["peak_measured_pure_mfma"] = MEASURED_MFMA_PEAK[roof["peak"]]
+        roof["frac_of_measured_peak"] = round(roof["achieved"] / MEASURED_MFMA_PEAK[roof["peak"]], 4)
+        roof["peak_measured_source"] = "profiles/r06_mfma_peak.txt (scripts/mfma_peak.hip: register-operand MFMA stream, pseudo-random operands, 256 blocks)"
     if LAST_CLOCK and roof is not None and LAST_CLOCK.get("sclk_mhz_mean"):
         held = roof["peak"] * LAST_CLOCK["sclk_mhz_mean"] / nominal_mhz
         roof["peak_at_held_clock"] = round(held, 1)

@@ -64,6 +64,7 @@ def test_clock_sampler_never_fails_the_benchmark():
     bench.LAST_CLOCK = None
     bench.attach_clock(roof)
     assert "peak_at_held_clock" not in roof
+    assert roof["peak_measured_pure_mfma"] == 2105.0 and abs(roof["frac_of_measured_peak"] - 1000.0 / 2105.0) < 1e-3
     bench.LAST_CLOCK = {"sclk_mhz_mean": 2100.0}
     bench.attach_clock(roof)
     assert roof["peak_at_held_clock"] == 2187.5 and abs(roof["frac_of_held_clock_peak"] - 1000.0 / 2187.5) < 1e-3
