@@ -442,7 +442,7 @@ class ClockSampler:
 
 # What the matrix pipe of an MI355X of this pool DELIVERS on a pure MFMA stream with operands that toggle like real data (scripts/mfma_peak.hip -> profiles/r06_mfma_peak.txt:
 # register operands only, eight different pseudo-random pairs, 256 blocks): the part's power management holds 2.17-2.19 GHz at ~1.25 kW on v_mfma_f32_16x16x32_bf16
-# (2102-2108 TFLOP/s = 0.84 of the nominal dense peak; constant operands: 2362-2425 at 2.39 GHz / 0.83 kW) and 2.39 GHz on v_mfma_f32_16x16x4_f32 (154.1-154.7 TFLOP/s = 0.98).
+# (2102-2108 TFLOP/s = 0.84 of the nominal dense peak on two boxes, 2043 at 2.10 GHz on a third; constant operands: 2362-2425 at 2.39 GHz / 0.83 kW) and 2.39 GHz on v_mfma_f32_16x16x4_f32 (154.1-154.7 TFLOP/s = 0.98).
 # Reported beside `peak` (the nominal figure of MI355X_MICROARCH.md, which `frac` is priced on); never replaces it.
 MEASURED_MFMA_PEAK = {2500.0: 2105.0, 157.3: 154.7}
 

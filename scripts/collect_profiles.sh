@@ -18,33 +18,33 @@ F3D="--workload 3d --dtype f32 --steps 3 --warmup 1 --no-cpu-baseline --no-extra
 P2D="--steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-kernel-timing"
 P3D="--workload 3d --dtype bf16 --size 160 --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-kernel-timing"
 PF3D="--workload 3d --dtype f32 --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-kernel-timing"
-echo "[1/13] 2-D PMC: SQ"; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py $P2D > /dev/null 2> $OUT/pmc_sq.err
-echo "[2/13] 2-D PMC: FETCH"; rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $P2D > /dev/null 2> $OUT/pmc_fetch.err
-echo "[3/13] 2-D PMC: WRITE"; rocprofv3 --pmc WRITE_SIZE SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py $P2D > /dev/null 2> $OUT/pmc_write.err
+echo "[1/14] 2-D PMC: SQ"; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py $P2D > /dev/null 2> $OUT/pmc_sq.err
+echo "[2/14] 2-D PMC: FETCH"; rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $P2D > /dev/null 2> $OUT/pmc_fetch.err
+echo "[3/14] 2-D PMC: WRITE"; rocprofv3 --pmc WRITE_SIZE SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py $P2D > /dev/null 2> $OUT/pmc_write.err
 python3 $ROOT/scripts/pmc_summary.py $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_summary.json
 (cd $ROOT && python3 scripts/make_traffic.py $OUT/pmc_summary.json ${TAG}_pmc_summary.json > $OUT/traffic.json)
 cp $OUT/traffic.json $ROOT/profiles/traffic.json
-echo "[4/13] cfg4 PMC: SQ"; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmcf32_sq -- python3 $ROOT/bench.py $PF3D > /dev/null 2> $OUT/pmcf32_sq.err
-echo "[5/13] cfg4 PMC: FETCH / WRITE"; rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmcf32_fetch -- python3 $ROOT/bench.py $PF3D > /dev/null 2> $OUT/pmcf32_fetch.err
+echo "[4/14] cfg4 PMC: SQ"; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmcf32_sq -- python3 $ROOT/bench.py $PF3D > /dev/null 2> $OUT/pmcf32_sq.err
+echo "[5/14] cfg4 PMC: FETCH / WRITE"; rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmcf32_fetch -- python3 $ROOT/bench.py $PF3D > /dev/null 2> $OUT/pmcf32_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmcf32_write -- python3 $ROOT/bench.py $PF3D > /dev/null 2> $OUT/pmcf32_write.err
 python3 $ROOT/scripts/pmc_summary.py $OUT/pmcf32_sq $OUT/pmcf32_fetch $OUT/pmcf32_write > $OUT/3d_f32_pmc_summary.json
 (cd $ROOT && python3 scripts/make_traffic.py $OUT/3d_f32_pmc_summary.json ${TAG}_3d_f32_pmc_summary.json 3d_f32 > $OUT/traffic_3d_f32.json)
 cp $OUT/traffic_3d_f32.json $ROOT/profiles/traffic_3d_f32.json
-echo "[6/13] 3-D bf16 PMC: SQ"; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc3d_sq -- python3 $ROOT/bench.py $P3D > /dev/null 2> $OUT/pmc3d_sq.err
-echo "[7/13] 3-D bf16 PMC: FETCH / WRITE"; rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc3d_fetch -- python3 $ROOT/bench.py $P3D > /dev/null 2> $OUT/pmc3d_fetch.err
+echo "[6/14] 3-D bf16 PMC: SQ"; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc3d_sq -- python3 $ROOT/bench.py $P3D > /dev/null 2> $OUT/pmc3d_sq.err
+echo "[7/14] 3-D bf16 PMC: FETCH / WRITE"; rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc3d_fetch -- python3 $ROOT/bench.py $P3D > /dev/null 2> $OUT/pmc3d_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc3d_write -- python3 $ROOT/bench.py $P3D > /dev/null 2> $OUT/pmc3d_write.err
 python3 $ROOT/scripts/pmc_summary.py $OUT/pmc3d_sq $OUT/pmc3d_fetch $OUT/pmc3d_write > $OUT/3d_bf16_160_pmc_summary.json
-echo "[8/13] 2-D kernel stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks2d -- python3 $ROOT/bench.py $B2D > $OUT/bench_under_rocprof.json 2> $OUT/ks2d.err
+echo "[8/14] 2-D kernel stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks2d -- python3 $ROOT/bench.py $B2D > $OUT/bench_under_rocprof.json 2> $OUT/ks2d.err
 cp $(ls $OUT/ks2d/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
-echo "[9/13] 3-D bf16 kernel stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks3d -- python3 $ROOT/bench.py $B3D > $OUT/3d_bf16_160_bench_under_rocprof.json 2> $OUT/ks3d.err
+echo "[9/14] 3-D bf16 kernel stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks3d -- python3 $ROOT/bench.py $B3D > $OUT/3d_bf16_160_bench_under_rocprof.json 2> $OUT/ks3d.err
 cp $(ls $OUT/ks3d/*/*kernel_stats.csv | head -1) $OUT/3d_bf16_160_kernel_stats.csv
-echo "[10/13] cfg4 kernel stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ksf32 -- python3 $ROOT/bench.py $F3D > $OUT/3d_f32_bench_under_rocprof.json 2> $OUT/ksf32.err
+echo "[10/14] cfg4 kernel stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ksf32 -- python3 $ROOT/bench.py $F3D > $OUT/3d_f32_bench_under_rocprof.json 2> $OUT/ksf32.err
 cp $(ls $OUT/ksf32/*/*kernel_stats.csv | head -1) $OUT/3d_f32_kernel_stats.csv
-echo "[11/13] full default bench line (what the driver runs)"; python3 $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+echo "[11/14] full default bench line (what the driver runs)"; python3 $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 # round 6: socket power / shader clock beside 50 steps of each workload (VERDICT r5 "settle the clock"), and what the on-device augmentation costs the 3-D steps
-echo "[12/13] power / sclk probes"
+echo "[12/14] power / sclk probes"
 for w in 2d 3d_bf16 3d_f32; do python3 $ROOT/scripts/power_probe.py $w 50 > $OUT/power_$w.csv 2> $OUT/power_$w.err; done
-echo "[13/13] MISAMD_BENCH_NOAUG A/B (cfg4, cfg5's shape; two runs each way)"
+echo "[13/14] MISAMD_BENCH_NOAUG A/B (cfg4, cfg5's shape; two runs each way)"
 NA="--steps 10 --warmup 3 --no-cpu-baseline --no-extra --no-kernel-timing"
 ( for i in 1 2; do
     for leg in "cfg4:--workload 3d --dtype f32" "cfg5shape:--workload 3d --dtype bf16 --size 160"; do
@@ -54,6 +54,8 @@ NA="--steps 10 --warmup 3 --no-cpu-baseline --no-extra --no-kernel-timing"
       echo "$name run $i: with augmentation (vol/s, ms/step) $a | MISAMD_BENCH_NOAUG=1 $b"
     done
   done ) > $OUT/noaug_delta.txt 2>&1
+echo "[14/14] what a pure MFMA stream delivers (scripts/mfma_peak.hip)"
+(cd $ROOT && bash scripts/mfma_peak.sh > /dev/null 2>&1 && cp gpurun_out/mfma_peak.txt $OUT/mfma_peak.txt) || echo "mfma_peak failed" > $OUT/mfma_peak.txt
 # the raw counter dumps are large: keep the summaries only
 rm -rf $OUT/ks2d $OUT/ks3d $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc3d_sq $OUT/pmc3d_fetch $OUT/pmc3d_write $OUT/ksf32 $OUT/pmcf32_sq $OUT/pmcf32_fetch $OUT/pmcf32_write
 ls -la $OUT
